@@ -1,0 +1,342 @@
+#!/usr/bin/env python3
+"""Golden-vector generator for the OneProt contrastive-step hot path.
+
+TEST INFRASTRUCTURE.  Runs ONLY in the build container, where the reference
+checkout is mounted read-only at /root/reference.  It imports the reference's
+own classes, feeds them seeded random weights / synthetic ids and stores
+*data only* (inputs, state dicts, outputs, gradients) under tests/golden/.
+No reference source is copied; the GPU box never sees /root/reference.
+
+Reference pieces exercised (file:line in /root/reference):
+  src/models/components/base_encoder.py:6-194      pooling / proj / norm
+  src/models/components/sequence_encoder.py:22-81  SequenceEncoder
+  src/models/components/struct_token_encoder.py:6-34
+  src/models/components/text_encoder.py:8-62
+  src/models/components/loss.py:19-311             gather_features/ClipLoss/SigLipLoss
+  src/distributed.py:8-38                          _get_first_node
+The training-step composition follows src/models/oneprot_module.py:92-107
+(that file itself cannot be imported: pytorch_lightning/torchmetrics absent).
+
+Third-party arithmetic under the reference (HF transformers EsmModel /
+BertModel) is whatever is installed here: transformers 5.15.0, torch 2.10 CPU,
+fp32, attention implementation "eager".
+
+Usage:  python tests/golden/make_golden.py            (writes *.pt / *.json)
+"""
+import json
+import os
+import sys
+import tempfile
+import types
+
+import numpy as np
+import torch
+
+REF = "/root/reference"
+OUT = os.path.dirname(os.path.abspath(__file__))
+
+
+def _import_reference():
+    if not os.path.isdir(REF):
+        raise SystemExit("reference checkout not present; goldens are generated in the build container only")
+    sys.path.insert(0, REF)
+    # peft is absent; LoRA is off in every shipped config, so placeholders that are
+    # never called are enough, and they are removed right after the import statement.
+    placeholder = types.ModuleType("peft")
+    for name in ("LoraConfig", "TaskType", "get_peft_model"):
+        setattr(placeholder, name, object)
+    had = sys.modules.get("peft")
+    sys.modules["peft"] = placeholder
+    try:
+        from src.models.components import base_encoder, loss  # noqa
+        from src.models.components.sequence_encoder import SequenceEncoder
+        from src.models.components.struct_token_encoder import StructTokenEncoder
+        from src.models.components.text_encoder import TextEncoder
+    finally:
+        if had is None:
+            del sys.modules["peft"]
+        else:
+            sys.modules["peft"] = had
+    import src.distributed as refdist
+    return base_encoder, loss, SequenceEncoder, StructTokenEncoder, TextEncoder, refdist
+
+
+def _esm_dir(tmp, name, layers, d, heads, ffn, seed):
+    from transformers import EsmConfig, EsmModel
+    cfg = EsmConfig(vocab_size=33, mask_token_id=32, pad_token_id=1, hidden_size=d,
+                    num_hidden_layers=layers, num_attention_heads=heads, intermediate_size=ffn,
+                    hidden_dropout_prob=0.0, attention_probs_dropout_prob=0.0,
+                    max_position_embeddings=1026, layer_norm_eps=1e-5,
+                    position_embedding_type="rotary", token_dropout=True,
+                    emb_layer_norm_before=False)
+    cfg._attn_implementation = "eager"
+    torch.manual_seed(seed)
+    m = EsmModel(cfg, add_pooling_layer=False)
+    # HF init leaves biases at 0 and LN at (1,0): perturb so every term is pinned
+    with torch.no_grad():
+        for n, p in m.named_parameters():
+            if n.endswith("bias"):
+                p.normal_(0, 0.05)
+            elif "LayerNorm.weight" in n or "layer_norm_after.weight" in n:
+                p.add_(torch.randn_like(p) * 0.1)
+            elif p.dim() == 2:
+                p.normal_(0, 0.08)
+    path = os.path.join(tmp, name)
+    m.save_pretrained(path)
+    return path
+
+
+def _bert_dir(tmp, name, layers, d, heads, ffn, vocab, seed):
+    from transformers import BertConfig, BertModel
+    cfg = BertConfig(vocab_size=vocab, hidden_size=d, num_hidden_layers=layers, num_attention_heads=heads,
+                     intermediate_size=ffn, max_position_embeddings=64, pad_token_id=0,
+                     hidden_dropout_prob=0.1, attention_probs_dropout_prob=0.1, layer_norm_eps=1e-12)
+    cfg._attn_implementation = "eager"
+    torch.manual_seed(seed)
+    m = BertModel(cfg)
+    with torch.no_grad():
+        for n, p in m.named_parameters():
+            if n.endswith("bias"):
+                p.normal_(0, 0.05)
+            elif "LayerNorm.weight" in n:
+                p.add_(torch.randn_like(p) * 0.1)
+            elif p.dim() == 2:
+                p.normal_(0, 0.08)
+    path = os.path.join(tmp, name)
+    m.save_pretrained(path)
+    return path
+
+
+def _ids(gen, B, L, lo, hi, lens, pad, cls=0, eos=2):
+    ids = torch.full((B, L), pad, dtype=torch.long)
+    for b, n in enumerate(lens):
+        ids[b, 0] = cls
+        ids[b, 1:n - 1] = torch.randint(lo, hi + 1, (n - 2,), generator=gen)
+        ids[b, n - 1] = eos
+    return ids
+
+
+def _perturb_head(enc, seed):
+    torch.manual_seed(seed)
+    with torch.no_grad():
+        for n, p in enc.proj.named_parameters():
+            if p.dim() == 1:
+                p.add_(torch.randn_like(p) * 0.1)
+
+
+def _sd(module):
+    return {k: v.detach().clone() for k, v in module.state_dict().items()}
+
+
+def gen_esm_pair(tag, layers, d, heads, ffn, B, L, lens, D_out, with_mask_tok, SequenceEncoder, StructTokenEncoder, lossmod):
+    """seq<->struct_token pair, composed as oneprot_module.py:92-107."""
+    with tempfile.TemporaryDirectory() as tmp:
+        p_seq = _esm_dir(tmp, "seq", layers, d, heads, ffn, seed=11)
+        p_st = _esm_dir(tmp, "st", layers, d, heads, ffn, seed=12)
+        torch.manual_seed(21)
+        seq = SequenceEncoder(p_seq, output_dim=D_out, pooling_type="mean", proj_type="mlp",
+                              use_logit_scale=False, learnable_logit_scale=False, pretrained=True,
+                              use_lora=False, frozen=False)
+        torch.manual_seed(22)
+        st = StructTokenEncoder(p_st, output_dim=D_out, pooling_type="mean", proj_type="linear",
+                                use_logit_scale=True, learnable_logit_scale=False)
+        for enc in (seq, st):
+            enc.transformer.config._attn_implementation = "eager"
+        _perturb_head(seq, 31)
+        _perturb_head(st, 32)
+        seq.train(); st.train()   # all dropouts are 0.0 in ESM-2 configs
+
+    gen = torch.Generator().manual_seed(1881)
+    seq_ids = _ids(gen, B, L, 4, 23, lens, pad=1)
+    st_ids = _ids(gen, B, L, 33, 52, lens, pad=1)
+    if with_mask_tok:
+        seq_ids[1, 3] = 32          # one <mask> token: pins the token-dropout rescale (modeling_esm.py:252-259)
+        seq_ids[1, 5] = 32
+
+    sd_seq0, sd_st0 = _sd(seq), _sd(st)
+
+    acts = {}
+    def hook(name):
+        def f(mod, inp, out):
+            acts[name] = (out[0] if isinstance(out, (tuple, list)) else out).detach().clone()
+        return f
+    hs = [seq.transformer.embeddings.register_forward_hook(hook("seq.embeddings")),
+          seq.transformer.encoder.layer[0].register_forward_hook(hook("seq.layer0")),
+          seq.transformer.encoder.register_forward_hook(lambda m, i, o: acts.__setitem__("seq.last_hidden", o[0].detach().clone())),
+          seq.pooling.register_forward_hook(hook("seq.pooled")),
+          seq.proj.register_forward_hook(hook("seq.projected")),
+          st.transformer.encoder.register_forward_hook(lambda m, i, o: acts.__setitem__("st.last_hidden", o[0].detach().clone())),
+          st.pooling.register_forward_hook(hook("st.pooled"))]
+
+    params = [p for p in list(seq.parameters()) + list(st.parameters()) if p.requires_grad]
+    opt = torch.optim.Adam(params, lr=1e-3, weight_decay=0.0)
+    loss_fn = lossmod.ClipLoss(local_loss=True, gather_with_grad=True, cache_labels=True, rank=0, world_size=1)
+
+    # --- oneprot_module.py:95-107 ---
+    sequence_features = seq(seq_ids)
+    modality_features = st(st_ids)
+    opt.zero_grad()
+    loss_clip = loss_fn(sequence_features, modality_features)
+    loss = loss_clip + 0.01 * (torch.abs(sequence_features).mean() + torch.abs(modality_features).mean())
+    loss.backward()
+    grads = {}
+    for pref, enc in (("seq.", seq), ("st.", st)):
+        for n, p in enc.named_parameters():
+            if p.grad is not None:
+                grads[pref + n] = p.grad.detach().clone()
+    total_norm = torch.nn.utils.clip_grad_norm_(params, 1.0)
+    opt.step()
+    for h in hs:
+        h.remove()
+
+    siglip = lossmod.SigLipLoss(cache_labels=True, rank=0, world_size=1)
+    with torch.no_grad():
+        loss_siglip = siglip(sequence_features, modality_features)
+
+    blob = {
+        "cfg": dict(layers=layers, hidden=d, heads=heads, ffn=ffn, vocab=33, st_vocab=54, pad=1, mask=32,
+                    eps=1e-5, output_dim=D_out, B=B, L=L, lens=list(lens)),
+        "seq_ids": seq_ids, "st_ids": st_ids,
+        "sd_seq": sd_seq0, "sd_st": sd_st0,
+        "acts": acts,
+        "sequence_features": sequence_features.detach().clone(),
+        "modality_features": modality_features.detach().clone(),
+        "loss_clip": loss_clip.detach().clone(), "loss_total": loss.detach().clone(),
+        "loss_siglip": loss_siglip.clone(),
+        "grads": grads, "grad_total_norm": total_norm.detach().clone(),
+        "sd_seq_after": _sd(seq), "sd_st_after": _sd(st),
+    }
+    # keep the files small: fp32 everywhere, drop unused HF heads from "after" (they get no grad)
+    torch.save(blob, os.path.join(OUT, f"esm_pair_{tag}.pt"))
+    print(tag, "loss", float(loss), "clip", float(loss_clip), "gnorm", float(total_norm))
+
+
+def gen_text(TextEncoder):
+    with tempfile.TemporaryDirectory() as tmp:
+        p = _bert_dir(tmp, "bert", layers=2, d=64, heads=4, ffn=128, vocab=120, seed=13)
+        torch.manual_seed(23)
+        enc = TextEncoder(p, output_dim=48, pooling_type="cls", proj_type="mlp", use_logit_scale=True,
+                          learnable_logit_scale=False, frozen=True, use_lora=False)
+        enc.transformer.config._attn_implementation = "eager"
+    _perturb_head(enc, 33)
+    enc.eval()   # BERT dropout 0.1 would otherwise make outputs random (text_encoder.py has no eval switch)
+    gen = torch.Generator().manual_seed(7)
+    B, T = 5, 20
+    lens = [20, 13, 7, 20, 2]
+    ids = torch.zeros(B, T, dtype=torch.long)
+    for b, n in enumerate(lens):
+        ids[b, 0] = 2
+        if n > 2:
+            ids[b, 1:n - 1] = torch.randint(5, 119, (n - 2,), generator=gen)
+        ids[b, n - 1] = 3
+    acts = {}
+    h = enc.transformer.encoder.register_forward_hook(lambda m, i, o: acts.__setitem__("last_hidden", o[0].detach().clone()))
+    h2 = enc.transformer.embeddings.register_forward_hook(lambda m, i, o: acts.__setitem__("embeddings", o.detach().clone()))
+    with torch.no_grad():
+        feats = enc(ids)
+    h.remove(); h2.remove()
+    torch.save({"cfg": dict(layers=2, hidden=64, heads=4, ffn=128, vocab=120, max_pos=64, pad=0, eps=1e-12,
+                            output_dim=48, B=B, T=T, lens=lens),
+                "ids": ids, "sd": _sd(enc), "acts": acts, "features": feats.clone()},
+               os.path.join(OUT, "bert_text.pt"))
+    print("text feats norm", feats.norm(dim=-1))
+
+
+def gen_pooling(base_encoder):
+    torch.manual_seed(5)
+    x = torch.randn(3, 7, 16)
+    mask = torch.tensor([[1] * 7, [1] * 4 + [0] * 3, [1] * 1 + [0] * 6])
+    att = base_encoder.Attention1dPooling(16)
+    out = {"x": x, "mask": mask,
+           "mean": base_encoder.MeanPooling()(x, mask),
+           "mean_nomask": base_encoder.MeanPooling()(x, None),
+           "cls": base_encoder.CLSTokenPooling()(x, mask),
+           "att_sd": _sd(att),
+           "att": att(x, mask.unsqueeze(-1)).detach(),
+           "normalize": base_encoder.Normalize(-1)(x[:, 0]),
+           "logit_scaled": base_encoder.LearnableLogitScaling(learnable=False)(x[:, 0]).detach(),
+           "logit_scale_clip": base_encoder.LearnableLogitScaling(logit_scale_init=500.0, learnable=False)(x[:, 0]).detach()}
+    torch.save(out, os.path.join(OUT, "pooling.pt"))
+
+
+def _rank_worker(rank, world, port, feats, q, REFPATH):
+    import torch.distributed as dist
+    sys.path.insert(0, REFPATH)
+    from src.models.components import loss as lossmod
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    res = {}
+    for local_loss in (False, True):
+        for gwg in (False, True):
+            m = feats["m"][rank].clone().requires_grad_(True)
+            s = feats["s"][rank].clone().requires_grad_(True)
+            fn = lossmod.ClipLoss(local_loss=local_loss, gather_with_grad=gwg, cache_labels=True, rank=rank, world_size=world)
+            l = fn(m, s, logit_scale=1.0)
+            l.backward()
+            res[f"clip_ll{int(local_loss)}_gwg{int(gwg)}"] = (l.detach().clone(), m.grad.clone(), s.grad.clone())
+    for bidir in (False, True):
+        m = feats["m"][rank].clone().requires_grad_(True)
+        s = feats["s"][rank].clone().requires_grad_(True)
+        fn = lossmod.SigLipLoss(cache_labels=True, rank=rank, world_size=world, bidir=bidir)
+        l = fn(m, s, logit_scale=1.0)
+        l.backward()
+        res[f"siglip_bidir{int(bidir)}"] = (l.detach().clone(), m.grad.clone(), s.grad.clone())
+    torch.save(res, q + f".rank{rank}")
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+def gen_multirank(world, port):
+    import torch.multiprocessing as mp
+    torch.manual_seed(99 + world)
+    B, D = 6, 32
+    m = torch.nn.functional.normalize(torch.randn(world, B, D), dim=-1) * (1 / 0.07)
+    s = torch.nn.functional.normalize(torch.randn(world, B, D), dim=-1)
+    feats = {"m": m, "s": s}
+    ctx = mp.get_context("spawn")
+    tmpd = tempfile.mkdtemp()
+    q = os.path.join(tmpd, "res")
+    procs = [ctx.Process(target=_rank_worker, args=(r, world, port, feats, q, REF)) for r in range(world)]
+    for p in procs:
+        p.start()
+    for p in procs:
+        p.join()
+    out = {r: torch.load(q + f".rank{r}") for r in range(world)}
+    torch.save({"world": world, "m": m, "s": s, "per_rank": out}, os.path.join(OUT, f"loss_world{world}.pt"))
+    print("world", world, {k: float(v[0]) for k, v in out[0].items()})
+
+
+def gen_distributed(refdist):
+    cases = []
+    for nl in ["n[01-04]", "n[3,5-7]", "a,b", "a", "jwb[0097,0101-0103]", "node12", "gpu[7]"]:
+        os.environ["SLURM_JOB_NODELIST"] = nl
+        cases.append({"nodelist": nl, "first": refdist._get_first_node()})
+    env_cases = []
+    for sysname in ["", "juwelsbooster", "jureca", "other"]:
+        os.environ.update(SLURM_JOB_NODELIST="jwb[0097,0101]", SLURM_NTASKS="8", SLURM_PROCID="3", SLURM_LOCALID="1",
+                          SYSTEMNAME=sysname)
+        refdist.init_distributed_mode(port=23456)
+        env_cases.append({"SYSTEMNAME": sysname,
+                          **{k: os.environ[k] for k in ("WORLD_SIZE", "RANK", "LOCAL_RANK", "MASTER_ADDR", "MASTER_PORT")}})
+    with open(os.path.join(OUT, "distributed_cases.json"), "w") as f:
+        json.dump({"first_node": cases, "env": env_cases}, f, indent=1)
+
+
+def main():
+    torch.set_num_threads(4)
+    base_encoder, lossmod, SequenceEncoder, StructTokenEncoder, TextEncoder, refdist = _import_reference()
+    gen_pooling(base_encoder)
+    # hd=16 (as ESM-2-8M), with ragged right-padding and <mask> tokens
+    gen_esm_pair("hd16", layers=2, d=64, heads=4, ffn=128, B=6, L=24, lens=[24, 17, 9, 24, 3, 12], D_out=48,
+                 with_mask_tok=True, SequenceEncoder=SequenceEncoder, StructTokenEncoder=StructTokenEncoder, lossmod=lossmod)
+    # hd=32 (as ESM-2-150M), L not a multiple of any tile size
+    gen_esm_pair("hd32", layers=2, d=64, heads=2, ffn=160, B=4, L=37, lens=[37, 20, 37, 5], D_out=64,
+                 with_mask_tok=False, SequenceEncoder=SequenceEncoder, StructTokenEncoder=StructTokenEncoder, lossmod=lossmod)
+    gen_text(TextEncoder)
+    gen_multirank(2, 29611)
+    gen_multirank(3, 29612)
+    gen_distributed(refdist)
+
+
+if __name__ == "__main__":
+    main()
