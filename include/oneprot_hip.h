@@ -1,0 +1,116 @@
+/*
+ * oneprot_hip.h -- C ABI of liboneprot_hip.so: the MI355X (gfx950) kernels behind the OneProt contrastive
+ * alignment training step.
+ *
+ * The reference (klemens-floege/oneprot) is pure Python: it has no FFI of its own.  Its "plugin API" for this path
+ * is the encoder/loss protocol used by OneProtLitModule (ref src/models/oneprot_module.py:67-108); the arithmetic is
+ * delegated to torch/ATen and HF transformers.  Each entry point below replaces one such library call site and cites
+ * it ("ref" = /root/reference, "hf" = transformers/models/esm/modeling_esm.py or .../bert/modeling_bert.py).
+ * INTEGRATION.md shows the ctypes binding a maintainer adds on the reference side.
+ *
+ * Conventions
+ *   - plain pointers (device memory owned by the caller), sizes, and an opaque stream (hipStream_t passed as void*);
+ *   - every function only enqueues work on `stream`; no allocation, no synchronisation, graph-capturable;
+ *   - return 0 on success, -1 invalid argument / unsupported shape, -2 launch failure.  Nothing throws;
+ *   - "bf16" pointers are raw 16-bit bfloat16 storage; statistics, residual stream, losses and all parameter
+ *     gradients are fp32;
+ *   - workspaces are caller-provided; *_workspace() returns the byte count.
+ */
+#ifndef ONEPROT_HIP_H
+#define ONEPROT_HIP_H
+#include <stddef.h>
+#include <stdint.h>
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+int oneprot_abi_version(void);
+
+/* ---------------- embeddings (hf modeling_esm.py:224-271; ref sequence_encoder.py:78) ---------------------------- */
+/* x[b,l,:] = table[id] * 0.88/(1 - n_mask_b/n_valid_b); rows of <mask> and <pad> ids are zero. row_scale[b] (optional) keeps the factor. */
+int oneprot_esm_embed_fwd(const int64_t* ids, const float* table, float* x, float* row_scale, int B, int L, int d, int vocab,
+                          int pad_id, int mask_id, int token_dropout, void* stream);
+size_t oneprot_esm_embed_bwd_workspace(int T, int d, int vocab);
+int oneprot_esm_embed_bwd(const int64_t* ids, const float* dx, const float* row_scale, float* dtable, void* workspace, int B, int L, int d,
+                          int vocab, int pad_id, int mask_id, int token_dropout, int accumulate, void* stream);
+/* BERT: x = LN(word[id] + pos[l] + type[0])  (hf modeling_bert.py:53-108; ref text_encoder.py:59) */
+int oneprot_bert_embed_fwd(const int64_t* ids, const float* word, const float* pos, const float* type0, const float* gamma, const float* beta,
+                           float* x_f32, void* x_bf16, int B, int L, int d, int vocab, float eps, void* stream);
+
+/* ---------------- LayerNorm (nn.LayerNorm: hf modeling_esm.py:429,518,552; ref base_encoder.py:153,158,162) ------ */
+int oneprot_layernorm_fwd(const void* x, int x_is_bf16, const float* gamma, const float* beta, void* y_bf16, float* y_f32, float* mean,
+                          float* rstd, int64_t T, int d, float eps, void* stream);
+size_t oneprot_layernorm_bwd_workspace(int d);
+/* dy_mode 0: bf16 [T,d]; 1: fp32 [T,d]; 2: dy[t] = dpool[t/L] * wrow[t].  dx = (add_to ? add_to : 0) + LN'(dy). */
+int oneprot_layernorm_bwd(const void* dy, int dy_mode, const float* wrow, int L, const void* x, int x_is_bf16, const float* gamma,
+                          const float* mean, const float* rstd, const float* add_to, float* dx, float* dgamma, float* dbeta, void* workspace,
+                          int64_t T, int d, int accumulate_param_grads, void* stream);
+/* final LayerNorm fused with pooling (ref base_encoder.py:109-126): mode 0 masked mean (CLS/EOS included), 1 CLS. */
+int oneprot_lnpool_fwd(const float* x, const int64_t* ids, int pad_id, const float* gamma, const float* beta, float* pooled, float* mean,
+                       float* rstd, float* wrow, void* hidden_bf16, float* hidden_f32, int B, int L, int d, float eps, int mode, void* stream);
+
+/* ---------------- dense contractions on MFMA (nn.Linear call sites: hf modeling_esm.py:362-368,399-409,442-463) -- */
+enum {
+  ONEPROT_EPI_BF16 = 0,        /* out0 bf16 [M,N] = acc (+bias)                                                   */
+  ONEPROT_EPI_F32 = 1,         /* out0 fp32 [M,N] = acc (+bias)                                                   */
+  ONEPROT_EPI_BIAS_GELU = 2,   /* z = acc+bias; out0 bf16 = gelu_erf(z); out1 bf16 = z (optional)                 */
+  ONEPROT_EPI_BIAS_RESID = 3,  /* out0 fp32 = acc + bias + resid fp32 (out0 may alias resid); out1 bf16 copy opt. */
+  ONEPROT_EPI_QKV_ROPE = 4,    /* N = 3*H*hd: q=(acc+b)*q_scale -> rope -> out0 [B,H,L,hd]; k -> rope -> out1; v -> out2 */
+  ONEPROT_EPI_GELU_BWD = 5     /* out0 bf16 = acc * gelu_erf'(aux bf16 [M,N])                                     */
+};
+/* C[M,N] = A[M,K] * B[N,K]^T, A and B bf16 row-major with leading dims lda/ldb (elements), fp32 accumulation. */
+int oneprot_gemm_bf16_nt(const void* A, const void* Bw, int64_t M, int N, int K, int lda, int ldb, int epilogue, const float* bias,
+                         void* out0, void* out1, void* out2, const void* aux, const float* rope_cos, const float* rope_sin, float q_scale,
+                         int L, int H, int hd, void* stream);
+/* dW[N,K] (+)= dY[M,N]^T * X[M,K]  (contraction over the M tokens; split over workgroups, fp32 slabs in workspace). */
+size_t oneprot_gemm_bf16_tn_workspace(int N, int K);
+int oneprot_gemm_bf16_tn(const void* dY, const void* X, int64_t M, int N, int K, int ldy, int ldx, float* dW, void* workspace, int accumulate,
+                         void* stream);
+/* fp32 GEMM for the small head / logits contractions (ref base_encoder.py:155,159,164; loss.py:91-99):
+   C[M,N] = alpha * op(A) * op(B) (+ C if accumulate);  transA: A stored [K,M]; transB: B stored [K,N] else [N,K]. */
+int oneprot_sgemm(const float* A, const float* B, float* C, int M, int N, int K, int transA, int b_is_kn, float alpha, int accumulate, void* stream);
+
+/* ---------------- attention (hf modeling_esm.py:292-317,340-395) ------------------------------------------------- */
+/* q (pre-scaled, rotated), k (rotated), v : bf16 [B,H,L,hd]; key_bias fp32 [B,L] (0 valid, -inf-like for padding);
+   ctx bf16 [B*L, H*hd]; lse fp32 [B,H,L] (natural log of the softmax denominator, incl. max). */
+int oneprot_attn_fwd(const void* q, const void* k, const void* v, const float* key_bias, void* ctx, float* lse, int B, int H, int L, int hd,
+                     void* stream);
+/* dctx bf16 [B*L, H*hd] -> dqkv bf16 [B*L, 3*H*hd] = gradient w.r.t. the un-rotated, un-scaled q/k/v projections. */
+size_t oneprot_attn_bwd_workspace(int B, int H, int L);
+int oneprot_attn_bwd(const void* q, const void* k, const void* v, const float* key_bias, const void* ctx, const void* dctx, const float* lse,
+                     const float* rope_cos, const float* rope_sin, float q_scale, void* dqkv, void* workspace, int B, int H, int L, int hd,
+                     void* stream);
+
+/* ---------------- small fp32 feature ops (ref base_encoder.py:6-38, loss.py:103-114, oneprot_module.py:99-101) --- */
+int oneprot_gelu_f32(const float* x, float* y, int64_t n, void* stream);
+int oneprot_gelu_bwd_f32(const float* x, const float* dy, float* dx, int64_t n, void* stream);
+/* y = scale * x / max(||x||, 1e-12) per row; inv_norm[r] saved for backward. */
+int oneprot_l2norm_fwd(const float* x, float* y, float* inv_norm, int R, int D, float scale, void* stream);
+/* dx = scale*inv_norm*(g - xhat*(xhat.g)), g = dy + l1_coef*sign(y)  (l1_coef = 0.01/(R*D) folds the L1 term's gradient). */
+int oneprot_l2norm_bwd(const float* y, const float* dy, const float* inv_norm, float* dx, int R, int D, float scale, float l1_coef, void* stream);
+/* Softmax cross-entropy over rows of logits [R,C] with label[r] = r + label_offset.  loss_sum += sum_r (lse_r - logit[r,label]) * row_weight;
+   logits are overwritten with dlogits = (softmax - onehot) * row_weight. */
+int oneprot_ce_fwd_bwd(float* logits, float* loss_sum, float* row_loss_ws /* R floats */, int R, int C, int label_offset, float row_weight, void* stream);
+/* sum_abs += coef * sum |x|   (L1 feature regulariser, ref oneprot_module.py:101) */
+int oneprot_abs_sum(const float* x, float* out_sum, void* workspace /* oneprot_sumsq_workspace() bytes */, int64_t n, float coef, void* stream);
+
+/* ---------------- optimiser (torch.optim.Adam, ref configs/model/default.yaml:2-6; clip: oneprot_module.py:106) -- */
+/* sumsq[0] += sum x^2 (two-stage deterministic reduction through workspace of oneprot_sumsq_workspace() bytes). */
+size_t oneprot_sumsq_workspace(void);
+int oneprot_sumsq(const float* x, int64_t n, float* sumsq, void* workspace, void* stream);
+/* coef[0] = min(1, max_norm / (sqrt(sumsq[0]) + 1e-6)); norm_out[0] = sqrt(sumsq[0]) */
+int oneprot_clip_coef(const float* sumsq, float max_norm, float* coef, float* norm_out, void* stream);
+/* Adam step on a flat arena; g is multiplied by grad_scale[0] (device scalar, may be NULL) before use. step >= 1. */
+int oneprot_adam_step(float* p, const float* g, float* m, float* v, int64_t n, float lr, float beta1, float beta2, float eps, float weight_decay,
+                      int step, const float* grad_scale, void* stream);
+
+/* ---------------- casts ------------------------------------------------------------------------------------------ */
+int oneprot_cast_f32_to_bf16(const float* src, void* dst, int64_t n, void* stream);
+int oneprot_transpose_cast_f32_to_bf16(const float* src, void* dst, int R, int C, void* stream);
+size_t oneprot_colsum_workspace(int N);
+int oneprot_colsum_bf16(const void* a, float* out, void* workspace, int64_t M, int N, int accumulate, void* stream);
+
+#ifdef __cplusplus
+}
+#endif
+#endif

@@ -1,0 +1,455 @@
+// Flash-style multi-head attention for the ESM-2 / BERT encoders on gfx950 (hf modeling_esm.py:292-317, 340-395).
+// Scores never touch HBM; the backward recomputes P from q, k and the saved log-sum-exp.
+//
+// Data layout: q (already scaled by hd^-1/2 and rotated), k (rotated), v are bf16 [B, H, L, hd] (head-major, written by
+// the QKV GEMM epilogue), so one (b, h) slab is a contiguous L*hd*2-byte run.  ctx / dctx are bf16 [B*L, H*hd]
+// (token-major, the A operand of the out-projection GEMM).  key_bias is the additive key-padding mask [B, L] fp32.
+//
+// MFMA mapping (v_mfma_f32_32x32x16_bf16, wave64; lane maps verified by csrc/probe_gfx950.hip):
+//   forward, per wave = 32 queries, per 32-key tile:
+//     S^T[key][query] = K * Q^T      (A = K rows from LDS, B = Q rows in registers)  -> query on the lane, keys in the 16
+//                                     accumulator registers: the softmax row-reduce is in-lane + one lane^32 exchange;
+//     O^T[d][query] += V^T * P       (P straight from the accumulator registers as the B operand -- no LDS round trip;
+//                                     A = V^T gathered with ds_read_b64_tr_b16 from the row-major V tile)
+//   backward dQ kernel mirrors the forward (+ dP^T = V dO^T, dQ^T += K^T dS^T);
+//   backward dK/dV kernel puts the key on the lane: S = Q K^T, dP = dO V^T, dV^T += dO^T P, dK^T += Q^T dS.
+// Tiles in LDS are row-major with a 16-byte-chunk XOR swizzle that keeps the ds_read_b128 row reads conflict-free.
+#include "common.h"
+#include "../../include/oneprot_hip.h"
+#include <float.h>
+
+#define LOG2E 1.4426950408889634f
+#define KC 256        // keys (or queries) staged per LDS chunk
+
+template <int HD> struct Cfg {
+  static constexpr int HDP = HD < 32 ? 32 : HD;      // LDS row pitch in elements (hd=16 rows are zero-padded to 32)
+  static constexpr int NCH = HDP / 8;                // 16-byte chunks per row
+  static constexpr int KSTEPS = HD / 16;             // 16-deep contraction steps over the head dim
+  static constexpr int DBLK = HDP / 32;              // 32-row blocks of the head dim on the MFMA M axis
+  static constexpr int ROWB = HDP * 2;               // row pitch in bytes
+};
+
+template <int HDP> __device__ __forceinline__ int swz(int row, int chunk) {
+  return HDP == 32 ? (chunk ^ ((row >> 2) & 3)) : (chunk ^ ((row >> 1) & 7));
+}
+
+// cooperative [nrows x HD] bf16 tile load (global row pitch `gpitch` elements) into a swizzled, zero-padded LDS tile
+template <int HD>
+__device__ __forceinline__ void load_tile(unsigned char* lds, const bf16_t* g, size_t gpitch, int rows_valid, int nrows) {
+  typedef Cfg<HD> C;
+  for (int idx = threadIdx.x; idx < nrows * C::NCH; idx += 256) {
+    const int row = idx / C::NCH, ch = idx - row * C::NCH;
+    u32x4 v = {0u, 0u, 0u, 0u};
+    if (row < rows_valid && ch < HD / 8) v = *reinterpret_cast<const u32x4*>(g + (size_t)row * gpitch + ch * 8);
+    *reinterpret_cast<u32x4*>(lds + row * C::ROWB + (swz<C::HDP>(row, ch) << 4)) = v;
+  }
+}
+
+// row fragment: 8 consecutive head-dim elements (16*step + 8*h ...) of `row`
+template <int HD>
+__device__ __forceinline__ bf8_t rd_row(const unsigned char* lds, int row, int step, int h) {
+  typedef Cfg<HD> C;
+  return *reinterpret_cast<const bf8_t*>(lds + row * C::ROWB + (swz<C::HDP>(row, 2 * step + h) << 4));
+}
+
+// transposed fragment for the 32-row tile starting at row kb: element j of lane (r, h) = T[kb + 16 s + 8 (j>>2) + 4 h + (j&3)][32 db + r]
+template <int HD>
+__device__ __forceinline__ bf8_t rd_tr(const unsigned char* lds, int kb, int s, int db, int lane) {
+  typedef Cfg<HD> C;
+  const int g = lane >> 4, i = lane & 15, h = lane >> 5;
+  const int col = 32 * db + 16 * (g & 1) + 4 * (i & 3);
+  const int r0 = kb + 16 * s + 4 * h + (i >> 2);
+  const int r1 = r0 + 8;
+  const unsigned char* p0 = lds + r0 * C::ROWB + (swz<C::HDP>(r0, col >> 3) << 4) + (col & 7) * 2;
+  const unsigned char* p1 = lds + r1 * C::ROWB + (swz<C::HDP>(r1, col >> 3) << 4) + (col & 7) * 2;
+  const s16x4 a = __builtin_amdgcn_ds_read_tr16_b64_v4i16((__attribute__((address_space(3))) s16x4*)p0);
+  const s16x4 b = __builtin_amdgcn_ds_read_tr16_b64_v4i16((__attribute__((address_space(3))) s16x4*)p1);
+  s16x8 o;
+  o[0] = a[0]; o[1] = a[1]; o[2] = a[2]; o[3] = a[3]; o[4] = b[0]; o[5] = b[1]; o[6] = b[2]; o[7] = b[3];
+  return __builtin_bit_cast(bf8_t, o);
+}
+
+__device__ __forceinline__ bf8_t pack8(const f32x16& x, int s) {
+  u32x4 w;
+  w.x = pack2bf(x[8 * s + 0], x[8 * s + 1]); w.y = pack2bf(x[8 * s + 2], x[8 * s + 3]);
+  w.z = pack2bf(x[8 * s + 4], x[8 * s + 5]); w.w = pack2bf(x[8 * s + 6], x[8 * s + 7]);
+  return __builtin_bit_cast(bf8_t, w);
+}
+#define MFMA32(a, b, c) __builtin_amdgcn_mfma_f32_32x32x16_bf16((a), (b), (c), 0, 0, 0)
+
+__device__ __forceinline__ f32x16 zero16() {
+  f32x16 z;
+#pragma unroll
+  for (int i = 0; i < 16; ++i) z[i] = 0.f;
+  return z;
+}
+
+// XCD-aware decode: blocks with the same (b,h) land on one XCD (they share K/V through its L2)
+__device__ __forceinline__ void decode_block(int nblk_per_bh, int nbh, int& bh, int& blk) {
+  const int id = blockIdx.x, xcd = id & 7, seq = id >> 3;
+  bh = (seq / nblk_per_bh) * 8 + xcd;
+  blk = seq % nblk_per_bh;
+  (void)nbh;
+}
+
+// =========================================================================================================
+// forward
+// =========================================================================================================
+template <int HD>
+__global__ void __launch_bounds__(256, 2) k_attn_fwd(const bf16_t* __restrict__ q, const bf16_t* __restrict__ k, const bf16_t* __restrict__ v,
+                                                  const float* __restrict__ key_bias, bf16_t* __restrict__ ctx, float* __restrict__ lse_out, int B, int H,
+                                                  int L, int nqb) {
+  typedef Cfg<HD> C;
+  extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+  unsigned char* sK = smem;
+  unsigned char* sV = sK + KC * C::ROWB;
+  float* sBias = reinterpret_cast<float*>(sV + KC * C::ROWB);
+  int bh, qb;
+  decode_block(nqb, B * H, bh, qb);
+  if (bh >= B * H) return;
+  const int b = bh / H, head = bh - b * H;
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, h = lane >> 5;
+  const int q0 = qb * 128 + wave * 32;
+  const int qidx = q0 + (lane & 31);
+  const int qrow = qidx < L ? qidx : L - 1;
+  const bf16_t* qbase = q + (size_t)bh * L * HD;
+  const bf16_t* kbase = k + (size_t)bh * L * HD;
+  const bf16_t* vbase = v + (size_t)bh * L * HD;
+  bf8_t qf[C::KSTEPS];
+#pragma unroll
+  for (int st = 0; st < C::KSTEPS; ++st) qf[st] = *reinterpret_cast<const bf8_t*>(qbase + (size_t)qrow * HD + 16 * st + 8 * h);
+  float m = -FLT_MAX, l = 0.f;
+  f32x16 acc[C::DBLK];
+#pragma unroll
+  for (int d = 0; d < C::DBLK; ++d) acc[d] = zero16();
+
+  for (int kc0 = 0; kc0 < L; kc0 += KC) {
+    const int nkeys = min(KC, L - kc0);
+    const int nrows = (nkeys + 31) & ~31;
+    __syncthreads();
+    load_tile<HD>(sK, kbase + (size_t)kc0 * HD, HD, nkeys, nrows);
+    load_tile<HD>(sV, vbase + (size_t)kc0 * HD, HD, nkeys, nrows);
+    for (int i = threadIdx.x; i < nrows; i += 256)
+      sBias[i] = i < nkeys ? (key_bias ? key_bias[(size_t)b * L + kc0 + i] : 0.f) : -INFINITY;
+    __syncthreads();
+    for (int t = 0; t < nrows / 32; ++t) {
+      f32x16 s = zero16();
+#pragma unroll
+      for (int st = 0; st < C::KSTEPS; ++st) s = MFMA32(rd_row<HD>(sK, t * 32 + (lane & 31), st, h), qf[st], s);
+      float mx = -FLT_MAX;
+#pragma unroll
+      for (int g = 0; g < 4; ++g) {
+        const float4 bv = *reinterpret_cast<const float4*>(sBias + t * 32 + 8 * g + 4 * h);
+        s[4 * g + 0] += bv.x; s[4 * g + 1] += bv.y; s[4 * g + 2] += bv.z; s[4 * g + 3] += bv.w;
+        mx = fmaxf(mx, fmaxf(fmaxf(s[4 * g + 0], s[4 * g + 1]), fmaxf(s[4 * g + 2], s[4 * g + 3])));
+      }
+      mx = fmaxf(mx, __shfl_xor(mx, 32, 64));
+      const float mn = fmaxf(m, mx);
+      if (__any(mn > m)) {
+        const float alpha = __builtin_amdgcn_exp2f((m - mn) * LOG2E);
+        l *= alpha;
+#pragma unroll
+        for (int d = 0; d < C::DBLK; ++d)
+#pragma unroll
+          for (int r = 0; r < 16; ++r) acc[d][r] *= alpha;
+        m = mn;
+      }
+      float ls = 0.f;
+#pragma unroll
+      for (int r = 0; r < 16; ++r) { s[r] = __builtin_amdgcn_exp2f((s[r] - m) * LOG2E); ls += s[r]; }
+      l += ls;
+#pragma unroll
+      for (int sb = 0; sb < 2; ++sb) {
+        const bf8_t pf = pack8(s, sb);
+#pragma unroll
+        for (int d = 0; d < C::DBLK; ++d) acc[d] = MFMA32(rd_tr<HD>(sV, t * 32, sb, d, lane), pf, acc[d]);
+      }
+    }
+  }
+  const float lt = l + __shfl_xor(l, 32, 64);
+  const float inv = 1.0f / lt;
+  if (qidx < L) {
+    bf16_t* dst = ctx + ((size_t)b * L + qidx) * (H * HD) + head * HD;
+#pragma unroll
+    for (int d = 0; d < C::DBLK; ++d)
+#pragma unroll
+      for (int g = 0; g < 4; ++g) {
+        const int dd = 32 * d + 8 * g + 4 * h;
+        if (dd < HD) {
+          u32x2 w; w.x = pack2bf(acc[d][4 * g] * inv, acc[d][4 * g + 1] * inv); w.y = pack2bf(acc[d][4 * g + 2] * inv, acc[d][4 * g + 3] * inv);
+          *reinterpret_cast<u32x2*>(dst + dd) = w;
+        }
+      }
+    if (lse_out && h == 0) lse_out[(size_t)bh * L + qidx] = m + __logf(lt);
+  }
+}
+
+template <int HD> static size_t fwd_lds() { return (size_t)2 * KC * Cfg<HD>::ROWB + KC * sizeof(float); }
+
+template <int HD>
+static int launch_fwd(const void* q, const void* k, const void* v, const float* key_bias, void* ctx, float* lse, int B, int H, int L, hipStream_t s) {
+  const int nqb = (L + 127) / 128;
+  const int nbh8 = ((B * H + 7) / 8) * 8;
+  hipLaunchKernelGGL(k_attn_fwd<HD>, dim3(nbh8 * nqb), dim3(256), fwd_lds<HD>(), s, (const bf16_t*)q, (const bf16_t*)k, (const bf16_t*)v, key_bias,
+                     (bf16_t*)ctx, lse, B, H, L, nqb);
+  return launch_status();
+}
+
+extern "C" int oneprot_attn_fwd(const void* q, const void* k, const void* v, const float* key_bias, void* ctx, float* lse, int B, int H, int L, int hd,
+                                void* stream) {
+  if (!q || !k || !v || !ctx || B <= 0 || H <= 0 || L <= 0) return OP_EINVAL;
+  hipStream_t s = (hipStream_t)stream;
+  switch (hd) {
+    case 16: return launch_fwd<16>(q, k, v, key_bias, ctx, lse, B, H, L, s);
+    case 32: return launch_fwd<32>(q, k, v, key_bias, ctx, lse, B, H, L, s);
+    case 64: return launch_fwd<64>(q, k, v, key_bias, ctx, lse, B, H, L, s);
+    default: return OP_EINVAL;
+  }
+}
+
+// =========================================================================================================
+// backward
+// =========================================================================================================
+// delta[b,h,l] = sum_d dctx[t, h*hd + d] * ctx[t, h*hd + d]
+template <int HD>
+__global__ void __launch_bounds__(256) k_attn_delta(const bf16_t* __restrict__ ctx, const bf16_t* __restrict__ dctx, float* __restrict__ delta, int B, int H, int L) {
+  const size_t idx = (size_t)blockIdx.x * 256 + threadIdx.x;     // (t, head)
+  if (idx >= (size_t)B * L * H) return;
+  const size_t t = idx / H; const int head = (int)(idx - t * H);
+  const bf16_t* a = ctx + t * (H * HD) + head * HD;
+  const bf16_t* g = dctx + t * (H * HD) + head * HD;
+  float s = 0.f;
+#pragma unroll
+  for (int c = 0; c < HD / 8; ++c) {
+    const u32x4 x = *reinterpret_cast<const u32x4*>(a + c * 8), y = *reinterpret_cast<const u32x4*>(g + c * 8);
+    s += bflo(x.x) * bflo(y.x) + bfhi(x.x) * bfhi(y.x) + bflo(x.y) * bflo(y.y) + bfhi(x.y) * bfhi(y.y) + bflo(x.z) * bflo(y.z) + bfhi(x.z) * bfhi(y.z) +
+         bflo(x.w) * bflo(y.w) + bfhi(x.w) * bfhi(y.w);
+  }
+  const size_t b = t / L; const int l = (int)(t - b * L);
+  delta[((size_t)b * H + head) * L + l] = s;
+}
+
+// inverse rotary on a gradient held as O^T-style accumulators: lane owns position `pos`, registers hold head-dim rows
+// d = 32 db + 8 g + 4 h + e.  dx1 = dy1 c + dy2 s ; dx2 = dy2 c - dy1 s   (transpose of hf modeling_esm.py:48-79), then * scale.
+template <int HD>
+__device__ __forceinline__ void unrope_store(f32x16 (&acc)[Cfg<HD>::DBLK], const float* __restrict__ cosT, const float* __restrict__ sinT, int pos, int h,
+                                             float scale, bool rope, bf16_t* dst) {
+  typedef Cfg<HD> C;
+  constexpr int HALF = HD / 2;
+#pragma unroll
+  for (int d = 0; d < C::DBLK; ++d)
+#pragma unroll
+    for (int g = 0; g < 4; ++g) {
+      const int dd = 32 * d + 8 * g + 4 * h;
+      if (dd >= HD) continue;
+      float o[4];
+      if (rope) {
+        const bool lo = dd < HALF;
+        const int jj = lo ? dd : dd - HALF;
+        const float4 c = *reinterpret_cast<const float4*>(cosT + (size_t)pos * HALF + jj);
+        const float4 sn = *reinterpret_cast<const float4*>(sinT + (size_t)pos * HALF + jj);
+        float own[4], par[4];
+#pragma unroll
+        for (int e = 0; e < 4; ++e) own[e] = acc[d][4 * g + e];
+        // partner rows: +-HALF in the head dim
+        if (HD == 64) {
+#pragma unroll
+          for (int e = 0; e < 4; ++e) par[e] = acc[C::DBLK - 1 - d][4 * g + e];
+        } else if (HD == 32) {
+#pragma unroll
+          for (int e = 0; e < 4; ++e) par[e] = acc[0][4 * (g ^ 2) + e];
+        } else {
+#pragma unroll
+          for (int e = 0; e < 4; ++e) par[e] = acc[0][4 * (g ^ 1) + e];
+        }
+        const float cv[4] = {c.x, c.y, c.z, c.w}, sv[4] = {sn.x, sn.y, sn.z, sn.w};
+#pragma unroll
+        for (int e = 0; e < 4; ++e) o[e] = (own[e] * cv[e] + (lo ? par[e] : -par[e]) * sv[e]) * scale;
+      } else {
+#pragma unroll
+        for (int e = 0; e < 4; ++e) o[e] = acc[d][4 * g + e] * scale;
+      }
+      u32x2 w; w.x = pack2bf(o[0], o[1]); w.y = pack2bf(o[2], o[3]);
+      *reinterpret_cast<u32x2*>(dst + dd) = w;
+    }
+}
+
+// ---- dQ: one wave = 32 queries, loops over all keys -------------------------------------------------------------
+template <int HD>
+__global__ void __launch_bounds__(256, 2) k_attn_bwd_dq(const bf16_t* __restrict__ q, const bf16_t* __restrict__ k, const bf16_t* __restrict__ v,
+                                                     const float* __restrict__ key_bias, const bf16_t* __restrict__ dctx, const float* __restrict__ lse,
+                                                     const float* __restrict__ delta, const float* __restrict__ cosT, const float* __restrict__ sinT,
+                                                     float q_scale, bf16_t* __restrict__ dqkv, int B, int H, int L, int nqb) {
+  typedef Cfg<HD> C;
+  extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+  unsigned char* sK = smem;
+  unsigned char* sV = sK + KC * C::ROWB;
+  float* sBias = reinterpret_cast<float*>(sV + KC * C::ROWB);
+  int bh, qb;
+  decode_block(nqb, B * H, bh, qb);
+  if (bh >= B * H) return;
+  const int b = bh / H, head = bh - b * H;
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, h = lane >> 5;
+  const int qidx = qb * 128 + wave * 32 + (lane & 31);
+  const int qrow = qidx < L ? qidx : L - 1;
+  const int dm = H * HD;
+  const bf16_t* kbase = k + (size_t)bh * L * HD;
+  const bf16_t* vbase = v + (size_t)bh * L * HD;
+  bf8_t qf[C::KSTEPS], dof[C::KSTEPS];
+#pragma unroll
+  for (int st = 0; st < C::KSTEPS; ++st) {
+    qf[st] = *reinterpret_cast<const bf8_t*>(q + ((size_t)bh * L + qrow) * HD + 16 * st + 8 * h);
+    dof[st] = *reinterpret_cast<const bf8_t*>(dctx + ((size_t)b * L + qrow) * dm + head * HD + 16 * st + 8 * h);
+  }
+  const float lse_q = lse[(size_t)bh * L + qrow], delta_q = delta[(size_t)bh * L + qrow];
+  f32x16 acc[C::DBLK];
+#pragma unroll
+  for (int d = 0; d < C::DBLK; ++d) acc[d] = zero16();
+  for (int kc0 = 0; kc0 < L; kc0 += KC) {
+    const int nkeys = min(KC, L - kc0);
+    const int nrows = (nkeys + 31) & ~31;
+    __syncthreads();
+    load_tile<HD>(sK, kbase + (size_t)kc0 * HD, HD, nkeys, nrows);
+    load_tile<HD>(sV, vbase + (size_t)kc0 * HD, HD, nkeys, nrows);
+    for (int i = threadIdx.x; i < nrows; i += 256)
+      sBias[i] = i < nkeys ? (key_bias ? key_bias[(size_t)b * L + kc0 + i] : 0.f) : -INFINITY;
+    __syncthreads();
+    for (int t = 0; t < nrows / 32; ++t) {
+      f32x16 s = zero16(), dp = zero16();
+#pragma unroll
+      for (int st = 0; st < C::KSTEPS; ++st) {
+        s = MFMA32(rd_row<HD>(sK, t * 32 + (lane & 31), st, h), qf[st], s);
+        dp = MFMA32(rd_row<HD>(sV, t * 32 + (lane & 31), st, h), dof[st], dp);
+      }
+#pragma unroll
+      for (int g = 0; g < 4; ++g) {
+        const float4 bv = *reinterpret_cast<const float4*>(sBias + t * 32 + 8 * g + 4 * h);
+        const float bb[4] = {bv.x, bv.y, bv.z, bv.w};
+#pragma unroll
+        for (int e = 0; e < 4; ++e) {
+          const float p = __builtin_amdgcn_exp2f((s[4 * g + e] + bb[e] - lse_q) * LOG2E);
+          s[4 * g + e] = p * (dp[4 * g + e] - delta_q);          // dS^T
+        }
+      }
+#pragma unroll
+      for (int sb = 0; sb < 2; ++sb) {
+        const bf8_t dsf = pack8(s, sb);
+#pragma unroll
+        for (int d = 0; d < C::DBLK; ++d) acc[d] = MFMA32(rd_tr<HD>(sK, t * 32, sb, d, lane), dsf, acc[d]);
+      }
+    }
+  }
+  if (qidx < L) unrope_store<HD>(acc, cosT, sinT, qidx, h, q_scale, cosT != nullptr, dqkv + ((size_t)b * L + qidx) * (3 * dm) + head * HD);
+}
+
+// ---- dK, dV: one wave = 32 keys, loops over all queries -----------------------------------------------------------
+template <int HD>
+__global__ void __launch_bounds__(256, 2) k_attn_bwd_dkv(const bf16_t* __restrict__ q, const bf16_t* __restrict__ k, const bf16_t* __restrict__ v,
+                                                      const float* __restrict__ key_bias, const bf16_t* __restrict__ dctx, const float* __restrict__ lse,
+                                                      const float* __restrict__ delta, const float* __restrict__ cosT, const float* __restrict__ sinT,
+                                                      bf16_t* __restrict__ dqkv, int B, int H, int L, int nkb) {
+  typedef Cfg<HD> C;
+  extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+  unsigned char* sQ = smem;
+  unsigned char* sdO = sQ + KC * C::ROWB;
+  float* sLse = reinterpret_cast<float*>(sdO + KC * C::ROWB);
+  float* sDelta = sLse + KC;
+  int bh, kb;
+  decode_block(nkb, B * H, bh, kb);
+  if (bh >= B * H) return;
+  const int b = bh / H, head = bh - b * H;
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, h = lane >> 5;
+  const int kidx = kb * 128 + wave * 32 + (lane & 31);
+  const int krow = kidx < L ? kidx : L - 1;
+  const int dm = H * HD;
+  bf8_t kf[C::KSTEPS], vf[C::KSTEPS];
+#pragma unroll
+  for (int st = 0; st < C::KSTEPS; ++st) {
+    kf[st] = *reinterpret_cast<const bf8_t*>(k + ((size_t)bh * L + krow) * HD + 16 * st + 8 * h);
+    vf[st] = *reinterpret_cast<const bf8_t*>(v + ((size_t)bh * L + krow) * HD + 16 * st + 8 * h);
+  }
+  const float bias_k = kidx < L ? (key_bias ? key_bias[(size_t)b * L + kidx] : 0.f) : -INFINITY;
+  f32x16 adk[C::DBLK], adv[C::DBLK];
+#pragma unroll
+  for (int d = 0; d < C::DBLK; ++d) { adk[d] = zero16(); adv[d] = zero16(); }
+  for (int qc0 = 0; qc0 < L; qc0 += KC) {
+    const int nq = min(KC, L - qc0);
+    const int nrows = (nq + 31) & ~31;
+    __syncthreads();
+    load_tile<HD>(sQ, q + ((size_t)bh * L + qc0) * HD, HD, nq, nrows);
+    load_tile<HD>(sdO, dctx + ((size_t)b * L + qc0) * dm + head * HD, dm, nq, nrows);
+    for (int i = threadIdx.x; i < nrows; i += 256) {
+      sLse[i] = i < nq ? lse[(size_t)bh * L + qc0 + i] : INFINITY;
+      sDelta[i] = i < nq ? delta[(size_t)bh * L + qc0 + i] : 0.f;
+    }
+    __syncthreads();
+    for (int t = 0; t < nrows / 32; ++t) {
+      f32x16 s = zero16(), dp = zero16();
+#pragma unroll
+      for (int st = 0; st < C::KSTEPS; ++st) {
+        s = MFMA32(rd_row<HD>(sQ, t * 32 + (lane & 31), st, h), kf[st], s);          // S[query][key]
+        dp = MFMA32(rd_row<HD>(sdO, t * 32 + (lane & 31), st, h), vf[st], dp);       // dP[query][key]
+      }
+      f32x16 p;
+#pragma unroll
+      for (int g = 0; g < 4; ++g) {
+        const float4 lv = *reinterpret_cast<const float4*>(sLse + t * 32 + 8 * g + 4 * h);
+        const float4 dv = *reinterpret_cast<const float4*>(sDelta + t * 32 + 8 * g + 4 * h);
+        const float ll[4] = {lv.x, lv.y, lv.z, lv.w}, de[4] = {dv.x, dv.y, dv.z, dv.w};
+#pragma unroll
+        for (int e = 0; e < 4; ++e) {
+          const float pe = __builtin_amdgcn_exp2f((s[4 * g + e] + bias_k - ll[e]) * LOG2E);
+          p[4 * g + e] = pe;
+          s[4 * g + e] = pe * (dp[4 * g + e] - de[e]);           // dS
+        }
+      }
+#pragma unroll
+      for (int sb = 0; sb < 2; ++sb) {
+        const bf8_t pf = pack8(p, sb), dsf = pack8(s, sb);
+#pragma unroll
+        for (int d = 0; d < C::DBLK; ++d) {
+          adv[d] = MFMA32(rd_tr<HD>(sdO, t * 32, sb, d, lane), pf, adv[d]);           // dV^T += dO^T P
+          adk[d] = MFMA32(rd_tr<HD>(sQ, t * 32, sb, d, lane), dsf, adk[d]);           // dK^T += Q^T dS
+        }
+      }
+    }
+  }
+  if (kidx < L) {
+    bf16_t* row = dqkv + ((size_t)b * L + kidx) * (3 * dm) + head * HD;
+    unrope_store<HD>(adk, cosT, sinT, kidx, h, 1.0f, cosT != nullptr, row + dm);
+    unrope_store<HD>(adv, cosT, sinT, kidx, h, 1.0f, false, row + 2 * dm);
+  }
+}
+
+template <int HD>
+static int launch_bwd(const void* q, const void* k, const void* v, const float* key_bias, const void* ctx, const void* dctx, const float* lse, float* delta,
+                      const float* cosT, const float* sinT, float q_scale, void* dqkv, int B, int H, int L, hipStream_t s) {
+  const size_t n = (size_t)B * L * H;
+  hipLaunchKernelGGL(k_attn_delta<HD>, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, s, (const bf16_t*)ctx, (const bf16_t*)dctx, delta, B, H, L);
+  const int nb = (L + 127) / 128;
+  const int nbh8 = ((B * H + 7) / 8) * 8;
+  const size_t lds_q = (size_t)2 * KC * Cfg<HD>::ROWB + KC * sizeof(float);
+  const size_t lds_kv = (size_t)2 * KC * Cfg<HD>::ROWB + 2 * KC * sizeof(float);
+  hipLaunchKernelGGL(k_attn_bwd_dq<HD>, dim3(nbh8 * nb), dim3(256), lds_q, s, (const bf16_t*)q, (const bf16_t*)k, (const bf16_t*)v, key_bias,
+                     (const bf16_t*)dctx, lse, (const float*)delta, cosT, sinT, q_scale, (bf16_t*)dqkv, B, H, L, nb);
+  hipLaunchKernelGGL(k_attn_bwd_dkv<HD>, dim3(nbh8 * nb), dim3(256), lds_kv, s, (const bf16_t*)q, (const bf16_t*)k, (const bf16_t*)v, key_bias,
+                     (const bf16_t*)dctx, lse, (const float*)delta, cosT, sinT, (bf16_t*)dqkv, B, H, L, nb);
+  return launch_status();
+}
+
+extern "C" size_t oneprot_attn_bwd_workspace(int B, int H, int L) { return (size_t)B * H * L * sizeof(float); }
+
+extern "C" int oneprot_attn_bwd(const void* q, const void* k, const void* v, const float* key_bias, const void* ctx, const void* dctx, const float* lse,
+                                const float* rope_cos, const float* rope_sin, float q_scale, void* dqkv, void* workspace, int B, int H, int L, int hd,
+                                void* stream) {
+  if (!q || !k || !v || !ctx || !dctx || !lse || !dqkv || !workspace || B <= 0 || H <= 0 || L <= 0) return OP_EINVAL;
+  if ((rope_cos == nullptr) != (rope_sin == nullptr)) return OP_EINVAL;
+  hipStream_t s = (hipStream_t)stream;
+  float* delta = (float*)workspace;
+  switch (hd) {
+    case 16: return launch_bwd<16>(q, k, v, key_bias, ctx, dctx, lse, delta, rope_cos, rope_sin, q_scale, dqkv, B, H, L, s);
+    case 32: return launch_bwd<32>(q, k, v, key_bias, ctx, dctx, lse, delta, rope_cos, rope_sin, q_scale, dqkv, B, H, L, s);
+    case 64: return launch_bwd<64>(q, k, v, key_bias, ctx, dctx, lse, delta, rope_cos, rope_sin, q_scale, dqkv, B, H, L, s);
+    default: return OP_EINVAL;
+  }
+}

@@ -1,0 +1,16 @@
+#!/bin/bash
+# Builds liboneprot_hip.so (gfx950) in-tree.  hipcc cross-compiles without a GPU.
+set -e
+cd "$(dirname "$0")"
+SRCS="rowops.hip gemm_nt.hip gemm_tn.hip sgemm.hip attention.hip featops.hip"
+OBJS=""
+for s in $SRCS; do
+  o="${s%.hip}.o"
+  if [ ! -f "$o" ] || [ "$s" -nt "$o" ] || [ common.h -nt "$o" ] || [ ../../include/oneprot_hip.h -nt "$o" ]; then
+    hipcc --offload-arch=gfx950 -O3 -fPIC -std=c++17 -Wno-unused-value -c "$s" -o "$o" &
+  fi
+  OBJS="$OBJS $o"
+done
+wait
+hipcc --offload-arch=gfx950 -shared -fPIC -o ../liboneprot_hip.so $OBJS
+echo "built $(cd .. && pwd)/liboneprot_hip.so"

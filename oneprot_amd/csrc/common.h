@@ -1,0 +1,50 @@
+// Shared device helpers for the gfx950 kernels (wave64, bf16 storage / fp32 math).
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+typedef unsigned short bf16_t;   // raw bf16 bits in memory
+typedef __attribute__((ext_vector_type(8))) __bf16 bf8_t;      // MFMA A/B fragment (4 VGPRs)
+typedef __attribute__((ext_vector_type(8))) short s16x8;
+typedef __attribute__((ext_vector_type(4))) short s16x4;
+typedef __attribute__((ext_vector_type(2))) short s16x2;
+typedef __attribute__((ext_vector_type(4))) float f32x4;
+typedef __attribute__((ext_vector_type(16))) float f32x16;
+typedef __attribute__((ext_vector_type(4))) unsigned int u32x4;
+typedef __attribute__((ext_vector_type(2))) unsigned int u32x2;
+
+#define LDS_PTR(p) ((__attribute__((address_space(3))) void*)(p))
+#define GLB_PTR(p) ((const __attribute__((address_space(1))) void*)(p))
+
+#define OP_OK 0
+#define OP_EINVAL (-1)     // bad shape / null pointer / unsupported configuration
+#define OP_ELAUNCH (-2)    // hipGetLastError() after the launch was not hipSuccess
+
+// NOTE: element extraction from __bf16 ext-vectors miscompiles on ROCm 7.2 (observed: every lane element read
+// element 0), so all packing/unpacking goes through integer bit operations.
+__device__ __forceinline__ float bf2f(bf16_t h) { return __builtin_bit_cast(float, (unsigned)h << 16); }
+__device__ __forceinline__ bf16_t f2bf(float f) { return __builtin_bit_cast(bf16_t, (__bf16)f); }   // RNE, NaN-preserving (v_cvt_pk_bf16_f32)
+__device__ __forceinline__ unsigned pack2bf(float lo, float hi) { return (unsigned)f2bf(lo) | ((unsigned)f2bf(hi) << 16); }
+__device__ __forceinline__ float bflo(unsigned u) { return __builtin_bit_cast(float, u << 16); }
+__device__ __forceinline__ float bfhi(unsigned u) { return __builtin_bit_cast(float, u & 0xffff0000u); }
+
+__device__ __forceinline__ float wave_sum(float v) {
+#pragma unroll
+  for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o, 64);
+  return v;
+}
+__device__ __forceinline__ float wave_max(float v) {
+#pragma unroll
+  for (int o = 32; o > 0; o >>= 1) v = fmaxf(v, __shfl_xor(v, o, 64));
+  return v;
+}
+
+__device__ __forceinline__ float gelu_erf(float x) { return 0.5f * x * (1.0f + erff(x * 0.70710678118654752f)); }
+// d/dx [x * Phi(x)] = Phi(x) + x * phi(x)
+__device__ __forceinline__ float gelu_erf_grad(float x) {
+  const float cdf = 0.5f * (1.0f + erff(x * 0.70710678118654752f));
+  const float pdf = 0.3989422804014327f * __expf(-0.5f * x * x);
+  return cdf + x * pdf;
+}
+
+static inline int launch_status() { return hipGetLastError() == hipSuccess ? OP_OK : OP_ELAUNCH; }

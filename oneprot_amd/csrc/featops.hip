@@ -1,0 +1,198 @@
+// Small fp32 kernels around the feature vectors and the optimiser:
+//   GELU (proj head), L2-normalise (+logit scale), softmax cross-entropy of the contrastive logits (fwd+bwd fused),
+//   L1 feature penalty, global grad-norm (two-stage deterministic reduction), clip coefficient, fused Adam.
+// All HBM-bound or latency-bound; reductions are deterministic (no float atomics).
+#include "common.h"
+#include "../../include/oneprot_hip.h"
+#include <float.h>
+
+#define RED_BLOCKS 1024
+
+// block-wide sum for 256 threads; result valid in thread 0
+__device__ __forceinline__ float block_sum_256(float v, float* s4) {
+  v = wave_sum(v);
+  if ((threadIdx.x & 63) == 0) s4[threadIdx.x >> 6] = v;
+  __syncthreads();
+  return s4[0] + s4[1] + s4[2] + s4[3];
+}
+
+// ---------------------------------------------------------------------------------------------------------
+__global__ void __launch_bounds__(256) k_gelu(const float* __restrict__ x, float* __restrict__ y, size_t n) {
+  for (size_t i = (size_t)blockIdx.x * 256 + threadIdx.x; i < n; i += (size_t)gridDim.x * 256) y[i] = gelu_erf(x[i]);
+}
+__global__ void __launch_bounds__(256) k_gelu_bwd(const float* __restrict__ x, const float* __restrict__ dy, float* __restrict__ dx, size_t n) {
+  for (size_t i = (size_t)blockIdx.x * 256 + threadIdx.x; i < n; i += (size_t)gridDim.x * 256) dx[i] = dy[i] * gelu_erf_grad(x[i]);
+}
+static inline unsigned ew_grid(size_t n) { size_t b = (n + 255) / 256; return (unsigned)(b > 4096 ? 4096 : b); }
+extern "C" int oneprot_gelu_f32(const float* x, float* y, int64_t n, void* stream) {
+  if (!x || !y || n <= 0) return OP_EINVAL;
+  hipLaunchKernelGGL(k_gelu, dim3(ew_grid(n)), dim3(256), 0, (hipStream_t)stream, x, y, (size_t)n);
+  return launch_status();
+}
+extern "C" int oneprot_gelu_bwd_f32(const float* x, const float* dy, float* dx, int64_t n, void* stream) {
+  if (!x || !dy || !dx || n <= 0) return OP_EINVAL;
+  hipLaunchKernelGGL(k_gelu_bwd, dim3(ew_grid(n)), dim3(256), 0, (hipStream_t)stream, x, dy, dx, (size_t)n);
+  return launch_status();
+}
+
+// ---------------------------------------------------------------------------------------------------------
+// y = scale * x / max(||x||, 1e-12)   (ref base_encoder.py:11-12, 32-33); one wave per row
+__global__ void __launch_bounds__(256) k_l2norm_fwd(const float* __restrict__ x, float* __restrict__ y, float* __restrict__ inv_norm, int R, int D, float scale) {
+  const int row = blockIdx.x * 4 + (threadIdx.x >> 6), lane = threadIdx.x & 63;
+  if (row >= R) return;
+  float s = 0.f;
+  for (int j = lane; j < D; j += 64) { const float v = x[(size_t)row * D + j]; s += v * v; }
+  s = wave_sum(s);
+  const float inv = 1.0f / fmaxf(sqrtf(s), 1e-12f);
+  if (lane == 0 && inv_norm) inv_norm[row] = inv;
+  for (int j = lane; j < D; j += 64) y[(size_t)row * D + j] = x[(size_t)row * D + j] * inv * scale;
+}
+// g = dy + l1_coef * sign(y);  dx = scale*inv*(g - xhat * (xhat . g)),  xhat = y / scale
+__global__ void __launch_bounds__(256) k_l2norm_bwd(const float* __restrict__ y, const float* __restrict__ dy, const float* __restrict__ inv_norm, float* __restrict__ dx,
+                                                    int R, int D, float scale, float l1_coef) {
+  const int row = blockIdx.x * 4 + (threadIdx.x >> 6), lane = threadIdx.x & 63;
+  if (row >= R) return;
+  const float rs = 1.0f / scale;
+  float dot = 0.f;
+  for (int j = lane; j < D; j += 64) {
+    const float yv = y[(size_t)row * D + j];
+    const float g = dy[(size_t)row * D + j] + l1_coef * (yv > 0.f ? 1.f : (yv < 0.f ? -1.f : 0.f));
+    dot += yv * rs * g;
+  }
+  dot = wave_sum(dot);
+  const float k = scale * inv_norm[row];
+  for (int j = lane; j < D; j += 64) {
+    const float yv = y[(size_t)row * D + j];
+    const float g = dy[(size_t)row * D + j] + l1_coef * (yv > 0.f ? 1.f : (yv < 0.f ? -1.f : 0.f));
+    dx[(size_t)row * D + j] = k * (g - yv * rs * dot);
+  }
+}
+extern "C" int oneprot_l2norm_fwd(const float* x, float* y, float* inv_norm, int R, int D, float scale, void* stream) {
+  if (!x || !y || R <= 0 || D <= 0) return OP_EINVAL;
+  hipLaunchKernelGGL(k_l2norm_fwd, dim3((R + 3) / 4), dim3(256), 0, (hipStream_t)stream, x, y, inv_norm, R, D, scale);
+  return launch_status();
+}
+extern "C" int oneprot_l2norm_bwd(const float* y, const float* dy, const float* inv_norm, float* dx, int R, int D, float scale, float l1_coef, void* stream) {
+  if (!y || !dy || !inv_norm || !dx || R <= 0 || D <= 0 || scale == 0.f) return OP_EINVAL;
+  hipLaunchKernelGGL(k_l2norm_bwd, dim3((R + 3) / 4), dim3(256), 0, (hipStream_t)stream, y, dy, inv_norm, dx, R, D, scale, l1_coef);
+  return launch_status();
+}
+
+// ---------------------------------------------------------------------------------------------------------
+// softmax cross-entropy, label[r] = r + label_offset (ref loss.py:72-83, 108-112).  One block per row.
+// row_loss[r] = (lse - logit[label]) * row_weight ; logits <- (softmax - onehot) * row_weight
+__global__ void __launch_bounds__(256) k_ce_fwd_bwd(float* __restrict__ logits, float* __restrict__ row_loss, int C, int label_offset, float row_weight) {
+  __shared__ float s4[4];
+  const int r = blockIdx.x;
+  float* row = logits + (size_t)r * C;
+  float mx = -FLT_MAX;
+  for (int j = threadIdx.x; j < C; j += 256) mx = fmaxf(mx, row[j]);
+  mx = wave_max(mx);
+  if ((threadIdx.x & 63) == 0) s4[threadIdx.x >> 6] = mx;
+  __syncthreads();
+  mx = fmaxf(fmaxf(s4[0], s4[1]), fmaxf(s4[2], s4[3]));
+  __syncthreads();
+  float se = 0.f;
+  for (int j = threadIdx.x; j < C; j += 256) se += __expf(row[j] - mx);
+  se = block_sum_256(se, s4);
+  const float lse = mx + logf(se);
+  const int label = r + label_offset;
+  if (threadIdx.x == 0) row_loss[r] = (lse - row[label]) * row_weight;
+  __syncthreads();
+  const float inv = 1.0f / se;
+  for (int j = threadIdx.x; j < C; j += 256) {
+    const float p = __expf(row[j] - mx) * inv;
+    row[j] = (p - (j == label ? 1.f : 0.f)) * row_weight;
+  }
+}
+// out[0] += sum_i v[i]  (single block, fixed order)
+__global__ void __launch_bounds__(256) k_final_sum(const float* __restrict__ v, int n, float* __restrict__ out, float coef) {
+  __shared__ float s4[4];
+  float s = 0.f;
+  for (int i = threadIdx.x; i < n; i += 256) s += v[i];
+  s = block_sum_256(s, s4);
+  if (threadIdx.x == 0) out[0] += coef * s;
+}
+extern "C" int oneprot_ce_fwd_bwd(float* logits, float* loss_sum, float* row_loss_ws, int R, int C, int label_offset, float row_weight, void* stream) {
+  if (!logits || !loss_sum || !row_loss_ws || R <= 0 || C <= 0 || label_offset < 0 || label_offset + R > C) return OP_EINVAL;
+  hipLaunchKernelGGL(k_ce_fwd_bwd, dim3(R), dim3(256), 0, (hipStream_t)stream, logits, row_loss_ws, C, label_offset, row_weight);
+  hipLaunchKernelGGL(k_final_sum, dim3(1), dim3(256), 0, (hipStream_t)stream, (const float*)row_loss_ws, R, loss_sum, 1.0f);
+  return launch_status();
+}
+
+// ---------------------------------------------------------------------------------------------------------
+// deterministic reductions: MODE 0 sum x^2, MODE 1 sum |x|
+template <int MODE>
+__global__ void __launch_bounds__(256) k_reduce_stage1(const float* __restrict__ x, size_t n, float* __restrict__ partial) {
+  __shared__ float s4[4];
+  float s = 0.f;
+  const size_t n4 = n >> 2;
+  for (size_t i = (size_t)blockIdx.x * 256 + threadIdx.x; i < n4; i += (size_t)gridDim.x * 256) {
+    const float4 v = reinterpret_cast<const float4*>(x)[i];
+    if (MODE == 0) s += (v.x * v.x + v.y * v.y) + (v.z * v.z + v.w * v.w);
+    else s += (fabsf(v.x) + fabsf(v.y)) + (fabsf(v.z) + fabsf(v.w));
+  }
+  if (blockIdx.x == 0 && threadIdx.x < (n & 3)) { const float t = x[(n4 << 2) + threadIdx.x]; s += MODE == 0 ? t * t : fabsf(t); }
+  s = block_sum_256(s, s4);
+  if (threadIdx.x == 0) partial[blockIdx.x] = s;
+}
+extern "C" size_t oneprot_sumsq_workspace(void) { return RED_BLOCKS * sizeof(float); }
+static int reduce_launch(int mode, const float* x, int64_t n, float* out, void* ws, float coef, hipStream_t s) {
+  if (!x || !out || !ws || n <= 0 || ((uintptr_t)x & 15)) return OP_EINVAL;
+  size_t blocks = ((size_t)n / 4 + 255) / 256; if (blocks > RED_BLOCKS) blocks = RED_BLOCKS; if (blocks == 0) blocks = 1;
+  if (mode == 0) hipLaunchKernelGGL(k_reduce_stage1<0>, dim3((unsigned)blocks), dim3(256), 0, s, x, (size_t)n, (float*)ws);
+  else hipLaunchKernelGGL(k_reduce_stage1<1>, dim3((unsigned)blocks), dim3(256), 0, s, x, (size_t)n, (float*)ws);
+  hipLaunchKernelGGL(k_final_sum, dim3(1), dim3(256), 0, s, (const float*)ws, (int)blocks, out, coef);
+  return launch_status();
+}
+extern "C" int oneprot_sumsq(const float* x, int64_t n, float* sumsq, void* workspace, void* stream) { return reduce_launch(0, x, n, sumsq, workspace, 1.0f, (hipStream_t)stream); }
+extern "C" int oneprot_abs_sum(const float* x, float* out_sum, void* workspace, int64_t n, float coef, void* stream) { return reduce_launch(1, x, n, out_sum, workspace, coef, (hipStream_t)stream); }
+
+__global__ void k_clip_coef(const float* __restrict__ sumsq, float max_norm, float* __restrict__ coef, float* __restrict__ norm_out) {
+  const float nrm = sqrtf(sumsq[0]);
+  if (norm_out) norm_out[0] = nrm;
+  coef[0] = fminf(1.0f, max_norm / (nrm + 1e-6f));      // torch.nn.utils.clip_grad_norm_ semantics
+}
+extern "C" int oneprot_clip_coef(const float* sumsq, float max_norm, float* coef, float* norm_out, void* stream) {
+  if (!sumsq || !coef) return OP_EINVAL;
+  hipLaunchKernelGGL(k_clip_coef, dim3(1), dim3(1), 0, (hipStream_t)stream, sumsq, max_norm, coef, norm_out);
+  return launch_status();
+}
+
+// ---------------------------------------------------------------------------------------------------------
+// torch.optim.Adam (no amsgrad, L2-style weight_decay added to the gradient), 28 B/param of HBM traffic
+__global__ void __launch_bounds__(256) k_adam(float* __restrict__ p, const float* __restrict__ g, float* __restrict__ m, float* __restrict__ v, size_t n4, float lr,
+                                              float b1, float b2, float eps, float wd, float bc1, float bc2_sqrt, const float* __restrict__ grad_scale) {
+  const float gs = grad_scale ? grad_scale[0] : 1.0f;
+  const float step_size = lr / bc1;
+  for (size_t i = (size_t)blockIdx.x * 256 + threadIdx.x; i < n4; i += (size_t)gridDim.x * 256) {
+    float4 pv = reinterpret_cast<float4*>(p)[i];
+    const float4 gv = reinterpret_cast<const float4*>(g)[i];
+    float4 mv = reinterpret_cast<float4*>(m)[i], vv = reinterpret_cast<float4*>(v)[i];
+    float pe[4] = {pv.x, pv.y, pv.z, pv.w}, ge[4] = {gv.x, gv.y, gv.z, gv.w}, me[4] = {mv.x, mv.y, mv.z, mv.w}, ve[4] = {vv.x, vv.y, vv.z, vv.w};
+#pragma unroll
+    for (int e = 0; e < 4; ++e) {
+      float gg = ge[e] * gs;
+      if (wd != 0.f) gg += wd * pe[e];
+      me[e] = b1 * me[e] + (1.f - b1) * gg;
+      ve[e] = b2 * ve[e] + (1.f - b2) * gg * gg;
+      const float denom = sqrtf(ve[e]) / bc2_sqrt + eps;
+      pe[e] -= step_size * me[e] / denom;
+    }
+    reinterpret_cast<float4*>(p)[i] = make_float4(pe[0], pe[1], pe[2], pe[3]);
+    reinterpret_cast<float4*>(m)[i] = make_float4(me[0], me[1], me[2], me[3]);
+    reinterpret_cast<float4*>(v)[i] = make_float4(ve[0], ve[1], ve[2], ve[3]);
+  }
+}
+extern "C" int oneprot_adam_step(float* p, const float* g, float* m, float* v, int64_t n, float lr, float beta1, float beta2, float eps, float weight_decay,
+                                 int step, const float* grad_scale, void* stream) {
+  if (!p || !g || !m || !v || n <= 0 || (n & 3) || step < 1) return OP_EINVAL;
+  const double bc1 = 1.0 - pow((double)beta1, step), bc2 = 1.0 - pow((double)beta2, step);
+  const size_t n4 = (size_t)n >> 2;
+  size_t blocks = (n4 + 255) / 256; if (blocks > 8192) blocks = 8192;
+  hipLaunchKernelGGL(k_adam, dim3((unsigned)blocks), dim3(256), 0, (hipStream_t)stream, p, g, m, v, n4, lr, beta1, beta2, eps, weight_decay, (float)bc1,
+                     (float)sqrt(bc2), grad_scale);
+  return launch_status();
+}
+
+extern "C" int oneprot_abi_version(void) { return 1; }

@@ -1,0 +1,170 @@
+// Weight-gradient GEMM on MFMA: dW[N,K] (+)= dY[M,N]^T * X[M,K], bf16 operands, fp32 accumulation.  gfx950 only.
+//
+// The contraction runs over the M = B*L token rows, along which BOTH operands are strided in memory.  The tiles are
+// therefore staged exactly as they lie in HBM (64 token rows x 128 columns, coalesced global_load_lds), and the MFMA
+// operand fragments (8 consecutive tokens for one output row / column) are gathered with ds_read_b64_tr_b16, the
+// gfx950 LDS transpose read -- no transposed copy of any activation is ever written to HBM.
+//   * output tile 128 (n) x 128 (k), 4 waves 2x2, 4x4 v_mfma_f32_16x16x32_bf16 accumulators per wave;
+//   * the token range is split over S workgroups per output tile (S*tiles ~ 2 waves of 256 CUs); each writes an fp32
+//     slab, a second kernel sums the slabs in fixed order (deterministic; no float atomics) into dW (= or +=);
+//   * LDS rows are 256 B; 16-byte chunks are XOR-swizzled with 2*((row&3)|((row>>3)&1)<<2) so the 8 rows a half-wave
+//     transposed read touches fall in 8 different 32-byte bank slots (source-side swizzle for the LDS-DMA).
+#include "common.h"
+#include "../../include/oneprot_hip.h"
+
+#define TN_BT 64                        // tokens per K-step
+#define TN_TILE_BYTES (TN_BT * 128 * 2) // 16 KiB per operand tile
+#define TN_STAGE_BYTES (2 * TN_TILE_BYTES)
+#define TN_MAX_SLAB_TILES 512
+
+static __device__ __attribute__((aligned(16))) unsigned int g_zero_page[4] = {0, 0, 0, 0};
+
+__device__ __forceinline__ int tn_f(int r) { return 2 * ((r & 3) | (((r >> 3) & 1) << 2)); }
+
+__device__ __forceinline__ bf8_t tn_frag(const unsigned char* tile, int mb, int c0, int lane) {
+  const int g = lane >> 4, i = lane & 15;
+  const int r0 = mb + 8 * g + (i >> 2), r1 = r0 + 4;
+  const int col = c0 + 4 * (i & 3);
+  const int chunk = col >> 3, within = (col & 7) * 2;
+  const unsigned char* p0 = tile + r0 * 256 + ((chunk ^ tn_f(r0)) << 4) + within;
+  const unsigned char* p1 = tile + r1 * 256 + ((chunk ^ tn_f(r1)) << 4) + within;
+  const s16x4 a = __builtin_amdgcn_ds_read_tr16_b64_v4i16((__attribute__((address_space(3))) s16x4*)p0);
+  const s16x4 b = __builtin_amdgcn_ds_read_tr16_b64_v4i16((__attribute__((address_space(3))) s16x4*)p1);
+  s16x8 o;
+  o[0] = a[0]; o[1] = a[1]; o[2] = a[2]; o[3] = a[3]; o[4] = b[0]; o[5] = b[1]; o[6] = b[2]; o[7] = b[3];
+  return __builtin_bit_cast(bf8_t, o);
+}
+
+__global__ void __launch_bounds__(256, 2) k_gemm_tn(const bf16_t* __restrict__ dY, const bf16_t* __restrict__ X, int M, int N, int K, int ldy, int ldx,
+                                                    float* __restrict__ slab, int tiles_k, int S, int m_per_split) {
+  extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+  const int tile = blockIdx.x, split = blockIdx.y;
+  const int tn = tile / tiles_k, tk = tile - tn * tiles_k;
+  const int n0 = tn * 128, k0 = tk * 128;
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int wr = wave >> 1, wc = wave & 1;
+  const int mbeg = split * m_per_split;
+  const int mend = min(M, mbeg + m_per_split);
+  const int nsteps = (mend - mbeg + TN_BT - 1) / TN_BT;
+
+  // staging: wave w issues 4 instructions per operand; instruction covers 4 token rows x 256 B
+  const int srow = lane >> 4, schunk = lane & 15;
+  const unsigned char* zero = reinterpret_cast<const unsigned char*>(g_zero_page);
+  int rows[4], ycol_ok[4], xcol_ok[4];
+  size_t yoff[4], xoff[4];
+#pragma unroll
+  for (int i = 0; i < 4; ++i) {
+    rows[i] = (wave * 4 + i) * 4 + srow;                         // 0..63
+    const int sc = schunk ^ tn_f(rows[i]);
+    ycol_ok[i] = (n0 + sc * 8) < N;
+    xcol_ok[i] = (k0 + sc * 8) < K;
+    yoff[i] = (size_t)(n0 + sc * 8);
+    xoff[i] = (size_t)(k0 + sc * 8);
+  }
+  auto stage = [&](int t, int buf) {
+    unsigned char* sY = smem + buf * TN_STAGE_BYTES;
+    unsigned char* sX = sY + TN_TILE_BYTES;
+    const int mb = mbeg + t * TN_BT;
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+      const int m = mb + rows[i];
+      const bool mok = m < mend;
+      const unsigned char* gy = (mok && ycol_ok[i]) ? reinterpret_cast<const unsigned char*>(dY + (size_t)m * ldy + yoff[i]) : zero;
+      const unsigned char* gx = (mok && xcol_ok[i]) ? reinterpret_cast<const unsigned char*>(X + (size_t)m * ldx + xoff[i]) : zero;
+      __builtin_amdgcn_global_load_lds(GLB_PTR(gy), LDS_PTR(sY + (wave * 4 + i) * 1024), 16, 0, 0);
+      __builtin_amdgcn_global_load_lds(GLB_PTR(gx), LDS_PTR(sX + (wave * 4 + i) * 1024), 16, 0, 0);
+    }
+  };
+
+  f32x4 acc[4][4];
+#pragma unroll
+  for (int i = 0; i < 4; ++i)
+#pragma unroll
+    for (int j = 0; j < 4; ++j) acc[i][j] = (f32x4){0.f, 0.f, 0.f, 0.f};
+
+  if (nsteps > 0) stage(0, 0);
+  for (int t = 0; t < nsteps; ++t) {
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    __syncthreads();
+    if (t + 1 < nsteps) stage(t + 1, (t + 1) & 1);
+    const unsigned char* sY = smem + (t & 1) * TN_STAGE_BYTES;
+    const unsigned char* sX = sY + TN_TILE_BYTES;
+#pragma unroll
+    for (int kk = 0; kk < 2; ++kk) {
+      bf8_t a[4], b[4];
+#pragma unroll
+      for (int i = 0; i < 4; ++i) {
+        a[i] = tn_frag(sY, kk * 32, wr * 64 + i * 16, lane);
+        b[i] = tn_frag(sX, kk * 32, wc * 64 + i * 16, lane);
+      }
+#pragma unroll
+      for (int i = 0; i < 4; ++i)
+#pragma unroll
+        for (int j = 0; j < 4; ++j) acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a[i], b[j], acc[i][j], 0, 0, 0);
+    }
+  }
+  float* out = slab + (size_t)split * N * K;
+  const int fq = lane >> 4, fr = lane & 15;
+#pragma unroll
+  for (int i = 0; i < 4; ++i)
+#pragma unroll
+    for (int r = 0; r < 4; ++r) {
+      const int n = n0 + wr * 64 + i * 16 + fq * 4 + r;
+      if (n >= N) continue;
+#pragma unroll
+      for (int j = 0; j < 4; ++j) {
+        const int k = k0 + wc * 64 + j * 16 + fr;
+        if (k < K) out[(size_t)n * K + k] = acc[i][j][r];
+      }
+    }
+}
+
+__global__ void __launch_bounds__(256) k_tn_reduce(const float* __restrict__ slab, float* __restrict__ dW, size_t n4, size_t stride4, int S, int accumulate) {
+  for (size_t i = (size_t)blockIdx.x * 256 + threadIdx.x; i < n4; i += (size_t)gridDim.x * 256) {
+    float4 s = reinterpret_cast<const float4*>(slab)[i];
+    for (int p = 1; p < S; ++p) {
+      const float4 v = reinterpret_cast<const float4*>(slab)[i + (size_t)p * stride4];
+      s.x += v.x; s.y += v.y; s.z += v.z; s.w += v.w;
+    }
+    if (accumulate) { const float4 o = reinterpret_cast<const float4*>(dW)[i]; s.x += o.x; s.y += o.y; s.z += o.z; s.w += o.w; }
+    reinterpret_cast<float4*>(dW)[i] = s;
+  }
+}
+
+static inline int tn_splits(int64_t M, int tiles) {
+  int S = TN_MAX_SLAB_TILES / tiles;
+  if (S < 1) S = 1;
+  const int64_t max_by_m = (M + 255) / 256;          // at least 256 tokens per split
+  if (S > max_by_m) S = (int)max_by_m;
+  if (S > 64) S = 64;
+  return S;
+}
+
+extern "C" size_t oneprot_gemm_bf16_tn_workspace(int N, int K) {
+  const int tiles = ((N + 127) / 128) * ((K + 127) / 128);
+  int S = TN_MAX_SLAB_TILES / tiles; if (S < 1) S = 1; if (S > 64) S = 64;
+  return (size_t)S * N * K * sizeof(float);
+}
+
+extern "C" int oneprot_gemm_bf16_tn(const void* dY, const void* X, int64_t M, int N, int K, int ldy, int ldx, float* dW, void* workspace, int accumulate,
+                                    void* stream) {
+  if (!dY || !X || !dW || !workspace || M <= 0 || N <= 0 || K <= 0 || M > 0x7fffffff) return OP_EINVAL;
+  if ((N & 7) || (K & 7) || (ldy & 7) || (ldx & 7) || ldy < N || ldx < K || ((N * (int64_t)K) & 3)) return OP_EINVAL;
+  if (((uintptr_t)dY | (uintptr_t)X | (uintptr_t)dW | (uintptr_t)workspace) & 15) return OP_EINVAL;
+  static bool configured = false;
+  if (!configured) {
+    if (hipFuncSetAttribute((const void*)k_gemm_tn, hipFuncAttributeMaxDynamicSharedMemorySize, 2 * TN_STAGE_BYTES) != hipSuccess) return OP_ELAUNCH;
+    configured = true;
+  }
+  const int tiles_n = (N + 127) / 128, tiles_k = (K + 127) / 128, tiles = tiles_n * tiles_k;
+  const int S = tn_splits(M, tiles);
+  int m_per = (int)((M + S - 1) / S);
+  m_per = ((m_per + TN_BT - 1) / TN_BT) * TN_BT;
+  hipStream_t s = (hipStream_t)stream;
+  hipLaunchKernelGGL(k_gemm_tn, dim3(tiles, S), dim3(256), 2 * TN_STAGE_BYTES, s, (const bf16_t*)dY, (const bf16_t*)X, (int)M, N, K, ldy, ldx,
+                     (float*)workspace, tiles_k, S, m_per);
+  const size_t n4 = ((size_t)N * K) >> 2;
+  size_t blocks = (n4 + 255) / 256; if (blocks > 4096) blocks = 4096;
+  hipLaunchKernelGGL(k_tn_reduce, dim3((unsigned)blocks), dim3(256), 0, s, (const float*)workspace, dW, n4, n4, S, accumulate);
+  return launch_status();
+}

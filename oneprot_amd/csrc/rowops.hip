@@ -1,0 +1,470 @@
+// HBM-bound row kernels: embedding gather (+token-dropout rescale, pad zeroing), LayerNorm fwd/bwd,
+// fused final-LayerNorm + pooling fwd/bwd, column reductions, casts.
+//
+// Layout rules: residual stream fp32 [T, d]; normalised activations bf16 [T, d];
+// one wave64 owns one row, lane l owns float4 columns l, l+64, ... so every access is a 16-byte (fp32) or
+// 8-byte (bf16) coalesced vector access and all row statistics are wave reductions (no LDS, no barriers).
+#include "common.h"
+#include "../../include/oneprot_hip.h"
+
+#define MAXV 8                 // float4s per lane -> rows up to 2048 wide
+#define ROWS_PER_BLOCK 4       // 256 threads = 4 waves = 4 rows in flight per block
+
+// --------------------------------------------------------------------------------------------------------
+// Embedding forward  (hf modeling_esm.py:224-271; ref call site sequence_encoder.py:78)
+// x[b,l,:] = W[id] * 0.88 / (1 - n_mask_b / n_valid_b)  ; 0 where id==mask ; 0 where id==pad
+// --------------------------------------------------------------------------------------------------------
+__global__ void __launch_bounds__(256) k_embed_fwd(const long long* __restrict__ ids, const float* __restrict__ W, float* __restrict__ x,
+                                                   float* __restrict__ row_scale, int L, int d, int vocab, int pad_id, int mask_id,
+                                                   int token_dropout, int tok_per_block) {
+  const int b = blockIdx.y, chunk = blockIdx.x, tid = threadIdx.x;
+  __shared__ float s_cnt[2][4];
+  __shared__ float s_scale;
+  float nvalid = 0.f, nmask = 0.f;
+  for (int l = tid; l < L; l += 256) {
+    const long long id = ids[(size_t)b * L + l];
+    nvalid += (id != pad_id);
+    nmask += (id == mask_id);
+  }
+  nvalid = wave_sum(nvalid); nmask = wave_sum(nmask);
+  if ((tid & 63) == 0) { s_cnt[0][tid >> 6] = nvalid; s_cnt[1][tid >> 6] = nmask; }
+  __syncthreads();
+  if (tid == 0) {
+    const float nv = s_cnt[0][0] + s_cnt[0][1] + s_cnt[0][2] + s_cnt[0][3];
+    const float nm = s_cnt[1][0] + s_cnt[1][1] + s_cnt[1][2] + s_cnt[1][3];
+    float sc = 1.0f;
+    if (token_dropout) sc = (1.0f - 0.15f * 0.8f) / (1.0f - nm / nv);
+    s_scale = sc;
+    if (chunk == 0 && row_scale) row_scale[b] = sc;
+  }
+  __syncthreads();
+  const float sc = s_scale;
+  const int nv4 = d >> 2;
+  const int l0 = chunk * tok_per_block;
+  const int l1 = min(L, l0 + tok_per_block);
+  const int wave = tid >> 6, lane = tid & 63;
+  for (int l = l0 + wave; l < l1; l += 4) {
+    const long long id = ids[(size_t)b * L + l];
+    const bool zero = (id == pad_id) || (token_dropout && id == mask_id) || id < 0 || id >= vocab;
+    const float4* src = reinterpret_cast<const float4*>(W + (size_t)(zero ? 0 : id) * d);
+    float4* dst = reinterpret_cast<float4*>(x + ((size_t)b * L + l) * d);
+    for (int v = lane; v < nv4; v += 64) {
+      float4 e = src[v];
+      if (zero) e = make_float4(0.f, 0.f, 0.f, 0.f);
+      else { e.x *= sc; e.y *= sc; e.z *= sc; e.w *= sc; }
+      dst[v] = e;
+    }
+  }
+}
+
+extern "C" int oneprot_esm_embed_fwd(const int64_t* ids, const float* table, float* x, float* row_scale, int B, int L, int d, int vocab,
+                                     int pad_id, int mask_id, int token_dropout, void* stream) {
+  if (!ids || !table || !x || B <= 0 || L <= 0 || d <= 0 || (d & 3)) return OP_EINVAL;
+  const int tpb = 32;
+  dim3 grid((L + tpb - 1) / tpb, B);
+  hipLaunchKernelGGL(k_embed_fwd, grid, dim3(256), 0, (hipStream_t)stream, (const long long*)ids, table, x, row_scale, L, d, vocab, pad_id,
+                     mask_id, token_dropout, tpb);
+  return launch_status();
+}
+
+// Embedding backward for small vocabularies (ESM: 33 / 54 rows): per-block private accumulators in LDS
+// (one thread per column => no atomics), partial tables to a workspace, then k_colsum_partials reduces.
+// dW[id] += row_scale[b] * dx[b,l,:]  for valid, non-mask tokens.
+__global__ void __launch_bounds__(256) k_embed_bwd_small(const long long* __restrict__ ids, const float* __restrict__ dx,
+                                                         const float* __restrict__ row_scale, float* __restrict__ partial, int T, int L, int d,
+                                                         int vocab, int pad_id, int mask_id, int token_dropout, int tok_per_block) {
+  extern __shared__ __attribute__((aligned(16))) float s_acc[];   // [vocab][256]
+  const int col = blockIdx.x * 256 + threadIdx.x;
+  const int chunk = blockIdx.y;
+  for (int v = 0; v < vocab; ++v) s_acc[v * 256 + threadIdx.x] = 0.f;
+  const int t0 = chunk * tok_per_block, t1 = min(T, t0 + tok_per_block);
+  if (col < d) {
+    for (int t = t0; t < t1; ++t) {
+      const long long id = ids[t];
+      if (id == pad_id || (token_dropout && id == mask_id) || id < 0 || id >= vocab) continue;   // block-uniform branch
+      const float sc = row_scale ? row_scale[t / L] : 1.0f;
+      s_acc[(int)id * 256 + threadIdx.x] += sc * dx[(size_t)t * d + col];
+    }
+    for (int v = 0; v < vocab; ++v) partial[((size_t)chunk * vocab + v) * d + col] = s_acc[v * 256 + threadIdx.x];
+  }
+}
+
+// out[j] (+)= sum_p partial[p][j]   for j in [0, n)
+__global__ void __launch_bounds__(256) k_reduce_partials(const float* __restrict__ partial, float* __restrict__ out, int nparts, size_t n, int accumulate) {
+  const size_t j = (size_t)blockIdx.x * 256 + threadIdx.x;
+  if (j >= n) return;
+  float s = 0.f;
+  for (int p = 0; p < nparts; ++p) s += partial[(size_t)p * n + j];
+  out[j] = accumulate ? out[j] + s : s;
+}
+
+extern "C" size_t oneprot_esm_embed_bwd_workspace(int T, int d, int vocab) {
+  const int chunks = 128;
+  (void)T;
+  return (size_t)chunks * vocab * d * sizeof(float);
+}
+
+extern "C" int oneprot_esm_embed_bwd(const int64_t* ids, const float* dx, const float* row_scale, float* dtable, void* workspace, int B, int L, int d,
+                                     int vocab, int pad_id, int mask_id, int token_dropout, int accumulate, void* stream) {
+  if (!ids || !dx || !dtable || !workspace || (d & 3) || vocab <= 0 || vocab > 160) return OP_EINVAL;   // 160*256*4 = 160 KiB of LDS
+  const int T = B * L, chunks = 128;
+  const int tpb = (T + chunks - 1) / chunks;
+  dim3 grid((d + 255) / 256, chunks);
+  const size_t lds = (size_t)vocab * 256 * sizeof(float);
+  if (lds > 64 * 1024) hipFuncSetAttribute((const void*)k_embed_bwd_small, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+  hipLaunchKernelGGL(k_embed_bwd_small, grid, dim3(256), lds, (hipStream_t)stream, (const long long*)ids, dx, row_scale, (float*)workspace, T, L, d,
+                     vocab, pad_id, mask_id, token_dropout, tpb);
+  const size_t n = (size_t)vocab * d;
+  hipLaunchKernelGGL(k_reduce_partials, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, (hipStream_t)stream, (const float*)workspace, dtable, chunks, n, accumulate);
+  return launch_status();
+}
+
+// --------------------------------------------------------------------------------------------------------
+// LayerNorm forward: y = (x - mean) * rstd * gamma + beta   (hf modeling_esm.py:429,518,552; nn.LayerNorm)
+// IN_BF16: input is bf16 instead of fp32.  Outputs: optional bf16 copy and/or fp32 copy, optional mean/rstd.
+// --------------------------------------------------------------------------------------------------------
+template <int IN_BF16>
+__global__ void __launch_bounds__(256) k_layernorm_fwd(const void* __restrict__ xin, const float* __restrict__ gamma, const float* __restrict__ beta,
+                                                       bf16_t* __restrict__ y_bf16, float* __restrict__ y_f32, float* __restrict__ mean_out,
+                                                       float* __restrict__ rstd_out, int T, int d, float eps) {
+  const int lane = threadIdx.x & 63;
+  const int nv4 = d >> 2;
+  const float inv_d = 1.0f / (float)d;
+  for (int row = blockIdx.x * ROWS_PER_BLOCK + (threadIdx.x >> 6); row < T; row += gridDim.x * ROWS_PER_BLOCK) {
+    float4 v[MAXV];
+    float s = 0.f;
+#pragma unroll
+    for (int i = 0; i < MAXV; ++i) {
+      const int c = lane + 64 * i;
+      if (c < nv4) {
+        if (IN_BF16) {
+          const u32x2 p = reinterpret_cast<const u32x2*>((const bf16_t*)xin + (size_t)row * d)[c];
+          v[i] = make_float4(bflo(p.x), bfhi(p.x), bflo(p.y), bfhi(p.y));
+        } else {
+          v[i] = reinterpret_cast<const float4*>((const float*)xin + (size_t)row * d)[c];
+        }
+        s += (v[i].x + v[i].y) + (v[i].z + v[i].w);
+      }
+    }
+    const float mean = wave_sum(s) * inv_d;
+    float q = 0.f;
+#pragma unroll
+    for (int i = 0; i < MAXV; ++i) {
+      const int c = lane + 64 * i;
+      if (c < nv4) {
+        const float a = v[i].x - mean, b = v[i].y - mean, cc = v[i].z - mean, dd = v[i].w - mean;
+        q += (a * a + b * b) + (cc * cc + dd * dd);
+      }
+    }
+    const float rstd = rsqrtf(wave_sum(q) * inv_d + eps);
+    if (lane == 0) {
+      if (mean_out) mean_out[row] = mean;
+      if (rstd_out) rstd_out[row] = rstd;
+    }
+#pragma unroll
+    for (int i = 0; i < MAXV; ++i) {
+      const int c = lane + 64 * i;
+      if (c < nv4) {
+        const float4 g = reinterpret_cast<const float4*>(gamma)[c];
+        const float4 bb = reinterpret_cast<const float4*>(beta)[c];
+        float4 o;
+        o.x = (v[i].x - mean) * rstd * g.x + bb.x;
+        o.y = (v[i].y - mean) * rstd * g.y + bb.y;
+        o.z = (v[i].z - mean) * rstd * g.z + bb.z;
+        o.w = (v[i].w - mean) * rstd * g.w + bb.w;
+        if (y_f32) reinterpret_cast<float4*>(y_f32 + (size_t)row * d)[c] = o;
+        if (y_bf16) {
+          u32x2 p; p.x = pack2bf(o.x, o.y); p.y = pack2bf(o.z, o.w);
+          reinterpret_cast<u32x2*>(y_bf16 + (size_t)row * d)[c] = p;
+        }
+      }
+    }
+  }
+}
+
+static inline int ln_grid(int T) {
+  const int blocks = (T + ROWS_PER_BLOCK - 1) / ROWS_PER_BLOCK;
+  return blocks < 256 * 16 ? blocks : 256 * 16;
+}
+
+extern "C" int oneprot_layernorm_fwd(const void* x, int x_is_bf16, const float* gamma, const float* beta, void* y_bf16, float* y_f32, float* mean,
+                                     float* rstd, int64_t T, int d, float eps, void* stream) {
+  if (!x || !gamma || !beta || (!y_bf16 && !y_f32) || T <= 0 || d <= 0 || (d & 3) || d > MAXV * 256) return OP_EINVAL;
+  if (x_is_bf16)
+    hipLaunchKernelGGL(k_layernorm_fwd<1>, dim3(ln_grid((int)T)), dim3(256), 0, (hipStream_t)stream, x, gamma, beta, (bf16_t*)y_bf16, y_f32, mean, rstd, (int)T, d, eps);
+  else
+    hipLaunchKernelGGL(k_layernorm_fwd<0>, dim3(ln_grid((int)T)), dim3(256), 0, (hipStream_t)stream, x, gamma, beta, (bf16_t*)y_bf16, y_f32, mean, rstd, (int)T, d, eps);
+  return launch_status();
+}
+
+// --------------------------------------------------------------------------------------------------------
+// LayerNorm backward.
+//   g = dy * gamma ; dx = rstd * (g - mean_d(g) - xhat * mean_d(g * xhat)) ; dgamma += dy * xhat ; dbeta += dy
+// DY_MODE 0: dy bf16 [T,d]   1: dy fp32 [T,d]   2: dy[t,:] = dpool[t / L, :] * wrow[t]  (pooled-gradient broadcast)
+// dx_out = (add_to ? add_to[t] : 0) + dx   (add_to may alias dx_out: residual-gradient accumulation in place)
+// dgamma/dbeta: per-wave register partials over the rows the wave visits -> partial[(block*4+wave)][2][d]
+// --------------------------------------------------------------------------------------------------------
+template <int DY_MODE, int X_BF16>
+__global__ void __launch_bounds__(256) k_layernorm_bwd(const void* __restrict__ dy, const float* __restrict__ wrow, int L, const void* __restrict__ x,
+                                                       const float* __restrict__ gamma, const float* __restrict__ mean_in, const float* __restrict__ rstd_in,
+                                                       const float* add_to, float* dx_out, float* __restrict__ partial, int T, int d) {
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  const int nv4 = d >> 2;
+  const float inv_d = 1.0f / (float)d;
+  float4 gam[MAXV], dg[MAXV], db[MAXV];
+#pragma unroll
+  for (int i = 0; i < MAXV; ++i) {
+    const int c = lane + 64 * i;
+    gam[i] = (c < nv4) ? reinterpret_cast<const float4*>(gamma)[c] : make_float4(0, 0, 0, 0);
+    dg[i] = make_float4(0, 0, 0, 0);
+    db[i] = make_float4(0, 0, 0, 0);
+  }
+  for (int row = blockIdx.x * ROWS_PER_BLOCK + wave; row < T; row += gridDim.x * ROWS_PER_BLOCK) {
+    const float mean = mean_in[row], rstd = rstd_in[row];
+    float w = 1.0f;
+    if (DY_MODE == 2) w = wrow[row];
+    float4 xh[MAXV], g[MAXV];
+    float s1 = 0.f, s2 = 0.f;
+#pragma unroll
+    for (int i = 0; i < MAXV; ++i) {
+      const int c = lane + 64 * i;
+      if (c < nv4) {
+        float4 xv;
+        if (X_BF16) {
+          const u32x2 p = reinterpret_cast<const u32x2*>((const bf16_t*)x + (size_t)row * d)[c];
+          xv = make_float4(bflo(p.x), bfhi(p.x), bflo(p.y), bfhi(p.y));
+        } else {
+          xv = reinterpret_cast<const float4*>((const float*)x + (size_t)row * d)[c];
+        }
+        float4 dyv;
+        if (DY_MODE == 0) {
+          const u32x2 p = reinterpret_cast<const u32x2*>((const bf16_t*)dy + (size_t)row * d)[c];
+          dyv = make_float4(bflo(p.x), bfhi(p.x), bflo(p.y), bfhi(p.y));
+        } else if (DY_MODE == 1) {
+          dyv = reinterpret_cast<const float4*>((const float*)dy + (size_t)row * d)[c];
+        } else {
+          dyv = reinterpret_cast<const float4*>((const float*)dy + (size_t)(row / L) * d)[c];
+          dyv.x *= w; dyv.y *= w; dyv.z *= w; dyv.w *= w;
+        }
+        xh[i] = make_float4((xv.x - mean) * rstd, (xv.y - mean) * rstd, (xv.z - mean) * rstd, (xv.w - mean) * rstd);
+        g[i] = make_float4(dyv.x * gam[i].x, dyv.y * gam[i].y, dyv.z * gam[i].z, dyv.w * gam[i].w);
+        s1 += (g[i].x + g[i].y) + (g[i].z + g[i].w);
+        s2 += (g[i].x * xh[i].x + g[i].y * xh[i].y) + (g[i].z * xh[i].z + g[i].w * xh[i].w);
+        dg[i].x += dyv.x * xh[i].x; dg[i].y += dyv.y * xh[i].y; dg[i].z += dyv.z * xh[i].z; dg[i].w += dyv.w * xh[i].w;
+        db[i].x += dyv.x; db[i].y += dyv.y; db[i].z += dyv.z; db[i].w += dyv.w;
+      }
+    }
+    const float m1 = wave_sum(s1) * inv_d, m2 = wave_sum(s2) * inv_d;
+#pragma unroll
+    for (int i = 0; i < MAXV; ++i) {
+      const int c = lane + 64 * i;
+      if (c < nv4) {
+        float4 o;
+        o.x = rstd * (g[i].x - m1 - xh[i].x * m2);
+        o.y = rstd * (g[i].y - m1 - xh[i].y * m2);
+        o.z = rstd * (g[i].z - m1 - xh[i].z * m2);
+        o.w = rstd * (g[i].w - m1 - xh[i].w * m2);
+        if (add_to) {
+          const float4 a = reinterpret_cast<const float4*>(add_to + (size_t)row * d)[c];
+          o.x += a.x; o.y += a.y; o.z += a.z; o.w += a.w;
+        }
+        reinterpret_cast<float4*>(dx_out + (size_t)row * d)[c] = o;
+      }
+    }
+  }
+  if (partial) {
+    float* pg = partial + ((size_t)(blockIdx.x * ROWS_PER_BLOCK + wave) * 2) * d;
+#pragma unroll
+    for (int i = 0; i < MAXV; ++i) {
+      const int c = lane + 64 * i;
+      if (c < nv4) {
+        reinterpret_cast<float4*>(pg)[c] = dg[i];
+        reinterpret_cast<float4*>(pg + d)[c] = db[i];
+      }
+    }
+  }
+}
+
+#define LN_BWD_BLOCKS 512
+extern "C" size_t oneprot_layernorm_bwd_workspace(int d) { return (size_t)LN_BWD_BLOCKS * ROWS_PER_BLOCK * 2 * d * sizeof(float); }
+
+// dgamma_dbeta: [2][d] laid out as dgamma then dbeta (the two may be non-adjacent: pass both pointers)
+__global__ void __launch_bounds__(256) k_ln_reduce(const float* __restrict__ partial, float* __restrict__ dgamma, float* __restrict__ dbeta, int nparts, int d, int accumulate) {
+  const int j = blockIdx.x * 256 + threadIdx.x;
+  if (j >= 2 * d) return;
+  float s = 0.f;
+  for (int p = 0; p < nparts; ++p) s += partial[(size_t)p * 2 * d + j];
+  float* out = j < d ? dgamma + j : dbeta + (j - d);
+  *out = accumulate ? *out + s : s;
+}
+
+extern "C" int oneprot_layernorm_bwd(const void* dy, int dy_mode, const float* wrow, int L, const void* x, int x_is_bf16, const float* gamma,
+                                     const float* mean, const float* rstd, const float* add_to, float* dx, float* dgamma, float* dbeta, void* workspace,
+                                     int64_t T, int d, int accumulate_param_grads, void* stream) {
+  if (!dy || !x || !gamma || !mean || !rstd || !dx || T <= 0 || (d & 3) || d > MAXV * 256) return OP_EINVAL;
+  if (dy_mode < 0 || dy_mode > 2 || (dy_mode == 2 && (!wrow || L <= 0))) return OP_EINVAL;
+  if ((dgamma || dbeta) && !(dgamma && dbeta && workspace)) return OP_EINVAL;
+  int blocks = (int)((T + ROWS_PER_BLOCK - 1) / ROWS_PER_BLOCK);
+  if (blocks > LN_BWD_BLOCKS) blocks = LN_BWD_BLOCKS;
+  float* partial = dgamma ? (float*)workspace : nullptr;
+  hipStream_t s = (hipStream_t)stream;
+#define LAUNCH_LNB(M, XB) hipLaunchKernelGGL((k_layernorm_bwd<M, XB>), dim3(blocks), dim3(256), 0, s, dy, wrow, L, x, gamma, mean, rstd, add_to, dx, partial, (int)T, d)
+  if (x_is_bf16) { if (dy_mode == 0) LAUNCH_LNB(0, 1); else if (dy_mode == 1) LAUNCH_LNB(1, 1); else LAUNCH_LNB(2, 1); }
+  else { if (dy_mode == 0) LAUNCH_LNB(0, 0); else if (dy_mode == 1) LAUNCH_LNB(1, 0); else LAUNCH_LNB(2, 0); }
+#undef LAUNCH_LNB
+  if (dgamma)
+    hipLaunchKernelGGL(k_ln_reduce, dim3((2 * d + 255) / 256), dim3(256), 0, s, (const float*)workspace, dgamma, dbeta, blocks * ROWS_PER_BLOCK, d, accumulate_param_grads);
+  return launch_status();
+}
+
+// --------------------------------------------------------------------------------------------------------
+// Fused final LayerNorm + pooling forward (hf modeling_esm.py:552 + ref base_encoder.py:109-126).
+//   mode 0 (mean): pooled[b] = sum_l valid[b,l] * LN(x[b,l]) / n_valid[b]   -- CLS/EOS included
+//   mode 1 (cls):  pooled[b] = LN(x[b,0])
+// One 512-thread block per sequence; wave w handles rows w, w+8, ...; lane owns float4 columns; per-wave register
+// accumulators are combined through LDS.  Also emits mean/rstd per token and wrow[t] = valid/n_valid (mode 0) or [l==0]
+// (mode 1), which is exactly the pooled-gradient broadcast weight used by oneprot_layernorm_bwd(dy_mode=2).
+// --------------------------------------------------------------------------------------------------------
+__global__ void __launch_bounds__(512) k_lnpool_fwd(const float* __restrict__ x, const long long* __restrict__ ids, int pad_id, const float* __restrict__ gamma,
+                                                    const float* __restrict__ beta, float* __restrict__ pooled, float* __restrict__ mean_out,
+                                                    float* __restrict__ rstd_out, float* __restrict__ wrow, bf16_t* __restrict__ hidden_bf16,
+                                                    float* __restrict__ hidden_f32, int L, int d, float eps, int mode) {
+  extern __shared__ __attribute__((aligned(16))) float s_pool[];    // [8][d]
+  __shared__ float s_n[8];
+  const int b = blockIdx.x, lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  const int nv4 = d >> 2;
+  const float inv_d = 1.0f / (float)d;
+  float cnt = 0.f;
+  for (int l = threadIdx.x; l < L; l += 512) cnt += (ids[(size_t)b * L + l] != pad_id);
+  cnt = wave_sum(cnt);
+  if (lane == 0) s_n[wave] = cnt;
+  __syncthreads();
+  float nvalid = 0.f;
+  for (int w = 0; w < 8; ++w) nvalid += s_n[w];
+  const float inv_n = 1.0f / nvalid;
+  float4 acc[MAXV];
+#pragma unroll
+  for (int i = 0; i < MAXV; ++i) acc[i] = make_float4(0, 0, 0, 0);
+  const int lend = (mode == 1 && !hidden_bf16 && !hidden_f32 && !mean_out) ? 1 : L;
+  for (int l = wave; l < lend; l += 8) {
+    const size_t row = (size_t)b * L + l;
+    const bool valid = ids[row] != pad_id;
+    const float wt = (mode == 0) ? (valid ? inv_n : 0.f) : (l == 0 ? 1.f : 0.f);
+    float4 v[MAXV];
+    float s = 0.f;
+#pragma unroll
+    for (int i = 0; i < MAXV; ++i) {
+      const int c = lane + 64 * i;
+      if (c < nv4) { v[i] = reinterpret_cast<const float4*>(x + row * d)[c]; s += (v[i].x + v[i].y) + (v[i].z + v[i].w); }
+    }
+    const float mean = wave_sum(s) * inv_d;
+    float q = 0.f;
+#pragma unroll
+    for (int i = 0; i < MAXV; ++i) {
+      const int c = lane + 64 * i;
+      if (c < nv4) { const float a = v[i].x - mean, bb = v[i].y - mean, cc = v[i].z - mean, dd = v[i].w - mean; q += (a * a + bb * bb) + (cc * cc + dd * dd); }
+    }
+    const float rstd = rsqrtf(wave_sum(q) * inv_d + eps);
+    if (lane == 0) {
+      if (mean_out) mean_out[row] = mean;
+      if (rstd_out) rstd_out[row] = rstd;
+      if (wrow) wrow[row] = wt;
+    }
+#pragma unroll
+    for (int i = 0; i < MAXV; ++i) {
+      const int c = lane + 64 * i;
+      if (c < nv4) {
+        const float4 g = reinterpret_cast<const float4*>(gamma)[c];
+        const float4 be = reinterpret_cast<const float4*>(beta)[c];
+        float4 o;
+        o.x = (v[i].x - mean) * rstd * g.x + be.x; o.y = (v[i].y - mean) * rstd * g.y + be.y;
+        o.z = (v[i].z - mean) * rstd * g.z + be.z; o.w = (v[i].w - mean) * rstd * g.w + be.w;
+        if (hidden_f32) reinterpret_cast<float4*>(hidden_f32 + row * d)[c] = o;
+        if (hidden_bf16) { u32x2 p; p.x = pack2bf(o.x, o.y); p.y = pack2bf(o.z, o.w); reinterpret_cast<u32x2*>(hidden_bf16 + row * d)[c] = p; }
+        acc[i].x += wt * o.x; acc[i].y += wt * o.y; acc[i].z += wt * o.z; acc[i].w += wt * o.w;
+      }
+    }
+  }
+#pragma unroll
+  for (int i = 0; i < MAXV; ++i) {
+    const int c = lane + 64 * i;
+    if (c < nv4) reinterpret_cast<float4*>(s_pool + (size_t)wave * d)[c] = acc[i];
+  }
+  __syncthreads();
+  for (int j = threadIdx.x; j < d; j += 512) {
+    float s = 0.f;
+#pragma unroll
+    for (int w = 0; w < 8; ++w) s += s_pool[(size_t)w * d + j];
+    pooled[(size_t)b * d + j] = s;
+  }
+}
+
+extern "C" int oneprot_lnpool_fwd(const float* x, const int64_t* ids, int pad_id, const float* gamma, const float* beta, float* pooled, float* mean,
+                                  float* rstd, float* wrow, void* hidden_bf16, float* hidden_f32, int B, int L, int d, float eps, int mode, void* stream) {
+  if (!x || !ids || !gamma || !beta || !pooled || (d & 3) || d > MAXV * 256 || mode < 0 || mode > 1) return OP_EINVAL;
+  hipLaunchKernelGGL(k_lnpool_fwd, dim3(B), dim3(512), (size_t)8 * d * sizeof(float), (hipStream_t)stream, x, (const long long*)ids, pad_id, gamma, beta, pooled,
+                     mean, rstd, wrow, (bf16_t*)hidden_bf16, hidden_f32, L, d, eps, mode);
+  return launch_status();
+}
+
+// --------------------------------------------------------------------------------------------------------
+// casts / fills / column sums
+// --------------------------------------------------------------------------------------------------------
+__global__ void __launch_bounds__(256) k_cast_f32_bf16(const float* __restrict__ src, bf16_t* __restrict__ dst, size_t n4) {
+  for (size_t i = (size_t)blockIdx.x * 256 + threadIdx.x; i < n4; i += (size_t)gridDim.x * 256) {
+    const float4 v = reinterpret_cast<const float4*>(src)[i];
+    u32x2 p; p.x = pack2bf(v.x, v.y); p.y = pack2bf(v.z, v.w);
+    reinterpret_cast<u32x2*>(dst)[i] = p;
+  }
+}
+extern "C" int oneprot_cast_f32_to_bf16(const float* src, void* dst, int64_t n, void* stream) {
+  if (!src || !dst || n <= 0 || (n & 3)) return OP_EINVAL;
+  const size_t n4 = (size_t)n >> 2;
+  size_t blocks = (n4 + 255) / 256; if (blocks > 8192) blocks = 8192;
+  hipLaunchKernelGGL(k_cast_f32_bf16, dim3((unsigned)blocks), dim3(256), 0, (hipStream_t)stream, src, (bf16_t*)dst, n4);
+  return launch_status();
+}
+
+// dst[c][r] = bf16(src[r][c]) : 64x64 tiles through LDS (weights only: a few MB per optimizer step)
+__global__ void __launch_bounds__(256) k_transpose_cast(const float* __restrict__ src, bf16_t* __restrict__ dst, int R, int C) {
+  __shared__ float tile[64][65];
+  const int r0 = blockIdx.y * 64, c0 = blockIdx.x * 64;
+  for (int i = threadIdx.x; i < 64 * 64; i += 256) {
+    const int r = i >> 6, c = i & 63;
+    tile[r][c] = (r0 + r < R && c0 + c < C) ? src[(size_t)(r0 + r) * C + c0 + c] : 0.f;
+  }
+  __syncthreads();
+  for (int i = threadIdx.x; i < 64 * 64; i += 256) {
+    const int c = i >> 6, r = i & 63;
+    if (r0 + r < R && c0 + c < C) dst[(size_t)(c0 + c) * R + r0 + r] = f2bf(tile[r][c]);
+  }
+}
+extern "C" int oneprot_transpose_cast_f32_to_bf16(const float* src, void* dst, int R, int C, void* stream) {
+  if (!src || !dst || R <= 0 || C <= 0) return OP_EINVAL;
+  hipLaunchKernelGGL(k_transpose_cast, dim3((C + 63) / 64, (R + 63) / 64), dim3(256), 0, (hipStream_t)stream, src, (bf16_t*)dst, R, C);
+  return launch_status();
+}
+
+// Column sums of a bf16 [M, N] matrix (bias gradients): partial[blockIdx.y][n] then reduce.
+__global__ void __launch_bounds__(256) k_colsum_bf16(const bf16_t* __restrict__ a, float* __restrict__ partial, int M, int N, int rows_per_block) {
+  const int c2 = blockIdx.x * 256 + threadIdx.x;      // pair of columns
+  if (c2 * 2 >= N) return;
+  const int r0 = blockIdx.y * rows_per_block, r1 = min(M, r0 + rows_per_block);
+  float s0 = 0.f, s1 = 0.f;
+  for (int r = r0; r < r1; ++r) {
+    const unsigned p = reinterpret_cast<const unsigned*>(a + (size_t)r * N)[c2];
+    s0 += bflo(p); s1 += bfhi(p);
+  }
+  partial[(size_t)blockIdx.y * N + 2 * c2] = s0;
+  partial[(size_t)blockIdx.y * N + 2 * c2 + 1] = s1;
+}
+#define COLSUM_PARTS 256
+extern "C" size_t oneprot_colsum_workspace(int N) { return (size_t)COLSUM_PARTS * N * sizeof(float); }
+extern "C" int oneprot_colsum_bf16(const void* a, float* out, void* workspace, int64_t M, int N, int accumulate, void* stream) {
+  if (!a || !out || !workspace || M <= 0 || N <= 0 || (N & 1)) return OP_EINVAL;
+  const int rpb = (int)((M + COLSUM_PARTS - 1) / COLSUM_PARTS);
+  const int parts = (int)((M + rpb - 1) / rpb);
+  hipLaunchKernelGGL(k_colsum_bf16, dim3((N / 2 + 255) / 256, parts), dim3(256), 0, (hipStream_t)stream, (const bf16_t*)a, (float*)workspace, (int)M, N, rpb);
+  hipLaunchKernelGGL(k_reduce_partials, dim3((N + 255) / 256), dim3(256), 0, (hipStream_t)stream, (const float*)workspace, out, parts, (size_t)N, accumulate);
+  return launch_status();
+}

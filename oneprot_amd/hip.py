@@ -1,0 +1,105 @@
+"""ctypes binding of liboneprot_hip.so (the C ABI in include/oneprot_hip.h).
+
+There is no CPU fallback: if the shared library is missing, or a kernel returns a non-zero status, this module
+raises.  torch is used only as the owner of device memory and streams (tensor.data_ptr(), current stream).
+"""
+import ctypes
+import os
+from ctypes import c_float, c_int, c_int64, c_size_t, c_void_p
+
+import torch
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(_HERE, "liboneprot_hip.so")
+
+EPI_BF16, EPI_F32, EPI_BIAS_GELU, EPI_BIAS_RESID, EPI_QKV_ROPE, EPI_GELU_BWD = range(6)
+
+
+class HipLibraryMissing(RuntimeError):
+    pass
+
+
+class HipKernelError(RuntimeError):
+    pass
+
+
+P, I, L64, F, SZ = c_void_p, c_int, c_int64, c_float, c_size_t
+
+# name -> (restype, argtypes)    (mirrors include/oneprot_hip.h line by line)
+_SIGS = {
+    "oneprot_abi_version": (I, []),
+    "oneprot_esm_embed_fwd": (I, [P, P, P, P, I, I, I, I, I, I, I, P]),
+    "oneprot_esm_embed_bwd_workspace": (SZ, [I, I, I]),
+    "oneprot_esm_embed_bwd": (I, [P, P, P, P, P, I, I, I, I, I, I, I, I, P]),
+    "oneprot_layernorm_fwd": (I, [P, I, P, P, P, P, P, P, L64, I, F, P]),
+    "oneprot_layernorm_bwd_workspace": (SZ, [I]),
+    "oneprot_layernorm_bwd": (I, [P, I, P, I, P, I, P, P, P, P, P, P, P, P, L64, I, I, P]),
+    "oneprot_lnpool_fwd": (I, [P, P, I, P, P, P, P, P, P, P, P, I, I, I, F, I, P]),
+    "oneprot_gemm_bf16_nt": (I, [P, P, L64, I, I, I, I, I, P, P, P, P, P, P, P, F, I, I, I, P]),
+    "oneprot_gemm_bf16_tn_workspace": (SZ, [I, I]),
+    "oneprot_gemm_bf16_tn": (I, [P, P, L64, I, I, I, I, P, P, I, P]),
+    "oneprot_sgemm": (I, [P, P, P, I, I, I, I, I, F, I, P]),
+    "oneprot_attn_fwd": (I, [P, P, P, P, P, P, I, I, I, I, P]),
+    "oneprot_attn_bwd_workspace": (SZ, [I, I, I]),
+    "oneprot_attn_bwd": (I, [P, P, P, P, P, P, P, P, P, F, P, P, I, I, I, I, P]),
+    "oneprot_gelu_f32": (I, [P, P, L64, P]),
+    "oneprot_gelu_bwd_f32": (I, [P, P, P, L64, P]),
+    "oneprot_l2norm_fwd": (I, [P, P, P, I, I, F, P]),
+    "oneprot_l2norm_bwd": (I, [P, P, P, P, I, I, F, F, P]),
+    "oneprot_ce_fwd_bwd": (I, [P, P, P, I, I, I, F, P]),
+    "oneprot_abs_sum": (I, [P, P, P, L64, F, P]),
+    "oneprot_sumsq_workspace": (SZ, []),
+    "oneprot_sumsq": (I, [P, L64, P, P, P]),
+    "oneprot_clip_coef": (I, [P, F, P, P, P]),
+    "oneprot_adam_step": (I, [P, P, P, P, L64, F, F, F, F, F, I, P, P]),
+    "oneprot_cast_f32_to_bf16": (I, [P, P, L64, P]),
+    "oneprot_transpose_cast_f32_to_bf16": (I, [P, P, I, I, P]),
+    "oneprot_colsum_workspace": (SZ, [I]),
+    "oneprot_colsum_bf16": (I, [P, P, P, L64, I, I, P]),
+}
+
+_lib = None
+
+
+def exported_symbols():
+    return sorted(_SIGS)
+
+
+def lib():
+    """Load (once) and return the ctypes handle.  Raises HipLibraryMissing if the .so was not built."""
+    global _lib
+    if _lib is None:
+        if not os.path.exists(LIB_PATH):
+            raise HipLibraryMissing(
+                f"{LIB_PATH} not found: build it with `python -c 'import __graft_entry__ as g; g.build()'` "
+                "(oneprot_amd/csrc/build.sh).  There is no CPU fallback for the OneProt hot path.")
+        h = ctypes.CDLL(LIB_PATH)
+        for name, (res, args) in _SIGS.items():
+            fn = getattr(h, name)          # AttributeError here = header/library mismatch: fail loudly
+            fn.restype, fn.argtypes = res, args
+        _lib = h
+    return _lib
+
+
+def ptr(t):
+    if t is None:
+        return None
+    if isinstance(t, int):
+        return t
+    return t.data_ptr()
+
+
+def stream():
+    return torch.cuda.current_stream().cuda_stream
+
+
+def call(name, *args):
+    """Invoke an int-returning entry point on the current torch stream; raise on a non-zero status."""
+    fn = getattr(lib(), name)
+    rc = fn(*[ptr(a) if isinstance(a, torch.Tensor) or a is None else a for a in args], stream())
+    if rc != 0:
+        raise HipKernelError(f"{name} returned {rc} ({'invalid argument' if rc == -1 else 'launch failure'})")
+
+
+def query(name, *args):
+    return getattr(lib(), name)(*args)

@@ -1,0 +1,373 @@
+"""Per-kernel parity: every C-ABI entry point vs a plain fp32 torch restatement of the same op (and the oracle's
+functions where the op is composite).  Runs on the MI355X only (-m gpu); all calls go through the C ABI.
+
+Tolerances: fp32 kernels 1e-5-ish; bf16-operand MFMA kernels are compared against an fp32 reference computed from the
+SAME bf16-rounded inputs, so the only difference is accumulation order / output rounding (bf16 outputs: 2^-8 rel)."""
+import math
+
+import pytest
+import torch
+
+pytestmark = pytest.mark.gpu
+
+from oneprot_amd import hip  # noqa: E402
+from oracle import oneprot_oracle as O  # noqa: E402
+
+DEV = "cuda"
+
+
+def bf(x):
+    return x.to(torch.bfloat16)
+
+
+def rel_err(a, b):
+    return ((a.float() - b.float()).norm() / (b.float().norm() + 1e-20)).item()
+
+
+def assert_close(a, b, rtol, atol, msg=""):
+    a, b = a.float(), b.float()
+    err = (a - b).abs()
+    tol = atol + rtol * b.abs()
+    bad = (err > tol)
+    assert not bad.any(), f"{msg}: {int(bad.sum())}/{bad.numel()} off, max err {err.max().item():.3e} (ref max {b.abs().max().item():.3e})"
+
+
+def ws(nbytes):
+    return torch.empty(max(int(nbytes), 16), dtype=torch.uint8, device=DEV)
+
+
+# ------------------------------------------------------------------------------------------------------
+def test_library_loads():
+    assert hip.query("oneprot_abi_version") == 1
+
+
+@pytest.mark.parametrize("B,L,d,vocab", [(3, 17, 64, 33), (4, 130, 640, 54)])
+def test_embed_fwd_bwd(B, L, d, vocab):
+    g = torch.Generator().manual_seed(0)
+    ids = torch.randint(4, vocab - 1, (B, L), generator=g)
+    ids[0, L - 5:] = 1
+    ids[1, 2] = 32
+    ids[1, 4] = 32
+    ids[:, 0] = 0
+    W = torch.randn(vocab, d, generator=g)
+    Wd, idd = W.to(DEV), ids.to(DEV)
+    x = torch.empty(B, L, d, device=DEV)
+    rs = torch.empty(B, device=DEV)
+    hip.call("oneprot_esm_embed_fwd", idd, Wd, x, rs, B, L, d, vocab, 1, 32, 1)
+    Wr = W.clone().requires_grad_(True)
+    ref = O.esm_embeddings(ids, (ids != 1).long(), Wr, 32)
+    assert_close(x.cpu(), ref.detach(), 1e-6, 1e-6, "embed fwd")
+    dx = torch.randn(B, L, d, generator=g)
+    ref.backward(dx)
+    dW = torch.full((vocab, d), 7.0, device=DEV)
+    w = ws(hip.query("oneprot_esm_embed_bwd_workspace", B * L, d, vocab))
+    hip.call("oneprot_esm_embed_bwd", idd, dx.to(DEV), rs, dW, w, B, L, d, vocab, 1, 32, 1, 0)
+    assert_close(dW.cpu(), Wr.grad, 1e-5, 1e-5, "embed bwd")
+
+
+@pytest.mark.parametrize("T,d", [(37, 64), (1000, 640), (130, 1280), (64, 48)])
+def test_layernorm_fwd_bwd(T, d):
+    g = torch.Generator().manual_seed(1)
+    x = (torch.randn(T, d, generator=g) * 2 + 0.5).to(DEV)
+    gamma = (1 + 0.1 * torch.randn(d, generator=g)).to(DEV)
+    beta = (0.1 * torch.randn(d, generator=g)).to(DEV)
+    yb = torch.empty(T, d, dtype=torch.bfloat16, device=DEV)
+    yf = torch.empty(T, d, device=DEV)
+    mean = torch.empty(T, device=DEV)
+    rstd = torch.empty(T, device=DEV)
+    hip.call("oneprot_layernorm_fwd", x, 0, gamma, beta, yb, yf, mean, rstd, T, d, 1e-5)
+    xr = x.clone().requires_grad_(True)
+    gr, br = gamma.clone().requires_grad_(True), beta.clone().requires_grad_(True)
+    ref = torch.nn.functional.layer_norm(xr, (d,), gr, br, 1e-5)
+    assert_close(yf, ref.detach(), 1e-5, 1e-5, "ln fwd f32")
+    assert_close(yb, ref.detach(), 2 ** -8, 1e-6, "ln fwd bf16")
+    # backward, fp32 dy, accumulate into an existing residual gradient
+    dy = torch.randn(T, d, generator=g).to(DEV)
+    add = torch.randn(T, d, generator=g).to(DEV)
+    ref.backward(dy)
+    dx = torch.empty(T, d, device=DEV)
+    dg = torch.zeros(d, device=DEV)
+    db = torch.zeros(d, device=DEV)
+    w = ws(hip.query("oneprot_layernorm_bwd_workspace", d))
+    hip.call("oneprot_layernorm_bwd", dy, 1, None, 0, x, 0, gamma, mean, rstd, add, dx, dg, db, w, T, d, 0)
+    assert_close(dx, xr.grad + add, 1e-4, 1e-4, "ln bwd dx")
+    assert_close(dg, gr.grad, 1e-4, 1e-3, "ln bwd dgamma")
+    assert_close(db, br.grad, 1e-4, 1e-3, "ln bwd dbeta")
+    # bf16 dy, in place on the residual gradient, accumulate param grads
+    dyb = bf(dy)
+    dx2 = add.clone()
+    hip.call("oneprot_layernorm_bwd", dyb, 0, None, 0, x, 0, gamma, mean, rstd, dx2, dx2, dg, db, w, T, d, 1)
+    xr2 = x.clone().requires_grad_(True)
+    torch.nn.functional.layer_norm(xr2, (d,), gamma, beta, 1e-5).backward(dyb.float())
+    assert_close(dx2, xr2.grad + add, 1e-4, 1e-4, "ln bwd dx (bf16 dy, in place)")
+
+
+@pytest.mark.parametrize("mode", [0, 1])
+def test_lnpool_fwd_and_pooled_bwd(mode):
+    B, L, d = 5, 37, 128
+    g = torch.Generator().manual_seed(2)
+    ids = torch.randint(4, 24, (B, L), generator=g)
+    for b, n in enumerate([37, 20, 5, 37, 1]):
+        ids[b, n:] = 1
+    x = torch.randn(B, L, d, generator=g)
+    gamma, beta = 1 + 0.1 * torch.randn(d, generator=g), 0.1 * torch.randn(d, generator=g)
+    xd, idd = x.to(DEV), ids.to(DEV)
+    pooled = torch.empty(B, d, device=DEV)
+    mean, rstd, wrow = (torch.empty(B * L, device=DEV) for _ in range(3))
+    hid = torch.empty(B, L, d, device=DEV)
+    hip.call("oneprot_lnpool_fwd", xd, idd, 1, gamma.to(DEV), beta.to(DEV), pooled, mean, rstd, wrow, None, hid, B, L, d, 1e-5, mode)
+    xr = x.clone().requires_grad_(True)
+    gr, br = gamma.clone().requires_grad_(True), beta.clone().requires_grad_(True)
+    h = O.layer_norm(xr, gr, br, 1e-5)
+    ref = O.mean_pool(h, (ids != 1).long()) if mode == 0 else O.cls_pool(h)
+    assert_close(hid.cpu(), h.detach(), 1e-5, 1e-5, "hidden")
+    assert_close(pooled.cpu(), ref.detach(), 1e-5, 1e-5, "pooled")
+    dp = torch.randn(B, d, generator=g)
+    ref.backward(dp)
+    dx = torch.empty(B * L, d, device=DEV)
+    dg, db = torch.zeros(d, device=DEV), torch.zeros(d, device=DEV)
+    w = ws(hip.query("oneprot_layernorm_bwd_workspace", d))
+    hip.call("oneprot_layernorm_bwd", dp.to(DEV), 2, wrow, L, xd, 0, gamma.to(DEV), mean, rstd, None, dx, dg, db, w, B * L, d, 0)
+    assert_close(dx.cpu().view(B, L, d), xr.grad, 1e-4, 1e-5, "pooled bwd dx")
+    assert_close(dg.cpu(), gr.grad, 1e-4, 1e-4, "pooled bwd dgamma")
+    assert_close(db.cpu(), br.grad, 1e-4, 1e-4, "pooled bwd dbeta")
+
+
+# ------------------------------------------------------------------------------------------------------
+def _gemm_inputs(M, N, K, seed):
+    g = torch.Generator().manual_seed(seed)
+    A = bf(torch.randn(M, K, generator=g)).to(DEV)
+    W = bf(torch.randn(N, K, generator=g) * 0.1).to(DEV)
+    bias = (torch.randn(N, generator=g) * 0.5).to(DEV)
+    return A, W, bias
+
+
+@pytest.mark.parametrize("M,N,K", [(300, 136, 72), (128, 128, 64), (1024, 640, 640), (257, 2560, 640), (515, 640, 2560), (144, 64, 160)])
+def test_gemm_nt_epilogues(M, N, K):
+    A, W, bias = _gemm_inputs(M, N, K, 3)
+    ref = A.float() @ W.float().t()
+    out = torch.empty(M, N, dtype=torch.bfloat16, device=DEV)
+    hip.call("oneprot_gemm_bf16_nt", A, W, M, N, K, K, K, hip.EPI_BF16, bias, out, None, None, None, None, None, 1.0, 0, 0, 0)
+    assert_close(out, ref + bias, 2 ** -7, 2e-2, "EPI_BF16")
+    outf = torch.empty(M, N, device=DEV)
+    hip.call("oneprot_gemm_bf16_nt", A, W, M, N, K, K, K, hip.EPI_F32, None, outf, None, None, None, None, None, 1.0, 0, 0, 0)
+    assert_close(outf, ref, 1e-4, 1e-3 * math.sqrt(K / 64), "EPI_F32")
+    # bias + gelu (+z)
+    u = torch.empty(M, N, dtype=torch.bfloat16, device=DEV)
+    z = torch.empty(M, N, dtype=torch.bfloat16, device=DEV)
+    hip.call("oneprot_gemm_bf16_nt", A, W, M, N, K, K, K, hip.EPI_BIAS_GELU, bias, u, z, None, None, None, None, 1.0, 0, 0, 0)
+    zr = ref + bias
+    assert_close(z, zr, 2 ** -7, 2e-2, "z")
+    assert_close(u, torch.nn.functional.gelu(zr), 2 ** -7, 2e-2, "gelu(z)")
+    # bias + fp32 residual, in place
+    g = torch.Generator().manual_seed(4)
+    resid = torch.randn(M, N, generator=g).to(DEV)
+    x = resid.clone()
+    hip.call("oneprot_gemm_bf16_nt", A, W, M, N, K, K, K, hip.EPI_BIAS_RESID, bias, x, None, None, x, None, None, 1.0, 0, 0, 0)
+    assert_close(x, ref + bias + resid, 1e-4, 1e-3 * math.sqrt(K / 64), "bias+resid")
+    # gelu backward epilogue
+    dz = torch.empty(M, N, dtype=torch.bfloat16, device=DEV)
+    hip.call("oneprot_gemm_bf16_nt", A, W, M, N, K, K, K, hip.EPI_GELU_BWD, None, dz, None, None, z, None, None, 1.0, 0, 0, 0)
+    zz = z.float().requires_grad_(True)
+    torch.nn.functional.gelu(zz).backward(ref)
+    assert_close(dz, zz.grad, 2 ** -6, 3e-2, "gelu bwd")
+
+
+@pytest.mark.parametrize("B,L,H,hd", [(3, 24, 4, 16), (2, 37, 2, 32), (2, 130, 20, 32), (2, 50, 2, 64)])
+def test_gemm_qkv_rope_epilogue(B, L, H, hd):
+    d = H * hd
+    M, N, K = B * L, 3 * d, d
+    A, W, bias = _gemm_inputs(M, N, K, 5)
+    cos, sin = O.rope_tables(L, hd)
+    cosd, sind = cos[:, : hd // 2].contiguous().to(DEV), sin[:, : hd // 2].contiguous().to(DEV)
+    q, k, v = (torch.empty(B, H, L, hd, dtype=torch.bfloat16, device=DEV) for _ in range(3))
+    hip.call("oneprot_gemm_bf16_nt", A, W, M, N, K, K, K, hip.EPI_QKV_ROPE, bias, q, k, v, None, cosd, sind, hd ** -0.5, L, H, hd)
+    y = (A.float() @ W.float().t() + bias).cpu().view(B, L, 3, H, hd).permute(2, 0, 3, 1, 4)
+    qr = O.apply_rope(y[0] * hd ** -0.5, cos, sin)
+    kr = O.apply_rope(y[1], cos, sin)
+    assert_close(q.cpu(), qr, 2 ** -7, 2e-2, "q")
+    assert_close(k.cpu(), kr, 2 ** -7, 2e-2, "k")
+    assert_close(v.cpu(), y[2], 2 ** -7, 2e-2, "v")
+
+
+@pytest.mark.parametrize("M,N,K", [(300, 136, 72), (4096, 640, 640), (5000, 1920, 640), (777, 160, 64)])
+def test_gemm_tn(M, N, K):
+    g = torch.Generator().manual_seed(6)
+    dY = bf(torch.randn(M, N, generator=g)).to(DEV)
+    X = bf(torch.randn(M, K, generator=g)).to(DEV)
+    ref = dY.float().t() @ X.float()
+    dW = torch.full((N, K), 3.0, device=DEV)
+    w = ws(hip.query("oneprot_gemm_bf16_tn_workspace", N, K))
+    hip.call("oneprot_gemm_bf16_tn", dY, X, M, N, K, N, K, dW, w, 0)
+    assert_close(dW, ref, 1e-4, 2e-3 * math.sqrt(M / 64), "tn")
+    hip.call("oneprot_gemm_bf16_tn", dY, X, M, N, K, N, K, dW, w, 1)
+    assert_close(dW, 2 * ref, 1e-4, 4e-3 * math.sqrt(M / 64), "tn accumulate")
+    # strided views: columns [N0:N0+n) of a wider matrix
+    cs = torch.full((N,), -1.0, device=DEV)
+    w2 = ws(hip.query("oneprot_colsum_workspace", N))
+    hip.call("oneprot_colsum_bf16", dY, cs, w2, M, N, 0)
+    assert_close(cs, dY.float().sum(0), 1e-4, 1e-2, "colsum")
+
+
+@pytest.mark.parametrize("tA,bkn", [(0, 0), (0, 1), (1, 1), (1, 0)])
+def test_sgemm(tA, bkn):
+    M, N, K = 70, 130, 45
+    g = torch.Generator().manual_seed(7)
+    A = torch.randn(M, K, generator=g)
+    Bm = torch.randn(K, N, generator=g)
+    Ad = (A.t().contiguous() if tA else A).to(DEV)
+    Bd = (Bm if bkn else Bm.t().contiguous()).to(DEV)
+    C = torch.ones(M, N, device=DEV)
+    hip.call("oneprot_sgemm", Ad, Bd, C, M, N, K, tA, bkn, 0.5, 1)
+    assert_close(C.cpu(), 1 + 0.5 * (A @ Bm), 1e-5, 1e-5, "sgemm")
+
+
+# ------------------------------------------------------------------------------------------------------
+def _attn_ref(q, k, v, bias):
+    s = q.float() @ k.float().transpose(-1, -2)
+    if bias is not None:
+        s = s + bias[:, None, None, :]
+    p = torch.softmax(s, -1)
+    return p @ v.float(), torch.logsumexp(s, -1)
+
+
+@pytest.mark.parametrize("B,H,L,hd", [(2, 3, 37, 32), (1, 2, 128, 16), (2, 2, 300, 32), (1, 2, 70, 64), (1, 1, 513, 32)])
+def test_attention_fwd_bwd(B, H, L, hd):
+    g = torch.Generator().manual_seed(8)
+    q = bf(torch.randn(B, H, L, hd, generator=g) * 0.7).to(DEV)
+    k = bf(torch.randn(B, H, L, hd, generator=g)).to(DEV)
+    v = bf(torch.randn(B, H, L, hd, generator=g)).to(DEV)
+    bias = torch.zeros(B, L)
+    bias[0, L - L // 3:] = torch.finfo(torch.float32).min
+    bias = bias.to(DEV)
+    ctx = torch.empty(B * L, H * hd, dtype=torch.bfloat16, device=DEV)
+    lse = torch.empty(B, H, L, device=DEV)
+    hip.call("oneprot_attn_fwd", q, k, v, bias, ctx, lse, B, H, L, hd)
+    qr, kr, vr = (t.float().requires_grad_(True) for t in (q, k, v))
+    o_ref, lse_ref = _attn_ref(qr, kr, vr, bias)
+    o_tok = o_ref.permute(0, 2, 1, 3).reshape(B * L, H * hd)
+    assert_close(ctx, o_tok.detach(), 2 ** -7, 1e-2, "attn fwd")
+    assert_close(lse, lse_ref.detach(), 1e-4, 1e-3, "lse")
+    # backward (no rope: cos/sin NULL => dqkv is the raw gradient * q_scale)
+    dctx = bf(torch.randn(B * L, H * hd, generator=g)).to(DEV)
+    o_tok.backward(dctx.float())
+    dqkv = torch.zeros(B * L, 3 * H * hd, dtype=torch.bfloat16, device=DEV)
+    w = ws(hip.query("oneprot_attn_bwd_workspace", B, H, L))
+    hip.call("oneprot_attn_bwd", q, k, v, bias, ctx, dctx, lse, None, None, 1.0, dqkv, w, B, H, L, hd)
+    got = dqkv.float().view(B, L, 3, H, hd).permute(2, 0, 3, 1, 4)
+    for name, gt, rf in (("dq", got[0], qr.grad), ("dk", got[1], kr.grad), ("dv", got[2], vr.grad)):
+        assert rel_err(gt, rf) < 2e-2, f"{name} rel err {rel_err(gt, rf)}"
+        assert_close(gt, rf, 5e-2, 5e-2 * rf.abs().max().item(), name)
+
+
+def test_attention_bwd_rope_chain():
+    """dqkv must be the gradient w.r.t. the un-rotated, un-scaled projections (transpose of q-scale + RoPE)."""
+    B, H, L, hd = 2, 2, 45, 32
+    g = torch.Generator().manual_seed(9)
+    ylin = (torch.randn(3, B, H, L, hd, generator=g)).requires_grad_(True)
+    cos, sin = O.rope_tables(L, hd)
+    qs = O.apply_rope(ylin[0] * hd ** -0.5, cos, sin)
+    ks = O.apply_rope(ylin[1], cos, sin)
+    qb, kb, vb = bf(qs.detach()).to(DEV), bf(ks.detach()).to(DEV), bf(ylin[2].detach()).to(DEV)
+    ctx = torch.empty(B * L, H * hd, dtype=torch.bfloat16, device=DEV)
+    lse = torch.empty(B, H, L, device=DEV)
+    hip.call("oneprot_attn_fwd", qb, kb, vb, None, ctx, lse, B, H, L, hd)
+    o, _ = _attn_ref(qs, ks, ylin[2], None)
+    dctx = bf(torch.randn(B * L, H * hd, generator=g))
+    o.permute(0, 2, 1, 3).reshape(B * L, H * hd).backward(dctx.float())
+    dqkv = torch.zeros(B * L, 3 * H * hd, dtype=torch.bfloat16, device=DEV)
+    w = ws(hip.query("oneprot_attn_bwd_workspace", B, H, L))
+    cosd, sind = cos[:, : hd // 2].contiguous().to(DEV), sin[:, : hd // 2].contiguous().to(DEV)
+    hip.call("oneprot_attn_bwd", qb, kb, vb, None, ctx, dctx.to(DEV), lse, cosd, sind, hd ** -0.5, dqkv, w, B, H, L, hd)
+    got = dqkv.float().cpu().view(B, L, 3, H, hd).permute(2, 0, 3, 1, 4)
+    for i, name in enumerate(("dq", "dk", "dv")):
+        assert rel_err(got[i], ylin.grad[i]) < 2e-2, f"{name}: {rel_err(got[i], ylin.grad[i])}"
+
+
+# ------------------------------------------------------------------------------------------------------
+def test_feature_ops():
+    R, D = 37, 100
+    g = torch.Generator().manual_seed(10)
+    x = torch.randn(R, D, generator=g)
+    xd = x.to(DEV)
+    y = torch.empty(R, D, device=DEV)
+    inv = torch.empty(R, device=DEV)
+    scale = 1 / 0.07
+    hip.call("oneprot_l2norm_fwd", xd, y, inv, R, D, scale)
+    xr = x.clone().requires_grad_(True)
+    yr = O.l2_normalize(xr) * scale
+    assert_close(y.cpu(), yr.detach(), 1e-5, 1e-5, "l2norm fwd")
+    dy = torch.randn(R, D, generator=g)
+    l1c = 0.01 / (R * D)
+    (yr * dy).sum().backward(retain_graph=True)
+    g0 = xr.grad.clone()
+    xr.grad = None
+    ((yr * dy).sum() + 0.01 * yr.abs().mean()).backward()
+    dx = torch.empty(R, D, device=DEV)
+    hip.call("oneprot_l2norm_bwd", y, dy.to(DEV), inv, dx, R, D, scale, 0.0)
+    assert_close(dx.cpu(), g0, 1e-4, 1e-5, "l2norm bwd")
+    hip.call("oneprot_l2norm_bwd", y, dy.to(DEV), inv, dx, R, D, scale, l1c)
+    assert_close(dx.cpu(), xr.grad, 1e-4, 1e-5, "l2norm bwd + L1")
+    # gelu
+    gy = torch.empty(R, D, device=DEV)
+    hip.call("oneprot_gelu_f32", xd, gy, R * D)
+    assert_close(gy.cpu(), O.gelu_erf(x), 1e-5, 1e-6, "gelu")
+    x2 = x.clone().requires_grad_(True)
+    O.gelu_erf(x2).backward(dy)
+    hip.call("oneprot_gelu_bwd_f32", xd, dy.to(DEV), gy, R * D)
+    assert_close(gy.cpu(), x2.grad, 1e-4, 1e-5, "gelu bwd")
+    # abs sum
+    acc = torch.ones(1, device=DEV)
+    w = ws(hip.query("oneprot_sumsq_workspace"))
+    hip.call("oneprot_abs_sum", xd, acc, w, R * D, 0.5)
+    assert abs(acc.item() - (1 + 0.5 * x.abs().sum().item())) < 1e-2
+
+
+@pytest.mark.parametrize("R,C,off", [(6, 6, 0), (5, 15, 5), (256, 2048, 512)])
+def test_cross_entropy(R, C, off):
+    g = torch.Generator().manual_seed(11)
+    logits = torch.randn(R, C, generator=g) * 8
+    lr = logits.clone().requires_grad_(True)
+    labels = torch.arange(R) + off
+    loss = torch.nn.functional.cross_entropy(lr, labels) / 2
+    loss.backward()
+    ld = logits.to(DEV)
+    out = torch.zeros(1, device=DEV)
+    rw = torch.empty(R, device=DEV)
+    hip.call("oneprot_ce_fwd_bwd", ld, out, rw, R, C, off, 0.5 / R)
+    assert abs(out.item() - loss.item()) < 1e-5 * max(1, abs(loss.item()))
+    assert_close(ld.cpu(), lr.grad, 1e-4, 1e-7, "dlogits")
+
+
+def test_optimizer_kernels():
+    n = 4 * 1000 + 8
+    g = torch.Generator().manual_seed(12)
+    p = torch.randn(n, generator=g)
+    grads = [torch.randn(n, generator=g) * 3 for _ in range(3)]
+    pr = p.clone().requires_grad_(True)
+    opt = torch.optim.Adam([pr], lr=1e-3)
+    pd, m, v = p.to(DEV), torch.zeros(n, device=DEV), torch.zeros(n, device=DEV)
+    w = ws(hip.query("oneprot_sumsq_workspace"))
+    for step, gr in enumerate(grads, 1):
+        pr.grad = gr.clone()
+        tn = torch.nn.utils.clip_grad_norm_([pr], 1.0)
+        opt.step()
+        gd = gr.to(DEV)
+        ss = torch.zeros(1, device=DEV)
+        coef, nrm = torch.empty(1, device=DEV), torch.empty(1, device=DEV)
+        hip.call("oneprot_sumsq", gd, n, ss, w)
+        hip.call("oneprot_clip_coef", ss, 1.0, coef, nrm)
+        assert abs(nrm.item() - tn.item()) < 1e-3 * tn.item()
+        hip.call("oneprot_adam_step", pd, gd, m, v, n, 1e-3, 0.9, 0.999, 1e-8, 0.0, step, coef)
+        assert_close(pd.cpu(), pr.detach(), 1e-5, 2e-6, f"adam step {step}")
+
+
+def test_casts():
+    g = torch.Generator().manual_seed(13)
+    x = torch.randn(70, 132, generator=g).to(DEV)
+    y = torch.empty(70, 132, dtype=torch.bfloat16, device=DEV)
+    hip.call("oneprot_cast_f32_to_bf16", x, y, x.numel())
+    assert torch.equal(y, x.to(torch.bfloat16))
+    yt = torch.empty(132, 70, dtype=torch.bfloat16, device=DEV)
+    hip.call("oneprot_transpose_cast_f32_to_bf16", x, yt, 70, 132)
+    assert torch.equal(yt, x.t().contiguous().to(torch.bfloat16))
