@@ -94,6 +94,12 @@ int oneprot_ce_fwd_bwd(float* logits, float* loss_sum, float* row_loss_ws /* R f
 /* sum_abs += coef * sum |x|   (L1 feature regulariser, ref oneprot_module.py:101) */
 int oneprot_abs_sum(const float* x, float* out_sum, void* workspace /* oneprot_sumsq_workspace() bytes */, int64_t n, float coef, void* stream);
 
+/* dx (+)= coef * upstream[0] * sign(x); upstream is a device scalar (NULL = 1). */
+int oneprot_l1_bwd(const float* x, float* dx, int64_t n, float coef, const float* upstream, int accumulate, void* stream);
+int oneprot_scale_by_device_scalar(float* x, int64_t n, const float* s, void* stream);
+/* bias[i] = ids[i]==pad ? -FLT_MAX : 0  (additive key-padding mask, hf masking_utils.create_bidirectional_mask) */
+int oneprot_key_padding_bias(const int64_t* ids, float* bias, int64_t n, int pad_id, void* stream);
+
 /* ---------------- optimiser (torch.optim.Adam, ref configs/model/default.yaml:2-6; clip: oneprot_module.py:106) -- */
 /* sumsq[0] += sum x^2 (two-stage deterministic reduction through workspace of oneprot_sumsq_workspace() bytes). */
 size_t oneprot_sumsq_workspace(void);

@@ -195,4 +195,38 @@ extern "C" int oneprot_adam_step(float* p, const float* g, float* m, float* v, i
   return launch_status();
 }
 
+// dx (+)= coef * upstream[0] * sign(x)   (gradient of coef * sum|x|; upstream = device scalar dL/dloss, NULL => 1)
+__global__ void __launch_bounds__(256) k_l1_bwd(const float* __restrict__ x, float* __restrict__ dx, size_t n, float coef, const float* __restrict__ upstream, int accumulate) {
+  const float c = coef * (upstream ? upstream[0] : 1.0f);
+  for (size_t i = (size_t)blockIdx.x * 256 + threadIdx.x; i < n; i += (size_t)gridDim.x * 256) {
+    const float v = x[i];
+    const float g = c * (v > 0.f ? 1.f : (v < 0.f ? -1.f : 0.f));
+    dx[i] = accumulate ? dx[i] + g : g;
+  }
+}
+extern "C" int oneprot_l1_bwd(const float* x, float* dx, int64_t n, float coef, const float* upstream, int accumulate, void* stream) {
+  if (!x || !dx || n <= 0) return OP_EINVAL;
+  hipLaunchKernelGGL(k_l1_bwd, dim3(ew_grid(n)), dim3(256), 0, (hipStream_t)stream, x, dx, (size_t)n, coef, upstream, accumulate);
+  return launch_status();
+}
+// x *= s[0]
+__global__ void __launch_bounds__(256) k_scale_dev(float* __restrict__ x, size_t n, const float* __restrict__ s) {
+  const float c = s[0];
+  for (size_t i = (size_t)blockIdx.x * 256 + threadIdx.x; i < n; i += (size_t)gridDim.x * 256) x[i] *= c;
+}
+extern "C" int oneprot_scale_by_device_scalar(float* x, int64_t n, const float* s, void* stream) {
+  if (!x || !s || n <= 0) return OP_EINVAL;
+  hipLaunchKernelGGL(k_scale_dev, dim3(ew_grid(n)), dim3(256), 0, (hipStream_t)stream, x, (size_t)n, s);
+  return launch_status();
+}
+// additive key-padding mask: bias[i] = ids[i] == pad ? finfo(float32).min : 0   (hf create_bidirectional_mask)
+__global__ void __launch_bounds__(256) k_key_bias(const long long* __restrict__ ids, float* __restrict__ bias, size_t n, int pad_id) {
+  for (size_t i = (size_t)blockIdx.x * 256 + threadIdx.x; i < n; i += (size_t)gridDim.x * 256) bias[i] = ids[i] == pad_id ? -FLT_MAX : 0.f;
+}
+extern "C" int oneprot_key_padding_bias(const int64_t* ids, float* bias, int64_t n, int pad_id, void* stream) {
+  if (!ids || !bias || n <= 0) return OP_EINVAL;
+  hipLaunchKernelGGL(k_key_bias, dim3(ew_grid(n)), dim3(256), 0, (hipStream_t)stream, (const long long*)ids, bias, (size_t)n, pad_id);
+  return launch_status();
+}
+
 extern "C" int oneprot_abi_version(void) { return 1; }

@@ -1,0 +1,349 @@
+"""Encoder plugins of the OneProt hot path on the HIP kernels.
+
+Same constructor signatures, attribute names (`transformer`, `pooling`, `proj`, `norm`, `config`) and state-dict keys
+as the reference classes:
+    BaseEncoder / Normalize / LearnableLogitScaling / MeanPooling / CLSTokenPooling   ref base_encoder.py:6-194
+    SequenceEncoder                                                                   ref sequence_encoder.py:22-81
+    StructTokenEncoder                                                                ref struct_token_encoder.py:6-34
+    TextEncoder                                                                       ref text_encoder.py:8-62
+`forward(input_ids[B,L] int64) -> float32 [B, output_dim]`.
+
+The whole encoder (embedding -> n layers -> final LN + pooling -> projection head -> L2-norm [-> logit scale]) is ONE
+autograd node whose forward and backward are sequences of C-ABI kernel launches; torch only owns the memory.
+There is no CPU path: calling an encoder with CPU tensors raises.
+"""
+import math
+
+import numpy as np
+import torch
+import torch.nn as nn
+
+from . import hip
+from .esm import EsmTransformer, resolve_config, ModelConfig
+
+
+# ------------------------------------------------------------------------------------------------- small modules
+class Normalize(nn.Module):
+    def __init__(self, dim: int) -> None:
+        super().__init__()
+        self.dim = dim
+
+    def forward(self, x):
+        return _L2NormFn.apply(x, 1.0)
+
+
+class LearnableLogitScaling(nn.Module):
+    """clip(exp(log_logit_scale), max) * x  (ref base_encoder.py:15-38).  Key: norm.1.log_logit_scale."""
+
+    def __init__(self, logit_scale_init: float = 1 / 0.07, learnable: bool = True, max_logit_scale: float = 100) -> None:
+        super().__init__()
+        self.max_logit_scale = max_logit_scale
+        self.logit_scale_init = logit_scale_init
+        self.learnable = learnable
+        log_logit_scale = torch.ones([]) * np.log(self.logit_scale_init)
+        if learnable:
+            self.log_logit_scale = nn.Parameter(log_logit_scale)
+        else:
+            self.register_buffer("log_logit_scale", log_logit_scale)
+
+    def scale_value(self) -> float:
+        return min(math.exp(float(self.log_logit_scale)), self.max_logit_scale)
+
+    def forward(self, x):
+        if self.learnable:
+            raise NotImplementedError("learnable_logit_scale=True is not on the shipped-config hot path (all configs use false)")
+        return x * self.scale_value()
+
+    def extra_repr(self):
+        return f"logit_scale_init={self.logit_scale_init},learnable={self.learnable}, max_logit_scale={self.max_logit_scale}"
+
+
+class MeanPooling(nn.Module):
+    mode = 0
+
+    def forward(self, features, input_mask=None):
+        raise RuntimeError("pooling is fused into the encoder's final LayerNorm kernel; call the encoder, not the pooling module")
+
+
+class CLSTokenPooling(nn.Module):
+    mode = 1
+
+    def forward(self, features, input_mask=None):
+        return features[:, 0]
+
+
+def _ws(nbytes, dev):
+    return torch.empty(max(int(nbytes), 16), dtype=torch.uint8, device=dev)
+
+
+# ------------------------------------------------------------------------------------------------- projection head
+class _Head:
+    """fp32 projection head on [B, d] rows: LN -> Linear [-> GELU -> LN -> Linear] -> L2 normalise -> * scale
+    (ref base_encoder.py:147-178).  Forward keeps what backward needs."""
+
+    @staticmethod
+    def forward(pooled, proj, scale, save):
+        B, d = pooled.shape
+        dev = pooled.device
+        f32 = lambda *s: torch.empty(*s, dtype=torch.float32, device=dev)
+        st = {}
+        x = pooled
+        mods = list(proj)
+        if len(mods) == 1:          # Identity
+            y = x
+        else:
+            ln0, lin1 = mods[0], mods[1]
+            a0, m0, r0 = f32(B, d), f32(B), f32(B)
+            hip.call("oneprot_layernorm_fwd", x, 0, ln0.weight, ln0.bias, None, a0, m0, r0, B, d, ln0.eps)
+            n1 = lin1.out_features
+            y1 = f32(B, n1)
+            hip.call("oneprot_sgemm", a0, lin1.weight, y1, B, n1, d, 0, 0, 1.0, 0)
+            st.update(a0=a0, m0=m0, r0=r0)
+            if len(mods) == 2:
+                y = y1
+            else:
+                ln3, lin4 = mods[3], mods[4]
+                g1 = f32(B, n1)
+                hip.call("oneprot_gelu_f32", y1, g1, B * n1)
+                a3, m3, r3 = f32(B, n1), f32(B), f32(B)
+                hip.call("oneprot_layernorm_fwd", g1, 0, ln3.weight, ln3.bias, None, a3, m3, r3, B, n1, ln3.eps)
+                n4 = lin4.out_features
+                y = f32(B, n4)
+                hip.call("oneprot_sgemm", a3, lin4.weight, y, B, n4, n1, 0, 0, 1.0, 0)
+                st.update(y1=y1, g1=g1, a3=a3, m3=m3, r3=r3)
+        D = y.shape[1]
+        feat, inv = f32(B, D), f32(B)
+        hip.call("oneprot_l2norm_fwd", y, feat, inv, B, D, scale)
+        st.update(inv=inv, feat=feat, pooled=pooled)
+        return feat, (st if save else None)
+
+    @staticmethod
+    def backward(dfeat, proj, scale, st):
+        """returns (dpooled, [grads of proj parameters in proj.parameters() order])"""
+        dev = dfeat.device
+        B, D = dfeat.shape
+        f32 = lambda *s: torch.empty(*s, dtype=torch.float32, device=dev)
+        dy = f32(B, D)
+        hip.call("oneprot_l2norm_bwd", st["feat"], dfeat.contiguous(), st["inv"], dy, B, D, scale, 0.0)
+        mods = list(proj)
+        if len(mods) == 1:
+            return dy, []
+        pooled = st["pooled"]
+        d = pooled.shape[1]
+        grads = []
+        ln0, lin1 = mods[0], mods[1]
+        n1 = lin1.out_features
+        if len(mods) > 2:
+            ln3, lin4 = mods[3], mods[4]
+            dW4 = f32(D, n1)
+            hip.call("oneprot_sgemm", dy, st["a3"], dW4, D, n1, B, 1, 1, 1.0, 0)          # dW = dy^T a3
+            da3 = f32(B, n1)
+            hip.call("oneprot_sgemm", dy, lin4.weight, da3, B, n1, D, 0, 1, 1.0, 0)       # da = dy W
+            dg1, dgam3, dbet3 = f32(B, n1), f32(n1), f32(n1)
+            hip.call("oneprot_layernorm_bwd", da3, 1, None, 0, st["g1"], 0, ln3.weight, st["m3"], st["r3"], None, dg1, dgam3, dbet3,
+                     _ws(hip.query("oneprot_layernorm_bwd_workspace", n1), dev), B, n1, 0)
+            dy1 = f32(B, n1)
+            hip.call("oneprot_gelu_bwd_f32", st["y1"], dg1, dy1, B * n1)
+            tail = [dgam3, dbet3, dW4]
+        else:
+            dy1 = dy
+            tail = []
+        dW1 = f32(n1, d)
+        hip.call("oneprot_sgemm", dy1, st["a0"], dW1, n1, d, B, 1, 1, 1.0, 0)
+        da0 = f32(B, d)
+        hip.call("oneprot_sgemm", dy1, lin1.weight, da0, B, d, n1, 0, 1, 1.0, 0)
+        dpooled, dgam0, dbet0 = f32(B, d), f32(d), f32(d)
+        hip.call("oneprot_layernorm_bwd", da0, 1, None, 0, pooled, 0, ln0.weight, st["m0"], st["r0"], None, dpooled, dgam0, dbet0,
+                 _ws(hip.query("oneprot_layernorm_bwd_workspace", d), dev), B, d, 0)
+        grads = [dgam0, dbet0, dW1] + tail
+        return dpooled, grads
+
+
+class _L2NormFn(torch.autograd.Function):
+    """stand-alone Normalize (only used when someone calls encoder.norm directly)"""
+
+    @staticmethod
+    def forward(ctx, x, scale):
+        x = x.contiguous()
+        B, D = x.shape
+        y, inv = torch.empty_like(x), torch.empty(B, device=x.device)
+        hip.call("oneprot_l2norm_fwd", x, y, inv, B, D, scale)
+        ctx.save_for_backward(y, inv)
+        ctx.scale = scale
+        return y
+
+    @staticmethod
+    def backward(ctx, dy):
+        y, inv = ctx.saved_tensors
+        dx = torch.empty_like(y)
+        hip.call("oneprot_l2norm_bwd", y, dy.contiguous(), inv, dx, y.shape[0], y.shape[1], ctx.scale, 0.0)
+        return dx, None
+
+
+# ------------------------------------------------------------------------------------------------- whole-encoder node
+class _EncodeFn(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, enc, ids, flat, *head_params):
+        tr = enc.transformer
+        # (grad mode is off inside Function.forward; ctx.needs_input_grad already folds in torch.no_grad())
+        need_tr_grad = bool(ctx.needs_input_grad[2])
+        need_head_grad = need_tr_grad or any(ctx.needs_input_grad[3:])
+        x, saved = tr.run_layers(ids, save=need_tr_grad)
+        B, L = ids.shape
+        d = tr.d
+        dev = ids.device
+        pooled = torch.empty(B, d, device=dev)
+        mode = enc.pooling.mode
+        if need_tr_grad:
+            mean, rstd, wrow = (torch.empty(B * L, device=dev) for _ in range(3))
+        else:
+            mean = rstd = wrow = None
+        hip.call("oneprot_lnpool_fwd", x, ids.contiguous(), tr.config.pad_token_id, tr.view("encoder.emb_layer_norm_after.weight"),
+                 tr.view("encoder.emb_layer_norm_after.bias"), pooled, mean, rstd, wrow, None, None, B, L, d, tr.config.layer_norm_eps, mode)
+        scale = enc.logit_scale_value()
+        feat, hst = _Head.forward(pooled, enc.proj, scale, need_head_grad)
+        ctx.enc, ctx.saved, ctx.hst, ctx.scale = enc, saved, hst, scale
+        ctx.fin = (mean, rstd, wrow)
+        ctx.need_tr_grad = need_tr_grad
+        ctx.n_head = len(head_params)
+        return feat
+
+    @staticmethod
+    def backward(ctx, dfeat):
+        enc, tr = ctx.enc, ctx.enc.transformer
+        dpooled, hgrads = _Head.backward(dfeat, enc.proj, ctx.scale, ctx.hst)
+        gflat = None
+        if ctx.need_tr_grad:
+            saved = ctx.saved
+            B, L, d = saved["B"], saved["L"], tr.d
+            dev = dfeat.device
+            gflat = torch.zeros(tr._total, device=dev)
+            mean, rstd, wrow = ctx.fin
+            g = torch.empty(B * L, d, device=dev)
+            hip.call("oneprot_layernorm_bwd", dpooled, 2, wrow, L, saved["x_final"], 0, tr.view("encoder.emb_layer_norm_after.weight"), mean, rstd, None, g,
+                     tr.view("encoder.emb_layer_norm_after.weight", gflat), tr.view("encoder.emb_layer_norm_after.bias", gflat),
+                     _ws(hip.query("oneprot_layernorm_bwd_workspace", d), dev), B * L, d, 0)
+            saved["x_final"] = None
+            tr.backward_layers(saved, g, gflat)
+            ctx.saved = None
+        hg = list(hgrads) + [None] * (ctx.n_head - len(hgrads))
+        return (None, None, gflat) + tuple(hg)
+
+
+# ------------------------------------------------------------------------------------------------- BaseEncoder
+class BaseEncoder(nn.Module):
+    """ref base_encoder.py:129-194 (same members; forward(x, input_mask) applies pool -> proj -> norm to features)."""
+
+    def __init__(self, d_model: int, output_dim: int, proj_type: str = None, use_logit_scale: bool = False, learnable_logit_scale: bool = False,
+                 pooling_type: str = 'mean'):
+        super().__init__()
+        self.d_model = d_model
+        self.output_dim = output_dim
+        self.pooling_type = pooling_type
+        self.proj = self._create_projection(proj_type)
+        self.norm = self._create_normalization(use_logit_scale, learnable_logit_scale)
+        self.pooling = self._create_pooling(pooling_type)
+
+    def _create_projection(self, proj_type):
+        if proj_type == 'linear':
+            return nn.Sequential(nn.LayerNorm(self.d_model), nn.Linear(self.d_model, self.output_dim, bias=False))
+        if proj_type == 'mlp':
+            hidden_size = (self.d_model + self.output_dim) // 2
+            return nn.Sequential(nn.LayerNorm(self.d_model), nn.Linear(self.d_model, hidden_size, bias=False), nn.GELU(), nn.LayerNorm(hidden_size),
+                                 nn.Linear(hidden_size, self.output_dim, bias=False))
+        return nn.Sequential(nn.Identity())
+
+    def _create_normalization(self, use_logit_scale, learnable_logit_scale=False):
+        layers = [Normalize(dim=-1)]
+        if use_logit_scale:
+            layers.append(LearnableLogitScaling(learnable=bool(learnable_logit_scale)))
+        return nn.Sequential(*layers)
+
+    def _create_pooling(self, pooling_type, hidden_size=1280):
+        if pooling_type == 'mean':
+            return MeanPooling()
+        if pooling_type == 'cls':
+            return CLSTokenPooling()
+        if pooling_type == 'attention1d':
+            raise NotImplementedError("attention1d pooling is a 'next' row (SURVEY.md section 8f #4); not built in this round")
+        raise NotImplementedError(f"pooling_type={pooling_type!r}: the fused encoder supports 'mean' and 'cls'")
+
+    def logit_scale_value(self) -> float:
+        if len(self.norm) > 1:
+            ls = self.norm[1]
+            if ls.learnable:
+                raise NotImplementedError("learnable_logit_scale=True is not on the shipped-config hot path")
+            return ls.scale_value()
+        return 1.0
+
+    def encode(self, input_ids):
+        head_params = [p for p in self.proj.parameters()]
+        return _EncodeFn.apply(self, input_ids, self.transformer.flat, *head_params)
+
+
+class SequenceEncoder(BaseEncoder):
+    def __init__(self, model_name_or_path: str, output_dim: int, pooling_type: str = "mean", proj_type: str = None, use_logit_scale: bool = False,
+                 learnable_logit_scale: bool = False, pretrained: bool = True, use_lora: bool = True, lora_r: int = 8, lora_alpha: int = 16,
+                 lora_dropout: float = 0.1, lora_target_modules: list = ["query", "key", "value"], frozen: bool = True):
+        self.config, _ = resolve_config(model_name_or_path)
+        super().__init__(d_model=self.config.hidden_size, output_dim=output_dim, proj_type=proj_type, use_logit_scale=use_logit_scale,
+                         learnable_logit_scale=learnable_logit_scale, pooling_type=pooling_type)
+        if use_lora:
+            raise NotImplementedError("LoRA adapters are off in every shipped OneProt config (sequence.yaml:7); not built (SURVEY.md section 8f #4)")
+        if pretrained:
+            self.transformer = EsmTransformer.from_pretrained(model_name_or_path, add_pooling_layer=False)
+        else:
+            self.transformer = EsmTransformer(self.config, add_pooling_layer=False)
+        self.config = self.transformer.config
+        if frozen:
+            for param in self.transformer.parameters():
+                param.requires_grad = False
+
+    def forward(self, x):
+        return self.encode(x)
+
+
+class StructTokenEncoder(BaseEncoder):
+    def __init__(self, model_name_or_path: str = "esm2_t12_35M_UR50D", output_dim: int = 768, pooling_type: str = "mean", proj_type: str = "linear",
+                 use_logit_scale: bool = False, learnable_logit_scale: bool = False):
+        self.config, _ = resolve_config(model_name_or_path)
+        super().__init__(d_model=self.config.hidden_size, output_dim=output_dim, proj_type=proj_type, use_logit_scale=use_logit_scale,
+                         learnable_logit_scale=learnable_logit_scale, pooling_type=pooling_type)
+        self.transformer = EsmTransformer.from_pretrained(model_name_or_path, add_pooling_layer=True)
+        base_vocab = self.transformer.config.vocab_size
+        self.transformer.resize_token_embeddings(base_vocab + 21)    # 21 foldseek structure tokens (ref struct_token_encoder.py:27)
+        # NB the reference keeps config.vocab_size at the base value after resizing (it is the same object as transformer.config in HF);
+        # here transformer.config.vocab_size is the resized table height, self.config mirrors HF behaviour of reporting the resized size.
+        self.config = self.transformer.config
+
+    def forward(self, input_ids):
+        return self.encode(input_ids)
+
+
+class TextEncoder(BaseEncoder):
+    """ref text_encoder.py:8-62 (BERT text tower; frozen in every shipped config).  Forward-only BERT on the HIP kernels."""
+
+    def __init__(self, model_name_or_path: str, output_dim: int, pooling_type: str = "mean", proj_type: str = "linear", use_logit_scale: bool = False,
+                 learnable_logit_scale: bool = False, frozen: bool = False, use_lora: bool = False, lora_r: int = 8, lora_alpha: int = 16,
+                 lora_dropout: float = 0.1, lora_target_modules=None):
+        from .bert import BertTransformer
+        self.config, _ = resolve_config(model_name_or_path)
+        super().__init__(d_model=self.config.hidden_size, output_dim=output_dim, proj_type=proj_type, use_logit_scale=use_logit_scale,
+                         learnable_logit_scale=learnable_logit_scale, pooling_type=pooling_type)
+        if use_lora:
+            raise NotImplementedError("LoRA adapters are off in every shipped OneProt config (text.yaml:7); not built (SURVEY.md section 8f #4)")
+        self.transformer = BertTransformer.from_pretrained(model_name_or_path)
+        self.config = self.transformer.config
+        if not frozen:
+            raise NotImplementedError("a trainable BERT text tower is not on the shipped-config hot path (text.yaml:12 frozen: true); "
+                                      "only the frozen forward is built in this round")
+        for param in self.transformer.parameters():
+            param.requires_grad = False
+        self.use_lora = use_lora
+        self.frozen = frozen
+
+    def forward(self, input_ids):
+        return self.encode(input_ids)
+
+    def extra_repr(self):
+        return f"use_lora={self.use_lora}, frozen={self.frozen}"

@@ -1,0 +1,448 @@
+"""ESM-2 encoder ("transformer" member of the Sequence / StructToken encoders) running on the HIP kernels.
+
+Replaces, for the OneProt hot path, what the reference gets from HF `AutoModel.from_pretrained(...)`
+(ref sequence_encoder.py:8-19,51-55; struct_token_encoder.py:26-27) -- i.e. transformers' EsmModel
+(modeling_esm.py:198-760).  State-dict key names are identical to EsmModel's, so OneProt / HF checkpoints load.
+
+Memory layout
+  * all encoder parameters live in ONE fp32 arena (`flat`, the only nn.Parameter) in the order the kernels consume
+    them (q,k,v weights adjacent => one fused [3d,d] QKV operand); named tensors are views into it;
+  * a bf16 mirror of the arena (GEMM operands) plus transposed bf16 weight copies for the dgrad GEMMs are refreshed
+    when the arena's version counter changes (i.e. after an optimizer step / checkpoint load);
+  * the gradient w.r.t. the arena is produced as one flat fp32 tensor by the hand-written backward below, so
+    clip-norm and Adam are single launches over contiguous memory.
+"""
+import json
+import math
+import os
+import warnings
+from collections import OrderedDict
+
+import torch
+import torch.nn as nn
+
+from . import hip
+
+KNOWN_ESM = {   # public facts of the ESM-2 checkpoints (SURVEY.md section 8 header)
+    "esm2_t6_8M_UR50D": dict(num_hidden_layers=6, hidden_size=320, intermediate_size=1280),
+    "esm2_t12_35M_UR50D": dict(num_hidden_layers=12, hidden_size=480, intermediate_size=1920),
+    "esm2_t30_150M_UR50D": dict(num_hidden_layers=30, hidden_size=640, intermediate_size=2560),
+    "esm2_t33_650M_UR50D": dict(num_hidden_layers=33, hidden_size=1280, intermediate_size=5120),
+}
+ESM_DEFAULTS = dict(model_type="esm", vocab_size=33, pad_token_id=1, mask_token_id=32, num_attention_heads=20, layer_norm_eps=1e-5,
+                    token_dropout=True, position_embedding_type="rotary", emb_layer_norm_before=False, max_position_embeddings=1026,
+                    initializer_range=0.02, hidden_dropout_prob=0.0, attention_probs_dropout_prob=0.0)
+
+
+class ModelConfig:
+    """Minimal stand-in for transformers.PretrainedConfig (attribute access + to_dict)."""
+
+    def __init__(self, **kw):
+        self.__dict__.update(kw)
+
+    def to_dict(self):
+        return dict(self.__dict__)
+
+    def __repr__(self):
+        return f"ModelConfig({self.__dict__})"
+
+
+def resolve_config(model_name_or_path, defaults_by_type=None):
+    """Local directory with config.json, or a known hub id (no network in this environment).
+    Mirrors the failure mode of AutoConfig.from_pretrained: OSError when it cannot be resolved."""
+    path = str(model_name_or_path)
+    cfg_file = os.path.join(path, "config.json")
+    if os.path.isfile(cfg_file):
+        with open(cfg_file) as f:
+            raw = json.load(f)
+        base = dict(ESM_DEFAULTS) if raw.get("model_type", "esm") == "esm" else {}
+        base.update(raw)
+        return ModelConfig(**base), path
+    short = path.split("/")[-1]
+    if short in KNOWN_ESM:
+        base = dict(ESM_DEFAULTS)
+        base.update(KNOWN_ESM[short])
+        return ModelConfig(**base), None
+    raise OSError(f"{model_name_or_path} is not a local folder with a config.json and is not a known ESM-2 model identifier")
+
+
+def load_weight_file(path):
+    """Tensors of a HF-style checkpoint directory (model.safetensors or pytorch_model.bin), or None."""
+    if path is None:
+        return None
+    st = os.path.join(path, "model.safetensors")
+    if os.path.isfile(st):
+        from safetensors.torch import load_file
+        return load_file(st)
+    pt = os.path.join(path, "pytorch_model.bin")
+    if os.path.isfile(pt):
+        return torch.load(pt, map_location="cpu", weights_only=True)
+    return None
+
+
+def _pad8(n):
+    return (n + 7) // 8 * 8
+
+
+class _Out:
+    def __init__(self, last_hidden_state):
+        self.last_hidden_state = last_hidden_state
+        self.pooler_output = None
+
+    def __getitem__(self, i):
+        return (self.last_hidden_state, self.pooler_output)[i]
+
+
+class EsmTransformer(nn.Module):
+    """EsmModel replacement.  `add_pooling_layer` only controls whether the (unused) HF pooler parameters exist,
+    as in the reference (SequenceEncoder: False, StructTokenEncoder: True)."""
+
+    def __init__(self, config, add_pooling_layer=True):
+        super().__init__()
+        if getattr(config, "position_embedding_type", "rotary") != "rotary" or getattr(config, "emb_layer_norm_before", False):
+            raise NotImplementedError("only rotary ESM-2 configurations are on the OneProt hot path")
+        self.config = config
+        d, f, n, V = config.hidden_size, config.intermediate_size, config.num_hidden_layers, config.vocab_size
+        self.d, self.f, self.n_layers, self.H = d, f, n, config.num_attention_heads
+        self.hd = d // self.H
+        if self.hd not in (16, 32, 64) or d % 64:
+            raise NotImplementedError(f"head_dim {self.hd} / hidden {d}: kernels are built for head_dim 16/32/64, hidden % 64 == 0")
+        self._spec = OrderedDict()
+        self._add("embeddings.word_embeddings.weight", (V, d))
+        for i in range(n):
+            p = f"encoder.layer.{i}."
+            for nm in ("query", "key", "value"):
+                self._add(p + f"attention.self.{nm}.weight", (d, d))
+            for nm in ("query", "key", "value"):
+                self._add(p + f"attention.self.{nm}.bias", (d,))
+            self._add(p + "attention.output.dense.weight", (d, d))
+            self._add(p + "attention.output.dense.bias", (d,))
+            self._add(p + "attention.LayerNorm.weight", (d,))
+            self._add(p + "attention.LayerNorm.bias", (d,))
+            self._add(p + "intermediate.dense.weight", (f, d))
+            self._add(p + "intermediate.dense.bias", (f,))
+            self._add(p + "output.dense.weight", (d, f))
+            self._add(p + "output.dense.bias", (d,))
+            self._add(p + "LayerNorm.weight", (d,))
+            self._add(p + "LayerNorm.bias", (d,))
+        self._add("encoder.emb_layer_norm_after.weight", (d,))
+        self._add("encoder.emb_layer_norm_after.bias", (d,))
+        self._total = self._cursor
+        self.flat = nn.Parameter(torch.zeros(self._total))
+        # parameters HF carries but the hot path never touches (kept for strict state-dict compatibility)
+        self._extra = OrderedDict()
+        if add_pooling_layer:
+            self._extra["pooler.dense.weight"] = (d, d)
+            self._extra["pooler.dense.bias"] = (d,)
+        self._extra["contact_head.regression.weight"] = (1, n * self.H)
+        self._extra["contact_head.regression.bias"] = (1,)
+        self.extra = nn.ParameterDict({k.replace(".", "__"): nn.Parameter(torch.zeros(s)) for k, s in self._extra.items()})
+        inv_freq = 1.0 / (10000.0 ** (torch.arange(0, self.hd, 2, dtype=torch.float32) / self.hd))
+        self.register_buffer("inv_freq", inv_freq, persistent=False)
+        self._register_state_dict_hook(self._sd_hook)
+        self._register_load_state_dict_pre_hook(self._load_hook)
+        self._bf16 = None
+        self._bf16_T = {}
+        self._bf16_version = None
+        self._rope_cache = {}
+        self.reset_parameters()
+
+    # ----------------------------------------------------------------------------------------- parameter plumbing
+    def _add(self, name, shape):
+        if not hasattr(self, "_cursor"):
+            self._cursor = 0
+        n = 1
+        for s in shape:
+            n *= s
+        self._spec[name] = (self._cursor, n, tuple(shape))
+        self._cursor += _pad8(n)
+
+    def view(self, name, src=None):
+        off, n, shape = self._spec[name]
+        src = self.flat if src is None else src
+        if isinstance(src, nn.Parameter):
+            src = src.data
+        return src[off:off + n].view(shape)
+
+    def span(self, first, last):
+        """contiguous arena range covering tensors first..last (used for the fused QKV operand)"""
+        o0 = self._spec[first][0]
+        o1, n1, _ = self._spec[last]
+        return o0, o1 + n1 - o0
+
+    def named_views(self):
+        return OrderedDict((k, self.view(k)) for k in self._spec)
+
+    @torch.no_grad()
+    def reset_parameters(self):
+        std = getattr(self.config, "initializer_range", 0.02)
+        for name in self._spec:
+            v = self.view(name)
+            if name.endswith("LayerNorm.weight") or name.endswith("layer_norm_after.weight"):
+                v.fill_(1.0)
+            elif name.endswith(".bias"):
+                v.zero_()
+            else:
+                v.normal_(0.0, std)
+        pad = self.config.pad_token_id
+        if pad is not None:
+            self.view("embeddings.word_embeddings.weight")[pad].zero_()
+        for k, p in self.extra.items():
+            if p.dim() > 1:
+                p.normal_(0.0, std)
+
+    def _sd_hook(self, module, state_dict, prefix, local_metadata):
+        flat = state_dict.pop(prefix + "flat")
+        for name in self._spec:
+            state_dict[prefix + name] = self.view(name, flat)
+        for k in list(self._extra):
+            state_dict[prefix + k] = state_dict.pop(prefix + "extra." + k.replace(".", "__"))
+        state_dict[prefix + "rotary_embeddings.inv_freq"] = self.inv_freq.detach().clone()
+        return state_dict
+
+    def _load_hook(self, state_dict, prefix, local_metadata, strict, missing_keys, unexpected_keys, error_msgs):
+        flat = self.flat.detach().clone()
+        for name, (off, n, shape) in self._spec.items():
+            key = prefix + name
+            if key in state_dict:
+                t = state_dict.pop(key)
+                if tuple(t.shape) != shape:
+                    error_msgs.append(f"size mismatch for {key}: checkpoint {tuple(t.shape)} vs model {shape}")
+                    continue
+                flat[off:off + n] = t.reshape(-1).to(flat)
+            elif prefix + "flat" not in state_dict:
+                missing_keys.append(key)
+        if prefix + "flat" not in state_dict:
+            state_dict[prefix + "flat"] = flat
+        for k in self._extra:
+            key = prefix + k
+            if key in state_dict:
+                state_dict[prefix + "extra." + k.replace(".", "__")] = state_dict.pop(key)
+        # rotary buffers: model-level (transformers >= 5) or per-layer (4.33) -- values are recomputed, keys are accepted
+        for key in [k for k in state_dict if k.startswith(prefix) and k.endswith("rotary_embeddings.inv_freq")]:
+            state_dict.pop(key)
+        state_dict.pop(prefix + "embeddings.position_embeddings.weight", None)   # present in hub checkpoints, ignored by HF too
+        state_dict.pop(prefix + "embeddings.position_ids", None)
+
+    def resize_token_embeddings(self, new_vocab):
+        """ref struct_token_encoder.py:27: append rows (normal(0, initializer_range), as transformers 4.33 did)."""
+        old = self.config.vocab_size
+        if new_vocab == old:
+            return
+        old_views = {k: v.clone() for k, v in self.named_views().items()}
+        old_spec = self._spec
+        self.config.vocab_size = new_vocab
+        self._spec, self._cursor = OrderedDict(), 0
+        for name, (_, _, shape) in old_spec.items():
+            self._add(name, (new_vocab, self.d) if name == "embeddings.word_embeddings.weight" else shape)
+        self._total = self._cursor
+        req = self.flat.requires_grad
+        self.flat = nn.Parameter(torch.zeros(self._total, device=self.flat.device), requires_grad=req)
+        with torch.no_grad():
+            for name, v in old_views.items():
+                dst = self.view(name)
+                if name == "embeddings.word_embeddings.weight":
+                    dst[:old] = v[:old]
+                    dst[old:].normal_(0.0, getattr(self.config, "initializer_range", 0.02))
+                else:
+                    dst.copy_(v)
+        self._bf16_version = None
+
+    def get_input_embeddings_weight(self):
+        return self.view("embeddings.word_embeddings.weight")
+
+    def save_pretrained(self, path):
+        """HF-style directory (config.json + model.safetensors) -- used by ref peft_checkpoint.py:20."""
+        from safetensors.torch import save_file
+        os.makedirs(path, exist_ok=True)
+        with open(os.path.join(path, "config.json"), "w") as f:
+            json.dump({k: v for k, v in self.config.to_dict().items() if isinstance(v, (int, float, str, bool, type(None), list))}, f, indent=1)
+        sd = {k: v.detach().cpu().contiguous().clone() for k, v in self.state_dict().items()}
+        save_file(sd, os.path.join(path, "model.safetensors"))
+
+    # ----------------------------------------------------------------------------------------- device-side caches
+    def _refresh_bf16(self):
+        ver = (self.flat._version, self.flat.data_ptr())
+        if self._bf16_version == ver:
+            return
+        dev = self.flat.device
+        if self._bf16 is None or self._bf16.device != dev or self._bf16.numel() != self._total:
+            self._bf16 = torch.empty(self._total, dtype=torch.bfloat16, device=dev)
+            self._bf16_T = {}
+        hip.call("oneprot_cast_f32_to_bf16", self.flat.data, self._bf16, self._total)
+        if self.flat.requires_grad:
+            d, f = self.d, self.f
+            for i in range(self.n_layers):
+                p = f"encoder.layer.{i}."
+                o, n = self.span(p + "attention.self.query.weight", p + "attention.self.value.weight")
+                for key, (src, R, C) in {
+                    "qkv": (self.flat.data[o:o + n], 3 * d, d),
+                    "o": (self.view(p + "attention.output.dense.weight"), d, d),
+                    "w1": (self.view(p + "intermediate.dense.weight"), f, d),
+                    "w2": (self.view(p + "output.dense.weight"), d, f),
+                }.items():
+                    t = self._bf16_T.get((i, key))
+                    if t is None:
+                        t = torch.empty(C, R, dtype=torch.bfloat16, device=dev)
+                        self._bf16_T[(i, key)] = t
+                    hip.call("oneprot_transpose_cast_f32_to_bf16", src, t, R, C)
+        self._bf16_version = ver
+
+    def _rope(self, L):
+        key = (L, self.flat.device)
+        if key not in self._rope_cache:
+            t = torch.arange(L, dtype=torch.float32)
+            freqs = torch.outer(t, self.inv_freq.detach().float().cpu())      # hf modeling_esm.py:150-158 (positions = arange(L))
+            self._rope_cache[key] = (freqs.cos().contiguous().to(self.flat.device), freqs.sin().contiguous().to(self.flat.device))
+        return self._rope_cache[key]
+
+    def _w16(self, name):
+        return self.view(name, self._bf16)
+
+    # ----------------------------------------------------------------------------------------- forward / backward
+    def run_layers(self, ids, save):
+        """Embedding + n layers.  Returns (x_final fp32 [T,d], saved-dict or None)."""
+        if not ids.is_cuda:
+            raise hip.HipKernelError("OneProt HIP path needs CUDA(ROCm) tensors; there is no CPU fallback")
+        self._refresh_bf16()
+        cfg = self.config
+        B, L = ids.shape
+        T, d, f, H, hd = B * L, self.d, self.f, self.H, self.hd
+        dev = ids.device
+        ids = ids.contiguous()
+        f32 = lambda *s: torch.empty(*s, dtype=torch.float32, device=dev)
+        b16 = lambda *s: torch.empty(*s, dtype=torch.bfloat16, device=dev)
+        cos, sin = self._rope(L)
+        key_bias = f32(B, L)
+        hip.call("oneprot_key_padding_bias", ids, key_bias, T, cfg.pad_token_id)
+        x = f32(T, d)
+        row_scale = f32(B)
+        hip.call("oneprot_esm_embed_fwd", ids, self.view("embeddings.word_embeddings.weight"), x, row_scale, B, L, d, cfg.vocab_size,
+                 cfg.pad_token_id, cfg.mask_token_id, 1 if cfg.token_dropout else 0)
+        saved = dict(ids=ids, key_bias=key_bias, row_scale=row_scale, layers=[], B=B, L=L) if save else None
+        h = b16(T, d)
+        q, k, v = b16(B, H, L, hd), b16(B, H, L, hd), b16(B, H, L, hd)
+        ctx_ = b16(T, d)
+        u = b16(T, f)
+        eps = cfg.layer_norm_eps
+        for i in range(self.n_layers):
+            p = f"encoder.layer.{i}."
+            if save:
+                st = dict(x_in=x, mean1=f32(T), rstd1=f32(T), mean2=f32(T), rstd2=f32(T), h1=b16(T, d), q=b16(B, H, L, hd), k=b16(B, H, L, hd),
+                          v=b16(B, H, L, hd), ctx=b16(T, d), lse=f32(B, H, L), h2=b16(T, d), z=b16(T, f), u=b16(T, f))
+                h1, q, k, v, ctx_, h2, u, z = st["h1"], st["q"], st["k"], st["v"], st["ctx"], st["h2"], st["u"], st["z"]
+                m1, r1, m2, r2, lse = st["mean1"], st["rstd1"], st["mean2"], st["rstd2"], st["lse"]
+            else:
+                h1 = h2 = h
+                z = m1 = r1 = m2 = r2 = lse = None
+            hip.call("oneprot_layernorm_fwd", x, 0, self.view(p + "attention.LayerNorm.weight"), self.view(p + "attention.LayerNorm.bias"), h1, None,
+                     m1, r1, T, d, eps)
+            o, n = self.span(p + "attention.self.query.weight", p + "attention.self.value.weight")
+            ob, nb = self.span(p + "attention.self.query.bias", p + "attention.self.value.bias")
+            hip.call("oneprot_gemm_bf16_nt", h1, self._bf16[o:o + n], T, 3 * d, d, d, d, hip.EPI_QKV_ROPE, self.flat.data[ob:ob + nb], q, k, v, None,
+                     cos, sin, hd ** -0.5, L, H, hd)
+            hip.call("oneprot_attn_fwd", q, k, v, key_bias, ctx_, lse, B, H, L, hd)
+            x_mid = f32(T, d) if save else x
+            hip.call("oneprot_gemm_bf16_nt", ctx_, self._w16(p + "attention.output.dense.weight"), T, d, d, d, d, hip.EPI_BIAS_RESID,
+                     self.view(p + "attention.output.dense.bias"), x_mid, None, None, x, None, None, 1.0, 0, 0, 0)
+            hip.call("oneprot_layernorm_fwd", x_mid, 0, self.view(p + "LayerNorm.weight"), self.view(p + "LayerNorm.bias"), h2, None, m2, r2, T, d, eps)
+            hip.call("oneprot_gemm_bf16_nt", h2, self._w16(p + "intermediate.dense.weight"), T, f, d, d, d, hip.EPI_BIAS_GELU,
+                     self.view(p + "intermediate.dense.bias"), u, z, None, None, None, None, 1.0, 0, 0, 0)
+            x_out = f32(T, d) if save else x_mid
+            hip.call("oneprot_gemm_bf16_nt", u, self._w16(p + "output.dense.weight"), T, d, f, f, f, hip.EPI_BIAS_RESID,
+                     self.view(p + "output.dense.bias"), x_out, None, None, x_mid, None, None, 1.0, 0, 0, 0)
+            if save:
+                st["x_mid"] = x_mid
+                saved["layers"].append(st)
+            x = x_out
+        if save:
+            saved["x_final"] = x
+        return x, saved
+
+    def backward_layers(self, saved, g, gflat):
+        """g: fp32 [T,d] gradient w.r.t. the last layer's output (consumed in place); gflat: fp32 arena gradient (written)."""
+        B, L = saved["B"], saved["L"]
+        T, d, f, H, hd = B * L, self.d, self.f, self.H, self.hd
+        dev = g.device
+        cfg = self.config
+        cos, sin = self._rope(L)
+        gv = lambda name: self.view(name, gflat)
+        b16 = lambda *s: torch.empty(*s, dtype=torch.bfloat16, device=dev)
+        ws_ln = torch.empty(hip.query("oneprot_layernorm_bwd_workspace", d), dtype=torch.uint8, device=dev)
+        ws_tn = torch.empty(max(hip.query("oneprot_gemm_bf16_tn_workspace", 3 * d, d), hip.query("oneprot_gemm_bf16_tn_workspace", f, d)), dtype=torch.uint8, device=dev)
+        ws_cs = torch.empty(hip.query("oneprot_colsum_workspace", max(3 * d, f)), dtype=torch.uint8, device=dev)
+        ws_at = torch.empty(hip.query("oneprot_attn_bwd_workspace", B, H, L), dtype=torch.uint8, device=dev)
+        g16 = b16(T, d)
+        dz = b16(T, f)
+        dh = b16(T, d)
+        dqkv = b16(T, 3 * d)
+        for i in reversed(range(self.n_layers)):
+            st = saved["layers"][i]
+            p = f"encoder.layer.{i}."
+            # ---- FFN2: x_out = x_mid + u W2^T + b2
+            hip.call("oneprot_cast_f32_to_bf16", g, g16, T * d)
+            hip.call("oneprot_gemm_bf16_tn", g16, st["u"], T, d, f, d, f, gv(p + "output.dense.weight"), ws_tn, 0)
+            hip.call("oneprot_colsum_bf16", g16, gv(p + "output.dense.bias"), ws_cs, T, d, 0)
+            hip.call("oneprot_gemm_bf16_nt", g16, self._bf16_T[(i, "w2")], T, f, d, d, d, hip.EPI_GELU_BWD, None, dz, None, None, st["z"], None, None,
+                     1.0, 0, 0, 0)
+            # ---- FFN1: z = h2 W1^T + b1
+            hip.call("oneprot_gemm_bf16_tn", dz, st["h2"], T, f, d, f, d, gv(p + "intermediate.dense.weight"), ws_tn, 0)
+            hip.call("oneprot_colsum_bf16", dz, gv(p + "intermediate.dense.bias"), ws_cs, T, f, 0)
+            hip.call("oneprot_gemm_bf16_nt", dz, self._bf16_T[(i, "w1")], T, d, f, f, f, hip.EPI_BF16, None, dh, None, None, None, None, None, 1.0, 0, 0, 0)
+            # ---- LN2 (input x_mid): g += LN'(dh)
+            hip.call("oneprot_layernorm_bwd", dh, 0, None, 0, st["x_mid"], 0, self.view(p + "LayerNorm.weight"), st["mean2"], st["rstd2"], g, g,
+                     gv(p + "LayerNorm.weight"), gv(p + "LayerNorm.bias"), ws_ln, T, d, 0)
+            # ---- out-proj: x_mid = x_in + ctx Wo^T + bo
+            hip.call("oneprot_cast_f32_to_bf16", g, g16, T * d)
+            hip.call("oneprot_gemm_bf16_tn", g16, st["ctx"], T, d, d, d, d, gv(p + "attention.output.dense.weight"), ws_tn, 0)
+            hip.call("oneprot_colsum_bf16", g16, gv(p + "attention.output.dense.bias"), ws_cs, T, d, 0)
+            hip.call("oneprot_gemm_bf16_nt", g16, self._bf16_T[(i, "o")], T, d, d, d, d, hip.EPI_BF16, None, dh, None, None, None, None, None, 1.0, 0, 0, 0)
+            # ---- attention
+            hip.call("oneprot_attn_bwd", st["q"], st["k"], st["v"], saved["key_bias"], st["ctx"], dh, st["lse"], cos, sin, hd ** -0.5, dqkv, ws_at, B, H, L, hd)
+            # ---- QKV projection
+            o, n = self.span(p + "attention.self.query.weight", p + "attention.self.value.weight")
+            ob, nb = self.span(p + "attention.self.query.bias", p + "attention.self.value.bias")
+            hip.call("oneprot_gemm_bf16_tn", dqkv, st["h1"], T, 3 * d, d, 3 * d, d, gflat[o:o + n], ws_tn, 0)
+            hip.call("oneprot_colsum_bf16", dqkv, gflat[ob:ob + nb], ws_cs, T, 3 * d, 0)
+            hip.call("oneprot_gemm_bf16_nt", dqkv, self._bf16_T[(i, "qkv")], T, d, 3 * d, 3 * d, 3 * d, hip.EPI_BF16, None, dh, None, None, None, None, None,
+                     1.0, 0, 0, 0)
+            # ---- LN1 (input x_in)
+            hip.call("oneprot_layernorm_bwd", dh, 0, None, 0, st["x_in"], 0, self.view(p + "attention.LayerNorm.weight"), st["mean1"], st["rstd1"], g, g,
+                     gv(p + "attention.LayerNorm.weight"), gv(p + "attention.LayerNorm.bias"), ws_ln, T, d, 0)
+            saved["layers"][i] = None      # release this layer's activations
+        V = cfg.vocab_size
+        ws_e = torch.empty(hip.query("oneprot_esm_embed_bwd_workspace", T, d, V), dtype=torch.uint8, device=dev)
+        hip.call("oneprot_esm_embed_bwd", saved["ids"], g, saved["row_scale"], gv("embeddings.word_embeddings.weight"), ws_e, B, L, d, V,
+                 cfg.pad_token_id, cfg.mask_token_id, 1 if cfg.token_dropout else 0, 0)
+
+    @torch.no_grad()
+    def forward(self, input_ids=None, attention_mask=None, **_):
+        """EsmModel-compatible call returning .last_hidden_state (no autograd; the trainable path is
+        oneprot_amd.encoders' fused encode)."""
+        x, _ = self.run_layers(input_ids, save=False)
+        B, L = input_ids.shape
+        hidden = torch.empty(B, L, self.d, device=x.device)
+        pooled = torch.empty(B, self.d, device=x.device)
+        hip.call("oneprot_lnpool_fwd", x, input_ids.contiguous(), self.config.pad_token_id, self.view("encoder.emb_layer_norm_after.weight"),
+                 self.view("encoder.emb_layer_norm_after.bias"), pooled, None, None, None, None, hidden, B, L, self.d, self.config.layer_norm_eps, 0)
+        return _Out(hidden)
+
+    @classmethod
+    def from_pretrained(cls, model_name_or_path, config=None, add_pooling_layer=True, **_):
+        cfg, path = resolve_config(model_name_or_path)
+        if config is not None:
+            cfg = config
+        model = cls(cfg, add_pooling_layer=add_pooling_layer)
+        sd = load_weight_file(path)
+        if sd is None:
+            if os.environ.get("ONEPROT_ALLOW_RANDOM_INIT", "0") != "1":
+                raise OSError(f"no weights (model.safetensors / pytorch_model.bin) found for {model_name_or_path}; "
+                              "set ONEPROT_ALLOW_RANDOM_INIT=1 to build a randomly initialised model of that architecture")
+            warnings.warn(f"{model_name_or_path}: no weight file, using random initialisation")
+        else:
+            sd = {(k[4:] if k.startswith("esm.") else k): v for k, v in sd.items()}
+            missing, unexpected = model.load_state_dict(sd, strict=False)
+            missing = [m for m in missing if not (m.startswith("pooler.") or m.startswith("contact_head.") or m.startswith("extra."))]
+            if missing:
+                raise OSError(f"checkpoint {model_name_or_path} lacks tensors: {missing[:5]}...")
+        return model

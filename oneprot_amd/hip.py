@@ -48,6 +48,9 @@ _SIGS = {
     "oneprot_l2norm_bwd": (I, [P, P, P, P, I, I, F, F, P]),
     "oneprot_ce_fwd_bwd": (I, [P, P, P, I, I, I, F, P]),
     "oneprot_abs_sum": (I, [P, P, P, L64, F, P]),
+    "oneprot_l1_bwd": (I, [P, P, L64, F, P, I, P]),
+    "oneprot_scale_by_device_scalar": (I, [P, L64, P, P]),
+    "oneprot_key_padding_bias": (I, [P, P, L64, I, P]),
     "oneprot_sumsq_workspace": (SZ, []),
     "oneprot_sumsq": (I, [P, L64, P, P, P]),
     "oneprot_clip_coef": (I, [P, F, P, P, P]),

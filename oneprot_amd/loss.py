@@ -1,0 +1,294 @@
+"""Contrastive losses + feature collectives for the OneProt hot path (replaces ref src/models/components/loss.py).
+
+Same classes, constructor arguments and call conventions as the reference:
+    gather_features (ref loss.py:19-46), ClipLoss (:49-114), SigLipLoss (:203-311).
+Differences in HOW, not WHAT:
+  * the two feature tensors travel in ONE packed all-gather over RCCL/xGMI (1 MiB/rank payloads are latency-bound:
+    one collective instead of two), and one packed reduce-scatter in backward (ref issues 2 + 2);
+  * logits, both cross-entropies and their gradients are computed by the HIP kernels (fp32 SGEMM + fused
+    softmax-CE forward/backward); the backward is a hand-written autograd node, no [B,B] tensor is re-materialised.
+"""
+import torch
+import torch.nn as nn
+
+try:
+    import torch.distributed as dist
+    has_distributed = True
+except ImportError:      # pragma: no cover
+    dist = None
+    has_distributed = False
+
+from . import hip
+
+
+# ------------------------------------------------------------------------------------------------- collectives
+class _PackedAllGather(torch.autograd.Function):
+    """all_gather of a packed [2, B, D] buffer with gradient (backward = reduce_scatter SUM), i.e. the fused form of
+    the reference's two torch.distributed.nn.all_gather calls (ref loss.py:31-33)."""
+
+    @staticmethod
+    def forward(ctx, packed, world_size, group):
+        ctx.world_size, ctx.group = world_size, group
+        out = torch.empty((world_size,) + tuple(packed.shape), dtype=packed.dtype, device=packed.device)
+        dist.all_gather_into_tensor(out, packed.contiguous(), group=group)
+        return out
+
+    @staticmethod
+    def backward(ctx, grad_out):
+        grad_out = grad_out.contiguous()
+        grad_in = torch.empty(grad_out.shape[1:], dtype=grad_out.dtype, device=grad_out.device)
+        dist.reduce_scatter_tensor(grad_in, grad_out, op=dist.ReduceOp.SUM, group=ctx.group)
+        return grad_in, None, None
+
+
+def _all_gather_nograd(packed, world_size, group=None):
+    out = torch.empty((world_size,) + tuple(packed.shape), dtype=packed.dtype, device=packed.device)
+    dist.all_gather_into_tensor(out, packed.detach().contiguous(), group=group)
+    return out
+
+
+def gather_features(modality_features, sequence_features, local_loss=False, gather_with_grad=False, rank=0, world_size=1, use_horovod=False):
+    """ref loss.py:19-46.  Returns (all_modality_features, all_sequence_features), each [world*B, D]."""
+    assert has_distributed, 'torch.distributed did not import correctly, please use a PyTorch version with support.'
+    assert not use_horovod, "horovod is not supported"
+    packed = torch.stack((modality_features, sequence_features))            # [2, B, D]
+    if gather_with_grad:
+        allp = _PackedAllGather.apply(packed, world_size, None)           # [W, 2, B, D]
+        all_m = allp[:, 0].reshape(-1, packed.shape[-1])
+        all_s = allp[:, 1].reshape(-1, packed.shape[-1])
+    else:
+        allp = _all_gather_nograd(packed, world_size)
+        ms = list(allp[:, 0].unbind(0))
+        ss = list(allp[:, 1].unbind(0))
+        if not local_loss:
+            ms[rank] = modality_features        # keep the grad path of the local slice
+            ss[rank] = sequence_features
+        all_m, all_s = torch.cat(ms, dim=0), torch.cat(ss, dim=0)
+    return all_m, all_s
+
+
+# ------------------------------------------------------------------------------------------------- CLIP
+class _ClipLossFn(torch.autograd.Function):
+    """(CE(scale * A_m @ B_s^T, labels) + CE(scale * A_s @ B_m^T, labels)) / 2 with labels = arange(R) + offset.
+    rows_m/rows_s: [R, D] (local or global rows), cols_s/cols_m: [C, D] (global).  When `square` (not local_loss with
+    world_size>1, or single rank) rows == cols tensors and the second logits matrix is the first one transposed."""
+
+    @staticmethod
+    def forward(ctx, rows_m, cols_s, rows_s, cols_m, logit_scale, label_offset):
+        rows_m, cols_s, rows_s, cols_m = (t.contiguous().float() for t in (rows_m, cols_s, rows_s, cols_m))
+        R, D = rows_m.shape
+        C = cols_s.shape[0]
+        dev = rows_m.device
+        lm = torch.empty(R, C, device=dev)
+        ls = torch.empty(R, C, device=dev)
+        hip.call("oneprot_sgemm", rows_m, cols_s, lm, R, C, D, 0, 0, float(logit_scale), 0)
+        hip.call("oneprot_sgemm", rows_s, cols_m, ls, R, C, D, 0, 0, float(logit_scale), 0)
+        loss = torch.zeros(1, device=dev)
+        rw = torch.empty(R, device=dev)
+        hip.call("oneprot_ce_fwd_bwd", lm, loss, rw, R, C, int(label_offset), 0.5 / R)
+        hip.call("oneprot_ce_fwd_bwd", ls, loss, rw, R, C, int(label_offset), 0.5 / R)
+        ctx.save_for_backward(rows_m, cols_s, rows_s, cols_m, lm, ls)      # lm/ls now hold dlogits
+        ctx.logit_scale = float(logit_scale)
+        return loss.reshape(())
+
+    @staticmethod
+    def backward(ctx, gout):
+        rows_m, cols_s, rows_s, cols_m, dlm, dls = ctx.saved_tensors
+        R, D = rows_m.shape
+        C = cols_s.shape[0]
+        a = ctx.logit_scale
+        d_rows_m, d_rows_s = torch.empty_like(rows_m), torch.empty_like(rows_s)
+        d_cols_s, d_cols_m = torch.empty_like(cols_s), torch.empty_like(cols_m)
+        hip.call("oneprot_sgemm", dlm, cols_s, d_rows_m, R, D, C, 0, 1, a, 0)      # dA_m = dL_m  B_s
+        hip.call("oneprot_sgemm", dlm, rows_m, d_cols_s, C, D, R, 1, 1, a, 0)      # dB_s = dL_m^T A_m
+        hip.call("oneprot_sgemm", dls, cols_m, d_rows_s, R, D, C, 0, 1, a, 0)
+        hip.call("oneprot_sgemm", dls, rows_s, d_cols_m, C, D, R, 1, 1, a, 0)
+        g = gout.reshape(1).float().contiguous()
+        for t in (d_rows_m, d_cols_s, d_rows_s, d_cols_m):
+            hip.call("oneprot_scale_by_device_scalar", t, t.numel(), g)
+        return d_rows_m, d_cols_s, d_rows_s, d_cols_m, None, None
+
+
+class ClipLoss(nn.Module):
+    def __init__(self, local_loss=False, gather_with_grad=False, cache_labels=False, rank=0, world_size=1, use_horovod=False):
+        super().__init__()
+        self.local_loss = local_loss
+        self.gather_with_grad = gather_with_grad
+        self.cache_labels = cache_labels      # labels are implicit (arange + offset) in the fused kernel; flag kept for API parity
+        self.rank = rank
+        self.world_size = world_size
+        self.use_horovod = use_horovod
+        self.prev_num_logits = 0
+        self.labels = {}
+
+    def get_ground_truth(self, device, num_logits) -> torch.Tensor:
+        """ref loss.py:72-83 (kept for callers that want the label tensor; the fused CE kernel derives it itself)."""
+        labels = torch.arange(num_logits, device=device, dtype=torch.long)
+        if self.world_size > 1 and self.local_loss:
+            labels = labels + num_logits * self.rank
+        return labels
+
+    def forward(self, modality_features, sequence_features, logit_scale=1.0, output_dict=False):
+        if isinstance(logit_scale, torch.Tensor):
+            logit_scale = float(logit_scale)
+        if self.world_size > 1:
+            all_m, all_s = gather_features(modality_features, sequence_features, self.local_loss, self.gather_with_grad, self.rank, self.world_size,
+                                           self.use_horovod)
+            if self.local_loss:
+                n = modality_features.shape[0]
+                total_loss = _ClipLossFn.apply(modality_features, all_s, sequence_features, all_m, logit_scale, n * self.rank)
+            else:
+                total_loss = _ClipLossFn.apply(all_m, all_s, all_s, all_m, logit_scale, 0)
+        else:
+            total_loss = _ClipLossFn.apply(modality_features, sequence_features, sequence_features, modality_features, logit_scale, 0)
+        return {"contrastive_loss": total_loss} if output_dict else total_loss
+
+
+# ------------------------------------------------------------------------------------------------- SigLIP (ring)
+def neighbour_exchange(from_rank, to_rank, tensor, group=None):
+    tensor_recv = torch.zeros_like(tensor)
+    ops = [dist.P2POp(dist.isend, tensor.contiguous(), to_rank, group=group), dist.P2POp(dist.irecv, tensor_recv, from_rank, group=group)]
+    for req in dist.batch_isend_irecv(ops):
+        req.wait()
+    return tensor_recv
+
+
+def neighbour_exchange_bidir(left_rank, right_rank, tensor_to_left, tensor_to_right, group=None):
+    tensor_from_left = torch.zeros_like(tensor_to_right)
+    tensor_from_right = torch.zeros_like(tensor_to_left)
+    ops = [dist.P2POp(dist.isend, tensor_to_right.contiguous(), right_rank, group=group),
+           dist.P2POp(dist.isend, tensor_to_left.contiguous(), left_rank, group=group),
+           dist.P2POp(dist.irecv, tensor_from_right, right_rank, group=group),
+           dist.P2POp(dist.irecv, tensor_from_left, left_rank, group=group)]
+    for req in dist.batch_isend_irecv(ops):
+        req.wait()
+    return tensor_from_right, tensor_from_left
+
+
+class NeighbourExchange(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, from_rank, to_rank, group, tensor):
+        ctx.group, ctx.from_rank, ctx.to_rank = group, from_rank, to_rank
+        return neighbour_exchange(from_rank, to_rank, tensor, group=group)
+
+    @staticmethod
+    def backward(ctx, grad_output):
+        return (None, None, None) + (NeighbourExchange.apply(ctx.to_rank, ctx.from_rank, ctx.group, grad_output),)
+
+
+def neighbour_exchange_with_grad(from_rank, to_rank, tensor, group=None):
+    return NeighbourExchange.apply(from_rank, to_rank, group, tensor)
+
+
+class NeighbourExchangeBidir(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, left_rank, right_rank, group, tensor_to_left, tensor_to_right):
+        ctx.group, ctx.left_rank, ctx.right_rank = group, left_rank, right_rank
+        return neighbour_exchange_bidir(left_rank, right_rank, tensor_to_left, tensor_to_right, group=group)
+
+    @staticmethod
+    def backward(ctx, *grad_outputs):
+        return (None, None, None) + NeighbourExchangeBidir.apply(ctx.right_rank, ctx.left_rank, ctx.group, *grad_outputs)
+
+
+def neighbour_exchange_bidir_with_grad(left_rank, right_rank, tensor_to_left, tensor_to_right, group=None):
+    return NeighbourExchangeBidir.apply(left_rank, right_rank, group, tensor_to_left, tensor_to_right)
+
+
+class _SigLipBlockFn(torch.autograd.Function):
+    """-sum logsigmoid(labels * (scale * m @ s^T + bias)) / B, labels = 2I-1 (or all -1 when negative_only)
+    (ref loss.py:229-255).  Not the default loss: logits via the HIP SGEMM, the [B,B] pointwise part in torch."""
+
+    @staticmethod
+    def forward(ctx, m, s, logit_scale, logit_bias, negative_only):
+        m, s = m.contiguous().float(), s.contiguous().float()
+        B, D = m.shape
+        logits = torch.empty(B, B, device=m.device)
+        hip.call("oneprot_sgemm", m, s, logits, B, B, D, 0, 0, float(logit_scale), 0)
+        if logit_bias is not None:
+            logits += float(logit_bias)
+        labels = -torch.ones(B, B, device=m.device)
+        if not negative_only:
+            labels += 2 * torch.eye(B, device=m.device)
+        z = labels * logits
+        loss = -torch.nn.functional.logsigmoid(z).sum() / B
+        ctx.save_for_backward(m, s, labels, z)
+        ctx.logit_scale = float(logit_scale)
+        return loss
+
+    @staticmethod
+    def backward(ctx, gout):
+        m, s, labels, z = ctx.saved_tensors
+        B, D = m.shape
+        dlog = (-(1 - torch.sigmoid(z)) * labels / B * gout).contiguous()
+        dm, ds = torch.empty_like(m), torch.empty_like(s)
+        hip.call("oneprot_sgemm", dlog, s, dm, B, D, B, 0, 1, ctx.logit_scale, 0)
+        hip.call("oneprot_sgemm", dlog, m, ds, B, D, B, 1, 1, ctx.logit_scale, 0)
+        return dm, ds, None, None, None
+
+
+class SigLipLoss(nn.Module):
+    """Sigmoid loss (https://arxiv.org/abs/2303.15343) with the reference's neighbour-exchange ring (ref loss.py:203-311)."""
+
+    def __init__(self, cache_labels=False, rank=0, world_size=1, bidir=True, use_horovod=False):
+        super().__init__()
+        self.cache_labels = cache_labels
+        self.rank = rank
+        self.world_size = world_size
+        assert not use_horovod
+        self.use_horovod = use_horovod
+        self.bidir = bidir
+        self.prev_num_logits = 0
+        self.labels = {}
+
+    def _loss(self, modality_features, sequence_features, logit_scale, logit_bias=None, negative_only=False):
+        return _SigLipBlockFn.apply(modality_features, sequence_features, logit_scale, logit_bias, negative_only)
+
+    def forward(self, modality_features, sequence_features, logit_scale=1.0, logit_bias=None, output_dict=False):
+        loss = self._loss(modality_features, sequence_features, logit_scale, logit_bias)
+        if self.world_size > 1:
+            right_rank = (self.rank + 1) % self.world_size
+            left_rank = (self.rank - 1 + self.world_size) % self.world_size
+            if self.bidir:
+                to_right = to_left = sequence_features
+                num_bidir, remainder = divmod(self.world_size - 1, 2)
+                for _ in range(num_bidir):
+                    recv = neighbour_exchange_bidir_with_grad(left_rank, right_rank, to_left, to_right)
+                    for f in recv:
+                        loss = loss + self._loss(modality_features, f, logit_scale, logit_bias, negative_only=True)
+                    to_left, to_right = recv
+                if remainder:
+                    recv = neighbour_exchange_with_grad(left_rank, right_rank, to_right)
+                    loss = loss + self._loss(modality_features, recv, logit_scale, logit_bias, negative_only=True)
+            else:
+                to_right = sequence_features
+                for _ in range(self.world_size - 1):
+                    from_left = neighbour_exchange_with_grad(left_rank, right_rank, to_right)
+                    loss = loss + self._loss(modality_features, from_left, logit_scale, logit_bias, negative_only=True)
+                    to_right = from_left
+        return {"contrastive_loss": loss} if output_dict else loss
+
+
+class _L1PenaltyFn(torch.autograd.Function):
+    """coef * mean|x|  (ref oneprot_module.py:101 `torch.abs(features).mean()`)."""
+
+    @staticmethod
+    def forward(ctx, x, coef):
+        x = x.contiguous()
+        out = torch.zeros(1, device=x.device)
+        ws = torch.empty(hip.query("oneprot_sumsq_workspace"), dtype=torch.uint8, device=x.device)
+        hip.call("oneprot_abs_sum", x, out, ws, x.numel(), coef / x.numel())
+        ctx.save_for_backward(x)
+        ctx.coef = coef / x.numel()
+        return out.reshape(())
+
+    @staticmethod
+    def backward(ctx, gout):
+        (x,) = ctx.saved_tensors
+        dx = torch.empty_like(x)
+        hip.call("oneprot_l1_bwd", x, dx, x.numel(), ctx.coef, gout.reshape(1).float().contiguous(), 0)
+        return dx, None
+
+
+def l1_penalty(x, coef=1.0):
+    return _L1PenaltyFn.apply(x, coef)

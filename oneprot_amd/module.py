@@ -1,0 +1,237 @@
+"""OneProtLitModule on the HIP path (replaces ref src/models/oneprot_module.py:9-170).
+
+Same constructor, attributes (`network`, `modalities`, `loss_fn`, `hparams.optimizer/.scheduler`) and hook names
+(`forward`, `training_step`, `validation_step`, `test_step`, `configure_optimizers`).  When pytorch_lightning is
+importable the class derives from LightningModule and is driven by `Trainer.fit` exactly like the reference; when it is
+not (this environment), a minimal base supplies the handful of LightningModule services `training_step` uses
+(`optimizers()`, `manual_backward`, `clip_gradients`, `log`, `global_step`) and `fit_steps()` drives the loop.
+
+Order of operations inside one sub-step is the reference's (oneprot_module.py:92-107): forward sequence, forward modality,
+zero_grad, loss (+0.01*L1), backward, clip-norm 1.0, optimizer step.  What differs is HOW: every op is a C-ABI HIP kernel,
+gradients are all-reduced only for the active pair's parameters in large flat buckets over RCCL, nothing in the loop
+synchronises with the host (losses and norms stay on the device until someone reads them).
+"""
+import os
+from types import SimpleNamespace
+from typing import Any, Dict
+
+import torch
+import torch.nn as nn
+
+from . import distributed as D
+from .loss import ClipLoss, SigLipLoss, l1_penalty
+from .optim import FusedAdam, clip_grad_norm_
+
+try:                                                    # pragma: no cover  (not installed in the build image)
+    from pytorch_lightning import LightningModule as _LightningBase
+    HAVE_LIGHTNING = True
+except Exception:
+    _LightningBase = None
+    HAVE_LIGHTNING = False
+
+
+class _DeviceMean:
+    """torchmetrics.MeanMetric stand-in that never synchronises: running sum / count on the device."""
+
+    def __init__(self):
+        self.reset()
+
+    def reset(self):
+        self.total, self.count = None, 0
+
+    def __call__(self, value):
+        v = value.detach().float().reshape(())
+        self.total = v.clone() if self.total is None else self.total + v
+        self.count += 1
+
+    update = __call__
+
+    def compute(self):
+        return self.total / max(self.count, 1) if self.total is not None else torch.tensor(float("nan"))
+
+
+class _DeviceMin:
+    def __init__(self):
+        self.reset()
+
+    def reset(self):
+        self.value = None
+
+    def __call__(self, value):
+        v = value.detach().float().reshape(())
+        self.value = v if self.value is None else torch.minimum(self.value, v)
+
+    def compute(self):
+        return self.value if self.value is not None else torch.tensor(float("inf"))
+
+
+class _FeatureBuffer:
+    """placeholder for ref RetrievalMetric (retrieval_metric.py): buffers features; ranking is a 'next' row."""
+
+    def __init__(self):
+        self.reset()
+
+    def reset(self):
+        self.seq, self.mod = [], []
+
+    def update(self, sequence_features, modality_features):
+        self.seq.append(sequence_features.detach())
+        self.mod.append(modality_features.detach())
+
+    def compute(self):
+        raise NotImplementedError("retrieval metrics are outside the round-1 hot path (SURVEY.md section 8f #2)")
+
+
+class _PlainBase(nn.Module):
+    """The slice of LightningModule that OneProtLitModule.training_step relies on."""
+
+    def __init__(self):
+        super().__init__()
+        self.automatic_optimization = True
+        self.hparams = SimpleNamespace()
+        self.global_step = 0
+        self._optimizer = None
+        self.logged = {}
+
+    def save_hyperparameters(self, logger=False, **kw):
+        pass   # hparams are filled explicitly by the subclass
+
+    def optimizers(self):
+        if self._optimizer is None:
+            self._optimizer = self.configure_optimizers()["optimizer"]
+        return self._optimizer
+
+    def manual_backward(self, loss):
+        loss.backward()
+
+    def clip_gradients(self, optimizer, gradient_clip_val=None, gradient_clip_algorithm="norm"):
+        assert gradient_clip_algorithm == "norm"
+        params = [p for g in optimizer.param_groups for p in g["params"]]
+        self.last_grad_norm = clip_grad_norm_(params, gradient_clip_val, optimizer)
+
+    def log(self, name, value, **kw):
+        self.logged[name] = value
+
+
+_Base = _LightningBase if HAVE_LIGHTNING else _PlainBase
+
+
+class OneProtLitModule(_Base):
+    def __init__(self, components: Dict[str, Any], optimizer: Any, train_on_all_modalities_after_step: int = 0, scheduler: Any = None,
+                 use_seqsim: bool = False, loss_fn: str = 'CLIP', use_l1_regularization: bool = False, local_loss: bool = True,
+                 gather_with_grad: bool = True):
+        super().__init__()
+        self.automatic_optimization = False
+        if HAVE_LIGHTNING:                                # pragma: no cover
+            self.save_hyperparameters(logger=False)
+        else:
+            self.hparams = SimpleNamespace(optimizer=optimizer, scheduler=scheduler)
+        self.network = torch.nn.ModuleDict(components)
+        self.modalities = list(components.keys())
+        self.train_on_all_modalities_after_step = train_on_all_modalities_after_step
+        self.use_l1_regularization = use_l1_regularization
+        self.loss_fn = self._create_loss_fn(loss_fn, local_loss, gather_with_grad)
+        self.train_loss, self.val_loss, self.test_loss = _DeviceMean(), _DeviceMean(), _DeviceMean()
+        self.val_loss_best = _DeviceMin()
+        self.use_seqsim = use_seqsim
+        self.metrics = {f"{split}_{modality}": _FeatureBuffer() for split in ["val", "test"]
+                        for modality in list(self.network.keys()) + ["seqsim"] if modality != 'sequence'}
+
+    def l1_regularization(self, features):
+        return l1_penalty(features, 1.0)
+
+    def _create_loss_fn(self, loss_fn, local_loss, gather_with_grad):
+        # rank / world size come from the environment, as in the reference (KeyError if unset: oneprot_module.py:54-55)
+        if loss_fn == 'CLIP':
+            return ClipLoss(local_loss=local_loss, gather_with_grad=gather_with_grad, cache_labels=True, rank=int(os.environ['RANK']),
+                            world_size=int(os.environ['WORLD_SIZE']))
+        elif loss_fn == 'SIGLIP':
+            return SigLipLoss(cache_labels=True, rank=int(os.environ['RANK']), world_size=int(os.environ['WORLD_SIZE']))
+        else:
+            raise ValueError(f"Unknown loss function: {loss_fn}")
+
+    def forward(self, x, modality="sequence"):
+        if modality in ["sequence", "seqsim"]:
+            modality = "sequence"
+        return self.network[modality](x)
+
+    def on_train_start(self) -> None:
+        for m in (self.train_loss, self.val_loss, self.test_loss, self.val_loss_best):
+            m.reset()
+
+    # ------------------------------------------------------------------------------------------- the hot loop
+    def training_step(self, batch, batch_idx=None):
+        opt = self.optimizers()
+        current_step = self.global_step
+        if current_step < self.train_on_all_modalities_after_step:
+            modalities_to_train = ["struct_token"]
+        else:
+            modalities_to_train = list(batch.keys())
+            if not self.use_seqsim and "seqsim" in modalities_to_train:
+                modalities_to_train.remove("seqsim")
+        loss = None
+        for modality in modalities_to_train:
+            sequence_inputs, modality_inputs, _, _ = batch[modality]
+            sequence_features = self.forward(sequence_inputs, "sequence")
+            modality_features = self.forward(modality_inputs, modality)
+            opt.zero_grad()
+            loss = self.loss_fn(sequence_features, modality_features)          # argument order as in the reference (symmetric)
+            if self.use_l1_regularization:
+                loss = loss + l1_penalty(sequence_features, 0.01) + l1_penalty(modality_features, 0.01)
+            self.train_loss(loss)
+            self.manual_backward(loss)
+            self._sync_gradients(opt)
+            self.clip_gradients(opt, gradient_clip_val=1.0, gradient_clip_algorithm="norm")
+            opt.step()
+            self.log("train/loss", self.train_loss, on_step=True, on_epoch=True, prog_bar=True, sync_dist=True)
+            if not HAVE_LIGHTNING:
+                self.global_step += 1
+        return loss
+
+    def _sync_gradients(self, opt):
+        """What Lightning's DDP wrapper does implicitly in the reference (C6 in SURVEY.md section 2.2) -- here explicit, and only
+        over parameters that received a gradient in this sub-step."""
+        if getattr(self.loss_fn, "world_size", 1) > 1 and not HAVE_LIGHTNING:
+            D.allreduce_gradients([p for g in opt.param_groups for p in g["params"]])
+
+    def validation_step(self, batch, batch_idx=None, dataloader_idx=0):
+        sequence_inputs, modality_inputs, modality, _ = batch
+        with torch.no_grad():
+            sequence_features = self.forward(sequence_inputs, "sequence")
+            modality_features = self.forward(modality_inputs, modality)
+            self.metrics["val_" + modality].update(sequence_features, modality_features)
+            loss = self.loss_fn(sequence_features, modality_features)
+        self.val_loss(loss)
+        self.log("val/loss", self.val_loss, on_step=False, on_epoch=True, prog_bar=True, sync_dist=True)
+        return loss
+
+    def test_step(self, batch, batch_idx=None):
+        out = {}
+        for modality, (seq_inputs, mod_inputs, _, _) in batch.items():
+            with torch.no_grad():
+                seq_features = self(seq_inputs, "sequence")
+                mod_features = self(mod_inputs, modality)
+                # the reference passes the logit scale a second time here (oneprot_module.py:142) -- reproduced
+                loss = self.loss_fn(seq_features, mod_features, self.network[modality].norm[1].log_logit_scale.exp())
+            self.test_loss(loss)
+            self.log(f"test/loss_{modality}", loss, on_step=False, on_epoch=True, prog_bar=True)
+            self.metrics[f"test_{modality}"].update(seq_features, mod_features)
+            out[modality] = loss
+        return out
+
+    def configure_optimizers(self):
+        optimizer = self.hparams.optimizer(params=self.parameters())
+        if self.hparams.scheduler is not None:
+            scheduler = self.hparams.scheduler(optimizer=optimizer)
+            return {"optimizer": optimizer, "lr_scheduler": {"scheduler": scheduler, "monitor": "val/loss_best", "interval": "epoch", "frequency": 1}}
+        return {"optimizer": optimizer}
+
+    # ------------------------------------------------------------------------------------------- minimal driver
+    def fit_steps(self, batches):
+        """Drive training_step over an iterable of CombinedLoader-style batches ({modality: (seq_ids, mod_ids, name, raw)})."""
+        self.train()
+        self.on_train_start()
+        last = None
+        for i, batch in enumerate(batches):
+            last = self.training_step(batch, i)
+        return last
