@@ -96,10 +96,38 @@ def stream():
     return torch.cuda.current_stream().cuda_stream
 
 
+_prof = None     # (entry point, epilogue or None, [(start_event, end_event), ...])
+
+
+def profile_begin(name, epilogue=None):
+    """Bracket every subsequent launch of `name` (optionally: only with this GEMM epilogue id) with HIP events recorded on the
+    launch stream; profile_end() returns the per-launch durations in ms.  Used by bench.py for the live roofline figure."""
+    global _prof
+    _prof = (name, epilogue, [])
+
+
+def profile_end():
+    global _prof
+    if _prof is None:
+        return []
+    torch.cuda.synchronize()
+    out = [a.elapsed_time(b) for a, b in _prof[2]]
+    _prof = None
+    return out
+
+
 def call(name, *args):
     """Invoke an int-returning entry point on the current torch stream; raise on a non-zero status."""
     fn = getattr(lib(), name)
-    rc = fn(*[ptr(a) if isinstance(a, torch.Tensor) or a is None else a for a in args], stream())
+    cargs = [ptr(a) if isinstance(a, torch.Tensor) or a is None else a for a in args]
+    if _prof is not None and _prof[0] == name and (_prof[1] is None or args[7] == _prof[1]):
+        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        e0.record()
+        rc = fn(*cargs, stream())
+        e1.record()
+        _prof[2].append((e0, e1))
+    else:
+        rc = fn(*cargs, stream())
     if rc != 0:
         raise HipKernelError(f"{name} returned {rc} ({'invalid argument' if rc == -1 else 'launch failure'})")
 
