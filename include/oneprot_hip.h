@@ -43,8 +43,8 @@ int oneprot_layernorm_fwd(const void* x, int x_is_bf16, const float* gamma, cons
 size_t oneprot_layernorm_bwd_workspace(int d);
 /* dy_mode 0: bf16 [T,d]; 1: fp32 [T,d]; 2: dy[t] = dpool[t/L] * wrow[t].  dx = (add_to ? add_to : 0) + LN'(dy). */
 int oneprot_layernorm_bwd(const void* dy, int dy_mode, const float* wrow, int L, const void* x, int x_is_bf16, const float* gamma,
-                          const float* mean, const float* rstd, const float* add_to, float* dx, float* dgamma, float* dbeta, void* workspace,
-                          int64_t T, int d, int accumulate_param_grads, void* stream);
+                          const float* mean, const float* rstd, const float* add_to, float* dx, void* dx_bf16 /* optional bf16 copy of dx */,
+                          float* dgamma, float* dbeta, void* workspace, int64_t T, int d, int accumulate_param_grads, void* stream);
 /* final LayerNorm fused with pooling (ref base_encoder.py:109-126): mode 0 masked mean (CLS/EOS included), 1 CLS. */
 int oneprot_lnpool_fwd(const float* x, const int64_t* ids, int pad_id, const float* gamma, const float* beta, float* pooled, float* mean,
                        float* rstd, float* wrow, void* hidden_bf16, float* hidden_f32, int B, int L, int d, float eps, int mode, void* stream);
@@ -62,10 +62,11 @@ enum {
 int oneprot_gemm_bf16_nt(const void* A, const void* Bw, int64_t M, int N, int K, int lda, int ldb, int epilogue, const float* bias,
                          void* out0, void* out1, void* out2, const void* aux, const float* rope_cos, const float* rope_sin, float q_scale,
                          int L, int H, int hd, void* stream);
-/* dW[N,K] (+)= dY[M,N]^T * X[M,K]  (contraction over the M tokens; split over workgroups, fp32 slabs in workspace). */
+/* dW[N,K] (+)= dY[M,N]^T * X[M,K]  (contraction over the M tokens; split over workgroups, fp32 slabs in workspace);
+   dbias[N] (+)= column sums of dY (optional, fused: an all-ones MFMA operand in the k-tile-0 workgroups). */
 size_t oneprot_gemm_bf16_tn_workspace(int N, int K);
-int oneprot_gemm_bf16_tn(const void* dY, const void* X, int64_t M, int N, int K, int ldy, int ldx, float* dW, void* workspace, int accumulate,
-                         void* stream);
+int oneprot_gemm_bf16_tn(const void* dY, const void* X, int64_t M, int N, int K, int ldy, int ldx, float* dW, float* dbias, void* workspace,
+                         int accumulate, void* stream);
 /* fp32 GEMM for the small head / logits contractions (ref base_encoder.py:155,159,164; loss.py:91-99):
    C[M,N] = alpha * op(A) * op(B) (+ C if accumulate);  transA: A stored [K,M]; transB: B stored [K,N] else [N,K]. */
 int oneprot_sgemm(const float* A, const float* B, float* C, int M, int N, int K, int transA, int b_is_kn, float alpha, int accumulate, void* stream);

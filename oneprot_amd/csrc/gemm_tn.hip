@@ -36,7 +36,7 @@ __device__ __forceinline__ bf8_t tn_frag(const unsigned char* tile, int mb, int 
 }
 
 __global__ void __launch_bounds__(256, 2) k_gemm_tn(const bf16_t* __restrict__ dY, const bf16_t* __restrict__ X, int M, int N, int K, int ldy, int ldx,
-                                                    float* __restrict__ slab, int tiles_k, int S, int m_per_split) {
+                                                    float* __restrict__ slab, float* __restrict__ bias_slab, int tiles_k, int S, int m_per_split) {
   extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
   const int tile = blockIdx.x, split = blockIdx.y;
   const int tn = tile / tiles_k, tk = tile - tn * tiles_k;
@@ -82,6 +82,15 @@ __global__ void __launch_bounds__(256, 2) k_gemm_tn(const bf16_t* __restrict__ d
 #pragma unroll
     for (int j = 0; j < 4; ++j) acc[i][j] = (f32x4){0.f, 0.f, 0.f, 0.f};
 
+  // bias gradient db[n] = sum_m dY[m,n]: the k-tile-0 column of workgroups multiplies the dY fragments with an all-ones B operand
+  // (every column of the 16x16 result then holds the row sums) -- 4 extra MFMAs per k-substep instead of a second pass over dY.
+  const bool do_bias = bias_slab != nullptr && tk == 0 && wc == 0;
+  f32x4 accb[4];
+#pragma unroll
+  for (int i = 0; i < 4; ++i) accb[i] = (f32x4){0.f, 0.f, 0.f, 0.f};
+  const u32x4 ones_u = {0x3F803F80u, 0x3F803F80u, 0x3F803F80u, 0x3F803F80u};
+  const bf8_t ones = __builtin_bit_cast(bf8_t, ones_u);
+
   if (nsteps > 0) stage(0, 0);
   for (int t = 0; t < nsteps; ++t) {
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
@@ -101,6 +110,10 @@ __global__ void __launch_bounds__(256, 2) k_gemm_tn(const bf16_t* __restrict__ d
       for (int i = 0; i < 4; ++i)
 #pragma unroll
         for (int j = 0; j < 4; ++j) acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a[i], b[j], acc[i][j], 0, 0, 0);
+      if (do_bias) {
+#pragma unroll
+        for (int i = 0; i < 4; ++i) accb[i] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a[i], ones, accb[i], 0, 0, 0);
+      }
     }
   }
   float* out = slab + (size_t)split * N * K;
@@ -117,6 +130,23 @@ __global__ void __launch_bounds__(256, 2) k_gemm_tn(const bf16_t* __restrict__ d
         if (k < K) out[(size_t)n * K + k] = acc[i][j][r];
       }
     }
+  if (do_bias && fr == 0) {
+#pragma unroll
+    for (int i = 0; i < 4; ++i)
+#pragma unroll
+      for (int r = 0; r < 4; ++r) {
+        const int n = n0 + wr * 64 + i * 16 + fq * 4 + r;
+        if (n < N) bias_slab[(size_t)split * N + n] = accb[i][r];
+      }
+  }
+}
+
+__global__ void __launch_bounds__(256) k_tn_bias_reduce(const float* __restrict__ bias_slab, float* __restrict__ db, int N, int S, int accumulate) {
+  const int n = blockIdx.x * 256 + threadIdx.x;
+  if (n >= N) return;
+  float s = 0.f;
+  for (int p = 0; p < S; ++p) s += bias_slab[(size_t)p * N + n];
+  db[n] = accumulate ? db[n] + s : s;
 }
 
 __global__ void __launch_bounds__(256) k_tn_reduce(const float* __restrict__ slab, float* __restrict__ dW, size_t n4, size_t stride4, int S, int accumulate) {
@@ -143,11 +173,11 @@ static inline int tn_splits(int64_t M, int tiles) {
 extern "C" size_t oneprot_gemm_bf16_tn_workspace(int N, int K) {
   const int tiles = ((N + 127) / 128) * ((K + 127) / 128);
   int S = TN_MAX_SLAB_TILES / tiles; if (S < 1) S = 1; if (S > 64) S = 64;
-  return (size_t)S * N * K * sizeof(float);
+  return (size_t)S * N * K * sizeof(float) + (size_t)S * N * sizeof(float);
 }
 
-extern "C" int oneprot_gemm_bf16_tn(const void* dY, const void* X, int64_t M, int N, int K, int ldy, int ldx, float* dW, void* workspace, int accumulate,
-                                    void* stream) {
+extern "C" int oneprot_gemm_bf16_tn(const void* dY, const void* X, int64_t M, int N, int K, int ldy, int ldx, float* dW, float* dbias, void* workspace,
+                                    int accumulate, void* stream) {
   if (!dY || !X || !dW || !workspace || M <= 0 || N <= 0 || K <= 0 || M > 0x7fffffff) return OP_EINVAL;
   if ((N & 7) || (K & 7) || (ldy & 7) || (ldx & 7) || ldy < N || ldx < K || ((N * (int64_t)K) & 3)) return OP_EINVAL;
   if (((uintptr_t)dY | (uintptr_t)X | (uintptr_t)dW | (uintptr_t)workspace) & 15) return OP_EINVAL;
@@ -161,8 +191,10 @@ extern "C" int oneprot_gemm_bf16_tn(const void* dY, const void* X, int64_t M, in
   int m_per = (int)((M + S - 1) / S);
   m_per = ((m_per + TN_BT - 1) / TN_BT) * TN_BT;
   hipStream_t s = (hipStream_t)stream;
+  float* bias_slab = dbias ? (float*)workspace + (size_t)S * N * K : nullptr;
   hipLaunchKernelGGL(k_gemm_tn, dim3(tiles, S), dim3(256), 2 * TN_STAGE_BYTES, s, (const bf16_t*)dY, (const bf16_t*)X, (int)M, N, K, ldy, ldx,
-                     (float*)workspace, tiles_k, S, m_per);
+                     (float*)workspace, bias_slab, tiles_k, S, m_per);
+  if (dbias) hipLaunchKernelGGL(k_tn_bias_reduce, dim3((N + 255) / 256), dim3(256), 0, s, (const float*)bias_slab, dbias, N, S, accumulate);
   const size_t n4 = ((size_t)N * K) >> 2;
   size_t blocks = (n4 + 255) / 256; if (blocks > 4096) blocks = 4096;
   hipLaunchKernelGGL(k_tn_reduce, dim3((unsigned)blocks), dim3(256), 0, s, (const float*)workspace, dW, n4, n4, S, accumulate);

@@ -123,7 +123,7 @@ extern "C" int oneprot_esm_embed_bwd(const int64_t* ids, const float* dx, const 
 // LayerNorm forward: y = (x - mean) * rstd * gamma + beta   (hf modeling_esm.py:429,518,552; nn.LayerNorm)
 // IN_BF16: input is bf16 instead of fp32.  Outputs: optional bf16 copy and/or fp32 copy, optional mean/rstd.
 // --------------------------------------------------------------------------------------------------------
-template <int IN_BF16>
+template <int IN_BF16, int NV>
 __global__ void __launch_bounds__(256) k_layernorm_fwd(const void* __restrict__ xin, const float* __restrict__ gamma, const float* __restrict__ beta,
                                                        bf16_t* __restrict__ y_bf16, float* __restrict__ y_f32, float* __restrict__ mean_out,
                                                        float* __restrict__ rstd_out, int T, int d, float eps) {
@@ -131,10 +131,10 @@ __global__ void __launch_bounds__(256) k_layernorm_fwd(const void* __restrict__ 
   const int nv4 = d >> 2;
   const float inv_d = 1.0f / (float)d;
   for (int row = blockIdx.x * ROWS_PER_BLOCK + (threadIdx.x >> 6); row < T; row += gridDim.x * ROWS_PER_BLOCK) {
-    float4 v[MAXV];
+    float4 v[NV];
     float s = 0.f;
 #pragma unroll
-    for (int i = 0; i < MAXV; ++i) {
+    for (int i = 0; i < NV; ++i) {
       const int c = lane + 64 * i;
       if (c < nv4) {
         if (IN_BF16) {
@@ -149,7 +149,7 @@ __global__ void __launch_bounds__(256) k_layernorm_fwd(const void* __restrict__ 
     const float mean = wave_sum(s) * inv_d;
     float q = 0.f;
 #pragma unroll
-    for (int i = 0; i < MAXV; ++i) {
+    for (int i = 0; i < NV; ++i) {
       const int c = lane + 64 * i;
       if (c < nv4) {
         const float a = v[i].x - mean, b = v[i].y - mean, cc = v[i].z - mean, dd = v[i].w - mean;
@@ -162,7 +162,7 @@ __global__ void __launch_bounds__(256) k_layernorm_fwd(const void* __restrict__ 
       if (rstd_out) rstd_out[row] = rstd;
     }
 #pragma unroll
-    for (int i = 0; i < MAXV; ++i) {
+    for (int i = 0; i < NV; ++i) {
       const int c = lane + 64 * i;
       if (c < nv4) {
         const float4 g = reinterpret_cast<const float4*>(gamma)[c];
@@ -190,10 +190,12 @@ static inline int ln_grid(int T) {
 extern "C" int oneprot_layernorm_fwd(const void* x, int x_is_bf16, const float* gamma, const float* beta, void* y_bf16, float* y_f32, float* mean,
                                      float* rstd, int64_t T, int d, float eps, void* stream) {
   if (!x || !gamma || !beta || (!y_bf16 && !y_f32) || T <= 0 || d <= 0 || (d & 3) || d > MAXV * 256) return OP_EINVAL;
-  if (x_is_bf16)
-    hipLaunchKernelGGL(k_layernorm_fwd<1>, dim3(ln_grid((int)T)), dim3(256), 0, (hipStream_t)stream, x, gamma, beta, (bf16_t*)y_bf16, y_f32, mean, rstd, (int)T, d, eps);
-  else
-    hipLaunchKernelGGL(k_layernorm_fwd<0>, dim3(ln_grid((int)T)), dim3(256), 0, (hipStream_t)stream, x, gamma, beta, (bf16_t*)y_bf16, y_f32, mean, rstd, (int)T, d, eps);
+  const int nv = (d / 4 + 63) / 64;
+#define LNF(B16, N) hipLaunchKernelGGL((k_layernorm_fwd<B16, N>), dim3(ln_grid((int)T)), dim3(256), 0, (hipStream_t)stream, x, gamma, beta, (bf16_t*)y_bf16, y_f32, mean, rstd, (int)T, d, eps)
+#define LNF_NV(B16) do { if (nv <= 1) LNF(B16, 1); else if (nv == 2) LNF(B16, 2); else if (nv == 3) LNF(B16, 3); else if (nv == 4) LNF(B16, 4); else if (nv == 5) LNF(B16, 5); else LNF(B16, 8); } while (0)
+  if (x_is_bf16) LNF_NV(1); else LNF_NV(0);
+#undef LNF_NV
+#undef LNF
   return launch_status();
 }
 
@@ -204,16 +206,17 @@ extern "C" int oneprot_layernorm_fwd(const void* x, int x_is_bf16, const float* 
 // dx_out = (add_to ? add_to[t] : 0) + dx   (add_to may alias dx_out: residual-gradient accumulation in place)
 // dgamma/dbeta: per-wave register partials over the rows the wave visits -> partial[(block*4+wave)][2][d]
 // --------------------------------------------------------------------------------------------------------
-template <int DY_MODE, int X_BF16>
+template <int DY_MODE, int X_BF16, int NV>
 __global__ void __launch_bounds__(256) k_layernorm_bwd(const void* __restrict__ dy, const float* __restrict__ wrow, int L, const void* __restrict__ x,
                                                        const float* __restrict__ gamma, const float* __restrict__ mean_in, const float* __restrict__ rstd_in,
-                                                       const float* add_to, float* dx_out, float* __restrict__ partial, int T, int d) {
+                                                       const float* add_to, float* dx_out, bf16_t* __restrict__ dx_bf16, float* __restrict__ partial, int T, int d) {
+  extern __shared__ __attribute__((aligned(16))) float s_part[];     // [4 waves][2][d]
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
   const int nv4 = d >> 2;
   const float inv_d = 1.0f / (float)d;
-  float4 gam[MAXV], dg[MAXV], db[MAXV];
+  float4 gam[NV], dg[NV], db[NV];
 #pragma unroll
-  for (int i = 0; i < MAXV; ++i) {
+  for (int i = 0; i < NV; ++i) {
     const int c = lane + 64 * i;
     gam[i] = (c < nv4) ? reinterpret_cast<const float4*>(gamma)[c] : make_float4(0, 0, 0, 0);
     dg[i] = make_float4(0, 0, 0, 0);
@@ -223,10 +226,10 @@ __global__ void __launch_bounds__(256) k_layernorm_bwd(const void* __restrict__ 
     const float mean = mean_in[row], rstd = rstd_in[row];
     float w = 1.0f;
     if (DY_MODE == 2) w = wrow[row];
-    float4 xh[MAXV], g[MAXV];
+    float4 xh[NV], g[NV];
     float s1 = 0.f, s2 = 0.f;
 #pragma unroll
-    for (int i = 0; i < MAXV; ++i) {
+    for (int i = 0; i < NV; ++i) {
       const int c = lane + 64 * i;
       if (c < nv4) {
         float4 xv;
@@ -256,7 +259,7 @@ __global__ void __launch_bounds__(256) k_layernorm_bwd(const void* __restrict__ 
     }
     const float m1 = wave_sum(s1) * inv_d, m2 = wave_sum(s2) * inv_d;
 #pragma unroll
-    for (int i = 0; i < MAXV; ++i) {
+    for (int i = 0; i < NV; ++i) {
       const int c = lane + 64 * i;
       if (c < nv4) {
         float4 o;
@@ -269,38 +272,51 @@ __global__ void __launch_bounds__(256) k_layernorm_bwd(const void* __restrict__ 
           o.x += a.x; o.y += a.y; o.z += a.z; o.w += a.w;
         }
         reinterpret_cast<float4*>(dx_out + (size_t)row * d)[c] = o;
+        if (dx_bf16) { u32x2 pk; pk.x = pack2bf(o.x, o.y); pk.y = pack2bf(o.z, o.w); reinterpret_cast<u32x2*>(dx_bf16 + (size_t)row * d)[c] = pk; }
       }
     }
   }
   if (partial) {
-    float* pg = partial + ((size_t)(blockIdx.x * ROWS_PER_BLOCK + wave) * 2) * d;
+    float* pw = s_part + (size_t)wave * 2 * d;
 #pragma unroll
-    for (int i = 0; i < MAXV; ++i) {
+    for (int i = 0; i < NV; ++i) {
       const int c = lane + 64 * i;
       if (c < nv4) {
-        reinterpret_cast<float4*>(pg)[c] = dg[i];
-        reinterpret_cast<float4*>(pg + d)[c] = db[i];
+        reinterpret_cast<float4*>(pw)[c] = dg[i];
+        reinterpret_cast<float4*>(pw + d)[c] = db[i];
       }
     }
+    __syncthreads();
+    float* pg = partial + (size_t)blockIdx.x * 2 * d;
+    for (int j = threadIdx.x; j < 2 * d; j += 256)
+      pg[j] = (s_part[j] + s_part[2 * d + j]) + (s_part[4 * d + j] + s_part[6 * d + j]);
   }
 }
 
 #define LN_BWD_BLOCKS 512
-extern "C" size_t oneprot_layernorm_bwd_workspace(int d) { return (size_t)LN_BWD_BLOCKS * ROWS_PER_BLOCK * 2 * d * sizeof(float); }
+extern "C" size_t oneprot_layernorm_bwd_workspace(int d) { return (size_t)LN_BWD_BLOCKS * 2 * d * sizeof(float); }
 
 // dgamma_dbeta: [2][d] laid out as dgamma then dbeta (the two may be non-adjacent: pass both pointers)
+// 64 columns per block, 4 part-slices per column (fixed summation order => deterministic)
 __global__ void __launch_bounds__(256) k_ln_reduce(const float* __restrict__ partial, float* __restrict__ dgamma, float* __restrict__ dbeta, int nparts, int d, int accumulate) {
-  const int j = blockIdx.x * 256 + threadIdx.x;
-  if (j >= 2 * d) return;
+  __shared__ float s_sl[4][64];
+  const int c = threadIdx.x & 63, sl = threadIdx.x >> 6;
+  const int j = blockIdx.x * 64 + c;
   float s = 0.f;
-  for (int p = 0; p < nparts; ++p) s += partial[(size_t)p * 2 * d + j];
-  float* out = j < d ? dgamma + j : dbeta + (j - d);
-  *out = accumulate ? *out + s : s;
+  if (j < 2 * d)
+    for (int p = sl; p < nparts; p += 4) s += partial[(size_t)p * 2 * d + j];
+  s_sl[sl][c] = s;
+  __syncthreads();
+  if (sl == 0 && j < 2 * d) {
+    const float t = (s_sl[0][c] + s_sl[1][c]) + (s_sl[2][c] + s_sl[3][c]);
+    float* out = j < d ? dgamma + j : dbeta + (j - d);
+    *out = accumulate ? *out + t : t;
+  }
 }
 
 extern "C" int oneprot_layernorm_bwd(const void* dy, int dy_mode, const float* wrow, int L, const void* x, int x_is_bf16, const float* gamma,
-                                     const float* mean, const float* rstd, const float* add_to, float* dx, float* dgamma, float* dbeta, void* workspace,
-                                     int64_t T, int d, int accumulate_param_grads, void* stream) {
+                                     const float* mean, const float* rstd, const float* add_to, float* dx, void* dx_bf16, float* dgamma, float* dbeta,
+                                     void* workspace, int64_t T, int d, int accumulate_param_grads, void* stream) {
   if (!dy || !x || !gamma || !mean || !rstd || !dx || T <= 0 || (d & 3) || d > MAXV * 256) return OP_EINVAL;
   if (dy_mode < 0 || dy_mode > 2 || (dy_mode == 2 && (!wrow || L <= 0))) return OP_EINVAL;
   if ((dgamma || dbeta) && !(dgamma && dbeta && workspace)) return OP_EINVAL;
@@ -308,12 +324,17 @@ extern "C" int oneprot_layernorm_bwd(const void* dy, int dy_mode, const float* w
   if (blocks > LN_BWD_BLOCKS) blocks = LN_BWD_BLOCKS;
   float* partial = dgamma ? (float*)workspace : nullptr;
   hipStream_t s = (hipStream_t)stream;
-#define LAUNCH_LNB(M, XB) hipLaunchKernelGGL((k_layernorm_bwd<M, XB>), dim3(blocks), dim3(256), 0, s, dy, wrow, L, x, gamma, mean, rstd, add_to, dx, partial, (int)T, d)
-  if (x_is_bf16) { if (dy_mode == 0) LAUNCH_LNB(0, 1); else if (dy_mode == 1) LAUNCH_LNB(1, 1); else LAUNCH_LNB(2, 1); }
-  else { if (dy_mode == 0) LAUNCH_LNB(0, 0); else if (dy_mode == 1) LAUNCH_LNB(1, 0); else LAUNCH_LNB(2, 0); }
+  const int nv = (d / 4 + 63) / 64;
+  const size_t lds = partial ? (size_t)4 * 2 * d * sizeof(float) : 0;
+  if (lds > 64 * 1024) return OP_EINVAL;
+#define LAUNCH_LNB(M, XB, N) hipLaunchKernelGGL((k_layernorm_bwd<M, XB, N>), dim3(blocks), dim3(256), lds, s, dy, wrow, L, x, gamma, mean, rstd, add_to, dx, (bf16_t*)dx_bf16, partial, (int)T, d)
+#define LNB_NV(M, XB) do { if (nv <= 1) LAUNCH_LNB(M, XB, 1); else if (nv == 2) LAUNCH_LNB(M, XB, 2); else if (nv == 3) LAUNCH_LNB(M, XB, 3); else if (nv == 4) LAUNCH_LNB(M, XB, 4); else if (nv == 5) LAUNCH_LNB(M, XB, 5); else LAUNCH_LNB(M, XB, 8); } while (0)
+  if (x_is_bf16) { if (dy_mode == 0) LNB_NV(0, 1); else if (dy_mode == 1) LNB_NV(1, 1); else LNB_NV(2, 1); }
+  else { if (dy_mode == 0) LNB_NV(0, 0); else if (dy_mode == 1) LNB_NV(1, 0); else LNB_NV(2, 0); }
+#undef LNB_NV
 #undef LAUNCH_LNB
   if (dgamma)
-    hipLaunchKernelGGL(k_ln_reduce, dim3((2 * d + 255) / 256), dim3(256), 0, s, (const float*)workspace, dgamma, dbeta, blocks * ROWS_PER_BLOCK, d, accumulate_param_grads);
+    hipLaunchKernelGGL(k_ln_reduce, dim3((2 * d + 63) / 64), dim3(256), 0, s, (const float*)workspace, dgamma, dbeta, blocks, d, accumulate_param_grads);
   return launch_status();
 }
 

@@ -140,7 +140,7 @@ class _Head:
             da3 = f32(B, n1)
             hip.call("oneprot_sgemm", dy, lin4.weight, da3, B, n1, D, 0, 1, 1.0, 0)       # da = dy W
             dg1, dgam3, dbet3 = f32(B, n1), f32(n1), f32(n1)
-            hip.call("oneprot_layernorm_bwd", da3, 1, None, 0, st["g1"], 0, ln3.weight, st["m3"], st["r3"], None, dg1, dgam3, dbet3,
+            hip.call("oneprot_layernorm_bwd", da3, 1, None, 0, st["g1"], 0, ln3.weight, st["m3"], st["r3"], None, dg1, None, dgam3, dbet3,
                      _ws(hip.query("oneprot_layernorm_bwd_workspace", n1), dev), B, n1, 0)
             dy1 = f32(B, n1)
             hip.call("oneprot_gelu_bwd_f32", st["y1"], dg1, dy1, B * n1)
@@ -153,7 +153,7 @@ class _Head:
         da0 = f32(B, d)
         hip.call("oneprot_sgemm", dy1, lin1.weight, da0, B, d, n1, 0, 1, 1.0, 0)
         dpooled, dgam0, dbet0 = f32(B, d), f32(d), f32(d)
-        hip.call("oneprot_layernorm_bwd", da0, 1, None, 0, pooled, 0, ln0.weight, st["m0"], st["r0"], None, dpooled, dgam0, dbet0,
+        hip.call("oneprot_layernorm_bwd", da0, 1, None, 0, pooled, 0, ln0.weight, st["m0"], st["r0"], None, dpooled, None, dgam0, dbet0,
                  _ws(hip.query("oneprot_layernorm_bwd_workspace", d), dev), B, d, 0)
         grads = [dgam0, dbet0, dW1] + tail
         return dpooled, grads
@@ -220,11 +220,12 @@ class _EncodeFn(torch.autograd.Function):
             gflat = torch.zeros(tr._total, device=dev)
             mean, rstd, wrow = ctx.fin
             g = torch.empty(B * L, d, device=dev)
-            hip.call("oneprot_layernorm_bwd", dpooled, 2, wrow, L, saved["x_final"], 0, tr.view("encoder.emb_layer_norm_after.weight"), mean, rstd, None, g,
+            g16 = torch.empty(B * L, d, dtype=torch.bfloat16, device=dev)
+            hip.call("oneprot_layernorm_bwd", dpooled, 2, wrow, L, saved["x_final"], 0, tr.view("encoder.emb_layer_norm_after.weight"), mean, rstd, None, g, g16,
                      tr.view("encoder.emb_layer_norm_after.weight", gflat), tr.view("encoder.emb_layer_norm_after.bias", gflat),
                      _ws(hip.query("oneprot_layernorm_bwd_workspace", d), dev), B * L, d, 0)
             saved["x_final"] = None
-            tr.backward_layers(saved, g, gflat)
+            tr.backward_layers(saved, g, g16, gflat)
             ctx.saved = None
         hg = list(hgrads) + [None] * (ctx.n_head - len(hgrads))
         return (None, None, gflat) + tuple(hg)

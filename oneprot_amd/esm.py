@@ -359,8 +359,9 @@ class EsmTransformer(nn.Module):
             saved["x_final"] = x
         return x, saved
 
-    def backward_layers(self, saved, g, gflat):
-        """g: fp32 [T,d] gradient w.r.t. the last layer's output (consumed in place); gflat: fp32 arena gradient (written)."""
+    def backward_layers(self, saved, g, g16, gflat):
+        """g: fp32 [T,d] gradient w.r.t. the last layer's output (consumed in place), g16: its bf16 copy;
+        gflat: fp32 arena gradient (written)."""
         B, L = saved["B"], saved["L"]
         T, d, f, H, hd = B * L, self.d, self.f, self.H, self.hd
         dev = g.device
@@ -370,44 +371,36 @@ class EsmTransformer(nn.Module):
         b16 = lambda *s: torch.empty(*s, dtype=torch.bfloat16, device=dev)
         ws_ln = torch.empty(hip.query("oneprot_layernorm_bwd_workspace", d), dtype=torch.uint8, device=dev)
         ws_tn = torch.empty(max(hip.query("oneprot_gemm_bf16_tn_workspace", 3 * d, d), hip.query("oneprot_gemm_bf16_tn_workspace", f, d)), dtype=torch.uint8, device=dev)
-        ws_cs = torch.empty(hip.query("oneprot_colsum_workspace", max(3 * d, f)), dtype=torch.uint8, device=dev)
         ws_at = torch.empty(hip.query("oneprot_attn_bwd_workspace", B, H, L), dtype=torch.uint8, device=dev)
-        g16 = b16(T, d)
         dz = b16(T, f)
         dh = b16(T, d)
         dqkv = b16(T, 3 * d)
         for i in reversed(range(self.n_layers)):
             st = saved["layers"][i]
             p = f"encoder.layer.{i}."
-            # ---- FFN2: x_out = x_mid + u W2^T + b2
-            hip.call("oneprot_cast_f32_to_bf16", g, g16, T * d)
-            hip.call("oneprot_gemm_bf16_tn", g16, st["u"], T, d, f, d, f, gv(p + "output.dense.weight"), ws_tn, 0)
-            hip.call("oneprot_colsum_bf16", g16, gv(p + "output.dense.bias"), ws_cs, T, d, 0)
+            # ---- FFN2: x_out = x_mid + u W2^T + b2        (weight grad + bias grad in one TN launch)
+            hip.call("oneprot_gemm_bf16_tn", g16, st["u"], T, d, f, d, f, gv(p + "output.dense.weight"), gv(p + "output.dense.bias"), ws_tn, 0)
             hip.call("oneprot_gemm_bf16_nt", g16, self._bf16_T[(i, "w2")], T, f, d, d, d, hip.EPI_GELU_BWD, None, dz, None, None, st["z"], None, None,
                      1.0, 0, 0, 0)
             # ---- FFN1: z = h2 W1^T + b1
-            hip.call("oneprot_gemm_bf16_tn", dz, st["h2"], T, f, d, f, d, gv(p + "intermediate.dense.weight"), ws_tn, 0)
-            hip.call("oneprot_colsum_bf16", dz, gv(p + "intermediate.dense.bias"), ws_cs, T, f, 0)
+            hip.call("oneprot_gemm_bf16_tn", dz, st["h2"], T, f, d, f, d, gv(p + "intermediate.dense.weight"), gv(p + "intermediate.dense.bias"), ws_tn, 0)
             hip.call("oneprot_gemm_bf16_nt", dz, self._bf16_T[(i, "w1")], T, d, f, f, f, hip.EPI_BF16, None, dh, None, None, None, None, None, 1.0, 0, 0, 0)
-            # ---- LN2 (input x_mid): g += LN'(dh)
-            hip.call("oneprot_layernorm_bwd", dh, 0, None, 0, st["x_mid"], 0, self.view(p + "LayerNorm.weight"), st["mean2"], st["rstd2"], g, g,
+            # ---- LN2 (input x_mid): g += LN'(dh); also refreshes the bf16 copy g16
+            hip.call("oneprot_layernorm_bwd", dh, 0, None, 0, st["x_mid"], 0, self.view(p + "LayerNorm.weight"), st["mean2"], st["rstd2"], g, g, g16,
                      gv(p + "LayerNorm.weight"), gv(p + "LayerNorm.bias"), ws_ln, T, d, 0)
             # ---- out-proj: x_mid = x_in + ctx Wo^T + bo
-            hip.call("oneprot_cast_f32_to_bf16", g, g16, T * d)
-            hip.call("oneprot_gemm_bf16_tn", g16, st["ctx"], T, d, d, d, d, gv(p + "attention.output.dense.weight"), ws_tn, 0)
-            hip.call("oneprot_colsum_bf16", g16, gv(p + "attention.output.dense.bias"), ws_cs, T, d, 0)
+            hip.call("oneprot_gemm_bf16_tn", g16, st["ctx"], T, d, d, d, d, gv(p + "attention.output.dense.weight"), gv(p + "attention.output.dense.bias"), ws_tn, 0)
             hip.call("oneprot_gemm_bf16_nt", g16, self._bf16_T[(i, "o")], T, d, d, d, d, hip.EPI_BF16, None, dh, None, None, None, None, None, 1.0, 0, 0, 0)
             # ---- attention
             hip.call("oneprot_attn_bwd", st["q"], st["k"], st["v"], saved["key_bias"], st["ctx"], dh, st["lse"], cos, sin, hd ** -0.5, dqkv, ws_at, B, H, L, hd)
             # ---- QKV projection
             o, n = self.span(p + "attention.self.query.weight", p + "attention.self.value.weight")
             ob, nb = self.span(p + "attention.self.query.bias", p + "attention.self.value.bias")
-            hip.call("oneprot_gemm_bf16_tn", dqkv, st["h1"], T, 3 * d, d, 3 * d, d, gflat[o:o + n], ws_tn, 0)
-            hip.call("oneprot_colsum_bf16", dqkv, gflat[ob:ob + nb], ws_cs, T, 3 * d, 0)
+            hip.call("oneprot_gemm_bf16_tn", dqkv, st["h1"], T, 3 * d, d, 3 * d, d, gflat[o:o + n], gflat[ob:ob + nb], ws_tn, 0)
             hip.call("oneprot_gemm_bf16_nt", dqkv, self._bf16_T[(i, "qkv")], T, d, 3 * d, 3 * d, 3 * d, hip.EPI_BF16, None, dh, None, None, None, None, None,
                      1.0, 0, 0, 0)
             # ---- LN1 (input x_in)
-            hip.call("oneprot_layernorm_bwd", dh, 0, None, 0, st["x_in"], 0, self.view(p + "attention.LayerNorm.weight"), st["mean1"], st["rstd1"], g, g,
+            hip.call("oneprot_layernorm_bwd", dh, 0, None, 0, st["x_in"], 0, self.view(p + "attention.LayerNorm.weight"), st["mean1"], st["rstd1"], g, g, g16,
                      gv(p + "attention.LayerNorm.weight"), gv(p + "attention.LayerNorm.bias"), ws_ln, T, d, 0)
             saved["layers"][i] = None      # release this layer's activations
         V = cfg.vocab_size

@@ -89,14 +89,16 @@ def test_layernorm_fwd_bwd(T, d):
     dg = torch.zeros(d, device=DEV)
     db = torch.zeros(d, device=DEV)
     w = ws(hip.query("oneprot_layernorm_bwd_workspace", d))
-    hip.call("oneprot_layernorm_bwd", dy, 1, None, 0, x, 0, gamma, mean, rstd, add, dx, dg, db, w, T, d, 0)
+    hip.call("oneprot_layernorm_bwd", dy, 1, None, 0, x, 0, gamma, mean, rstd, add, dx, None, dg, db, w, T, d, 0)
     assert_close(dx, xr.grad + add, 1e-4, 1e-4, "ln bwd dx")
     assert_close(dg, gr.grad, 1e-4, 1e-3, "ln bwd dgamma")
     assert_close(db, br.grad, 1e-4, 1e-3, "ln bwd dbeta")
     # bf16 dy, in place on the residual gradient, accumulate param grads
     dyb = bf(dy)
     dx2 = add.clone()
-    hip.call("oneprot_layernorm_bwd", dyb, 0, None, 0, x, 0, gamma, mean, rstd, dx2, dx2, dg, db, w, T, d, 1)
+    dx2b = torch.empty(T, d, dtype=torch.bfloat16, device=DEV)
+    hip.call("oneprot_layernorm_bwd", dyb, 0, None, 0, x, 0, gamma, mean, rstd, dx2, dx2, dx2b, dg, db, w, T, d, 1)
+    assert torch.equal(dx2b, dx2.to(torch.bfloat16))
     xr2 = x.clone().requires_grad_(True)
     torch.nn.functional.layer_norm(xr2, (d,), gamma, beta, 1e-5).backward(dyb.float())
     assert_close(dx2, xr2.grad + add, 1e-4, 1e-4, "ln bwd dx (bf16 dy, in place)")
@@ -127,7 +129,7 @@ def test_lnpool_fwd_and_pooled_bwd(mode):
     dx = torch.empty(B * L, d, device=DEV)
     dg, db = torch.zeros(d, device=DEV), torch.zeros(d, device=DEV)
     w = ws(hip.query("oneprot_layernorm_bwd_workspace", d))
-    hip.call("oneprot_layernorm_bwd", dp.to(DEV), 2, wrow, L, xd, 0, gamma.to(DEV), mean, rstd, None, dx, dg, db, w, B * L, d, 0)
+    hip.call("oneprot_layernorm_bwd", dp.to(DEV), 2, wrow, L, xd, 0, gamma.to(DEV), mean, rstd, None, dx, None, dg, db, w, B * L, d, 0)
     assert_close(dx.cpu().view(B, L, d), xr.grad, 1e-4, 1e-5, "pooled bwd dx")
     assert_close(dg.cpu(), gr.grad, 1e-4, 1e-4, "pooled bwd dgamma")
     assert_close(db.cpu(), br.grad, 1e-4, 1e-4, "pooled bwd dbeta")
@@ -198,9 +200,11 @@ def test_gemm_tn(M, N, K):
     ref = dY.float().t() @ X.float()
     dW = torch.full((N, K), 3.0, device=DEV)
     w = ws(hip.query("oneprot_gemm_bf16_tn_workspace", N, K))
-    hip.call("oneprot_gemm_bf16_tn", dY, X, M, N, K, N, K, dW, w, 0)
+    db = torch.full((N,), 5.0, device=DEV)
+    hip.call("oneprot_gemm_bf16_tn", dY, X, M, N, K, N, K, dW, db, w, 0)
     assert_close(dW, ref, 1e-4, 2e-3 * math.sqrt(M / 64), "tn")
-    hip.call("oneprot_gemm_bf16_tn", dY, X, M, N, K, N, K, dW, w, 1)
+    assert_close(db, dY.float().sum(0), 1e-4, 1e-2, "tn fused bias grad")
+    hip.call("oneprot_gemm_bf16_tn", dY, X, M, N, K, N, K, dW, None, w, 1)
     assert_close(dW, 2 * ref, 1e-4, 4e-3 * math.sqrt(M / 64), "tn accumulate")
     # strided views: columns [N0:N0+n) of a wider matrix
     cs = torch.full((N,), -1.0, device=DEV)

@@ -62,7 +62,7 @@ def main():
         dY = rnd(T, N).to(torch.bfloat16); X = rnd(T, K).to(torch.bfloat16)
         dW = torch.empty(N, K, device=DEV)
         w = torch.empty(hip.query("oneprot_gemm_bf16_tn_workspace", N, K), dtype=torch.uint8, device=DEV)
-        ms = timeit(lambda: hip.call("oneprot_gemm_bf16_tn", dY, X, T, N, K, N, K, dW, w, 0))
+        ms = timeit(lambda: hip.call("oneprot_gemm_bf16_tn", dY, X, T, N, K, N, K, dW, None, w, 0))
         res[name] = (ms, 2.0 * T * N * K / ms / 1e9)
         del dY, X
     # ---- attention
@@ -82,7 +82,7 @@ def main():
     res["ln_fwd"] = (ms, T * d * 6 / ms / 1e6)   # GB/s
     dx = torch.empty(T, d, device=DEV); dg = torch.zeros(d, device=DEV); db = torch.zeros(d, device=DEV)
     w = torch.empty(hip.query("oneprot_layernorm_bwd_workspace", d), dtype=torch.uint8, device=DEV)
-    ms = timeit(lambda: hip.call("oneprot_layernorm_bwd", y, 0, None, 0, x, 0, gamma, mean, rstd, dx, dx, dg, db, w, T, d, 0))
+    ms = timeit(lambda: hip.call("oneprot_layernorm_bwd", y, 0, None, 0, x, 0, gamma, mean, rstd, dx, dx, y, dg, db, w, T, d, 0))
     res["ln_bwd"] = (ms, T * d * (2 + 4 + 4 + 4) / ms / 1e6)
     for k_, (ms, rate) in res.items():
         unit = "GB/s" if k_.startswith("ln") else "TFLOP/s"
