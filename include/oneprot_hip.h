@@ -49,6 +49,9 @@ int oneprot_layernorm_bwd(const void* dy, int dy_mode, const float* wrow, int L,
 int oneprot_lnpool_fwd(const float* x, const int64_t* ids, int pad_id, const float* gamma, const float* beta, float* pooled, float* mean,
                        float* rstd, float* wrow, void* hidden_bf16, float* hidden_f32, int B, int L, int d, float eps, int mode, void* stream);
 
+/* pooling of an already-normalised hidden state (BERT): mode 0 masked mean, 1 CLS (ref base_encoder.py:109-126). */
+int oneprot_pool_fwd(const float* x, const int64_t* ids, int pad_id, float* pooled, int B, int L, int d, int mode, void* stream);
+
 /* ---------------- dense contractions on MFMA (nn.Linear call sites: hf modeling_esm.py:362-368,399-409,442-463) -- */
 enum {
   ONEPROT_EPI_BF16 = 0,        /* out0 bf16 [M,N] = acc (+bias)                                                   */

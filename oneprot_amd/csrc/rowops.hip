@@ -429,6 +429,91 @@ extern "C" int oneprot_lnpool_fwd(const float* x, const int64_t* ids, int pad_id
 }
 
 // --------------------------------------------------------------------------------------------------------
+// BERT embeddings: x = LayerNorm(word[id] + pos[l] + type[0])   (hf modeling_bert.py:53-108; eval mode, dropout off)
+// one wave per token, lane owns float4 columns (same scheme as LayerNorm)
+// --------------------------------------------------------------------------------------------------------
+__global__ void __launch_bounds__(256) k_bert_embed(const long long* __restrict__ ids, const float* __restrict__ word, const float* __restrict__ pos,
+                                                    const float* __restrict__ type0, const float* __restrict__ gamma, const float* __restrict__ beta,
+                                                    float* __restrict__ x_f32, bf16_t* __restrict__ x_bf16, int T, int L, int d, int vocab, float eps) {
+  const int lane = threadIdx.x & 63;
+  const int nv4 = d >> 2;
+  const float inv_d = 1.0f / (float)d;
+  for (int row = blockIdx.x * ROWS_PER_BLOCK + (threadIdx.x >> 6); row < T; row += gridDim.x * ROWS_PER_BLOCK) {
+    long long id = ids[row];
+    if (id < 0 || id >= vocab) id = 0;
+    const int l = row % L;
+    float4 v[MAXV];
+    float s = 0.f;
+#pragma unroll
+    for (int i = 0; i < MAXV; ++i) {
+      const int c = lane + 64 * i;
+      if (c < nv4) {
+        const float4 a = reinterpret_cast<const float4*>(word + (size_t)id * d)[c];
+        const float4 b = reinterpret_cast<const float4*>(pos + (size_t)l * d)[c];
+        const float4 t = reinterpret_cast<const float4*>(type0)[c];
+        v[i] = make_float4(a.x + t.x + b.x, a.y + t.y + b.y, a.z + t.z + b.z, a.w + t.w + b.w);
+        s += (v[i].x + v[i].y) + (v[i].z + v[i].w);
+      }
+    }
+    const float mean = wave_sum(s) * inv_d;
+    float q = 0.f;
+#pragma unroll
+    for (int i = 0; i < MAXV; ++i) {
+      const int c = lane + 64 * i;
+      if (c < nv4) { const float a = v[i].x - mean, b = v[i].y - mean, cc = v[i].z - mean, dd = v[i].w - mean; q += (a * a + b * b) + (cc * cc + dd * dd); }
+    }
+    const float rstd = rsqrtf(wave_sum(q) * inv_d + eps);
+#pragma unroll
+    for (int i = 0; i < MAXV; ++i) {
+      const int c = lane + 64 * i;
+      if (c < nv4) {
+        const float4 g = reinterpret_cast<const float4*>(gamma)[c];
+        const float4 be = reinterpret_cast<const float4*>(beta)[c];
+        float4 o;
+        o.x = (v[i].x - mean) * rstd * g.x + be.x; o.y = (v[i].y - mean) * rstd * g.y + be.y;
+        o.z = (v[i].z - mean) * rstd * g.z + be.z; o.w = (v[i].w - mean) * rstd * g.w + be.w;
+        if (x_f32) reinterpret_cast<float4*>(x_f32 + (size_t)row * d)[c] = o;
+        if (x_bf16) { u32x2 pk; pk.x = pack2bf(o.x, o.y); pk.y = pack2bf(o.z, o.w); reinterpret_cast<u32x2*>(x_bf16 + (size_t)row * d)[c] = pk; }
+      }
+    }
+  }
+}
+extern "C" int oneprot_bert_embed_fwd(const int64_t* ids, const float* word, const float* pos, const float* type0, const float* gamma, const float* beta,
+                                      float* x_f32, void* x_bf16, int B, int L, int d, int vocab, float eps, void* stream) {
+  if (!ids || !word || !pos || !type0 || !gamma || !beta || (!x_f32 && !x_bf16) || B <= 0 || L <= 0 || (d & 3) || d > MAXV * 256) return OP_EINVAL;
+  hipLaunchKernelGGL(k_bert_embed, dim3(ln_grid(B * L)), dim3(256), 0, (hipStream_t)stream, (const long long*)ids, word, pos, type0, gamma, beta, x_f32,
+                     (bf16_t*)x_bf16, B * L, L, d, vocab, eps);
+  return launch_status();
+}
+
+// Pooling without a LayerNorm in front (BERT's last layer output is already normalised): mode 0 masked mean, 1 CLS (ref base_encoder.py:109-126)
+__global__ void __launch_bounds__(256) k_pool_fwd(const float* __restrict__ x, const long long* __restrict__ ids, int pad_id, float* __restrict__ pooled, int L, int d, int mode) {
+  const int b = blockIdx.x;
+  __shared__ float s_n[4];
+  float cnt = 0.f;
+  for (int l = threadIdx.x; l < L; l += 256) cnt += (ids[(size_t)b * L + l] != pad_id);
+  cnt = wave_sum(cnt);
+  if ((threadIdx.x & 63) == 0) s_n[threadIdx.x >> 6] = cnt;
+  __syncthreads();
+  const float inv_n = 1.0f / (s_n[0] + s_n[1] + s_n[2] + s_n[3]);
+  for (int j = threadIdx.x; j < d; j += 256) {
+    float s = 0.f;
+    if (mode == 1) s = x[(size_t)b * L * d + j];
+    else {
+      for (int l = 0; l < L; ++l)
+        if (ids[(size_t)b * L + l] != pad_id) s += x[((size_t)b * L + l) * d + j];
+      s *= inv_n;
+    }
+    pooled[(size_t)b * d + j] = s;
+  }
+}
+extern "C" int oneprot_pool_fwd(const float* x, const int64_t* ids, int pad_id, float* pooled, int B, int L, int d, int mode, void* stream) {
+  if (!x || !ids || !pooled || B <= 0 || L <= 0 || d <= 0 || mode < 0 || mode > 1) return OP_EINVAL;
+  hipLaunchKernelGGL(k_pool_fwd, dim3(B), dim3(256), 0, (hipStream_t)stream, x, (const long long*)ids, pad_id, pooled, L, d, mode);
+  return launch_status();
+}
+
+// --------------------------------------------------------------------------------------------------------
 // casts / fills / column sums
 // --------------------------------------------------------------------------------------------------------
 __global__ void __launch_bounds__(256) k_cast_f32_bf16(const float* __restrict__ src, bf16_t* __restrict__ dst, size_t n4) {

@@ -198,8 +198,11 @@ class _EncodeFn(torch.autograd.Function):
             mean, rstd, wrow = (torch.empty(B * L, device=dev) for _ in range(3))
         else:
             mean = rstd = wrow = None
-        hip.call("oneprot_lnpool_fwd", x, ids.contiguous(), tr.config.pad_token_id, tr.view("encoder.emb_layer_norm_after.weight"),
-                 tr.view("encoder.emb_layer_norm_after.bias"), pooled, mean, rstd, wrow, None, None, B, L, d, tr.config.layer_norm_eps, mode)
+        if getattr(tr, "final_layer_norm", True):
+            hip.call("oneprot_lnpool_fwd", x, ids.contiguous(), tr.config.pad_token_id, tr.view("encoder.emb_layer_norm_after.weight"),
+                     tr.view("encoder.emb_layer_norm_after.bias"), pooled, mean, rstd, wrow, None, None, B, L, d, tr.config.layer_norm_eps, mode)
+        else:       # BERT: the last layer's output is already post-LN
+            hip.call("oneprot_pool_fwd", x, ids.contiguous(), tr.config.pad_token_id, pooled, B, L, d, mode)
         scale = enc.logit_scale_value()
         feat, hst = _Head.forward(pooled, enc.proj, scale, need_head_grad)
         ctx.enc, ctx.saved, ctx.hst, ctx.scale = enc, saved, hst, scale
@@ -328,7 +331,8 @@ class TextEncoder(BaseEncoder):
                  learnable_logit_scale: bool = False, frozen: bool = False, use_lora: bool = False, lora_r: int = 8, lora_alpha: int = 16,
                  lora_dropout: float = 0.1, lora_target_modules=None):
         from .bert import BertTransformer
-        self.config, _ = resolve_config(model_name_or_path)
+        from .bert import resolve_bert_config
+        self.config, _ = resolve_bert_config(model_name_or_path)
         super().__init__(d_model=self.config.hidden_size, output_dim=output_dim, proj_type=proj_type, use_logit_scale=use_logit_scale,
                          learnable_logit_scale=learnable_logit_scale, pooling_type=pooling_type)
         if use_lora:

@@ -93,64 +93,26 @@ class _Out:
         return (self.last_hidden_state, self.pooler_output)[i]
 
 
-class EsmTransformer(nn.Module):
-    """EsmModel replacement.  `add_pooling_layer` only controls whether the (unused) HF pooler parameters exist,
-    as in the reference (SequenceEncoder: False, StructTokenEncoder: True)."""
+class ArenaModule(nn.Module):
+    """Parameters of a whole encoder in one fp32 arena (`flat`) with named views, a bf16 mirror for the MFMA GEMMs, and
+    state-dict hooks that expose / accept the HF key names."""
 
-    def __init__(self, config, add_pooling_layer=True):
-        super().__init__()
-        if getattr(config, "position_embedding_type", "rotary") != "rotary" or getattr(config, "emb_layer_norm_before", False):
-            raise NotImplementedError("only rotary ESM-2 configurations are on the OneProt hot path")
-        self.config = config
-        d, f, n, V = config.hidden_size, config.intermediate_size, config.num_hidden_layers, config.vocab_size
-        self.d, self.f, self.n_layers, self.H = d, f, n, config.num_attention_heads
-        self.hd = d // self.H
-        if self.hd not in (16, 32, 64) or d % 64:
-            raise NotImplementedError(f"head_dim {self.hd} / hidden {d}: kernels are built for head_dim 16/32/64, hidden % 64 == 0")
+    def _init_arena(self):
         self._spec = OrderedDict()
-        self._add("embeddings.word_embeddings.weight", (V, d))
-        for i in range(n):
-            p = f"encoder.layer.{i}."
-            for nm in ("query", "key", "value"):
-                self._add(p + f"attention.self.{nm}.weight", (d, d))
-            for nm in ("query", "key", "value"):
-                self._add(p + f"attention.self.{nm}.bias", (d,))
-            self._add(p + "attention.output.dense.weight", (d, d))
-            self._add(p + "attention.output.dense.bias", (d,))
-            self._add(p + "attention.LayerNorm.weight", (d,))
-            self._add(p + "attention.LayerNorm.bias", (d,))
-            self._add(p + "intermediate.dense.weight", (f, d))
-            self._add(p + "intermediate.dense.bias", (f,))
-            self._add(p + "output.dense.weight", (d, f))
-            self._add(p + "output.dense.bias", (d,))
-            self._add(p + "LayerNorm.weight", (d,))
-            self._add(p + "LayerNorm.bias", (d,))
-        self._add("encoder.emb_layer_norm_after.weight", (d,))
-        self._add("encoder.emb_layer_norm_after.bias", (d,))
+        self._cursor = 0
+        self._extra = OrderedDict()
+
+    def _finish_arena(self):
         self._total = self._cursor
         self.flat = nn.Parameter(torch.zeros(self._total))
-        # parameters HF carries but the hot path never touches (kept for strict state-dict compatibility)
-        self._extra = OrderedDict()
-        if add_pooling_layer:
-            self._extra["pooler.dense.weight"] = (d, d)
-            self._extra["pooler.dense.bias"] = (d,)
-        self._extra["contact_head.regression.weight"] = (1, n * self.H)
-        self._extra["contact_head.regression.bias"] = (1,)
         self.extra = nn.ParameterDict({k.replace(".", "__"): nn.Parameter(torch.zeros(s)) for k, s in self._extra.items()})
-        inv_freq = 1.0 / (10000.0 ** (torch.arange(0, self.hd, 2, dtype=torch.float32) / self.hd))
-        self.register_buffer("inv_freq", inv_freq, persistent=False)
         self._register_state_dict_hook(self._sd_hook)
         self._register_load_state_dict_pre_hook(self._load_hook)
         self._bf16 = None
         self._bf16_T = {}
         self._bf16_version = None
-        self._rope_cache = {}
-        self.reset_parameters()
 
-    # ----------------------------------------------------------------------------------------- parameter plumbing
     def _add(self, name, shape):
-        if not hasattr(self, "_cursor"):
-            self._cursor = 0
         n = 1
         for s in shape:
             n *= s
@@ -173,23 +135,11 @@ class EsmTransformer(nn.Module):
     def named_views(self):
         return OrderedDict((k, self.view(k)) for k in self._spec)
 
-    @torch.no_grad()
-    def reset_parameters(self):
-        std = getattr(self.config, "initializer_range", 0.02)
-        for name in self._spec:
-            v = self.view(name)
-            if name.endswith("LayerNorm.weight") or name.endswith("layer_norm_after.weight"):
-                v.fill_(1.0)
-            elif name.endswith(".bias"):
-                v.zero_()
-            else:
-                v.normal_(0.0, std)
-        pad = self.config.pad_token_id
-        if pad is not None:
-            self.view("embeddings.word_embeddings.weight")[pad].zero_()
-        for k, p in self.extra.items():
-            if p.dim() > 1:
-                p.normal_(0.0, std)
+    def _w16(self, name):
+        return self.view(name, self._bf16)
+
+    _sd_extra_buffers = ()
+    _load_ignore_suffixes = ()
 
     def _sd_hook(self, module, state_dict, prefix, local_metadata):
         flat = state_dict.pop(prefix + "flat")
@@ -197,7 +147,8 @@ class EsmTransformer(nn.Module):
             state_dict[prefix + name] = self.view(name, flat)
         for k in list(self._extra):
             state_dict[prefix + k] = state_dict.pop(prefix + "extra." + k.replace(".", "__"))
-        state_dict[prefix + "rotary_embeddings.inv_freq"] = self.inv_freq.detach().clone()
+        for key, fn in self._sd_extra_buffers:
+            state_dict[prefix + key] = fn(self)
         return state_dict
 
     def _load_hook(self, state_dict, prefix, local_metadata, strict, missing_keys, unexpected_keys, error_msgs):
@@ -218,11 +169,100 @@ class EsmTransformer(nn.Module):
             key = prefix + k
             if key in state_dict:
                 state_dict[prefix + "extra." + k.replace(".", "__")] = state_dict.pop(key)
-        # rotary buffers: model-level (transformers >= 5) or per-layer (4.33) -- values are recomputed, keys are accepted
-        for key in [k for k in state_dict if k.startswith(prefix) and k.endswith("rotary_embeddings.inv_freq")]:
+        for key in [k for k in state_dict if k.startswith(prefix) and k.endswith(tuple(self._load_ignore_suffixes))] if self._load_ignore_suffixes else []:
             state_dict.pop(key)
-        state_dict.pop(prefix + "embeddings.position_embeddings.weight", None)   # present in hub checkpoints, ignored by HF too
-        state_dict.pop(prefix + "embeddings.position_ids", None)
+
+    def _refresh_bf16_mirror(self):
+        """returns True when the mirror was rebuilt"""
+        ver = (self.flat._version, self.flat.data_ptr())
+        if self._bf16_version == ver:
+            return False
+        dev = self.flat.device
+        if self._bf16 is None or self._bf16.device != dev or self._bf16.numel() != self._total:
+            self._bf16 = torch.empty(self._total, dtype=torch.bfloat16, device=dev)
+            self._bf16_T = {}
+        hip.call("oneprot_cast_f32_to_bf16", self.flat.data, self._bf16, self._total)
+        self._bf16_version = ver
+        return True
+
+    def save_pretrained(self, path):
+        """HF-style directory (config.json + model.safetensors) -- used by ref peft_checkpoint.py:20."""
+        from safetensors.torch import save_file
+        os.makedirs(path, exist_ok=True)
+        with open(os.path.join(path, "config.json"), "w") as f:
+            json.dump({k: v for k, v in self.config.to_dict().items() if isinstance(v, (int, float, str, bool, type(None), list))}, f, indent=1)
+        sd = {k: v.detach().cpu().contiguous().clone() for k, v in self.state_dict().items()}
+        save_file(sd, os.path.join(path, "model.safetensors"))
+
+
+class EsmTransformer(ArenaModule):
+    """EsmModel replacement.  `add_pooling_layer` only controls whether the (unused) HF pooler parameters exist,
+    as in the reference (SequenceEncoder: False, StructTokenEncoder: True)."""
+
+    def __init__(self, config, add_pooling_layer=True):
+        super().__init__()
+        if getattr(config, "position_embedding_type", "rotary") != "rotary" or getattr(config, "emb_layer_norm_before", False):
+            raise NotImplementedError("only rotary ESM-2 configurations are on the OneProt hot path")
+        self.config = config
+        d, f, n, V = config.hidden_size, config.intermediate_size, config.num_hidden_layers, config.vocab_size
+        self.d, self.f, self.n_layers, self.H = d, f, n, config.num_attention_heads
+        self.hd = d // self.H
+        if self.hd not in (16, 32, 64) or d % 64:
+            raise NotImplementedError(f"head_dim {self.hd} / hidden {d}: kernels are built for head_dim 16/32/64, hidden % 64 == 0")
+        self._init_arena()
+        self._add("embeddings.word_embeddings.weight", (V, d))
+        for i in range(n):
+            p = f"encoder.layer.{i}."
+            for nm in ("query", "key", "value"):
+                self._add(p + f"attention.self.{nm}.weight", (d, d))
+            for nm in ("query", "key", "value"):
+                self._add(p + f"attention.self.{nm}.bias", (d,))
+            self._add(p + "attention.output.dense.weight", (d, d))
+            self._add(p + "attention.output.dense.bias", (d,))
+            self._add(p + "attention.LayerNorm.weight", (d,))
+            self._add(p + "attention.LayerNorm.bias", (d,))
+            self._add(p + "intermediate.dense.weight", (f, d))
+            self._add(p + "intermediate.dense.bias", (f,))
+            self._add(p + "output.dense.weight", (d, f))
+            self._add(p + "output.dense.bias", (d,))
+            self._add(p + "LayerNorm.weight", (d,))
+            self._add(p + "LayerNorm.bias", (d,))
+        self._add("encoder.emb_layer_norm_after.weight", (d,))
+        self._add("encoder.emb_layer_norm_after.bias", (d,))
+        # parameters HF carries but the hot path never touches (kept for strict state-dict compatibility)
+        if add_pooling_layer:
+            self._extra["pooler.dense.weight"] = (d, d)
+            self._extra["pooler.dense.bias"] = (d,)
+        self._extra["contact_head.regression.weight"] = (1, n * self.H)
+        self._extra["contact_head.regression.bias"] = (1,)
+        self._finish_arena()
+        inv_freq = 1.0 / (10000.0 ** (torch.arange(0, self.hd, 2, dtype=torch.float32) / self.hd))
+        self.register_buffer("inv_freq", inv_freq, persistent=False)
+        self._rope_cache = {}
+        self.reset_parameters()
+
+    @torch.no_grad()
+    def reset_parameters(self):
+        std = getattr(self.config, "initializer_range", 0.02)
+        for name in self._spec:
+            v = self.view(name)
+            if name.endswith("LayerNorm.weight") or name.endswith("layer_norm_after.weight"):
+                v.fill_(1.0)
+            elif name.endswith(".bias"):
+                v.zero_()
+            else:
+                v.normal_(0.0, std)
+        pad = self.config.pad_token_id
+        if pad is not None:
+            self.view("embeddings.word_embeddings.weight")[pad].zero_()
+        for k, p in self.extra.items():
+            if p.dim() > 1:
+                p.normal_(0.0, std)
+
+    _sd_extra_buffers = (("rotary_embeddings.inv_freq", lambda self: self.inv_freq.detach().clone()),)
+    # rotary buffers: model-level (transformers >= 5) or per-layer (4.33) keys are accepted, values recomputed;
+    # hub checkpoints also carry an unused absolute position table that HF ignores as well
+    _load_ignore_suffixes = ("rotary_embeddings.inv_freq", "embeddings.position_embeddings.weight", "embeddings.position_ids")
 
     def resize_token_embeddings(self, new_vocab):
         """ref struct_token_encoder.py:27: append rows (normal(0, initializer_range), as transformers 4.33 did)."""
@@ -251,25 +291,11 @@ class EsmTransformer(nn.Module):
     def get_input_embeddings_weight(self):
         return self.view("embeddings.word_embeddings.weight")
 
-    def save_pretrained(self, path):
-        """HF-style directory (config.json + model.safetensors) -- used by ref peft_checkpoint.py:20."""
-        from safetensors.torch import save_file
-        os.makedirs(path, exist_ok=True)
-        with open(os.path.join(path, "config.json"), "w") as f:
-            json.dump({k: v for k, v in self.config.to_dict().items() if isinstance(v, (int, float, str, bool, type(None), list))}, f, indent=1)
-        sd = {k: v.detach().cpu().contiguous().clone() for k, v in self.state_dict().items()}
-        save_file(sd, os.path.join(path, "model.safetensors"))
-
     # ----------------------------------------------------------------------------------------- device-side caches
     def _refresh_bf16(self):
-        ver = (self.flat._version, self.flat.data_ptr())
-        if self._bf16_version == ver:
+        if not self._refresh_bf16_mirror():
             return
         dev = self.flat.device
-        if self._bf16 is None or self._bf16.device != dev or self._bf16.numel() != self._total:
-            self._bf16 = torch.empty(self._total, dtype=torch.bfloat16, device=dev)
-            self._bf16_T = {}
-        hip.call("oneprot_cast_f32_to_bf16", self.flat.data, self._bf16, self._total)
         if self.flat.requires_grad:
             d, f = self.d, self.f
             for i in range(self.n_layers):
@@ -286,7 +312,6 @@ class EsmTransformer(nn.Module):
                         t = torch.empty(C, R, dtype=torch.bfloat16, device=dev)
                         self._bf16_T[(i, key)] = t
                     hip.call("oneprot_transpose_cast_f32_to_bf16", src, t, R, C)
-        self._bf16_version = ver
 
     def _rope(self, L):
         key = (L, self.flat.device)
@@ -295,9 +320,6 @@ class EsmTransformer(nn.Module):
             freqs = torch.outer(t, self.inv_freq.detach().float().cpu())      # hf modeling_esm.py:150-158 (positions = arange(L))
             self._rope_cache[key] = (freqs.cos().contiguous().to(self.flat.device), freqs.sin().contiguous().to(self.flat.device))
         return self._rope_cache[key]
-
-    def _w16(self, name):
-        return self.view(name, self._bf16)
 
     # ----------------------------------------------------------------------------------------- forward / backward
     def run_layers(self, ids, save):

@@ -169,3 +169,29 @@ def test_full_size_shapes_vs_oracle():
         got = enc(ids.to(DEV)).cpu()
     cs = torch.nn.functional.cosine_similarity(got, ref, dim=-1)
     assert cs.min() > 0.999, cs
+
+
+def test_text_encoder_vs_reference(golden_dir, tmp_path):
+    """BERT text tower (cls pooling, mlp head, logit scale; frozen, eval) vs the reference's TextEncoder output."""
+    os.environ.update(RANK="0", WORLD_SIZE="1", ONEPROT_ALLOW_RANDOM_INIT="1")
+    from src.models.components.text_encoder import TextEncoder
+    g = torch.load(os.path.join(golden_dir, "bert_text.pt"), weights_only=False)
+    cfg = g["cfg"]
+    path = os.path.join(str(tmp_path), "bert")
+    os.makedirs(path)
+    with open(os.path.join(path, "config.json"), "w") as f:
+        json.dump(dict(model_type="bert", vocab_size=cfg["vocab"], hidden_size=cfg["hidden"], num_hidden_layers=cfg["layers"], num_attention_heads=cfg["heads"],
+                       intermediate_size=cfg["ffn"], max_position_embeddings=cfg["max_pos"], pad_token_id=cfg["pad"], layer_norm_eps=cfg["eps"]), f)
+    enc = TextEncoder(path, output_dim=cfg["output_dim"], pooling_type="cls", proj_type="mlp", use_logit_scale=True, learnable_logit_scale=False, frozen=True,
+                      use_lora=False)
+    enc.load_state_dict(g["sd"], strict=True)
+    enc = enc.to(DEV).eval()
+    with torch.no_grad():
+        feats = enc(g["ids"].to(DEV)).cpu()
+        hidden = enc.transformer(input_ids=g["ids"].to(DEV)).last_hidden_state.cpu()
+    mask = (g["ids"] != 0).unsqueeze(-1).float()
+    ref_h = g["acts"]["last_hidden"]
+    assert ((hidden - ref_h) * mask).abs().max() < 0.05 * ref_h.abs().max()
+    cs = torch.nn.functional.cosine_similarity(feats, g["features"], dim=-1)
+    assert cs.min() > 0.999, cs
+    assert abs(feats.norm(dim=-1) - 1 / 0.07).max() < 1e-3
