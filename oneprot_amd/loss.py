@@ -28,23 +28,30 @@ class _PackedAllGather(torch.autograd.Function):
 
     @staticmethod
     def forward(ctx, packed, world_size, group):
-        ctx.world_size, ctx.group = world_size, group
-        out = torch.empty((world_size,) + tuple(packed.shape), dtype=packed.dtype, device=packed.device)
-        dist.all_gather_into_tensor(out, packed.contiguous(), group=group)
-        return out
+        ctx.world_size, ctx.group, ctx.rank = world_size, group, dist.get_rank(group)
+        return _all_gather_nograd(packed, world_size, group)
 
     @staticmethod
     def backward(ctx, grad_out):
+        W = ctx.world_size
         grad_out = grad_out.contiguous()
+        flat = grad_out.view((W * grad_out.shape[1],) + tuple(grad_out.shape[2:]))
         grad_in = torch.empty(grad_out.shape[1:], dtype=grad_out.dtype, device=grad_out.device)
-        dist.reduce_scatter_tensor(grad_in, grad_out, op=dist.ReduceOp.SUM, group=ctx.group)
+        try:
+            dist.reduce_scatter_tensor(grad_in, flat, op=dist.ReduceOp.SUM, group=ctx.group)
+        except RuntimeError:      # backends without reduce_scatter (gloo): all-reduce, keep the own slice
+            buf = grad_out.clone()
+            dist.all_reduce(buf, op=dist.ReduceOp.SUM, group=ctx.group)
+            grad_in = buf[ctx.rank].clone()
         return grad_in, None, None
 
 
 def _all_gather_nograd(packed, world_size, group=None):
-    out = torch.empty((world_size,) + tuple(packed.shape), dtype=packed.dtype, device=packed.device)
+    """[k, B, D] -> [W, k, B, D] (one collective for both feature tensors)"""
+    shape = tuple(packed.shape)
+    out = torch.empty((world_size * shape[0],) + shape[1:], dtype=packed.dtype, device=packed.device)
     dist.all_gather_into_tensor(out, packed.detach().contiguous(), group=group)
-    return out
+    return out.view((world_size,) + shape)
 
 
 def gather_features(modality_features, sequence_features, local_loss=False, gather_with_grad=False, rank=0, world_size=1, use_horovod=False):

@@ -1,0 +1,77 @@
+"""world_size 2 / 3 tests of the N>1 path on CPU (gloo): the packed feature all-gather (+ reduce-scatter backward), the SigLIP ring
+exchange and the bucketed gradient all-reduce -- checked against goldens the reference produced on real gloo ranks."""
+import json
+import os
+
+import pytest
+import torch
+import torch.multiprocessing as mp
+
+from tests import _dist_workers as W
+
+
+def _run(fn, world, port, *args):
+    ctx = mp.get_context("spawn")
+    procs = [ctx.Process(target=fn, args=(r, world, port) + args) for r in range(world)]
+    for p in procs:
+        p.start()
+    for p in procs:
+        p.join(180)
+    for p in procs:
+        assert p.exitcode == 0, f"rank exited with {p.exitcode}"
+
+
+def _close(a, b, tol=2e-6):
+    assert (a - b).abs().max() <= tol + 1e-5 * b.abs().max(), (a - b).abs().max()
+
+
+@pytest.mark.parametrize("world,port", [(2, 29721), (3, 29722)])
+def test_gather_features_matches_reference_ranks(golden_dir, tmp_path, world, port):
+    gp = os.path.join(golden_dir, f"loss_world{world}.pt")
+    _run(W.clip_gather_worker, world, port, gp, str(tmp_path))
+    g = torch.load(gp, weights_only=False)
+    for r in range(world):
+        got = torch.load(os.path.join(str(tmp_path), f"clip_rank{r}.pt"), weights_only=False)
+        for key, (loss, gm, gs) in got.items():
+            rl, rgm, rgs = g["per_rank"][r][key]
+            assert abs(loss - rl) / abs(rl) < 1e-5, key
+            _close(gm, rgm); _close(gs, rgs)
+
+
+@pytest.mark.parametrize("world,port", [(2, 29723), (3, 29724)])
+def test_siglip_ring_matches_reference_ranks(golden_dir, tmp_path, world, port):
+    gp = os.path.join(golden_dir, f"loss_world{world}.pt")
+    _run(W.siglip_ring_worker, world, port, gp, str(tmp_path))
+    g = torch.load(gp, weights_only=False)
+    for r in range(world):
+        got = torch.load(os.path.join(str(tmp_path), f"siglip_rank{r}.pt"), weights_only=False)
+        for key, (loss, gm, gs) in got.items():
+            rl, rgm, rgs = g["per_rank"][r][key]
+            assert abs(loss - rl) / abs(rl) < 1e-5, key
+            _close(gm, rgm, 1e-5); _close(gs, rgs, 1e-5)
+
+
+def test_bucketed_gradient_allreduce(tmp_path):
+    _run(W.allreduce_worker, 2, 29725, str(tmp_path))
+    a = torch.load(os.path.join(str(tmp_path), "ar_rank0.pt"), weights_only=False)
+    b = torch.load(os.path.join(str(tmp_path), "ar_rank1.pt"), weights_only=False)
+    for i in range(3):
+        mean = (a["mine"][i] + b["mine"][i]) / 2
+        _close(a["reduced"][i], mean); _close(b["reduced"][i], mean)
+
+
+def test_first_node_and_env_mapping(golden_dir, monkeypatch):
+    from oneprot_amd import distributed as D
+    with open(os.path.join(golden_dir, "distributed_cases.json")) as f:
+        cases = json.load(f)
+    for c in cases["first_node"]:
+        monkeypatch.setenv("SLURM_JOB_NODELIST", c["nodelist"])
+        assert D._get_first_node() == c["first"], c
+    for c in cases["env"]:
+        for k, v in dict(SLURM_JOB_NODELIST="jwb[0097,0101]", SLURM_NTASKS="8", SLURM_PROCID="3", SLURM_LOCALID="1", SYSTEMNAME=c["SYSTEMNAME"]).items():
+            monkeypatch.setenv(k, v)
+        D.init_distributed_mode(port=23456)
+        for k in ("WORLD_SIZE", "RANK", "LOCAL_RANK", "MASTER_ADDR", "MASTER_PORT"):
+            assert os.environ[k] == c[k], (k, c)
+    import src.distributed as SD      # the reference's import path
+    assert SD.init_distributed_mode is D.init_distributed_mode

@@ -1,0 +1,173 @@
+"""CPU-side checks (no GPU compute): the C-ABI library loads and exports every symbol include/oneprot_hip.h declares, the ctypes
+table matches the header, the drop-in classes keep the reference's import paths / constructor signatures / state-dict keys, the
+config composer handles the reference's YAML, and the product path refuses to run without the GPU (no silent fallback)."""
+import ctypes
+import inspect
+import json
+import os
+import re
+import subprocess
+
+import pytest
+import torch
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+HEADER = os.path.join(ROOT, "include", "oneprot_hip.h")
+REF = "/root/reference"
+
+
+@pytest.fixture(scope="session")
+def built_lib():
+    from oneprot_amd import hip
+    if not os.path.exists(hip.LIB_PATH):
+        subprocess.check_call(["bash", os.path.join(ROOT, "oneprot_amd", "csrc", "build.sh")])
+    return hip
+
+
+def _declared():
+    txt = open(HEADER).read()
+    txt = re.sub(r"/\*.*?\*/", "", txt, flags=re.S)
+    return sorted(set(re.findall(r"\b(oneprot_[a-z0-9_]+)\s*\(", txt)))
+
+
+def test_library_exports_every_declared_symbol(built_lib):
+    names = _declared()
+    assert len(names) >= 30
+    h = ctypes.CDLL(built_lib.LIB_PATH)
+    missing = [n for n in names if not hasattr(h, n)]
+    assert not missing, missing
+    assert h.oneprot_abi_version() == 1
+    # the ctypes table and the header agree (both directions)
+    assert sorted(built_lib.exported_symbols()) == names
+
+
+def test_ctypes_arity_matches_header(built_lib):
+    txt = re.sub(r"/\*.*?\*/", "", open(HEADER).read(), flags=re.S)
+    for name, (res, args) in built_lib._SIGS.items():
+        m = re.search(r"\b" + name + r"\s*\(([^;]*?)\)\s*;", txt, flags=re.S)
+        assert m, name
+        params = m.group(1).strip()
+        n = 0 if params in ("void", "") else params.count(",") + 1
+        assert n == len(args), (name, n, len(args))
+
+
+def test_argument_validation_without_gpu(built_lib):
+    h = built_lib.lib()
+    # NULL pointers / bad shapes are rejected with -1 before any launch
+    assert h.oneprot_layernorm_fwd(None, 0, None, None, None, None, None, None, 10, 64, 1e-5, None) == -1
+    assert h.oneprot_gemm_bf16_nt(None, None, 128, 128, 64, 64, 64, 0, None, None, None, None, None, None, None, 1.0, 0, 0, 0, None) == -1
+    assert h.oneprot_attn_fwd(None, None, None, None, None, None, 1, 1, 16, 32, None) == -1
+    assert h.oneprot_adam_step(None, None, None, None, 16, 1e-3, 0.9, 0.999, 1e-8, 0.0, 1, None, None) == -1
+    assert h.oneprot_gemm_bf16_tn_workspace(640, 640) > 0 and h.oneprot_layernorm_bwd_workspace(640) > 0
+
+
+def test_missing_library_fails_loudly(monkeypatch, built_lib):
+    monkeypatch.setattr(built_lib, "_lib", None)
+    monkeypatch.setattr(built_lib, "LIB_PATH", "/nonexistent/liboneprot_hip.so")
+    with pytest.raises(built_lib.HipLibraryMissing):
+        built_lib.lib()
+
+
+def _tiny_dir(tmp_path, model_type="esm"):
+    p = os.path.join(str(tmp_path), model_type)
+    os.makedirs(p, exist_ok=True)
+    cfg = dict(model_type=model_type, vocab_size=33, hidden_size=64, num_hidden_layers=2, num_attention_heads=4, intermediate_size=128)
+    if model_type == "bert":
+        cfg.update(vocab_size=120, max_position_embeddings=64, pad_token_id=0, layer_norm_eps=1e-12)
+    with open(os.path.join(p, "config.json"), "w") as f:
+        json.dump(cfg, f)
+    return p
+
+
+def test_dropin_paths_signatures_and_state_dict(golden_dir, tmp_path, monkeypatch):
+    monkeypatch.setenv("ONEPROT_ALLOW_RANDOM_INIT", "1")
+    monkeypatch.setenv("RANK", "0"); monkeypatch.setenv("WORLD_SIZE", "1")
+    from src.models.components.sequence_encoder import SequenceEncoder
+    from src.models.components.struct_token_encoder import StructTokenEncoder
+    from src.models.components.text_encoder import TextEncoder
+    from src.models.components.loss import ClipLoss, SigLipLoss, gather_features  # noqa: F401
+    from src.models.components.base_encoder import BaseEncoder, Normalize, LearnableLogitScaling  # noqa: F401
+    from src.models.oneprot_module import OneProtLitModule
+    # constructor parameter names of the reference (ref sequence_encoder.py:23-38, struct_token_encoder.py:7-15, text_encoder.py:9-23, oneprot_module.py:10-21)
+    assert list(inspect.signature(SequenceEncoder.__init__).parameters)[1:] == [
+        "model_name_or_path", "output_dim", "pooling_type", "proj_type", "use_logit_scale", "learnable_logit_scale", "pretrained", "use_lora", "lora_r",
+        "lora_alpha", "lora_dropout", "lora_target_modules", "frozen"]
+    assert list(inspect.signature(StructTokenEncoder.__init__).parameters)[1:] == [
+        "model_name_or_path", "output_dim", "pooling_type", "proj_type", "use_logit_scale", "learnable_logit_scale"]
+    assert list(inspect.signature(TextEncoder.__init__).parameters)[1:] == [
+        "model_name_or_path", "output_dim", "pooling_type", "proj_type", "use_logit_scale", "learnable_logit_scale", "frozen", "use_lora", "lora_r", "lora_alpha",
+        "lora_dropout", "lora_target_modules"]
+    assert list(inspect.signature(OneProtLitModule.__init__).parameters)[1:] == [
+        "components", "optimizer", "train_on_all_modalities_after_step", "scheduler", "use_seqsim", "loss_fn", "use_l1_regularization", "local_loss",
+        "gather_with_grad"]
+    assert list(inspect.signature(ClipLoss.__init__).parameters)[1:] == ["local_loss", "gather_with_grad", "cache_labels", "rank", "world_size", "use_horovod"]
+    assert list(inspect.signature(SigLipLoss.__init__).parameters)[1:] == ["cache_labels", "rank", "world_size", "bidir", "use_horovod"]
+    g = torch.load(os.path.join(golden_dir, "esm_pair_hd16.pt"), weights_only=False)
+    p = _tiny_dir(tmp_path)
+    seq = SequenceEncoder(p, output_dim=48, proj_type="mlp", use_lora=False, frozen=True)
+    st = StructTokenEncoder(p, output_dim=48, proj_type="linear", use_logit_scale=True)
+    # strict load of the reference's own state dicts, and identical key sets on the way out
+    seq.load_state_dict(g["sd_seq"], strict=True)
+    st.load_state_dict(g["sd_st"], strict=True)
+    for enc, ref in ((seq, g["sd_seq"]), (st, g["sd_st"])):
+        sd = enc.state_dict()
+        assert set(sd) == set(ref)
+        for k in sd:
+            assert "inv_freq" in k or torch.equal(sd[k], ref[k]), k
+    assert all(not p_.requires_grad for p_ in seq.transformer.parameters())          # frozen=True
+    assert st.transformer.config.vocab_size == 54 and st.config.pad_token_id == 1
+    assert abs(st.logit_scale_value() - 1 / 0.07) < 1e-4 and seq.logit_scale_value() == 1.0
+    assert st.norm[1].log_logit_scale.ndim == 0                                        # attribute the reference's test_step reads
+    tb = torch.load(os.path.join(golden_dir, "bert_text.pt"), weights_only=False)
+    txt = TextEncoder(_tiny_dir(tmp_path, "bert"), output_dim=48, pooling_type="cls", proj_type="mlp", use_logit_scale=True, frozen=True, use_lora=False)
+    txt.load_state_dict(tb["sd"], strict=True)
+    assert set(txt.state_dict()) == set(tb["sd"])
+    # module: loss selection and error conventions of the reference
+    import functools
+    mod = OneProtLitModule(components={"sequence": seq, "struct_token": st}, optimizer=functools.partial(torch.optim.Adam, lr=1e-3))
+    assert mod.modalities == ["sequence", "struct_token"] and isinstance(mod.loss_fn, ClipLoss) and mod.loss_fn.local_loss and mod.loss_fn.gather_with_grad
+    assert isinstance(mod.configure_optimizers()["optimizer"], torch.optim.Adam)
+    with pytest.raises(ValueError):
+        OneProtLitModule(components={"sequence": seq}, optimizer=None, loss_fn="NOPE")
+    monkeypatch.delenv("RANK")
+    with pytest.raises(KeyError):
+        OneProtLitModule(components={"sequence": seq}, optimizer=None)
+    # no CPU fallback anywhere on the product path
+    from oneprot_amd import hip
+    with pytest.raises(hip.HipKernelError):
+        seq(g["seq_ids"])
+    with pytest.raises(OSError):
+        SequenceEncoder("not/a-model", output_dim=8, use_lora=False)
+    monkeypatch.delenv("ONEPROT_ALLOW_RANDOM_INIT")
+    with pytest.raises(OSError):
+        StructTokenEncoder(p, output_dim=48)          # config only, no weight file: refuses unless random init is explicitly allowed
+    with pytest.raises(NotImplementedError):
+        SequenceEncoder(p, output_dim=48, use_lora=True)
+
+
+def test_config_composer_own_tree():
+    from oneprot_amd.config import compose, instantiate
+    c = compose(os.path.join(ROOT, "configs"), "train")
+    m = c["model"]
+    assert m["_target_"] == "src.models.oneprot_module.OneProtLitModule"
+    assert m["components"]["struct_token"]["output_dim"] == 1024 and m["components"]["sequence"]["frozen"] is True
+    assert m["loss_fn"] == "CLIP" and m["local_loss"] and m["gather_with_grad"] and m["use_l1_regularization"]
+    opt = instantiate(m["optimizer"])
+    assert opt.func.__name__ == "FusedAdam" and opt.keywords["lr"] == 0.001
+    c2 = compose(os.path.join(ROOT, "configs"), "train", overrides={"model": "oneprot_text", "model.components.sequence.output_dim": 256})
+    assert c2["model"]["components"]["text"]["output_dim"] == 256 and c2["model"]["components"]["struct_token"]["output_dim"] == 256
+
+
+@pytest.mark.skipif(not os.path.isdir(os.path.join(REF, "configs")), reason="reference checkout only exists in the build container")
+def test_config_composer_reads_reference_yaml_unchanged():
+    from oneprot_amd.config import compose
+    c = compose(os.path.join(REF, "configs"), "model/oneprot")["model"]
+    assert c["_target_"] == "src.models.oneprot_module.OneProtLitModule"
+    assert c["optimizer"] == {"_target_": "torch.optim.Adam", "_partial_": True, "lr": 0.001, "weight_decay": 0.0}
+    assert c["components"]["sequence"]["_target_"] == "src.models.components.sequence_encoder.SequenceEncoder"
+    assert c["components"]["text"]["output_dim"] == c["components"]["sequence"]["output_dim"] == 1024        # ${..sequence.output_dim}
+    assert c["loss_fn"] == "CLIP" and c["use_l1_regularization"] is True
+    t = compose(os.path.join(REF, "configs"), "trainer/ddp", resolve=False)["trainer"]      # (${paths.*} needs the paths group)
+    assert t["devices"] == 4 and t["strategy"] == "ddp_find_unused_parameters_true" and t["accelerator"] == "gpu"
+    s = compose(os.path.join(REF, "configs"), "model/components/struct_token", resolve=False)
+    assert s["model"]["components"]["struct_token"]["use_logit_scale"] is True
