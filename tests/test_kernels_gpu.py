@@ -375,3 +375,30 @@ def test_casts():
     yt = torch.empty(132, 70, dtype=torch.bfloat16, device=DEV)
     hip.call("oneprot_transpose_cast_f32_to_bf16", x, yt, 70, 132)
     assert torch.equal(yt, x.t().contiguous().to(torch.bfloat16))
+
+
+@pytest.mark.parametrize("world,local_loss", [(2, True), (3, True), (2, False)])
+def test_clip_loss_node_multirank_semantics(golden_dir, world, local_loss):
+    """The fused CLIP node (SGEMM logits + fused CE fwd/bwd) on gathered features, per rank, vs the losses/gradients the reference
+    produced on real ranks (gather_with_grad=False variant: the local gradient is exactly d loss_rank / d local features)."""
+    import os
+    from oneprot_amd.loss import _ClipLossFn
+    g = torch.load(os.path.join(golden_dir, f"loss_world{world}.pt"), weights_only=False)
+    M, S = g["m"], g["s"]
+    B, D = M.shape[1:]
+    for rank in range(world):
+        m = M[rank].clone().to(DEV).requires_grad_(True)
+        s = S[rank].clone().to(DEV).requires_grad_(True)
+        if local_loss:
+            all_m = M.reshape(-1, D).to(DEV)
+            all_s = S.reshape(-1, D).to(DEV)
+            loss = _ClipLossFn.apply(m, all_s, s, all_m, 1.0, B * rank)
+        else:
+            am = torch.cat([m if r == rank else M[r].to(DEV) for r in range(world)])
+            as_ = torch.cat([s if r == rank else S[r].to(DEV) for r in range(world)])
+            loss = _ClipLossFn.apply(am, as_, as_, am, 1.0, 0)
+        loss.backward()
+        rl, rgm, rgs = g["per_rank"][rank][f"clip_ll{int(local_loss)}_gwg0"]
+        assert abs(loss.item() - rl.item()) / abs(rl.item()) < 1e-5
+        assert_close(m.grad.cpu(), rgm, 1e-4, 1e-6, "dm")
+        assert_close(s.grad.cpu(), rgs, 1e-4, 1e-6, "ds")
