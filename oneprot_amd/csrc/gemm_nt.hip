@@ -1,11 +1,16 @@
 // bf16 MFMA GEMM, C[M,N] = A[M,K] * B[N,K]^T (+ fused epilogue), fp32 accumulation.  gfx950 only.
 //
 // Structure:
-//   * workgroup = 256 threads = 4 waves (2x2), block tile 128x128, BK = 64; each wave owns a 64x64 sub-tile as
-//     4x4 v_mfma_f32_16x16x32_bf16 accumulators (64 VGPRs);
-//   * A and B K-slices go HBM -> LDS with global_load_lds_dwordx4 (LDS-DMA, no VGPR staging), double buffered,
-//     one barrier per K-step; the LDS image is lane-linear (128-byte rows) and the bank-conflict XOR swizzle
-//     (chunk ^= (row>>1)&7) is applied on the per-lane SOURCE address and again on the ds_read_b128 address;
+//   * three block shapes from one template <WM x WN waves, MT 16-row tiles per wave>, BK = 64, v_mfma_f32_16x16x32_bf16:
+//       256x256 (8 waves 2x4, wave tile 128x64, 2 LDS stages)   large N: half the L2->LDS bytes per FLOP of a 128^2 tile
+//       256x128 (8 waves 4x2, wave tile  64x64, 3 LDS stages)   N = 640-class outputs
+//       128x128 (4 waves 2x2, wave tile  64x64, 2 LDS stages, 2 blocks/CU)   small problems
+//     (measured: the 128^2 / 2-stage form is bound by bytes-in-flight / load latency at K = 640 -- 64 KB in flight per CU
+//      sustains ~12 TB/s of L2->LDS traffic -- so the larger shapes raise FLOPs per staged byte and the 3-stage form keeps
+//      two K-slices in flight behind a COUNTED s_waitcnt vmcnt(N) and a raw s_barrier);
+//   * A and B K-slices go HBM -> LDS with global_load_lds_dwordx4 (LDS-DMA, no VGPR staging); the LDS image is lane-linear
+//     (128-byte rows) and the bank-conflict XOR swizzle (chunk ^= (row>>1)&7) is applied on the per-lane SOURCE address
+//     and again on the ds_read_b128 address;
 //   * rows/cols beyond M/N/K read from a 16-byte zero page (per-lane source select), so any M, any N%8==0,
 //     any K%8==0 works without a tail path;
 //   * blockIdx -> tile mapping is XCD-aware: the 8 XCDs take interleaved row panels and sweep N fastest, so an
@@ -16,13 +21,7 @@
 #include "common.h"
 #include "../../include/oneprot_hip.h"
 
-#define BM 128
-#define BN 128
-#define BK 64
-#define STAGE_BYTES (BM * BK * 2 + BN * BK * 2)     // 32 KiB
-#define EPI_LD 68                                   // fp32 row pitch of a wave's 64x64 epilogue tile
-#define EPI_BYTES (4 * 64 * EPI_LD * 4)             // 69632
-#define LDS_BYTES (EPI_BYTES > 2 * STAGE_BYTES ? EPI_BYTES : 2 * STAGE_BYTES)
+#define EPI_LD 68                                   // fp32 row pitch of a wave's epilogue tile (64 columns + pad)
 
 static __device__ __attribute__((aligned(16))) unsigned int g_zero_page[4] = {0, 0, 0, 0};
 
@@ -38,8 +37,35 @@ struct GemmArgs {
   int tiles_m, tiles_n;
 };
 
-template <int EPI>
-__global__ void __launch_bounds__(256, 2) k_gemm_nt(const GemmArgs p) {
+// WM x WN waves, MT 16-row tiles per wave (wave tile = MT*16 x 64), BKT = K-slice per LDS stage (32 or 64), NSTAGE ring depth,
+// EPH = rows per epilogue staging pass (wave-private LDS tile EPH x 64 fp32)
+template <int WM, int WN, int MT, int BKT, int NSTAGE, int EPH> struct Shape {
+  static constexpr int NW = WM * WN;
+  static constexpr int BM_ = WM * MT * 16;
+  static constexpr int BN_ = WN * 64;
+  static constexpr int ROWB = BKT * 2;              // LDS row pitch in bytes
+  static constexpr int RPI = 1024 / ROWB;           // rows covered by one global_load_lds wave-instruction
+  static constexpr int A_IPW = BM_ / RPI / NW;      // instructions per wave per stage
+  static constexpr int B_IPW = BN_ / RPI / NW;
+  static constexpr int LPS = A_IPW + B_IPW;
+  static constexpr int STAGE = (BM_ + BN_) * ROWB;
+  static constexpr int EPI_WAVE = EPH * EPI_LD * 4;
+  static constexpr int LDS = (NSTAGE * STAGE > NW * EPI_WAVE) ? NSTAGE * STAGE : NW * EPI_WAVE;
+};
+
+// 16-byte-chunk XOR swizzle keeping ds_read_b128 fragment reads conflict-free:
+//   128-B rows (BK 64): chunk ^ ((row>>1)&7);   64-B rows (BK 32): chunk ^ G[(row>>2)&3], G = {0,2,3,1}
+template <int BKT> __device__ __forceinline__ int swz(int row, int chunk) {
+  return BKT == 64 ? (chunk ^ ((row >> 1) & 7)) : (chunk ^ ((0x1320 >> (((row >> 2) & 3) << 2)) & 3));
+}
+
+template <int N> __device__ __forceinline__ void wait_vmcnt() { asm volatile("s_waitcnt vmcnt(%0)" ::"n"(N) : "memory"); }
+
+template <int EPI, int WM, int WN, int MT, int BKT, int NSTAGE, int EPH, int MINW>
+__global__ void __launch_bounds__(WM * WN * 64, MINW) k_gemm_nt(const GemmArgs p) {
+  typedef Shape<WM, WN, MT, BKT, NSTAGE, EPH> S;
+  constexpr int CH = BKT / 8;                      // chunks per row
+  constexpr int KK = BKT / 32;                     // MFMA k-substeps per stage
   extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
   // ---- XCD-aware tile assignment
   const int bid = blockIdx.x;
@@ -47,107 +73,111 @@ __global__ void __launch_bounds__(256, 2) k_gemm_nt(const GemmArgs p) {
   const int tm = (seq / p.tiles_n) * 8 + xcd;
   const int tn = seq % p.tiles_n;
   if (tm >= p.tiles_m) return;
-  const int m0 = tm * BM, n0 = tn * BN;
+  const int m0 = tm * S::BM_, n0 = tn * S::BN_;
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-  const int wr = wave >> 1, wc = wave & 1;
+  const int wr = wave / WN, wc = wave % WN;
 
-  // ---- per-lane staging addresses: wave w issues instructions i=0..3 for A and for B, each covering 8 rows x 128 B
-  const int srow = lane >> 3;                 // row within the 8-row group
-  const int schunk = lane & 7;                // LDS chunk (16 B) within the 128-byte row
+  // ---- per-lane staging addresses: one global_load_lds instruction covers RPI rows of ROWB bytes (1 KiB, lane-linear)
+  const int srow = lane / CH;
+  const int schunk = lane % CH;
   const unsigned char* zero = reinterpret_cast<const unsigned char*>(g_zero_page);
-  const unsigned char* a_src[4]; const unsigned char* b_src[4];
-  int a_ok[4], b_ok[4], src_chunk[4];
+  const unsigned char* a_src[S::A_IPW]; const unsigned char* b_src[S::B_IPW];
+  int a_chunk[S::A_IPW], b_chunk[S::B_IPW];
+  bool a_ok[S::A_IPW], b_ok[S::B_IPW];
 #pragma unroll
-  for (int i = 0; i < 4; ++i) {
-    const int row = (wave * 4 + i) * 8 + srow;             // 0..127
-    src_chunk[i] = schunk ^ ((row >> 1) & 7);
+  for (int i = 0; i < S::A_IPW; ++i) {
+    const int row = (wave * S::A_IPW + i) * S::RPI + srow;
+    a_chunk[i] = swz<BKT>(row, schunk);
     a_ok[i] = (m0 + row) < p.M;
-    b_ok[i] = (n0 + row) < p.N;
-    a_src[i] = reinterpret_cast<const unsigned char*>(p.A + (size_t)(a_ok[i] ? m0 + row : 0) * p.lda + src_chunk[i] * 8);
-    b_src[i] = reinterpret_cast<const unsigned char*>(p.B + (size_t)(b_ok[i] ? n0 + row : 0) * p.ldb + src_chunk[i] * 8);
+    a_src[i] = reinterpret_cast<const unsigned char*>(p.A + (size_t)(a_ok[i] ? m0 + row : 0) * p.lda + a_chunk[i] * 8);
   }
-  const int nk = (p.K + BK - 1) / BK;
+#pragma unroll
+  for (int i = 0; i < S::B_IPW; ++i) {
+    const int row = (wave * S::B_IPW + i) * S::RPI + srow;
+    b_chunk[i] = swz<BKT>(row, schunk);
+    b_ok[i] = (n0 + row) < p.N;
+    b_src[i] = reinterpret_cast<const unsigned char*>(p.B + (size_t)(b_ok[i] ? n0 + row : 0) * p.ldb + b_chunk[i] * 8);
+  }
+  const int nk = (p.K + BKT - 1) / BKT;
 
   auto stage = [&](int t, int buf) {
-    unsigned char* sA = smem + buf * STAGE_BYTES;
-    unsigned char* sB = sA + BM * BK * 2;
-    const int k0 = t * BK;
+    unsigned char* sA = smem + buf * S::STAGE;
+    unsigned char* sB = sA + S::BM_ * S::ROWB;
+    const int k0 = t * BKT;
 #pragma unroll
-    for (int i = 0; i < 4; ++i) {
-      const bool kin = (k0 + src_chunk[i] * 8) < p.K;
-      const unsigned char* ga = (a_ok[i] && kin) ? a_src[i] + (size_t)k0 * 2 : zero;
-      const unsigned char* gb = (b_ok[i] && kin) ? b_src[i] + (size_t)k0 * 2 : zero;
-      __builtin_amdgcn_global_load_lds(GLB_PTR(ga), LDS_PTR(sA + (wave * 4 + i) * 1024), 16, 0, 0);
-      __builtin_amdgcn_global_load_lds(GLB_PTR(gb), LDS_PTR(sB + (wave * 4 + i) * 1024), 16, 0, 0);
+    for (int i = 0; i < S::A_IPW; ++i) {
+      const unsigned char* ga = (a_ok[i] && (k0 + a_chunk[i] * 8) < p.K) ? a_src[i] + (size_t)k0 * 2 : zero;
+      __builtin_amdgcn_global_load_lds(GLB_PTR(ga), LDS_PTR(sA + (wave * S::A_IPW + i) * 1024), 16, 0, 0);
+    }
+#pragma unroll
+    for (int i = 0; i < S::B_IPW; ++i) {
+      const unsigned char* gb = (b_ok[i] && (k0 + b_chunk[i] * 8) < p.K) ? b_src[i] + (size_t)k0 * 2 : zero;
+      __builtin_amdgcn_global_load_lds(GLB_PTR(gb), LDS_PTR(sB + (wave * S::B_IPW + i) * 1024), 16, 0, 0);
     }
   };
 
-  f32x4 acc[4][4];
+  f32x4 acc[MT][4];
 #pragma unroll
-  for (int i = 0; i < 4; ++i)
+  for (int i = 0; i < MT; ++i)
 #pragma unroll
     for (int j = 0; j < 4; ++j) acc[i][j] = (f32x4){0.f, 0.f, 0.f, 0.f};
 
-  // fragment read offsets (bytes within a stage's A or B image)
+  // fragment read offsets (bytes within a stage's A or B image) for k-substep 0; substep 1 (BK 64) flips chunk bit 2
   const int frow = lane & 15, fq = lane >> 4;
-  int a_off[4][2], b_off[4][2];
+  int a_off[MT], b_off[4];
 #pragma unroll
-  for (int i = 0; i < 4; ++i) {
-    const int ra = wr * 64 + i * 16 + frow, rb = wc * 64 + i * 16 + frow;
+  for (int i = 0; i < MT; ++i) {
+    const int ra = wr * (MT * 16) + i * 16 + frow;
+    a_off[i] = ra * S::ROWB + (swz<BKT>(ra, fq) << 4);
+  }
 #pragma unroll
-    for (int kk = 0; kk < 2; ++kk) {
-      const int c = kk * 4 + fq;
-      a_off[i][kk] = ra * 128 + ((c ^ ((ra >> 1) & 7)) << 4);
-      b_off[i][kk] = rb * 128 + ((c ^ ((rb >> 1) & 7)) << 4);
-    }
+  for (int j = 0; j < 4; ++j) {
+    const int rb = wc * 64 + j * 16 + frow;
+    b_off[j] = rb * S::ROWB + (swz<BKT>(rb, fq) << 4);
   }
 
-  stage(0, 0);
+  // ---- K loop: NSTAGE-deep LDS ring, NSTAGE-1 K-slices in flight, counted vmcnt + raw barrier (never a vmcnt(0) drain mid-loop)
+#pragma unroll
+  for (int s = 0; s < NSTAGE - 1; ++s)
+    if (s < nk) stage(s, s);
+  int buf = 0, nbuf = NSTAGE - 1;
   for (int t = 0; t < nk; ++t) {
-    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-    __syncthreads();
-    if (t + 1 < nk) stage(t + 1, (t + 1) & 1);
-    const unsigned char* sA = smem + (t & 1) * STAGE_BYTES;
-    const unsigned char* sB = sA + BM * BK * 2;
+    if (t + NSTAGE - 2 < nk) wait_vmcnt<(NSTAGE - 2) * S::LPS>(); else wait_vmcnt<0>();
+    asm volatile("s_barrier" ::: "memory");
+    if (t + NSTAGE - 1 < nk) stage(t + NSTAGE - 1, nbuf);
+    const unsigned char* sA = smem + buf * S::STAGE;
+    const unsigned char* sB = sA + S::BM_ * S::ROWB;
 #pragma unroll
-    for (int kk = 0; kk < 2; ++kk) {
-      bf8_t a[4], b[4];
+    for (int kk = 0; kk < KK; ++kk) {
+      bf8_t a[MT], b[4];
 #pragma unroll
-      for (int i = 0; i < 4; ++i) {
-        a[i] = *reinterpret_cast<const bf8_t*>(sA + a_off[i][kk]);
-        b[i] = *reinterpret_cast<const bf8_t*>(sB + b_off[i][kk]);
-      }
+      for (int j = 0; j < 4; ++j) b[j] = *reinterpret_cast<const bf8_t*>(sB + (b_off[j] ^ (kk << 6)));
 #pragma unroll
-      for (int i = 0; i < 4; ++i)
+      for (int i = 0; i < MT; ++i) a[i] = *reinterpret_cast<const bf8_t*>(sA + (a_off[i] ^ (kk << 6)));
+#pragma unroll
+      for (int i = 0; i < MT; ++i)
 #pragma unroll
         for (int j = 0; j < 4; ++j) acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a[i], b[j], acc[i][j], 0, 0, 0);
     }
+    buf = (buf + 1 == NSTAGE) ? 0 : buf + 1;
+    nbuf = (nbuf + 1 == NSTAGE) ? 0 : nbuf + 1;
   }
-  __syncthreads();          // everyone done with the staging buffers before they are reused as epilogue tiles
+  __syncthreads();          // everyone done with the staging ring before it is reused as epilogue tiles
 
-  // ---- epilogue: wave-private 64x64 fp32 tile in LDS
-  float* et = reinterpret_cast<float*>(smem) + wave * 64 * EPI_LD;
-#pragma unroll
-  for (int i = 0; i < 4; ++i)
-#pragma unroll
-    for (int j = 0; j < 4; ++j)
-#pragma unroll
-      for (int r = 0; r < 4; ++r) et[(i * 16 + fq * 4 + r) * EPI_LD + j * 16 + frow] = acc[i][j][r];
-  // (same wave wrote and reads: LDS ops of one wave complete in order; the compiler inserts the lgkmcnt wait)
-  __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+  // ---- epilogue: wave-private EPH x 64 fp32 tile in LDS, (MT*16)/EPH passes
+  float* et = reinterpret_cast<float*>(smem) + wave * EPH * EPI_LD;
   const int er = lane >> 3, ec = (lane & 7) * 8;
   const int gn = n0 + wc * 64 + ec;
-  if (gn >= p.N) return;
   float bias8[8];
 #pragma unroll
   for (int e = 0; e < 8; ++e) bias8[e] = 0.f;
-  if (p.bias) {
+  if (p.bias && gn < p.N) {
     const float4 b0 = *reinterpret_cast<const float4*>(p.bias + gn), b1 = *reinterpret_cast<const float4*>(p.bias + gn + 4);
     bias8[0] = b0.x; bias8[1] = b0.y; bias8[2] = b0.z; bias8[3] = b0.w; bias8[4] = b1.x; bias8[5] = b1.y; bias8[6] = b1.z; bias8[7] = b1.w;
   }
   // QKV/RoPE constants for this lane's 8 columns
   int sec = 0, head = 0, j0 = 0, pc = 0; float pbias8[8]; float sgn = 0.f;
-  if (EPI == ONEPROT_EPI_QKV_ROPE) {
+  if (EPI == ONEPROT_EPI_QKV_ROPE && gn < p.N) {
     const int dm = p.H * p.hd;
     sec = gn / dm;
     const int within = gn - sec * dm;
@@ -164,10 +194,21 @@ __global__ void __launch_bounds__(256, 2) k_gemm_nt(const GemmArgs p) {
       pbias8[0] = b0.x; pbias8[1] = b0.y; pbias8[2] = b0.z; pbias8[3] = b0.w; pbias8[4] = b1.x; pbias8[5] = b1.y; pbias8[6] = b1.z; pbias8[7] = b1.w;
     }
   }
+#pragma unroll
+  for (int half = 0; half < (MT * 16) / EPH; ++half) {
+#pragma unroll
+    for (int i = 0; i < EPH / 16; ++i)
+#pragma unroll
+      for (int j = 0; j < 4; ++j)
+#pragma unroll
+        for (int r = 0; r < 4; ++r) et[(i * 16 + fq * 4 + r) * EPI_LD + j * 16 + frow] = acc[half * (EPH / 16) + i][j][r];
+    // same wave writes and reads: LDS operations of one wave complete in order
+    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+    if (gn < p.N) {
 #pragma unroll 2
-  for (int pass = 0; pass < 8; ++pass) {
+    for (int pass = 0; pass < EPH / 8; ++pass) {
     const int r = pass * 8 + er;
-    const int gm = m0 + wr * 64 + r;
+    const int gm = m0 + wr * (MT * 16) + half * EPH + r;
     if (gm >= p.M) continue;
     float v[8];
     {
@@ -233,18 +274,44 @@ __global__ void __launch_bounds__(256, 2) k_gemm_nt(const GemmArgs p) {
       *reinterpret_cast<u32x4*>(dst + oo) = w;
     }
   }
+    }
+    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");     // reads of this pass done before the next pass overwrites the tile
+  }
 }
 
-template <int EPI>
-static int launch_gemm(const GemmArgs& a, hipStream_t s) {
+template <int EPI, int WM, int WN, int MT, int BKT, int NSTAGE, int EPH, int MINW>
+static int launch_shape(GemmArgs a, hipStream_t s) {
+  typedef Shape<WM, WN, MT, BKT, NSTAGE, EPH> S;
   static bool configured = false;
   if (!configured) {
-    if (hipFuncSetAttribute((const void*)k_gemm_nt<EPI>, hipFuncAttributeMaxDynamicSharedMemorySize, LDS_BYTES) != hipSuccess) return OP_ELAUNCH;
+    if (hipFuncSetAttribute((const void*)k_gemm_nt<EPI, WM, WN, MT, BKT, NSTAGE, EPH, MINW>, hipFuncAttributeMaxDynamicSharedMemorySize, S::LDS) != hipSuccess)
+      return OP_ELAUNCH;
     configured = true;
   }
+  a.tiles_m = (a.M + S::BM_ - 1) / S::BM_;
+  a.tiles_n = (a.N + S::BN_ - 1) / S::BN_;
   const int grid = ((a.tiles_m + 7) / 8) * 8 * a.tiles_n;
-  hipLaunchKernelGGL(k_gemm_nt<EPI>, dim3(grid), dim3(256), LDS_BYTES, s, a);
+  hipLaunchKernelGGL((k_gemm_nt<EPI, WM, WN, MT, BKT, NSTAGE, EPH, MINW>), dim3(grid), dim3(S::NW * 64), S::LDS, s, a);
   return launch_status();
+}
+
+static int g_force_shape = -1;     // test / tuning hook, see launch_gemm
+extern "C" void oneprot_gemm_force_shape(int shape) { g_force_shape = shape; }
+
+// shapes: 0 = 128x128 (BK32, 3 stages, 48 KB LDS -> 3 blocks/CU)      1 = 256x128 (BK32, 3 stages, 72 KB -> 2 blocks/CU)
+//         2 = 256x256 (BK32, 4 stages, 128 KB, 1 block/CU)            3 = 128x128 BK64 2 stages (round-1 first version, kept for A/B runs)
+template <int EPI>
+static int launch_gemm(const GemmArgs& a, hipStream_t s) {
+  int shape;
+  if (g_force_shape >= 0) shape = g_force_shape;
+  else if (a.M < 2048) shape = 0;
+  else shape = 1;
+  switch (shape) {
+    case 3: return launch_shape<EPI, 2, 2, 4, 64, 2, 64, 2>(a, s);
+    case 2: return launch_shape<EPI, 2, 4, 8, 32, 4, 32, 2>(a, s);
+    case 1: return launch_shape<EPI, 4, 2, 4, 32, 3, 32, 4>(a, s);
+    default: return launch_shape<EPI, 2, 2, 4, 32, 3, 32, 3>(a, s);
+  }
 }
 
 extern "C" int oneprot_gemm_bf16_nt(const void* A, const void* Bw, int64_t M, int N, int K, int lda, int ldb, int epilogue, const float* bias,
@@ -256,7 +323,7 @@ extern "C" int oneprot_gemm_bf16_nt(const void* A, const void* Bw, int64_t M, in
   GemmArgs a;
   a.A = (const bf16_t*)A; a.B = (const bf16_t*)Bw; a.M = (int)M; a.N = N; a.K = K; a.lda = lda; a.ldb = ldb; a.bias = bias;
   a.out0 = out0; a.out1 = out1; a.out2 = out2; a.aux = aux; a.cos = rope_cos; a.sin = rope_sin; a.q_scale = q_scale; a.L = L; a.H = H; a.hd = hd;
-  a.tiles_m = (int)((M + BM - 1) / BM); a.tiles_n = (N + BN - 1) / BN;
+  a.tiles_m = 0; a.tiles_n = 0;
   hipStream_t s = (hipStream_t)stream;
   switch (epilogue) {
     case ONEPROT_EPI_BF16: return launch_gemm<ONEPROT_EPI_BF16>(a, s);

@@ -35,28 +35,34 @@ def main():
     h = rnd(T, d).to(torch.bfloat16)
     x = rnd(T, d)
     res = {}
+    only = os.environ.get("MB_ONLY", "")
     # ---- GEMMs
-    for name, N, K, epi in (("qkv", 3 * d, d, hip.EPI_QKV_ROPE), ("out", d, d, hip.EPI_BIAS_RESID), ("ffn1", f, d, hip.EPI_BIAS_GELU), ("ffn2", d, f, hip.EPI_BIAS_RESID),
+    for shape in ([-1] if not os.environ.get("MB_SHAPES") else [int(x) for x in os.environ["MB_SHAPES"].split(",")]):
+      hip.query("oneprot_gemm_force_shape", shape)
+      for name, N, K, epi in (("qkv", 3 * d, d, hip.EPI_QKV_ROPE), ("out", d, d, hip.EPI_BIAS_RESID), ("ffn1", f, d, hip.EPI_BIAS_GELU), ("ffn2", d, f, hip.EPI_BIAS_RESID),
                             ("plain_ffn1", f, d, hip.EPI_BF16)):
-        A = rnd(T, K).to(torch.bfloat16)
-        W = (rnd(N, K) * 0.05).to(torch.bfloat16)
-        bias = rnd(N)
-        cos = torch.rand(L, hd // 2, device=DEV); sin = torch.rand(L, hd // 2, device=DEV)
-        if epi == hip.EPI_QKV_ROPE:
-            o0, o1, o2 = (torch.empty(B, H, L, hd, dtype=torch.bfloat16, device=DEV) for _ in range(3))
-            fn = lambda: hip.call("oneprot_gemm_bf16_nt", A, W, T, N, K, K, K, epi, bias, o0, o1, o2, None, cos, sin, hd ** -0.5, L, H, hd)
-        elif epi == hip.EPI_BIAS_RESID:
-            o0 = rnd(T, N)
-            fn = lambda: hip.call("oneprot_gemm_bf16_nt", A, W, T, N, K, K, K, epi, bias, o0, None, None, o0, None, None, 1.0, 0, 0, 0)
-        elif epi == hip.EPI_BIAS_GELU:
-            o0 = torch.empty(T, N, dtype=torch.bfloat16, device=DEV); o1 = torch.empty_like(o0)
-            fn = lambda: hip.call("oneprot_gemm_bf16_nt", A, W, T, N, K, K, K, epi, bias, o0, o1, None, None, None, None, 1.0, 0, 0, 0)
-        else:
-            o0 = torch.empty(T, N, dtype=torch.bfloat16, device=DEV)
-            fn = lambda: hip.call("oneprot_gemm_bf16_nt", A, W, T, N, K, K, K, epi, bias, o0, None, None, None, None, None, 1.0, 0, 0, 0)
-        ms = timeit(fn)
-        res[name] = (ms, 2.0 * T * N * K / ms / 1e9)
-        del A, W
+          A = rnd(T, K).to(torch.bfloat16)
+          W = (rnd(N, K) * 0.05).to(torch.bfloat16)
+          bias = rnd(N)
+          cos = torch.rand(L, hd // 2, device=DEV); sin = torch.rand(L, hd // 2, device=DEV)
+          if epi == hip.EPI_QKV_ROPE:
+              o0, o1, o2 = (torch.empty(B, H, L, hd, dtype=torch.bfloat16, device=DEV) for _ in range(3))
+              fn = lambda: hip.call("oneprot_gemm_bf16_nt", A, W, T, N, K, K, K, epi, bias, o0, o1, o2, None, cos, sin, hd ** -0.5, L, H, hd)
+          elif epi == hip.EPI_BIAS_RESID:
+              o0 = rnd(T, N)
+              fn = lambda: hip.call("oneprot_gemm_bf16_nt", A, W, T, N, K, K, K, epi, bias, o0, None, None, o0, None, None, 1.0, 0, 0, 0)
+          elif epi == hip.EPI_BIAS_GELU:
+              o0 = torch.empty(T, N, dtype=torch.bfloat16, device=DEV); o1 = torch.empty_like(o0)
+              fn = lambda: hip.call("oneprot_gemm_bf16_nt", A, W, T, N, K, K, K, epi, bias, o0, o1, None, None, None, None, 1.0, 0, 0, 0)
+          else:
+              o0 = torch.empty(T, N, dtype=torch.bfloat16, device=DEV)
+              fn = lambda: hip.call("oneprot_gemm_bf16_nt", A, W, T, N, K, K, K, epi, bias, o0, None, None, None, None, None, 1.0, 0, 0, 0)
+          ms = timeit(fn)
+          res[f"{name}[s{shape}]"] = (ms, 2.0 * T * N * K / ms / 1e9)
+          del A, W
+    hip.query("oneprot_gemm_force_shape", -1)
+    if only == "gemm":
+        return _report(res)
     # ---- wgrad
     for name, N, K in (("wgrad_qkv", 3 * d, d), ("wgrad_ffn1", f, d), ("wgrad_ffn2", d, f), ("wgrad_out", d, d)):
         dY = rnd(T, N).to(torch.bfloat16); X = rnd(T, K).to(torch.bfloat16)
@@ -84,6 +90,10 @@ def main():
     w = torch.empty(hip.query("oneprot_layernorm_bwd_workspace", d), dtype=torch.uint8, device=DEV)
     ms = timeit(lambda: hip.call("oneprot_layernorm_bwd", y, 0, None, 0, x, 0, gamma, mean, rstd, dx, dx, y, dg, db, w, T, d, 0))
     res["ln_bwd"] = (ms, T * d * (2 + 4 + 4 + 4) / ms / 1e6)
+    _report(res)
+
+
+def _report(res):
     for k_, (ms, rate) in res.items():
         unit = "GB/s" if k_.startswith("ln") else "TFLOP/s"
         val = rate if k_.startswith("ln") else rate / 1e3
