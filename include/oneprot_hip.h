@@ -56,10 +56,10 @@ int oneprot_pool_fwd(const float* x, const int64_t* ids, int pad_id, float* pool
 enum {
   ONEPROT_EPI_BF16 = 0,        /* out0 bf16 [M,N] = acc (+bias)                                                   */
   ONEPROT_EPI_F32 = 1,         /* out0 fp32 [M,N] = acc (+bias)                                                   */
-  ONEPROT_EPI_BIAS_GELU = 2,   /* z = acc+bias; out0 bf16 = gelu_erf(z); out1 bf16 = z (optional)                 */
+  ONEPROT_EPI_BIAS_GELU = 2,   /* z = acc+bias; out0 bf16 = gelu_erf(z); out1 bf16 = gelu_erf'(z) (optional, for bwd) */
   ONEPROT_EPI_BIAS_RESID = 3,  /* out0 fp32 = acc + bias + resid fp32 (out0 may alias resid); out1 bf16 copy opt. */
   ONEPROT_EPI_QKV_ROPE = 4,    /* N = 3*H*hd: q=(acc+b)*q_scale -> rope -> out0 [B,H,L,hd]; k -> rope -> out1; v -> out2 */
-  ONEPROT_EPI_GELU_BWD = 5     /* out0 bf16 = acc * gelu_erf'(aux bf16 [M,N])                                     */
+  ONEPROT_EPI_GELU_BWD = 5     /* out0 bf16 = acc * aux, aux bf16 [M,N] = gelu_erf'(z) saved by ONEPROT_EPI_BIAS_GELU  */
 };
 /* C[M,N] = A[M,K] * B[N,K]^T, A and B bf16 row-major with leading dims lda/ldb (elements), fp32 accumulation. */
 int oneprot_gemm_bf16_nt(const void* A, const void* Bw, int64_t M, int N, int K, int lda, int ldb, int epilogue, const float* bias,

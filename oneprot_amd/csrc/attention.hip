@@ -20,6 +20,7 @@
 
 #define LOG2E 1.4426950408889634f
 #define KC 256        // keys (or queries) staged per LDS chunk
+#define RESCALE_THR 10.0f
 
 template <int HD> struct Cfg {
   static constexpr int HDP = HD < 32 ? 32 : HD;      // LDS row pitch in elements (hd=16 rows are zero-padded to 32)
@@ -118,7 +119,7 @@ __global__ void __launch_bounds__(256, 2) k_attn_fwd(const bf16_t* __restrict__ 
   bf8_t qf[C::KSTEPS];
 #pragma unroll
   for (int st = 0; st < C::KSTEPS; ++st) qf[st] = *reinterpret_cast<const bf8_t*>(qbase + (size_t)qrow * HD + 16 * st + 8 * h);
-  float m = -FLT_MAX, l = 0.f;
+  float m = -1e30f, l = 0.f;      // (finite floor: -m*log2e must not overflow; masked scores are -FLT_MAX and still underflow to p = 0)
   f32x16 acc[C::DBLK];
 #pragma unroll
   for (int d = 0; d < C::DBLK; ++d) acc[d] = zero16();
@@ -133,19 +134,23 @@ __global__ void __launch_bounds__(256, 2) k_attn_fwd(const bf16_t* __restrict__ 
       sBias[i] = i < nkeys ? (key_bias ? key_bias[(size_t)b * L + kc0 + i] : 0.f) : -INFINITY;
     __syncthreads();
     for (int t = 0; t < nrows / 32; ++t) {
-      f32x16 s = zero16();
-#pragma unroll
-      for (int st = 0; st < C::KSTEPS; ++st) s = MFMA32(rd_row<HD>(sK, t * 32 + (lane & 31), st, h), qf[st], s);
-      float mx = -FLT_MAX;
+      // the additive key bias rides in as the initial accumulator (costs what zeroing it would)
+      f32x16 s;
 #pragma unroll
       for (int g = 0; g < 4; ++g) {
         const float4 bv = *reinterpret_cast<const float4*>(sBias + t * 32 + 8 * g + 4 * h);
-        s[4 * g + 0] += bv.x; s[4 * g + 1] += bv.y; s[4 * g + 2] += bv.z; s[4 * g + 3] += bv.w;
-        mx = fmaxf(mx, fmaxf(fmaxf(s[4 * g + 0], s[4 * g + 1]), fmaxf(s[4 * g + 2], s[4 * g + 3])));
+        s[4 * g + 0] = bv.x; s[4 * g + 1] = bv.y; s[4 * g + 2] = bv.z; s[4 * g + 3] = bv.w;
       }
+#pragma unroll
+      for (int st = 0; st < C::KSTEPS; ++st) s = MFMA32(rd_row<HD>(sK, t * 32 + (lane & 31), st, h), qf[st], s);
+      float mx = fmaxf(fmaxf(s[0], s[1]), s[2]);
+#pragma unroll
+      for (int r = 3; r < 15; r += 2) mx = fmaxf(fmaxf(mx, s[r]), s[r + 1]);
+      mx = fmaxf(mx, s[15]);
       mx = fmaxf(mx, __shfl_xor(mx, 32, 64));
-      const float mn = fmaxf(m, mx);
-      if (__any(mn > m)) {
+      // deferred rescale: the running max only moves when a tile exceeds it by more than RESCALE_THR (p stays <= e^THR, fp32 sums)
+      if (__any(mx > m + RESCALE_THR)) {
+        const float mn = fmaxf(m, mx);
         const float alpha = __builtin_amdgcn_exp2f((m - mn) * LOG2E);
         l *= alpha;
 #pragma unroll
@@ -154,9 +159,10 @@ __global__ void __launch_bounds__(256, 2) k_attn_fwd(const bf16_t* __restrict__ 
           for (int r = 0; r < 16; ++r) acc[d][r] *= alpha;
         m = mn;
       }
+      const float negm = -m * LOG2E;
       float ls = 0.f;
 #pragma unroll
-      for (int r = 0; r < 16; ++r) { s[r] = __builtin_amdgcn_exp2f((s[r] - m) * LOG2E); ls += s[r]; }
+      for (int r = 0; r < 16; ++r) { s[r] = __builtin_amdgcn_exp2f(fmaf(s[r], LOG2E, negm)); ls += s[r]; }
       l += ls;
 #pragma unroll
       for (int sb = 0; sb < 2; ++sb) {
@@ -167,7 +173,7 @@ __global__ void __launch_bounds__(256, 2) k_attn_fwd(const bf16_t* __restrict__ 
     }
   }
   const float lt = l + __shfl_xor(l, 32, 64);
-  const float inv = 1.0f / lt;
+  const float inv = lt > 0.f ? 1.0f / lt : 0.f;
   if (qidx < L) {
     bf16_t* dst = ctx + ((size_t)b * L + qidx) * (H * HD) + head * HD;
 #pragma unroll
@@ -315,22 +321,22 @@ __global__ void __launch_bounds__(256, 2) k_attn_bwd_dq(const bf16_t* __restrict
       sBias[i] = i < nkeys ? (key_bias ? key_bias[(size_t)b * L + kc0 + i] : 0.f) : -INFINITY;
     __syncthreads();
     for (int t = 0; t < nrows / 32; ++t) {
-      f32x16 s = zero16(), dp = zero16();
+      // accumulator initialisers carry the row constants: S starts at bias[key] - lse[query], dP at -delta[query]
+      f32x16 s, dp;
+#pragma unroll
+      for (int g = 0; g < 4; ++g) {
+        const float4 bv = *reinterpret_cast<const float4*>(sBias + t * 32 + 8 * g + 4 * h);
+        s[4 * g + 0] = bv.x - lse_q; s[4 * g + 1] = bv.y - lse_q; s[4 * g + 2] = bv.z - lse_q; s[4 * g + 3] = bv.w - lse_q;
+      }
+#pragma unroll
+      for (int r = 0; r < 16; ++r) dp[r] = -delta_q;
 #pragma unroll
       for (int st = 0; st < C::KSTEPS; ++st) {
         s = MFMA32(rd_row<HD>(sK, t * 32 + (lane & 31), st, h), qf[st], s);
         dp = MFMA32(rd_row<HD>(sV, t * 32 + (lane & 31), st, h), dof[st], dp);
       }
 #pragma unroll
-      for (int g = 0; g < 4; ++g) {
-        const float4 bv = *reinterpret_cast<const float4*>(sBias + t * 32 + 8 * g + 4 * h);
-        const float bb[4] = {bv.x, bv.y, bv.z, bv.w};
-#pragma unroll
-        for (int e = 0; e < 4; ++e) {
-          const float p = __builtin_amdgcn_exp2f((s[4 * g + e] + bb[e] - lse_q) * LOG2E);
-          s[4 * g + e] = p * (dp[4 * g + e] - delta_q);          // dS^T
-        }
-      }
+      for (int r = 0; r < 16; ++r) s[r] = __builtin_amdgcn_exp2f(s[r] * LOG2E) * dp[r];          // dS^T = P * (dP - delta)
 #pragma unroll
       for (int sb = 0; sb < 2; ++sb) {
         const bf8_t dsf = pack8(s, sb);
@@ -379,30 +385,27 @@ __global__ void __launch_bounds__(256, 2) k_attn_bwd_dkv(const bf16_t* __restric
     load_tile<HD>(sQ, q + ((size_t)bh * L + qc0) * HD, HD, nq, nrows);
     load_tile<HD>(sdO, dctx + ((size_t)b * L + qc0) * dm + head * HD, dm, nq, nrows);
     for (int i = threadIdx.x; i < nrows; i += 256) {
-      sLse[i] = i < nq ? lse[(size_t)bh * L + qc0 + i] : INFINITY;
-      sDelta[i] = i < nq ? delta[(size_t)bh * L + qc0 + i] : 0.f;
+      sLse[i] = i < nq ? -lse[(size_t)bh * L + qc0 + i] : -INFINITY;       // negated: added to the S accumulator initialiser
+      sDelta[i] = i < nq ? -delta[(size_t)bh * L + qc0 + i] : 0.f;
     }
     __syncthreads();
     for (int t = 0; t < nrows / 32; ++t) {
-      f32x16 s = zero16(), dp = zero16();
+      f32x16 s, dp;
+#pragma unroll
+      for (int g = 0; g < 4; ++g) {
+        const float4 lv = *reinterpret_cast<const float4*>(sLse + t * 32 + 8 * g + 4 * h);       // staged as bias-free -lse
+        const float4 dv = *reinterpret_cast<const float4*>(sDelta + t * 32 + 8 * g + 4 * h);    // staged as -delta
+        s[4 * g + 0] = bias_k + lv.x; s[4 * g + 1] = bias_k + lv.y; s[4 * g + 2] = bias_k + lv.z; s[4 * g + 3] = bias_k + lv.w;
+        dp[4 * g + 0] = dv.x; dp[4 * g + 1] = dv.y; dp[4 * g + 2] = dv.z; dp[4 * g + 3] = dv.w;
+      }
 #pragma unroll
       for (int st = 0; st < C::KSTEPS; ++st) {
-        s = MFMA32(rd_row<HD>(sQ, t * 32 + (lane & 31), st, h), kf[st], s);          // S[query][key]
-        dp = MFMA32(rd_row<HD>(sdO, t * 32 + (lane & 31), st, h), vf[st], dp);       // dP[query][key]
+        s = MFMA32(rd_row<HD>(sQ, t * 32 + (lane & 31), st, h), kf[st], s);          // S[query][key] + bias - lse
+        dp = MFMA32(rd_row<HD>(sdO, t * 32 + (lane & 31), st, h), vf[st], dp);       // dP[query][key] - delta
       }
       f32x16 p;
 #pragma unroll
-      for (int g = 0; g < 4; ++g) {
-        const float4 lv = *reinterpret_cast<const float4*>(sLse + t * 32 + 8 * g + 4 * h);
-        const float4 dv = *reinterpret_cast<const float4*>(sDelta + t * 32 + 8 * g + 4 * h);
-        const float ll[4] = {lv.x, lv.y, lv.z, lv.w}, de[4] = {dv.x, dv.y, dv.z, dv.w};
-#pragma unroll
-        for (int e = 0; e < 4; ++e) {
-          const float pe = __builtin_amdgcn_exp2f((s[4 * g + e] + bias_k - ll[e]) * LOG2E);
-          p[4 * g + e] = pe;
-          s[4 * g + e] = pe * (dp[4 * g + e] - de[e]);           // dS
-        }
-      }
+      for (int r = 0; r < 16; ++r) { p[r] = __builtin_amdgcn_exp2f(s[r] * LOG2E); s[r] = p[r] * dp[r]; }      // P, dS
 #pragma unroll
       for (int sb = 0; sb < 2; ++sb) {
         const bf8_t pf = pack8(p, sb), dsf = pack8(s, sb);

@@ -24,7 +24,13 @@ typedef __attribute__((ext_vector_type(2))) unsigned int u32x2;
 // element 0), so all packing/unpacking goes through integer bit operations.
 __device__ __forceinline__ float bf2f(bf16_t h) { return __builtin_bit_cast(float, (unsigned)h << 16); }
 __device__ __forceinline__ bf16_t f2bf(float f) { return __builtin_bit_cast(bf16_t, (__bf16)f); }   // RNE, NaN-preserving (v_cvt_pk_bf16_f32)
-__device__ __forceinline__ unsigned pack2bf(float lo, float hi) { return (unsigned)f2bf(lo) | ((unsigned)f2bf(hi) << 16); }
+typedef __attribute__((ext_vector_type(2))) float f32x2_t;
+typedef __attribute__((ext_vector_type(2))) __bf16 bf2_t;
+// two floats -> packed bf16 pair (lo in bits 0..15): whole-vector convert so hipcc emits one v_cvt_pk_bf16_f32
+__device__ __forceinline__ unsigned pack2bf(float lo, float hi) {
+  const f32x2_t v = {lo, hi};
+  return __builtin_bit_cast(unsigned, __builtin_convertvector(v, bf2_t));
+}
 __device__ __forceinline__ float bflo(unsigned u) { return __builtin_bit_cast(float, u << 16); }
 __device__ __forceinline__ float bfhi(unsigned u) { return __builtin_bit_cast(float, u & 0xffff0000u); }
 
@@ -45,6 +51,23 @@ __device__ __forceinline__ float gelu_erf_grad(float x) {
   const float cdf = 0.5f * (1.0f + erff(x * 0.70710678118654752f));
   const float pdf = 0.3989422804014327f * __expf(-0.5f * x * x);
   return cdf + x * pdf;
+}
+
+// erf-GELU and its derivative from ONE exponential: erf(y), y = x/sqrt2, by Abramowitz-Stegun 7.1.26 (|err| <= 1.5e-7 on erf,
+// far below the bf16 rounding of the stored results); exp(-y^2) = exp(-x^2/2) is also the Gaussian pdf factor of the derivative.
+__device__ __forceinline__ void gelu_fwd_and_grad(float x, float& g, float& dg) {
+  const float ax = fabsf(x) * 0.70710678118654752f;
+  const float t = __builtin_amdgcn_rcpf(fmaf(0.3275911f, ax, 1.0f));
+  const float e = __expf(-ax * ax);
+  float poly = fmaf(1.061405429f, t, -1.453152027f);
+  poly = fmaf(poly, t, 1.421413741f);
+  poly = fmaf(poly, t, -0.284496736f);
+  poly = fmaf(poly, t, 0.254829592f);
+  const float erf_abs = 1.0f - poly * t * e;
+  const float erfv = copysignf(erf_abs, x);
+  const float cdf = 0.5f * (1.0f + erfv);
+  g = x * cdf;
+  dg = fmaf(x * e, 0.3989422804014327f, cdf);
 }
 
 static inline int launch_status() { return hipGetLastError() == hipSuccess ? OP_OK : OP_ELAUNCH; }

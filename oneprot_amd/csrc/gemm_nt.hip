@@ -226,12 +226,13 @@ __global__ void __launch_bounds__(WM * WN * 64, MINW) k_gemm_nt(const GemmArgs p
       *reinterpret_cast<float4*>(c) = make_float4(v[0], v[1], v[2], v[3]);
       *reinterpret_cast<float4*>(c + 4) = make_float4(v[4], v[5], v[6], v[7]);
     } else if (EPI == ONEPROT_EPI_BIAS_GELU) {
-      if (p.out1) {
-        u32x4 z; z.x = pack2bf(v[0], v[1]); z.y = pack2bf(v[2], v[3]); z.z = pack2bf(v[4], v[5]); z.w = pack2bf(v[6], v[7]);
+      float dg[8];
+#pragma unroll
+      for (int e = 0; e < 8; ++e) gelu_fwd_and_grad(v[e], v[e], dg[e]);
+      if (p.out1) {          // gelu'(z), consumed by the GELU_BWD epilogue of the dgrad GEMM
+        u32x4 z; z.x = pack2bf(dg[0], dg[1]); z.y = pack2bf(dg[2], dg[3]); z.z = pack2bf(dg[4], dg[5]); z.w = pack2bf(dg[6], dg[7]);
         *reinterpret_cast<u32x4*>((bf16_t*)p.out1 + o) = z;
       }
-#pragma unroll
-      for (int e = 0; e < 8; ++e) v[e] = gelu_erf(v[e]);
       u32x4 w; w.x = pack2bf(v[0], v[1]); w.y = pack2bf(v[2], v[3]); w.z = pack2bf(v[4], v[5]); w.w = pack2bf(v[6], v[7]);
       *reinterpret_cast<u32x4*>((bf16_t*)p.out0 + o) = w;
     } else if (EPI == ONEPROT_EPI_BIAS_RESID) {
@@ -246,9 +247,9 @@ __global__ void __launch_bounds__(WM * WN * 64, MINW) k_gemm_nt(const GemmArgs p
         *reinterpret_cast<u32x4*>((bf16_t*)p.out1 + o) = w;
       }
     } else if (EPI == ONEPROT_EPI_GELU_BWD) {
-      const u32x4 z = *reinterpret_cast<const u32x4*>((const bf16_t*)p.aux + o);
-      v[0] *= gelu_erf_grad(bflo(z.x)); v[1] *= gelu_erf_grad(bfhi(z.x)); v[2] *= gelu_erf_grad(bflo(z.y)); v[3] *= gelu_erf_grad(bfhi(z.y));
-      v[4] *= gelu_erf_grad(bflo(z.z)); v[5] *= gelu_erf_grad(bfhi(z.z)); v[6] *= gelu_erf_grad(bflo(z.w)); v[7] *= gelu_erf_grad(bfhi(z.w));
+      const u32x4 z = *reinterpret_cast<const u32x4*>((const bf16_t*)p.aux + o);     // aux = gelu'(z) saved by the forward epilogue
+      v[0] *= bflo(z.x); v[1] *= bfhi(z.x); v[2] *= bflo(z.y); v[3] *= bfhi(z.y);
+      v[4] *= bflo(z.z); v[5] *= bfhi(z.z); v[6] *= bflo(z.w); v[7] *= bfhi(z.w);
       u32x4 w; w.x = pack2bf(v[0], v[1]); w.y = pack2bf(v[2], v[3]); w.z = pack2bf(v[4], v[5]); w.w = pack2bf(v[6], v[7]);
       *reinterpret_cast<u32x4*>((bf16_t*)p.out0 + o) = w;
     } else if (EPI == ONEPROT_EPI_QKV_ROPE) {

@@ -293,7 +293,7 @@ __global__ void __launch_bounds__(256) k_layernorm_bwd(const void* __restrict__ 
   }
 }
 
-#define LN_BWD_BLOCKS 512
+#define LN_BWD_BLOCKS 2048
 extern "C" size_t oneprot_layernorm_bwd_workspace(int d) { return (size_t)LN_BWD_BLOCKS * 2 * d * sizeof(float); }
 
 // dgamma_dbeta: [2][d] laid out as dgamma then dbeta (the two may be non-adjacent: pass both pointers)
