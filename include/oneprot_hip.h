@@ -97,6 +97,9 @@ int oneprot_l2norm_bwd(const float* y, const float* dy, const float* inv_norm, f
 /* Softmax cross-entropy over rows of logits [R,C] with label[r] = r + label_offset.  loss_sum += sum_r (lse_r - logit[r,label]) * row_weight;
    logits are overwritten with dlogits = (softmax - onehot) * row_weight. */
 int oneprot_ce_fwd_bwd(float* logits, float* loss_sum, float* row_loss_ws /* R floats */, int R, int C, int label_offset, float row_weight, void* stream);
+/* SigLIP block (ref loss.py:229-255) on logits [B,B] = scale*m@s^T: loss_sum += -sum logsigmoid(label*(logit+bias))/B with label +1 on the
+   diagonal (-1 everywhere if negative_only); logits are overwritten with dloss/dlogit. */
+int oneprot_siglip_fwd_bwd(float* logits, float* loss_sum, float* row_loss_ws /* B floats */, int B, float logit_bias, int negative_only, void* stream);
 /* sum_abs += coef * sum |x|   (L1 feature regulariser, ref oneprot_module.py:101) */
 int oneprot_abs_sum(const float* x, float* out_sum, void* workspace /* oneprot_sumsq_workspace() bytes */, int64_t n, float coef, void* stream);
 

@@ -229,4 +229,28 @@ extern "C" int oneprot_key_padding_bias(const int64_t* ids, float* bias, int64_t
   return launch_status();
 }
 
+// SigLIP block (ref loss.py:229-255): logits [B,B] (already scale*m@s^T) -> loss_sum += -sum logsigmoid(label*(logit+bias)) * inv_b,
+// logits <- dloss/dlogit = -label * sigmoid(-label*(logit+bias)) * inv_b;  label = +1 on the diagonal (unless negative_only), else -1.
+__global__ void __launch_bounds__(256) k_siglip_fwd_bwd(float* __restrict__ logits, float* __restrict__ row_loss, int B, float bias, int negative_only, float inv_b) {
+  __shared__ float s4[4];
+  const int r = blockIdx.x;
+  float acc = 0.f;
+  for (int j = threadIdx.x; j < B; j += 256) {
+    const float label = (!negative_only && j == r) ? 1.f : -1.f;
+    const float z = label * (logits[(size_t)r * B + j] + bias);
+    // logsigmoid(z) = min(z,0) - log1p(exp(-|z|))
+    acc -= fminf(z, 0.f) - log1pf(__expf(-fabsf(z)));
+    const float sig_neg = 1.0f / (1.0f + __expf(z));           // sigmoid(-z)
+    logits[(size_t)r * B + j] = -label * sig_neg * inv_b;
+  }
+  acc = block_sum_256(acc, s4);
+  if (threadIdx.x == 0) row_loss[r] = acc * inv_b;
+}
+extern "C" int oneprot_siglip_fwd_bwd(float* logits, float* loss_sum, float* row_loss_ws, int B, float logit_bias, int negative_only, void* stream) {
+  if (!logits || !loss_sum || !row_loss_ws || B <= 0) return OP_EINVAL;
+  hipLaunchKernelGGL(k_siglip_fwd_bwd, dim3(B), dim3(256), 0, (hipStream_t)stream, logits, row_loss_ws, B, logit_bias, negative_only, 1.0f / (float)B);
+  hipLaunchKernelGGL(k_final_sum, dim3(1), dim3(256), 0, (hipStream_t)stream, (const float*)row_loss_ws, B, loss_sum, 1.0f);
+  return launch_status();
+}
+
 extern "C" int oneprot_abi_version(void) { return 1; }

@@ -204,7 +204,7 @@ def neighbour_exchange_bidir_with_grad(left_rank, right_rank, tensor_to_left, te
 
 class _SigLipBlockFn(torch.autograd.Function):
     """-sum logsigmoid(labels * (scale * m @ s^T + bias)) / B, labels = 2I-1 (or all -1 when negative_only)
-    (ref loss.py:229-255).  Not the default loss: logits via the HIP SGEMM, the [B,B] pointwise part in torch."""
+    (ref loss.py:229-255): HIP SGEMM for the logits, one fused kernel for the pointwise loss + its gradient."""
 
     @staticmethod
     def forward(ctx, m, s, logit_scale, logit_bias, negative_only):
@@ -212,25 +212,23 @@ class _SigLipBlockFn(torch.autograd.Function):
         B, D = m.shape
         logits = torch.empty(B, B, device=m.device)
         hip.call("oneprot_sgemm", m, s, logits, B, B, D, 0, 0, float(logit_scale), 0)
-        if logit_bias is not None:
-            logits += float(logit_bias)
-        labels = -torch.ones(B, B, device=m.device)
-        if not negative_only:
-            labels += 2 * torch.eye(B, device=m.device)
-        z = labels * logits
-        loss = -torch.nn.functional.logsigmoid(z).sum() / B
-        ctx.save_for_backward(m, s, labels, z)
+        loss = torch.zeros(1, device=m.device)
+        rw = torch.empty(B, device=m.device)
+        hip.call("oneprot_siglip_fwd_bwd", logits, loss, rw, B, 0.0 if logit_bias is None else float(logit_bias), 1 if negative_only else 0)
+        ctx.save_for_backward(m, s, logits)          # logits now hold dloss/dlogits
         ctx.logit_scale = float(logit_scale)
-        return loss
+        return loss.reshape(())
 
     @staticmethod
     def backward(ctx, gout):
-        m, s, labels, z = ctx.saved_tensors
+        m, s, dlog = ctx.saved_tensors
         B, D = m.shape
-        dlog = (-(1 - torch.sigmoid(z)) * labels / B * gout).contiguous()
         dm, ds = torch.empty_like(m), torch.empty_like(s)
         hip.call("oneprot_sgemm", dlog, s, dm, B, D, B, 0, 1, ctx.logit_scale, 0)
         hip.call("oneprot_sgemm", dlog, m, ds, B, D, B, 1, 1, ctx.logit_scale, 0)
+        g = gout.reshape(1).float().contiguous()
+        hip.call("oneprot_scale_by_device_scalar", dm, dm.numel(), g)
+        hip.call("oneprot_scale_by_device_scalar", ds, ds.numel(), g)
         return dm, ds, None, None, None
 
 

@@ -409,3 +409,21 @@ def test_clip_loss_node_multirank_semantics(golden_dir, world, local_loss):
         assert abs(loss.item() - rl.item()) / abs(rl.item()) < 1e-5
         assert_close(m.grad.cpu(), rgm, 1e-4, 1e-6, "dm")
         assert_close(s.grad.cpu(), rgs, 1e-4, 1e-6, "ds")
+
+
+@pytest.mark.parametrize("negative_only", [False, True])
+def test_siglip_block(negative_only):
+    from oneprot_amd.loss import _SigLipBlockFn
+    g = torch.Generator().manual_seed(14)
+    B, D = 37, 48
+    m = (torch.nn.functional.normalize(torch.randn(B, D, generator=g), dim=-1) * (1 / 0.07))
+    s = torch.nn.functional.normalize(torch.randn(B, D, generator=g), dim=-1)
+    mr, sr = m.clone().requires_grad_(True), s.clone().requires_grad_(True)
+    ref = O.siglip_block(mr, sr, 1.0, -2.5, negative_only)
+    (ref * 0.7).backward()
+    md, sd = m.to(DEV).requires_grad_(True), s.to(DEV).requires_grad_(True)
+    loss = _SigLipBlockFn.apply(md, sd, 1.0, -2.5, negative_only)
+    (loss * 0.7).backward()
+    assert abs(loss.item() - ref.item()) < 1e-4 * abs(ref.item())
+    assert_close(md.grad.cpu(), mr.grad, 1e-4, 1e-6, "siglip dm")
+    assert_close(sd.grad.cpu(), sr.grad, 1e-4, 1e-6, "siglip ds")
