@@ -4,13 +4,15 @@ set -e
 cd "$(dirname "$0")"
 SRCS="rowops.hip gemm_nt.hip gemm_tn.hip sgemm.hip attention.hip featops.hip"
 OBJS=""
+PIDS=""
 for s in $SRCS; do
   o="${s%.hip}.o"
   if [ ! -f "$o" ] || [ "$s" -nt "$o" ] || [ common.h -nt "$o" ] || [ ../../include/oneprot_hip.h -nt "$o" ]; then
-    hipcc --offload-arch=gfx950 -O3 -fPIC -std=c++17 -Wno-unused-value -c "$s" -o "$o" &
+    ( hipcc --offload-arch=gfx950 -O3 -fPIC -std=c++17 -Wno-unused-value -c "$s" -o "$o.tmp" && mv "$o.tmp" "$o" ) &
+    PIDS="$PIDS $!"
   fi
   OBJS="$OBJS $o"
 done
-wait
+for p in $PIDS; do wait $p || { echo "compile failed"; exit 1; }; done
 hipcc --offload-arch=gfx950 -shared -fPIC -o ../liboneprot_hip.so $OBJS
 echo "built $(cd .. && pwd)/liboneprot_hip.so"

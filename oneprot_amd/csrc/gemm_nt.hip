@@ -67,11 +67,26 @@ __global__ void __launch_bounds__(WM * WN * 64, MINW) k_gemm_nt(const GemmArgs p
   constexpr int CH = BKT / 8;                      // chunks per row
   constexpr int KK = BKT / 32;                     // MFMA k-substeps per stage
   extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
-  // ---- XCD-aware tile assignment
+  // ---- XCD-aware, L2-blocked tile assignment.  Blocks b and b+8 share an XCD (round-robin dispatch), so XCD x walks the row panels
+  // x, x+8, ... ; inside an XCD the order is super-tiles of SUP_M panels x SUP_N column tiles (n fastest) so that the A panels and
+  // the W slices of one super-tile (~3 MB) stay resident in the XCD's 4 MB L2 while its ~40 tiles run (measured with FETCH_SIZE:
+  // 1.65 GB -> 1.1 GB of fabric reads for the FFN-1 launch, whose operand set is 171 MB).
   const int bid = blockIdx.x;
   const int xcd = bid & 7, seq = bid >> 3;
-  const int tm = (seq / p.tiles_n) * 8 + xcd;
-  const int tn = seq % p.tiles_n;
+  constexpr int SUP_M = 4, SUP_N = 10;
+  const int pm_total = (p.tiles_m + 7) >> 3;
+  const int per_mgroup = SUP_M * SUP_N * ((p.tiles_n + SUP_N - 1) / SUP_N);      // slots per m-group (partial groups leave idle slots)
+  const int mg = seq / per_mgroup;
+  int r_ = seq - mg * per_mgroup;
+  const int mb_here = min(SUP_M, pm_total - mg * SUP_M);
+  if (mb_here <= 0) return;
+  const int ng = r_ / (mb_here * SUP_N);
+  r_ -= ng * mb_here * SUP_N;
+  const int nb_here = min(SUP_N, p.tiles_n - ng * SUP_N);
+  if (nb_here <= 0 || r_ >= mb_here * nb_here) return;
+  const int m_in = r_ / nb_here, n_in = r_ - m_in * nb_here;
+  const int tm = (mg * SUP_M + m_in) * 8 + xcd;
+  const int tn = ng * SUP_N + n_in;
   if (tm >= p.tiles_m) return;
   const int m0 = tm * S::BM_, n0 = tn * S::BN_;
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
@@ -291,7 +306,8 @@ static int launch_shape(GemmArgs a, hipStream_t s) {
   }
   a.tiles_m = (a.M + S::BM_ - 1) / S::BM_;
   a.tiles_n = (a.N + S::BN_ - 1) / S::BN_;
-  const int grid = ((a.tiles_m + 7) / 8) * 8 * a.tiles_n;
+  const int pm_total = (a.tiles_m + 7) / 8;
+  const int grid = ((pm_total + 3) / 4) * (4 * 10 * ((a.tiles_n + 9) / 10)) * 8;       // super-tile slots (SUP_M=4, SUP_N=10); surplus blocks exit at once
   hipLaunchKernelGGL((k_gemm_nt<EPI, WM, WN, MT, BKT, NSTAGE, EPH, MINW>), dim3(grid), dim3(S::NW * 64), S::LDS, s, a);
   return launch_status();
 }
