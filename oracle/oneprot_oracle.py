@@ -353,6 +353,38 @@ def train_substep(seq_ids: Tensor, mod_ids: Tensor, sd_seq: Dict[str, Tensor], s
                 grads=grads, grad_total_norm=total, new_params=new)
 
 
+def train_multi_substeps(seq_ids, mod_ids, sd_seq, sd_mod, cfg_seq, cfg_mod, seq_spec, mod_spec, n_steps, use_l1=True, frozen_seq=False, lr=1e-3):
+    """n consecutive iterations of the loop body at ref oneprot_module.py:92-107 with ONE persistent torch.optim.Adam over all
+    trainable tensors (ref configure_optimizers :157-170 + configs/model/default.yaml:2-6) and clip-norm 1.0 before every step.
+    Returns the list of per-step total losses and the final parameter dicts."""
+    def leafify(sd, trainable):
+        out = {}
+        for k, v in sd.items():
+            t = v.detach().clone()
+            if trainable(k) and t.is_floating_point() and k != "norm.1.log_logit_scale" and "inv_freq" not in k and not k.startswith("transformer.pooler") \
+                    and not k.startswith("transformer.contact_head"):
+                t.requires_grad_(True)
+            out[k] = t
+        return out
+    ps = leafify(sd_seq, lambda k: (not frozen_seq) or not k.startswith("transformer."))
+    pm = leafify(sd_mod, lambda k: True)
+    params = [t for t in list(ps.values()) + list(pm.values()) if t.requires_grad]
+    opt = torch.optim.Adam(params, lr=lr, weight_decay=0.0)
+    losses = []
+    for _ in range(n_steps):
+        sf = encoder_features(seq_spec["kind"], seq_ids, ps, cfg_seq, seq_spec["pooling"], seq_spec["proj_type"], seq_spec["use_logit_scale"])
+        mf = encoder_features(mod_spec["kind"], mod_ids, pm, cfg_mod, mod_spec["pooling"], mod_spec["proj_type"], mod_spec["use_logit_scale"])
+        opt.zero_grad()
+        loss = clip_loss(sf, mf)
+        if use_l1:
+            loss = loss + 0.01 * (sf.abs().mean() + mf.abs().mean())
+        loss.backward()
+        torch.nn.utils.clip_grad_norm_(params, 1.0)
+        opt.step()
+        losses.append(float(loss))
+    return losses, {k: v.detach() for k, v in ps.items()}, {k: v.detach() for k, v in pm.items()}
+
+
 # --------------------------------------------------------------------------------------
 # src/distributed.py:8-38 restated (string logic only)
 # --------------------------------------------------------------------------------------
