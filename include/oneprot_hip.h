@@ -65,7 +65,7 @@ enum {
 int oneprot_gemm_bf16_nt(const void* A, const void* Bw, int64_t M, int N, int K, int lda, int ldb, int epilogue, const float* bias,
                          void* out0, void* out1, void* out2, const void* aux, const float* rope_cos, const float* rope_sin, float q_scale,
                          int L, int H, int hd, void* stream);
-/* test / tuning hook: force the block shape of oneprot_gemm_bf16_nt (0 = 128x128, 1 = 256x128, 2 = 256x256, 3 = 128x128 BK64 2-stage, -1 = heuristic). */
+/* test / tuning hook: force the block shape of oneprot_gemm_bf16_nt (0..5, see csrc/gemm_nt.hip; -1 = heuristic). */
 void oneprot_gemm_force_shape(int shape);
 /* dW[N,K] (+)= dY[M,N]^T * X[M,K]  (contraction over the M tokens; split over workgroups, fp32 slabs in workspace);
    dbias[N] (+)= column sums of dY (optional, fused: an all-ones MFMA operand in the k-tile-0 workgroups). */

@@ -20,6 +20,7 @@
 //     q-scale + RoPE + head-major q/k/v, GELU').
 #include "common.h"
 #include "../../include/oneprot_hip.h"
+#include <type_traits>
 
 #define EPI_LD 68                                   // fp32 row pitch of a wave's epilogue tile (64 columns + pad)
 
@@ -61,7 +62,7 @@ template <int BKT> __device__ __forceinline__ int swz(int row, int chunk) {
 
 template <int N> __device__ __forceinline__ void wait_vmcnt() { asm volatile("s_waitcnt vmcnt(%0)" ::"n"(N) : "memory"); }
 
-template <int EPI, int WM, int WN, int MT, int BKT, int NSTAGE, int EPH, int MINW>
+template <int EPI, int WM, int WN, int MT, int BKT, int NSTAGE, int EPH, int MINW, bool PIPE>
 __global__ void __launch_bounds__(WM * WN * 64, MINW) k_gemm_nt(const GemmArgs p) {
   typedef Shape<WM, WN, MT, BKT, NSTAGE, EPH> S;
   constexpr int CH = BKT / 8;                      // chunks per row
@@ -151,31 +152,84 @@ __global__ void __launch_bounds__(WM * WN * 64, MINW) k_gemm_nt(const GemmArgs p
     b_off[j] = rb * S::ROWB + (swz<BKT>(rb, fq) << 4);
   }
 
-  // ---- K loop: NSTAGE-deep LDS ring, NSTAGE-1 K-slices in flight, counted vmcnt + raw barrier (never a vmcnt(0) drain mid-loop)
-#pragma unroll
-  for (int s = 0; s < NSTAGE - 1; ++s)
-    if (s < nk) stage(s, s);
-  int buf = 0, nbuf = NSTAGE - 1;
-  for (int t = 0; t < nk; ++t) {
-    if (t + NSTAGE - 2 < nk) wait_vmcnt<(NSTAGE - 2) * S::LPS>(); else wait_vmcnt<0>();
+  if constexpr (PIPE) {
+    // ---- K loop.  NSTAGE-deep LDS ring filled by LDS-DMA, counted vmcnt + raw s_barrier (never a vmcnt(0) drain mid-loop), and the MFMA
+    // operand fragments are software-pipelined in registers: while the MFMAs of sub-step (t,kk) run, the ds_read_b128 of the next sub-step
+    // are already in flight (two fragment sets, selected by compile-time parity; the t loop is unrolled by two so no register copies).
+    //   end of K-step t:  own fragment reads retired (lgkmcnt 0) -> stage t+1 landed (counted vmcnt) -> barrier -> the buffer of stage t
+    //   is free for everyone -> refill it with stage t+NSTAGE -> read the first fragments of stage t+1 -> MFMAs of (t, last kk).
+    bf8_t fa[2][MT], fb[2][4];
+    auto load_frags = [&](int set, const unsigned char* sA, const unsigned char* sB, int kk) {
+  #pragma unroll
+      for (int j = 0; j < 4; ++j) fb[set][j] = *reinterpret_cast<const bf8_t*>(sB + (b_off[j] ^ (kk << 6)));
+  #pragma unroll
+      for (int i = 0; i < MT; ++i) fa[set][i] = *reinterpret_cast<const bf8_t*>(sA + (a_off[i] ^ (kk << 6)));
+    };
+  #pragma unroll
+    for (int s = 0; s < NSTAGE; ++s)
+      if (s < nk) stage(s, s);
+    if (nk >= NSTAGE) wait_vmcnt<(NSTAGE - 1) * S::LPS>(); else wait_vmcnt<0>();
     asm volatile("s_barrier" ::: "memory");
-    if (t + NSTAGE - 1 < nk) stage(t + NSTAGE - 1, nbuf);
-    const unsigned char* sA = smem + buf * S::STAGE;
-    const unsigned char* sB = sA + S::BM_ * S::ROWB;
-#pragma unroll
-    for (int kk = 0; kk < KK; ++kk) {
-      bf8_t a[MT], b[4];
-#pragma unroll
-      for (int j = 0; j < 4; ++j) b[j] = *reinterpret_cast<const bf8_t*>(sB + (b_off[j] ^ (kk << 6)));
-#pragma unroll
-      for (int i = 0; i < MT; ++i) a[i] = *reinterpret_cast<const bf8_t*>(sA + (a_off[i] ^ (kk << 6)));
-#pragma unroll
-      for (int i = 0; i < MT; ++i)
-#pragma unroll
-        for (int j = 0; j < 4; ++j) acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a[i], b[j], acc[i][j], 0, 0, 0);
+    load_frags(0, smem, smem + S::BM_ * S::ROWB, 0);
+    int buf = 0;
+    auto kstep = [&](int t, auto parity) {
+      constexpr int P = decltype(parity)::value;
+  #pragma unroll
+      for (int kk = 0; kk < KK; ++kk) {
+        constexpr int dummy = 0; (void)dummy;
+        const int cur = (P * KK + kk) & 1;
+        const int nxt = cur ^ 1;
+        if (kk + 1 < KK) {
+          const unsigned char* sA = smem + buf * S::STAGE;
+          load_frags(nxt, sA, sA + S::BM_ * S::ROWB, kk + 1);
+        } else if (t + 1 < nk) {
+          asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+          if (t + NSTAGE - 1 < nk) wait_vmcnt<(NSTAGE - 2) * S::LPS>(); else wait_vmcnt<0>();
+          asm volatile("s_barrier" ::: "memory");
+          if (t + NSTAGE < nk) stage(t + NSTAGE, buf);
+          const int nb = (buf + 1 == NSTAGE) ? 0 : buf + 1;
+          const unsigned char* sA = smem + nb * S::STAGE;
+          load_frags(nxt, sA, sA + S::BM_ * S::ROWB, 0);
+        }
+  #pragma unroll
+        for (int i = 0; i < MT; ++i)
+  #pragma unroll
+          for (int j = 0; j < 4; ++j) acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(fa[cur][i], fb[cur][j], acc[i][j], 0, 0, 0);
+      }
+      buf = (buf + 1 == NSTAGE) ? 0 : buf + 1;
+    };
+    for (int t = 0; t < nk; t += 2) {
+      kstep(t, std::integral_constant<int, 0>{});
+      if (t + 1 < nk) kstep(t + 1, std::integral_constant<int, 1>{});
     }
-    buf = (buf + 1 == NSTAGE) ? 0 : buf + 1;
-    nbuf = (nbuf + 1 == NSTAGE) ? 0 : nbuf + 1;
+  } else {
+    // ---- K loop (plain form, used where the second fragment set would cost a resident workgroup): NSTAGE-deep LDS ring, NSTAGE-1
+    // K-slices in flight, counted vmcnt + raw barrier (never a vmcnt(0) drain mid-loop)
+  #pragma unroll
+    for (int s = 0; s < NSTAGE - 1; ++s)
+      if (s < nk) stage(s, s);
+    int buf = 0, nbuf = NSTAGE - 1;
+    for (int t = 0; t < nk; ++t) {
+      if (t + NSTAGE - 2 < nk) wait_vmcnt<(NSTAGE - 2) * S::LPS>(); else wait_vmcnt<0>();
+      asm volatile("s_barrier" ::: "memory");
+      if (t + NSTAGE - 1 < nk) stage(t + NSTAGE - 1, nbuf);
+      const unsigned char* sA = smem + buf * S::STAGE;
+      const unsigned char* sB = sA + S::BM_ * S::ROWB;
+  #pragma unroll
+      for (int kk = 0; kk < KK; ++kk) {
+        bf8_t a[MT], b[4];
+  #pragma unroll
+        for (int j = 0; j < 4; ++j) b[j] = *reinterpret_cast<const bf8_t*>(sB + (b_off[j] ^ (kk << 6)));
+  #pragma unroll
+        for (int i = 0; i < MT; ++i) a[i] = *reinterpret_cast<const bf8_t*>(sA + (a_off[i] ^ (kk << 6)));
+  #pragma unroll
+        for (int i = 0; i < MT; ++i)
+  #pragma unroll
+          for (int j = 0; j < 4; ++j) acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a[i], b[j], acc[i][j], 0, 0, 0);
+      }
+      buf = (buf + 1 == NSTAGE) ? 0 : buf + 1;
+      nbuf = (nbuf + 1 == NSTAGE) ? 0 : nbuf + 1;
+    }
   }
   __syncthreads();          // everyone done with the staging ring before it is reused as epilogue tiles
 
@@ -295,12 +349,12 @@ __global__ void __launch_bounds__(WM * WN * 64, MINW) k_gemm_nt(const GemmArgs p
   }
 }
 
-template <int EPI, int WM, int WN, int MT, int BKT, int NSTAGE, int EPH, int MINW>
+template <int EPI, int WM, int WN, int MT, int BKT, int NSTAGE, int EPH, int MINW, bool PIPE>
 static int launch_shape(GemmArgs a, hipStream_t s) {
   typedef Shape<WM, WN, MT, BKT, NSTAGE, EPH> S;
   static bool configured = false;
   if (!configured) {
-    if (hipFuncSetAttribute((const void*)k_gemm_nt<EPI, WM, WN, MT, BKT, NSTAGE, EPH, MINW>, hipFuncAttributeMaxDynamicSharedMemorySize, S::LDS) != hipSuccess)
+    if (hipFuncSetAttribute((const void*)k_gemm_nt<EPI, WM, WN, MT, BKT, NSTAGE, EPH, MINW, PIPE>, hipFuncAttributeMaxDynamicSharedMemorySize, S::LDS) != hipSuccess)
       return OP_ELAUNCH;
     configured = true;
   }
@@ -308,26 +362,33 @@ static int launch_shape(GemmArgs a, hipStream_t s) {
   a.tiles_n = (a.N + S::BN_ - 1) / S::BN_;
   const int pm_total = (a.tiles_m + 7) / 8;
   const int grid = ((pm_total + 3) / 4) * (4 * 10 * ((a.tiles_n + 9) / 10)) * 8;       // super-tile slots (SUP_M=4, SUP_N=10); surplus blocks exit at once
-  hipLaunchKernelGGL((k_gemm_nt<EPI, WM, WN, MT, BKT, NSTAGE, EPH, MINW>), dim3(grid), dim3(S::NW * 64), S::LDS, s, a);
+  hipLaunchKernelGGL((k_gemm_nt<EPI, WM, WN, MT, BKT, NSTAGE, EPH, MINW, PIPE>), dim3(grid), dim3(S::NW * 64), S::LDS, s, a);
   return launch_status();
 }
 
 static int g_force_shape = -1;     // test / tuning hook, see launch_gemm
 extern "C" void oneprot_gemm_force_shape(int shape) { g_force_shape = shape; }
 
-// shapes: 0 = 128x128 (BK32, 3 stages, 48 KB LDS -> 3 blocks/CU)      1 = 256x128 (BK32, 3 stages, 72 KB -> 2 blocks/CU)
-//         2 = 256x256 (BK32, 4 stages, 128 KB, 1 block/CU)            3 = 128x128 BK64 2 stages (round-1 first version, kept for A/B runs)
+// shapes: 0 = 128x128 (BK32, 3 stages, pipelined fragments, 48 KB LDS -> 3 blocks/CU)     1 = 256x128 (BK32, 3 stages, 72 KB -> 2 blocks/CU)
+//         2 = 256x256 (BK32, 4 stages, pipelined fragments, 128 KB)   3 = 128x128 BK64 2 stages (first version; still the best for long K)
+//         4 = 256x256 BK64 2 stages, pipelined fragments               5 = 256x256 BK32 4 stages, plain loop
+// Heuristic from in-process A/B on the training shapes (tools/gemm_ab.py; all shapes lie within ~10 % of each other, vendor hipBLASLt
+// runs the same plain shapes at 650-1030 TFLOP/s): long K -> 3, wide N with short K -> 4, otherwise 1; small problems -> 0.
 template <int EPI>
 static int launch_gemm(const GemmArgs& a, hipStream_t s) {
   int shape;
   if (g_force_shape >= 0) shape = g_force_shape;
   else if (a.M < 2048) shape = 0;
+  else if (a.K >= 1024) shape = 3;
+  else if (a.N >= 2048) shape = 4;
   else shape = 1;
   switch (shape) {
-    case 3: return launch_shape<EPI, 2, 2, 4, 64, 2, 64, 2>(a, s);
-    case 2: return launch_shape<EPI, 2, 4, 8, 32, 4, 32, 2>(a, s);
-    case 1: return launch_shape<EPI, 4, 2, 4, 32, 3, 32, 4>(a, s);
-    default: return launch_shape<EPI, 2, 2, 4, 32, 3, 32, 3>(a, s);
+    case 5: return launch_shape<EPI, 2, 4, 8, 32, 4, 32, 2, false>(a, s);      // 256x256 without fragment pipelining (A/B runs)
+    case 4: return launch_shape<EPI, 2, 4, 8, 64, 2, 32, 2, true>(a, s);       // 256x256, BK64, 2 stages, pipelined fragments
+    case 3: return launch_shape<EPI, 2, 2, 4, 64, 2, 64, 2, false>(a, s);
+    case 2: return launch_shape<EPI, 2, 4, 8, 32, 4, 32, 2, true>(a, s);
+    case 1: return launch_shape<EPI, 4, 2, 4, 32, 3, 32, 4, false>(a, s);
+    default: return launch_shape<EPI, 2, 2, 4, 32, 3, 32, 3, true>(a, s);
   }
 }
 
