@@ -12,9 +12,6 @@
 #include "common.h"
 #include "../../include/oneprot_hip.h"
 
-#define TN_BT 64                        // tokens per K-step
-#define TN_TILE_BYTES (TN_BT * 128 * 2) // 16 KiB per operand tile
-#define TN_STAGE_BYTES (2 * TN_TILE_BYTES)
 #define TN_MAX_SLAB_TILES 512
 
 static __device__ __attribute__((aligned(16))) unsigned int g_zero_page[4] = {0, 0, 0, 0};
@@ -35,8 +32,16 @@ __device__ __forceinline__ bf8_t tn_frag(const unsigned char* tile, int mb, int 
   return __builtin_bit_cast(bf8_t, o);
 }
 
-__global__ void __launch_bounds__(256, 2) k_gemm_tn(const bf16_t* __restrict__ dY, const bf16_t* __restrict__ X, int M, int N, int K, int ldy, int ldx,
-                                                    float* __restrict__ slab, float* __restrict__ bias_slab, int tiles_k, int S, int m_per_split) {
+template <int N> __device__ __forceinline__ void tn_wait_vmcnt() { asm volatile("s_waitcnt vmcnt(%0)" ::"n"(N) : "memory"); }
+
+// BT tokens per LDS stage (32 or 64), NSTAGE-deep ring filled by LDS-DMA with NSTAGE-1 stages in flight (counted vmcnt + raw barrier)
+template <int BT, int NSTAGE, int MINW>
+__global__ void __launch_bounds__(256, MINW) k_gemm_tn(const bf16_t* __restrict__ dY, const bf16_t* __restrict__ X, int M, int N, int K, int ldy, int ldx,
+                                                       float* __restrict__ slab, float* __restrict__ bias_slab, int tiles_k, int S, int m_per_split) {
+  constexpr int TILE_BYTES = BT * 256;              // one operand tile: BT token rows x 128 columns
+  constexpr int STAGE_BYTES = 2 * TILE_BYTES;
+  constexpr int IPW = BT / 4 / 4;                   // global_load_lds instructions per wave per operand per stage (4 rows each)
+  constexpr int LPS = 2 * IPW;
   extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
   const int tile = blockIdx.x, split = blockIdx.y;
   const int tn = tile / tiles_k, tk = tile - tn * tiles_k;
@@ -45,16 +50,16 @@ __global__ void __launch_bounds__(256, 2) k_gemm_tn(const bf16_t* __restrict__ d
   const int wr = wave >> 1, wc = wave & 1;
   const int mbeg = split * m_per_split;
   const int mend = min(M, mbeg + m_per_split);
-  const int nsteps = (mend - mbeg + TN_BT - 1) / TN_BT;
+  const int nsteps = (mend - mbeg + BT - 1) / BT;
 
-  // staging: wave w issues 4 instructions per operand; instruction covers 4 token rows x 256 B
+  // staging: one instruction covers 4 token rows x 256 B
   const int srow = lane >> 4, schunk = lane & 15;
   const unsigned char* zero = reinterpret_cast<const unsigned char*>(g_zero_page);
-  int rows[4], ycol_ok[4], xcol_ok[4];
-  size_t yoff[4], xoff[4];
+  int rows[IPW], ycol_ok[IPW], xcol_ok[IPW];
+  size_t yoff[IPW], xoff[IPW];
 #pragma unroll
-  for (int i = 0; i < 4; ++i) {
-    rows[i] = (wave * 4 + i) * 4 + srow;                         // 0..63
+  for (int i = 0; i < IPW; ++i) {
+    rows[i] = (wave * IPW + i) * 4 + srow;
     const int sc = schunk ^ tn_f(rows[i]);
     ycol_ok[i] = (n0 + sc * 8) < N;
     xcol_ok[i] = (k0 + sc * 8) < K;
@@ -62,17 +67,17 @@ __global__ void __launch_bounds__(256, 2) k_gemm_tn(const bf16_t* __restrict__ d
     xoff[i] = (size_t)(k0 + sc * 8);
   }
   auto stage = [&](int t, int buf) {
-    unsigned char* sY = smem + buf * TN_STAGE_BYTES;
-    unsigned char* sX = sY + TN_TILE_BYTES;
-    const int mb = mbeg + t * TN_BT;
+    unsigned char* sY = smem + buf * STAGE_BYTES;
+    unsigned char* sX = sY + TILE_BYTES;
+    const int mb = mbeg + t * BT;
 #pragma unroll
-    for (int i = 0; i < 4; ++i) {
+    for (int i = 0; i < IPW; ++i) {
       const int m = mb + rows[i];
       const bool mok = m < mend;
       const unsigned char* gy = (mok && ycol_ok[i]) ? reinterpret_cast<const unsigned char*>(dY + (size_t)m * ldy + yoff[i]) : zero;
       const unsigned char* gx = (mok && xcol_ok[i]) ? reinterpret_cast<const unsigned char*>(X + (size_t)m * ldx + xoff[i]) : zero;
-      __builtin_amdgcn_global_load_lds(GLB_PTR(gy), LDS_PTR(sY + (wave * 4 + i) * 1024), 16, 0, 0);
-      __builtin_amdgcn_global_load_lds(GLB_PTR(gx), LDS_PTR(sX + (wave * 4 + i) * 1024), 16, 0, 0);
+      __builtin_amdgcn_global_load_lds(GLB_PTR(gy), LDS_PTR(sY + (wave * IPW + i) * 1024), 16, 0, 0);
+      __builtin_amdgcn_global_load_lds(GLB_PTR(gx), LDS_PTR(sX + (wave * IPW + i) * 1024), 16, 0, 0);
     }
   };
 
@@ -91,15 +96,18 @@ __global__ void __launch_bounds__(256, 2) k_gemm_tn(const bf16_t* __restrict__ d
   const u32x4 ones_u = {0x3F803F80u, 0x3F803F80u, 0x3F803F80u, 0x3F803F80u};
   const bf8_t ones = __builtin_bit_cast(bf8_t, ones_u);
 
-  if (nsteps > 0) stage(0, 0);
-  for (int t = 0; t < nsteps; ++t) {
-    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-    __syncthreads();
-    if (t + 1 < nsteps) stage(t + 1, (t + 1) & 1);
-    const unsigned char* sY = smem + (t & 1) * TN_STAGE_BYTES;
-    const unsigned char* sX = sY + TN_TILE_BYTES;
 #pragma unroll
-    for (int kk = 0; kk < 2; ++kk) {
+  for (int s = 0; s < NSTAGE - 1; ++s)
+    if (s < nsteps) stage(s, s);
+  int buf = 0, nbuf = NSTAGE - 1;
+  for (int t = 0; t < nsteps; ++t) {
+    if (t + NSTAGE - 2 < nsteps) tn_wait_vmcnt<(NSTAGE - 2) * LPS>(); else tn_wait_vmcnt<0>();
+    asm volatile("s_barrier" ::: "memory");
+    if (t + NSTAGE - 1 < nsteps) stage(t + NSTAGE - 1, nbuf);
+    const unsigned char* sY = smem + buf * STAGE_BYTES;
+    const unsigned char* sX = sY + TILE_BYTES;
+#pragma unroll
+    for (int kk = 0; kk < BT / 32; ++kk) {
       bf8_t a[4], b[4];
 #pragma unroll
       for (int i = 0; i < 4; ++i) {
@@ -115,6 +123,8 @@ __global__ void __launch_bounds__(256, 2) k_gemm_tn(const bf16_t* __restrict__ d
         for (int i = 0; i < 4; ++i) accb[i] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a[i], ones, accb[i], 0, 0, 0);
       }
     }
+    buf = (buf + 1 == NSTAGE) ? 0 : buf + 1;
+    nbuf = (nbuf + 1 == NSTAGE) ? 0 : nbuf + 1;
   }
   float* out = slab + (size_t)split * N * K;
   const int fq = lane >> 4, fr = lane & 15;
@@ -161,6 +171,9 @@ __global__ void __launch_bounds__(256) k_tn_reduce(const float* __restrict__ sla
   }
 }
 
+static int g_tn_variant = 0;     // measured in-process: 64-token x2 stages beats 32-token x3 (0.55 vs 0.69 ms on the QKV wgrad)
+extern "C" void oneprot_gemm_tn_variant(int v) { g_tn_variant = v; }
+
 static inline int tn_splits(int64_t M, int tiles) {
   int S = TN_MAX_SLAB_TILES / tiles;
   if (S < 1) S = 1;
@@ -181,19 +194,26 @@ extern "C" int oneprot_gemm_bf16_tn(const void* dY, const void* X, int64_t M, in
   if (!dY || !X || !dW || !workspace || M <= 0 || N <= 0 || K <= 0 || M > 0x7fffffff) return OP_EINVAL;
   if ((N & 7) || (K & 7) || (ldy & 7) || (ldx & 7) || ldy < N || ldx < K || ((N * (int64_t)K) & 3)) return OP_EINVAL;
   if (((uintptr_t)dY | (uintptr_t)X | (uintptr_t)dW | (uintptr_t)workspace) & 15) return OP_EINVAL;
-  static bool configured = false;
-  if (!configured) {
-    if (hipFuncSetAttribute((const void*)k_gemm_tn, hipFuncAttributeMaxDynamicSharedMemorySize, 2 * TN_STAGE_BYTES) != hipSuccess) return OP_ELAUNCH;
-    configured = true;
-  }
   const int tiles_n = (N + 127) / 128, tiles_k = (K + 127) / 128, tiles = tiles_n * tiles_k;
   const int S = tn_splits(M, tiles);
-  int m_per = (int)((M + S - 1) / S);
-  m_per = ((m_per + TN_BT - 1) / TN_BT) * TN_BT;
   hipStream_t s = (hipStream_t)stream;
   float* bias_slab = dbias ? (float*)workspace + (size_t)S * N * K : nullptr;
-  hipLaunchKernelGGL(k_gemm_tn, dim3(tiles, S), dim3(256), 2 * TN_STAGE_BYTES, s, (const bf16_t*)dY, (const bf16_t*)X, (int)M, N, K, ldy, ldx,
-                     (float*)workspace, bias_slab, tiles_k, S, m_per);
+  // variant 0: 64-token stages, 2-stage ring (64 KB, 2 workgroups/CU); variant 1: 32-token stages, 3-stage ring (48 KB, 3 workgroups/CU)
+  const int variant = g_tn_variant;
+  const int BT = variant == 0 ? 64 : 32;
+  int m_per = (int)((M + S - 1) / S);
+  m_per = ((m_per + BT - 1) / BT) * BT;
+  if (variant == 0) {
+    static bool c0 = false;
+    if (!c0) { if (hipFuncSetAttribute((const void*)k_gemm_tn<64, 2, 2>, hipFuncAttributeMaxDynamicSharedMemorySize, 2 * 2 * 64 * 256) != hipSuccess) return OP_ELAUNCH; c0 = true; }
+    hipLaunchKernelGGL((k_gemm_tn<64, 2, 2>), dim3(tiles, S), dim3(256), 2 * 2 * 64 * 256, s, (const bf16_t*)dY, (const bf16_t*)X, (int)M, N, K, ldy, ldx,
+                       (float*)workspace, bias_slab, tiles_k, S, m_per);
+  } else {
+    static bool c1 = false;
+    if (!c1) { if (hipFuncSetAttribute((const void*)k_gemm_tn<32, 3, 3>, hipFuncAttributeMaxDynamicSharedMemorySize, 3 * 2 * 32 * 256) != hipSuccess) return OP_ELAUNCH; c1 = true; }
+    hipLaunchKernelGGL((k_gemm_tn<32, 3, 3>), dim3(tiles, S), dim3(256), 3 * 2 * 32 * 256, s, (const bf16_t*)dY, (const bf16_t*)X, (int)M, N, K, ldy, ldx,
+                       (float*)workspace, bias_slab, tiles_k, S, m_per);
+  }
   if (dbias) hipLaunchKernelGGL(k_tn_bias_reduce, dim3((N + 255) / 256), dim3(256), 0, s, (const float*)bias_slab, dbias, N, S, accumulate);
   const size_t n4 = ((size_t)N * K) >> 2;
   size_t blocks = (n4 + 255) / 256; if (blocks > 4096) blocks = 4096;

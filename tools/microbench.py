@@ -68,8 +68,13 @@ def main():
         dY = rnd(T, N).to(torch.bfloat16); X = rnd(T, K).to(torch.bfloat16)
         dW = torch.empty(N, K, device=DEV)
         w = torch.empty(hip.query("oneprot_gemm_bf16_tn_workspace", N, K), dtype=torch.uint8, device=DEV)
-        ms = timeit(lambda: hip.call("oneprot_gemm_bf16_tn", dY, X, T, N, K, N, K, dW, None, w, 0))
-        res[name] = (ms, 2.0 * T * N * K / ms / 1e9)
+        for variant in (0, 1, 0, 1):
+            hip.query("oneprot_gemm_tn_variant", variant)
+            ms = timeit(lambda: hip.call("oneprot_gemm_bf16_tn", dY, X, T, N, K, N, K, dW, None, w, 0))
+            key = f"{name}[v{variant}]"
+            if key not in res or ms < res[key][0]:
+                res[key] = (ms, 2.0 * T * N * K / ms / 1e9)
+        hip.query("oneprot_gemm_tn_variant", 0)
         del dY, X
     # ---- attention
     q, k, v = (rnd(B, H, L, hd).to(torch.bfloat16) for _ in range(3))
