@@ -171,3 +171,57 @@ def test_config_composer_reads_reference_yaml_unchanged():
     assert t["devices"] == 4 and t["strategy"] == "ddp_find_unused_parameters_true" and t["accelerator"] == "gpu"
     s = compose(os.path.join(REF, "configs"), "model/components/struct_token", resolve=False)
     assert s["model"]["components"]["struct_token"]["use_logit_scale"] is True
+
+
+def test_combined_loader_and_synthetic_batches():
+    from oneprot_amd.data import CombinedLoader, SyntheticPairs
+    st = SyntheticPairs("struct_token", 4, 16, n_batches=3, ragged=True)
+    tx = SyntheticPairs("text", 2, 16, mod_len=8, n_batches=2, text_vocab=120)
+    steps = list(CombinedLoader({"struct_token": st, "text": tx}, "min_size"))
+    assert len(steps) == 2 and set(steps[0]) == {"struct_token", "text"}                 # min_size: the shorter loader ends the epoch
+    seq, mod, name, _ = steps[0]["struct_token"]
+    assert seq.shape == (4, 16) and mod.shape == (4, 16) and name == "struct_token" and seq.dtype == torch.int64
+    assert (seq[:, 0] == 0).all() and ((mod == 1) | ((mod >= 33) & (mod <= 52)) | (mod == 0) | (mod == 2)).all()
+    assert ((seq != 1).sum(1) == (mod != 1).sum(1)).all() is not None
+    tseq, tmod, tname, _ = steps[1]["text"]
+    assert tmod.shape == (2, 8) and tname == "text" and tmod.max() < 120
+    seqm = list(CombinedLoader({"struct_token": st, "text": tx}, "sequential"))
+    assert len(seqm) == 5 and [x[2] for x in seqm] == [0, 0, 0, 1, 1]
+    again = list(CombinedLoader({"struct_token": st}, "min_size"))                       # re-iterable, deterministic
+    assert torch.equal(again[0]["struct_token"][0], steps[0]["struct_token"][0])
+    with pytest.raises(ValueError):
+        CombinedLoader({}, "max_size")
+
+
+def test_checkpoint_wire_format(golden_dir, tmp_path, monkeypatch):
+    monkeypatch.setenv("ONEPROT_ALLOW_RANDOM_INIT", "1")
+    monkeypatch.setenv("RANK", "0"); monkeypatch.setenv("WORLD_SIZE", "1")
+    import functools
+    from oneprot_amd.data import load_weights_only, save_checkpoint
+    from src.models.components.sequence_encoder import SequenceEncoder
+    from src.models.components.struct_token_encoder import StructTokenEncoder
+    from src.models.oneprot_module import OneProtLitModule
+    g = torch.load(os.path.join(golden_dir, "esm_pair_hd16.pt"), weights_only=False)
+    p = _tiny_dir(tmp_path)
+
+    def make():
+        seq = SequenceEncoder(p, output_dim=48, proj_type="mlp", use_lora=False, frozen=True)
+        st = StructTokenEncoder(p, output_dim=48, proj_type="linear", use_logit_scale=True)
+        return OneProtLitModule(components={"sequence": seq, "struct_token": st}, optimizer=functools.partial(torch.optim.Adam, lr=1e-3))
+    m1 = make()
+    m1.network["sequence"].load_state_dict(g["sd_seq"]); m1.network["struct_token"].load_state_dict(g["sd_st"])
+    keys = set(m1.state_dict())
+    # the on-disk contract of the reference: network.<modality>.{transformer.*, proj.*, norm.1.log_logit_scale}
+    assert "network.struct_token.transformer.encoder.layer.0.attention.self.query.weight" in keys
+    assert "network.struct_token.norm.1.log_logit_scale" in keys and "network.sequence.proj.4.weight" in keys
+    assert not any(".flat" in k or ".extra." in k for k in keys)
+    ck = os.path.join(str(tmp_path), "last.ckpt")
+    save_checkpoint(m1, ck)
+    m2 = make()
+    load_weights_only(m2, ck)
+    for k, v in m1.state_dict().items():
+        assert torch.equal(v, m2.state_dict()[k]), k
+    # Lightning-wrapped variant with the 'model.' prefix the reference strips (src/train.py:77-79)
+    sd = torch.load(ck, weights_only=True)["state_dict"]
+    torch.save({"state_dict": {"model." + k: v for k, v in sd.items()}}, ck)
+    load_weights_only(make(), ck)

@@ -261,3 +261,46 @@ def test_cfg1_shape_train_step_vs_oracle():
     loss = float(module.training_step({"struct_token": (seq_ids.to(DEV), st_ids.to(DEV), "struct_token", None)}, 0).detach())
     assert abs(loss - float(ref["loss"])) / float(ref["loss"]) < 1e-3
     assert abs(float(module.last_grad_norm) - float(ref["grad_total_norm"])) / float(ref["grad_total_norm"]) < 2e-2
+
+
+def test_mixed_batch_round_robin(golden_dir, tmp_path):
+    """CombinedLoader('min_size') batches with two modalities (struct_token, text): one optimiser sub-step per modality per batch
+    (ref oneprot_module.py:84-92), frozen text tower untouched, warm-up gate `train_on_all_modalities_after_step`."""
+    os.environ.update(RANK="0", WORLD_SIZE="1", ONEPROT_ALLOW_RANDOM_INIT="1")
+    from oneprot_amd.data import CombinedLoader, SyntheticPairs
+    from oneprot_amd.optim import FusedAdam
+    from src.models.components.sequence_encoder import SequenceEncoder
+    from src.models.components.struct_token_encoder import StructTokenEncoder
+    from src.models.components.text_encoder import TextEncoder
+    from src.models.oneprot_module import OneProtLitModule
+    g = torch.load(os.path.join(golden_dir, "esm_pair_hd16.pt"), weights_only=False)
+    tb = torch.load(os.path.join(golden_dir, "bert_text.pt"), weights_only=False)
+    p = _write_cfg(str(tmp_path), g["cfg"], "esm")
+    pb = os.path.join(str(tmp_path), "bert"); os.makedirs(pb)
+    c = tb["cfg"]
+    with open(os.path.join(pb, "config.json"), "w") as f:
+        json.dump(dict(model_type="bert", vocab_size=c["vocab"], hidden_size=c["hidden"], num_hidden_layers=c["layers"], num_attention_heads=c["heads"],
+                       intermediate_size=c["ffn"], max_position_embeddings=c["max_pos"], pad_token_id=0, layer_norm_eps=c["eps"]), f)
+    seq = SequenceEncoder(p, output_dim=48, pooling_type="mean", proj_type="mlp", use_lora=False, frozen=True)
+    st = StructTokenEncoder(p, output_dim=48, pooling_type="mean", proj_type="linear", use_logit_scale=True)
+    tx = TextEncoder(pb, output_dim=48, pooling_type="cls", proj_type="mlp", use_logit_scale=True, frozen=True, use_lora=False)
+    seq.load_state_dict(g["sd_seq"]); st.load_state_dict(g["sd_st"]); tx.load_state_dict(tb["sd"])
+    module = OneProtLitModule(components={"sequence": seq, "struct_token": st, "text": tx}, optimizer=functools.partial(FusedAdam, lr=1e-3), loss_fn="CLIP",
+                              use_l1_regularization=True, train_on_all_modalities_after_step=1).to(DEV)
+    loader = CombinedLoader({"struct_token": SyntheticPairs("struct_token", 6, 24, n_batches=3, device=DEV, ragged=True),
+                             "text": SyntheticPairs("text", 6, 24, mod_len=20, n_batches=3, device=DEV, ragged=True, text_vocab=c["vocab"])}, "min_size")
+    text_before = module.network["text"].transformer.flat.detach().clone()
+    text_head_before = module.network["text"].proj[1].weight.detach().clone()
+    st_before = module.network["struct_token"].transformer.flat.detach().clone()
+    loss = module.fit_steps(loader)
+    # batch 0: warm-up gate -> struct_token only (1 sub-step); batches 1, 2: both modalities (2 sub-steps each)
+    assert module.global_step == 5
+    assert torch.isfinite(loss)
+    assert torch.equal(text_before, module.network["text"].transformer.flat.detach())            # frozen tower
+    assert not torch.equal(text_head_before, module.network["text"].proj[1].weight.detach())      # its projection head trains
+    assert not torch.equal(st_before, module.network["struct_token"].transformer.flat.detach())
+    # validation / test hooks run forward-only
+    vb = next(iter(SyntheticPairs("text", 6, 24, mod_len=20, device=DEV, text_vocab=c["vocab"])))
+    assert torch.isfinite(module.validation_step(vb, 0))
+    out = module.test_step({"text": vb}, 0)
+    assert torch.isfinite(out["text"])
