@@ -38,12 +38,12 @@ struct GemmArgs {
   int tiles_m, tiles_n;
 };
 
-// WM x WN waves, MT 16-row tiles per wave (wave tile = MT*16 x 64), BKT = K-slice per LDS stage (32 or 64), NSTAGE ring depth,
+// WM x WN waves, MT x NTW 16x16 accumulator tiles per wave (wave tile = MT*16 x NTW*16), BKT = K-slice per LDS stage (32 or 64), NSTAGE ring depth,
 // EPH = rows per epilogue staging pass (wave-private LDS tile EPH x 64 fp32)
-template <int WM, int WN, int MT, int BKT, int NSTAGE, int EPH> struct Shape {
+template <int WM, int WN, int MT, int NTW, int BKT, int NSTAGE, int EPH> struct Shape {
   static constexpr int NW = WM * WN;
   static constexpr int BM_ = WM * MT * 16;
-  static constexpr int BN_ = WN * 64;
+  static constexpr int BN_ = WN * NTW * 16;
   static constexpr int ROWB = BKT * 2;              // LDS row pitch in bytes
   static constexpr int RPI = 1024 / ROWB;           // rows covered by one global_load_lds wave-instruction
   static constexpr int A_IPW = BM_ / RPI / NW;      // instructions per wave per stage
@@ -62,9 +62,9 @@ template <int BKT> __device__ __forceinline__ int swz(int row, int chunk) {
 
 template <int N> __device__ __forceinline__ void wait_vmcnt() { asm volatile("s_waitcnt vmcnt(%0)" ::"n"(N) : "memory"); }
 
-template <int EPI, int WM, int WN, int MT, int BKT, int NSTAGE, int EPH, int MINW, bool PIPE>
+template <int EPI, int WM, int WN, int MT, int NTW, int BKT, int NSTAGE, int EPH, int MINW, bool PIPE>
 __global__ void __launch_bounds__(WM * WN * 64, MINW) k_gemm_nt(const GemmArgs p) {
-  typedef Shape<WM, WN, MT, BKT, NSTAGE, EPH> S;
+  typedef Shape<WM, WN, MT, NTW, BKT, NSTAGE, EPH> S;
   constexpr int CH = BKT / 8;                      // chunks per row
   constexpr int KK = BKT / 32;                     // MFMA k-substeps per stage
   extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
@@ -132,23 +132,23 @@ __global__ void __launch_bounds__(WM * WN * 64, MINW) k_gemm_nt(const GemmArgs p
     }
   };
 
-  f32x4 acc[MT][4];
+  f32x4 acc[MT][NTW];
 #pragma unroll
   for (int i = 0; i < MT; ++i)
 #pragma unroll
-    for (int j = 0; j < 4; ++j) acc[i][j] = (f32x4){0.f, 0.f, 0.f, 0.f};
+    for (int j = 0; j < NTW; ++j) acc[i][j] = (f32x4){0.f, 0.f, 0.f, 0.f};
 
   // fragment read offsets (bytes within a stage's A or B image) for k-substep 0; substep 1 (BK 64) flips chunk bit 2
   const int frow = lane & 15, fq = lane >> 4;
-  int a_off[MT], b_off[4];
+  int a_off[MT], b_off[NTW];
 #pragma unroll
   for (int i = 0; i < MT; ++i) {
     const int ra = wr * (MT * 16) + i * 16 + frow;
     a_off[i] = ra * S::ROWB + (swz<BKT>(ra, fq) << 4);
   }
 #pragma unroll
-  for (int j = 0; j < 4; ++j) {
-    const int rb = wc * 64 + j * 16 + frow;
+  for (int j = 0; j < NTW; ++j) {
+    const int rb = wc * (NTW * 16) + j * 16 + frow;
     b_off[j] = rb * S::ROWB + (swz<BKT>(rb, fq) << 4);
   }
 
@@ -158,10 +158,10 @@ __global__ void __launch_bounds__(WM * WN * 64, MINW) k_gemm_nt(const GemmArgs p
     // are already in flight (two fragment sets, selected by compile-time parity; the t loop is unrolled by two so no register copies).
     //   end of K-step t:  own fragment reads retired (lgkmcnt 0) -> stage t+1 landed (counted vmcnt) -> barrier -> the buffer of stage t
     //   is free for everyone -> refill it with stage t+NSTAGE -> read the first fragments of stage t+1 -> MFMAs of (t, last kk).
-    bf8_t fa[2][MT], fb[2][4];
+    bf8_t fa[2][MT], fb[2][NTW];
     auto load_frags = [&](int set, const unsigned char* sA, const unsigned char* sB, int kk) {
   #pragma unroll
-      for (int j = 0; j < 4; ++j) fb[set][j] = *reinterpret_cast<const bf8_t*>(sB + (b_off[j] ^ (kk << 6)));
+      for (int j = 0; j < NTW; ++j) fb[set][j] = *reinterpret_cast<const bf8_t*>(sB + (b_off[j] ^ (kk << 6)));
   #pragma unroll
       for (int i = 0; i < MT; ++i) fa[set][i] = *reinterpret_cast<const bf8_t*>(sA + (a_off[i] ^ (kk << 6)));
     };
@@ -194,7 +194,7 @@ __global__ void __launch_bounds__(WM * WN * 64, MINW) k_gemm_nt(const GemmArgs p
   #pragma unroll
         for (int i = 0; i < MT; ++i)
   #pragma unroll
-          for (int j = 0; j < 4; ++j) acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(fa[cur][i], fb[cur][j], acc[i][j], 0, 0, 0);
+          for (int j = 0; j < NTW; ++j) acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(fa[cur][i], fb[cur][j], acc[i][j], 0, 0, 0);
       }
       buf = (buf + 1 == NSTAGE) ? 0 : buf + 1;
     };
@@ -217,15 +217,15 @@ __global__ void __launch_bounds__(WM * WN * 64, MINW) k_gemm_nt(const GemmArgs p
       const unsigned char* sB = sA + S::BM_ * S::ROWB;
   #pragma unroll
       for (int kk = 0; kk < KK; ++kk) {
-        bf8_t a[MT], b[4];
+        bf8_t a[MT], b[NTW];
   #pragma unroll
-        for (int j = 0; j < 4; ++j) b[j] = *reinterpret_cast<const bf8_t*>(sB + (b_off[j] ^ (kk << 6)));
+        for (int j = 0; j < NTW; ++j) b[j] = *reinterpret_cast<const bf8_t*>(sB + (b_off[j] ^ (kk << 6)));
   #pragma unroll
         for (int i = 0; i < MT; ++i) a[i] = *reinterpret_cast<const bf8_t*>(sA + (a_off[i] ^ (kk << 6)));
   #pragma unroll
         for (int i = 0; i < MT; ++i)
   #pragma unroll
-          for (int j = 0; j < 4; ++j) acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a[i], b[j], acc[i][j], 0, 0, 0);
+          for (int j = 0; j < NTW; ++j) acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a[i], b[j], acc[i][j], 0, 0, 0);
       }
       buf = (buf + 1 == NSTAGE) ? 0 : buf + 1;
       nbuf = (nbuf + 1 == NSTAGE) ? 0 : nbuf + 1;
@@ -236,7 +236,9 @@ __global__ void __launch_bounds__(WM * WN * 64, MINW) k_gemm_nt(const GemmArgs p
   // ---- epilogue: wave-private EPH x 64 fp32 tile in LDS, (MT*16)/EPH passes
   float* et = reinterpret_cast<float*>(smem) + wave * EPH * EPI_LD;
   const int er = lane >> 3, ec = (lane & 7) * 8;
-  const int gn = n0 + wc * 64 + ec;
+#pragma unroll
+  for (int nh = 0; nh < NTW / 4; ++nh) {       // 64-column halves of the wave tile
+  const int gn = n0 + wc * (NTW * 16) + nh * 64 + ec;
   float bias8[8];
 #pragma unroll
   for (int e = 0; e < 8; ++e) bias8[e] = 0.f;
@@ -270,7 +272,7 @@ __global__ void __launch_bounds__(WM * WN * 64, MINW) k_gemm_nt(const GemmArgs p
 #pragma unroll
       for (int j = 0; j < 4; ++j)
 #pragma unroll
-        for (int r = 0; r < 4; ++r) et[(i * 16 + fq * 4 + r) * EPI_LD + j * 16 + frow] = acc[half * (EPH / 16) + i][j][r];
+        for (int r = 0; r < 4; ++r) et[(i * 16 + fq * 4 + r) * EPI_LD + j * 16 + frow] = acc[half * (EPH / 16) + i][nh * 4 + j][r];
     // same wave writes and reads: LDS operations of one wave complete in order
     asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
     if (gn < p.N) {
@@ -347,14 +349,15 @@ __global__ void __launch_bounds__(WM * WN * 64, MINW) k_gemm_nt(const GemmArgs p
     }
     asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");     // reads of this pass done before the next pass overwrites the tile
   }
+  }
 }
 
-template <int EPI, int WM, int WN, int MT, int BKT, int NSTAGE, int EPH, int MINW, bool PIPE>
+template <int EPI, int WM, int WN, int MT, int NTW, int BKT, int NSTAGE, int EPH, int MINW, bool PIPE>
 static int launch_shape(GemmArgs a, hipStream_t s) {
-  typedef Shape<WM, WN, MT, BKT, NSTAGE, EPH> S;
+  typedef Shape<WM, WN, MT, NTW, BKT, NSTAGE, EPH> S;
   static bool configured = false;
   if (!configured) {
-    if (hipFuncSetAttribute((const void*)k_gemm_nt<EPI, WM, WN, MT, BKT, NSTAGE, EPH, MINW, PIPE>, hipFuncAttributeMaxDynamicSharedMemorySize, S::LDS) != hipSuccess)
+    if (hipFuncSetAttribute((const void*)k_gemm_nt<EPI, WM, WN, MT, NTW, BKT, NSTAGE, EPH, MINW, PIPE>, hipFuncAttributeMaxDynamicSharedMemorySize, S::LDS) != hipSuccess)
       return OP_ELAUNCH;
     configured = true;
   }
@@ -362,7 +365,7 @@ static int launch_shape(GemmArgs a, hipStream_t s) {
   a.tiles_n = (a.N + S::BN_ - 1) / S::BN_;
   const int pm_total = (a.tiles_m + 7) / 8;
   const int grid = ((pm_total + 3) / 4) * (4 * 10 * ((a.tiles_n + 9) / 10)) * 8;       // super-tile slots (SUP_M=4, SUP_N=10); surplus blocks exit at once
-  hipLaunchKernelGGL((k_gemm_nt<EPI, WM, WN, MT, BKT, NSTAGE, EPH, MINW, PIPE>), dim3(grid), dim3(S::NW * 64), S::LDS, s, a);
+  hipLaunchKernelGGL((k_gemm_nt<EPI, WM, WN, MT, NTW, BKT, NSTAGE, EPH, MINW, PIPE>), dim3(grid), dim3(S::NW * 64), S::LDS, s, a);
   return launch_status();
 }
 
@@ -383,12 +386,14 @@ static int launch_gemm(const GemmArgs& a, hipStream_t s) {
   else if (a.N >= 2048) shape = 4;
   else shape = 1;
   switch (shape) {
-    case 5: return launch_shape<EPI, 2, 4, 8, 32, 4, 32, 2, false>(a, s);      // 256x256 without fragment pipelining (A/B runs)
-    case 4: return launch_shape<EPI, 2, 4, 8, 64, 2, 32, 2, true>(a, s);       // 256x256, BK64, 2 stages, pipelined fragments
-    case 3: return launch_shape<EPI, 2, 2, 4, 64, 2, 64, 2, false>(a, s);
-    case 2: return launch_shape<EPI, 2, 4, 8, 32, 4, 32, 2, true>(a, s);
-    case 1: return launch_shape<EPI, 4, 2, 4, 32, 3, 32, 4, false>(a, s);
-    default: return launch_shape<EPI, 2, 2, 4, 32, 3, 32, 3, true>(a, s);
+    case 7: return launch_shape<EPI, 2, 2, 8, 8, 32, 4, 32, 1, false>(a, s);      // 256x256, 4 waves x (128x128), BK32 x4, one wave per SIMD
+    case 6: return launch_shape<EPI, 2, 2, 8, 8, 64, 2, 32, 1, false>(a, s);      // 256x256, 4 waves x (128x128), BK64 x2, one wave per SIMD
+    case 5: return launch_shape<EPI, 2, 4, 8, 4, 32, 4, 32, 2, false>(a, s);      // 256x256 without fragment pipelining (A/B runs)
+    case 4: return launch_shape<EPI, 2, 4, 8, 4, 64, 2, 32, 2, true>(a, s);       // 256x256, BK64, 2 stages, pipelined fragments
+    case 3: return launch_shape<EPI, 2, 2, 4, 4, 64, 2, 64, 2, false>(a, s);
+    case 2: return launch_shape<EPI, 2, 4, 8, 4, 32, 4, 32, 2, true>(a, s);
+    case 1: return launch_shape<EPI, 4, 2, 4, 4, 32, 3, 32, 4, false>(a, s);
+    default: return launch_shape<EPI, 2, 2, 4, 4, 32, 3, 32, 3, true>(a, s);
   }
 }
 

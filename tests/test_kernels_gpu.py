@@ -144,7 +144,7 @@ def _gemm_inputs(M, N, K, seed):
     return A, W, bias
 
 
-@pytest.fixture(params=[-1, 0, 1, 2, 3, 4, 5], ids=["auto", "128x128", "256x128", "256x256", "128x128bk64", "256x256bk64", "256x256nopipe"])
+@pytest.fixture(params=[-1, 0, 1, 2, 3, 4, 5, 6, 7], ids=["auto", "128x128", "256x128", "256x256", "128x128bk64", "256x256bk64", "256x256nopipe", "4w128x128bk64", "4w128x128bk32"])
 def gemm_shape(request):
     hip.query("oneprot_gemm_force_shape", request.param)
     yield request.param
