@@ -52,6 +52,14 @@ int oneprot_lnpool_fwd(const float* x, const int64_t* ids, int pad_id, const flo
 /* pooling of an already-normalised hidden state (BERT): mode 0 masked mean, 1 CLS (ref base_encoder.py:109-126). */
 int oneprot_pool_fwd(const float* x, const int64_t* ids, int pad_id, float* pooled, int B, int L, int d, int mode, void* stream);
 
+/* Attention1dPooling (ref base_encoder.py:40-103): pooled = sum_l softmax_l(x_l.w + b | padding -> -inf) x_l on an fp32 hidden state [B,L,d];
+   attn [B,L] (optional in fwd, required by bwd).  bwd: dw [d], db [1], dx [B,L,d] (optional). */
+int oneprot_attnpool_fwd(const float* x, const int64_t* ids, int pad_id, const float* w, const float* bias, float* pooled, float* attn, int B, int L,
+                         int d, void* stream);
+size_t oneprot_attnpool_bwd_workspace(int B, int d);
+int oneprot_attnpool_bwd(const float* x, const float* attn, const float* w, const float* dpooled, float* dw, float* db, float* dx, void* workspace,
+                         int B, int L, int d, void* stream);
+
 /* ---------------- dense contractions on MFMA (nn.Linear call sites: hf modeling_esm.py:362-368,399-409,442-463) -- */
 enum {
   ONEPROT_EPI_BF16 = 0,        /* out0 bf16 [M,N] = acc (+bias)                                                   */

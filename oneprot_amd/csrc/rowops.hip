@@ -516,6 +516,112 @@ extern "C" int oneprot_pool_fwd(const float* x, const int64_t* ids, int pad_id, 
 }
 
 // --------------------------------------------------------------------------------------------------------
+// Attention1dPooling (ref base_encoder.py:88-103; MaskedConv1d with kernel 1 = one dot product per token):
+//   s_l = x_l . w + b ; s_l = -inf where the token is padding ; a = softmax_l(s) ; pooled = sum_l a_l x_l
+// One 256-thread block per sequence; scores and weights live in LDS ([L] floats), x is read twice (fp32, float4).
+// --------------------------------------------------------------------------------------------------------
+__global__ void __launch_bounds__(256) k_attnpool_fwd(const float* __restrict__ x, const long long* __restrict__ ids, int pad_id, const float* __restrict__ w,
+                                                      const float* __restrict__ bias, float* __restrict__ pooled, float* __restrict__ attn, int L, int d) {
+  extern __shared__ __attribute__((aligned(16))) float s_a[];      // [L]
+  __shared__ float s_red[4];
+  const int b = blockIdx.x, lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  const int nv4 = d >> 2;
+  const float* xb = x + (size_t)b * L * d;
+  for (int l = wave; l < L; l += 4) {
+    float s = 0.f;
+    for (int c = lane; c < nv4; c += 64) {
+      const float4 xv = reinterpret_cast<const float4*>(xb + (size_t)l * d)[c];
+      const float4 wv = reinterpret_cast<const float4*>(w)[c];
+      s += (xv.x * wv.x + xv.y * wv.y) + (xv.z * wv.z + xv.w * wv.w);
+    }
+    s = wave_sum(s);
+    if (lane == 0) s_a[l] = (ids[(size_t)b * L + l] != pad_id) ? s + bias[0] : -INFINITY;
+  }
+  __syncthreads();
+  float mx = -INFINITY;
+  for (int l = threadIdx.x; l < L; l += 256) mx = fmaxf(mx, s_a[l]);
+  mx = wave_max(mx);
+  if (lane == 0) s_red[wave] = mx;
+  __syncthreads();
+  mx = fmaxf(fmaxf(s_red[0], s_red[1]), fmaxf(s_red[2], s_red[3]));
+  __syncthreads();
+  float se = 0.f;
+  for (int l = threadIdx.x; l < L; l += 256) { const float e = __expf(s_a[l] - mx); s_a[l] = e; se += e; }
+  se = wave_sum(se);
+  if (lane == 0) s_red[wave] = se;
+  __syncthreads();
+  const float inv = 1.0f / (s_red[0] + s_red[1] + s_red[2] + s_red[3]);
+  for (int l = threadIdx.x; l < L; l += 256) { const float a = s_a[l] * inv; s_a[l] = a; if (attn) attn[(size_t)b * L + l] = a; }
+  __syncthreads();
+  for (int j = threadIdx.x; j < d; j += 256) {
+    float acc = 0.f;
+    for (int l = 0; l < L; ++l) acc += s_a[l] * xb[(size_t)l * d + j];
+    pooled[(size_t)b * d + j] = acc;
+  }
+}
+extern "C" int oneprot_attnpool_fwd(const float* x, const int64_t* ids, int pad_id, const float* w, const float* bias, float* pooled, float* attn, int B, int L,
+                                    int d, void* stream) {
+  if (!x || !ids || !w || !bias || !pooled || B <= 0 || L <= 0 || (d & 3) || (size_t)L * 4 > 60 * 1024) return OP_EINVAL;
+  hipLaunchKernelGGL(k_attnpool_fwd, dim3(B), dim3(256), (size_t)L * sizeof(float), (hipStream_t)stream, x, (const long long*)ids, pad_id, w, bias, pooled, attn, L, d);
+  return launch_status();
+}
+// backward: da_l = x_l . dp ; ds = a * (da - sum a da) ; dw_partial[b] = sum_l ds_l x_l ; db_partial[b] = sum_l ds_l ;
+//           dx_l = a_l dp + ds_l w (optional)
+__global__ void __launch_bounds__(256) k_attnpool_bwd(const float* __restrict__ x, const float* __restrict__ attn, const float* __restrict__ w,
+                                                      const float* __restrict__ dpooled, float* __restrict__ dw_part, float* __restrict__ db_part,
+                                                      float* __restrict__ dx, int L, int d) {
+  extern __shared__ __attribute__((aligned(16))) float s_ds[];     // [L]
+  __shared__ float s_red[4];
+  const int b = blockIdx.x, lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  const int nv4 = d >> 2;
+  const float* xb = x + (size_t)b * L * d;
+  const float* dp = dpooled + (size_t)b * d;
+  float dot = 0.f;
+  for (int l = wave; l < L; l += 4) {
+    float s = 0.f;
+    for (int c = lane; c < nv4; c += 64) {
+      const float4 xv = reinterpret_cast<const float4*>(xb + (size_t)l * d)[c];
+      const float4 gv = reinterpret_cast<const float4*>(dp)[c];
+      s += (xv.x * gv.x + xv.y * gv.y) + (xv.z * gv.z + xv.w * gv.w);
+    }
+    s = wave_sum(s);
+    const float a = attn[(size_t)b * L + l];
+    if (lane == 0) { s_ds[l] = s; }
+    dot += a * s;                 // identical in every lane of the wave
+  }
+  if (lane == 0) s_red[wave] = dot;
+  __syncthreads();
+  const float tot = s_red[0] + s_red[1] + s_red[2] + s_red[3];
+  float dbs = 0.f;
+  for (int l = threadIdx.x; l < L; l += 256) { const float v = attn[(size_t)b * L + l] * (s_ds[l] - tot); s_ds[l] = v; dbs += v; }
+  __syncthreads();
+  dbs = wave_sum(dbs);
+  if (lane == 0) s_red[wave] = dbs;
+  __syncthreads();
+  if (threadIdx.x == 0) db_part[b] = s_red[0] + s_red[1] + s_red[2] + s_red[3];
+  for (int j = threadIdx.x; j < d; j += 256) {
+    float acc = 0.f;
+    const float wj = w[j], gj = dp[j];
+    for (int l = 0; l < L; ++l) {
+      const float dsl = s_ds[l];
+      acc += dsl * xb[(size_t)l * d + j];
+      if (dx) dx[((size_t)b * L + l) * d + j] = attn[(size_t)b * L + l] * gj + dsl * wj;
+    }
+    dw_part[(size_t)b * d + j] = acc;
+  }
+}
+extern "C" int oneprot_attnpool_bwd(const float* x, const float* attn, const float* w, const float* dpooled, float* dw, float* db, float* dx, void* workspace,
+                                    int B, int L, int d, void* stream) {
+  if (!x || !attn || !w || !dpooled || !dw || !db || !workspace || B <= 0 || L <= 0 || (d & 3) || (size_t)L * 4 > 60 * 1024) return OP_EINVAL;
+  float* part = (float*)workspace;              // [B][d] dw partials then [B] db partials
+  hipLaunchKernelGGL(k_attnpool_bwd, dim3(B), dim3(256), (size_t)L * sizeof(float), (hipStream_t)stream, x, attn, w, dpooled, part, part + (size_t)B * d, dx, L, d);
+  hipLaunchKernelGGL(k_reduce_partials, dim3((d + 255) / 256), dim3(256), 0, (hipStream_t)stream, (const float*)part, dw, B, (size_t)d, 0);
+  hipLaunchKernelGGL(k_reduce_partials, dim3(1), dim3(256), 0, (hipStream_t)stream, (const float*)(part + (size_t)B * d), db, B, (size_t)1, 0);
+  return launch_status();
+}
+extern "C" size_t oneprot_attnpool_bwd_workspace(int B, int d) { return ((size_t)B * d + B) * sizeof(float); }
+
+// --------------------------------------------------------------------------------------------------------
 // casts / fills / column sums
 // --------------------------------------------------------------------------------------------------------
 __global__ void __launch_bounds__(256) k_cast_f32_bf16(const float* __restrict__ src, bf16_t* __restrict__ dst, size_t n4) {

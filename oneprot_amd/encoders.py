@@ -47,11 +47,16 @@ class LearnableLogitScaling(nn.Module):
             self.register_buffer("log_logit_scale", log_logit_scale)
 
     def scale_value(self) -> float:
-        return min(math.exp(float(self.log_logit_scale)), self.max_logit_scale)
+        """clip(exp(log_logit_scale), max) as a host float; cached on the tensor's version so the hot loop does not synchronise."""
+        key = (self.log_logit_scale._version, self.log_logit_scale.data_ptr())
+        if getattr(self, "_cached", (None, None))[0] != key:
+            self._cached = (key, min(math.exp(float(self.log_logit_scale.detach())), self.max_logit_scale))
+        return self._cached[1]
+
+    def is_clipped(self) -> bool:
+        return math.exp(float(self.log_logit_scale.detach())) >= self.max_logit_scale
 
     def forward(self, x):
-        if self.learnable:
-            raise NotImplementedError("learnable_logit_scale=True is not on the shipped-config hot path (all configs use false)")
         return x * self.scale_value()
 
     def extra_repr(self):
@@ -70,6 +75,27 @@ class CLSTokenPooling(nn.Module):
 
     def forward(self, features, input_mask=None):
         return features[:, 0]
+
+
+class MaskedConv1d(nn.Conv1d):
+    """kernel-1 convolution holder of Attention1dPooling (ref base_encoder.py:40-86); only its parameters are used (fused kernel)."""
+
+    def __init__(self, in_channels: int, out_channels: int, kernel_size: int, stride: int = 1, dilation: int = 1, groups: int = 1, bias: bool = True):
+        padding = dilation * (kernel_size - 1) // 2
+        super().__init__(in_channels, out_channels, kernel_size, stride=stride, dilation=dilation, groups=groups, bias=bias, padding=padding)
+
+
+class Attention1dPooling(nn.Module):
+    """ref base_encoder.py:88-103.  NB the reference builds it with hidden_size hard-coded to 1280 (base_encoder.py:180), i.e. it only
+    matches ESM-2-650M-width encoders; same here."""
+    mode = 2
+
+    def __init__(self, hidden_size):
+        super().__init__()
+        self.layer = MaskedConv1d(hidden_size, 1, 1)
+
+    def forward(self, x, input_mask=None):
+        raise RuntimeError("pooling is fused into the encoder node; call the encoder, not the pooling module")
 
 
 def _ws(nbytes, dev):
@@ -183,55 +209,97 @@ class _L2NormFn(torch.autograd.Function):
 # ------------------------------------------------------------------------------------------------- whole-encoder node
 class _EncodeFn(torch.autograd.Function):
     @staticmethod
-    def forward(ctx, enc, ids, flat, *head_params):
+    def forward(ctx, enc, ids, flat, n_extra, *params):
         tr = enc.transformer
         # (grad mode is off inside Function.forward; ctx.needs_input_grad already folds in torch.no_grad())
         need_tr_grad = bool(ctx.needs_input_grad[2])
-        need_head_grad = need_tr_grad or any(ctx.needs_input_grad[3:])
+        need_any = need_tr_grad or any(ctx.needs_input_grad[4:])
         x, saved = tr.run_layers(ids, save=need_tr_grad)
         B, L = ids.shape
         d = tr.d
         dev = ids.device
+        ids = ids.contiguous()
         pooled = torch.empty(B, d, device=dev)
         mode = enc.pooling.mode
+        final_ln = getattr(tr, "final_layer_norm", True)
+        mean = rstd = wrow = hidden = attn = None
         if need_tr_grad:
             mean, rstd, wrow = (torch.empty(B * L, device=dev) for _ in range(3))
-        else:
-            mean = rstd = wrow = None
-        if getattr(tr, "final_layer_norm", True):
-            hip.call("oneprot_lnpool_fwd", x, ids.contiguous(), tr.config.pad_token_id, tr.view("encoder.emb_layer_norm_after.weight"),
+        if mode == 2:                                   # attention1d: needs the normalised hidden state itself
+            pw = enc.pooling.layer.weight
+            if pw.numel() != d:
+                raise RuntimeError(f"Attention1dPooling was built for hidden size {pw.numel()} but the encoder width is {d} "
+                                   "(the reference hard-codes 1280: base_encoder.py:180)")
+            if final_ln:
+                hidden = torch.empty(B, L, d, device=dev)
+                hip.call("oneprot_lnpool_fwd", x, ids, tr.config.pad_token_id, tr.view("encoder.emb_layer_norm_after.weight"),
+                         tr.view("encoder.emb_layer_norm_after.bias"), pooled, mean, rstd, wrow, None, hidden, B, L, d, tr.config.layer_norm_eps, 0)
+            else:
+                hidden = x.view(B, L, d)
+            attn = torch.empty(B, L, device=dev)
+            hip.call("oneprot_attnpool_fwd", hidden, ids, tr.config.pad_token_id, pw, enc.pooling.layer.bias, pooled, attn, B, L, d)
+        elif final_ln:
+            hip.call("oneprot_lnpool_fwd", x, ids, tr.config.pad_token_id, tr.view("encoder.emb_layer_norm_after.weight"),
                      tr.view("encoder.emb_layer_norm_after.bias"), pooled, mean, rstd, wrow, None, None, B, L, d, tr.config.layer_norm_eps, mode)
         else:       # BERT: the last layer's output is already post-LN
-            hip.call("oneprot_pool_fwd", x, ids.contiguous(), tr.config.pad_token_id, pooled, B, L, d, mode)
+            hip.call("oneprot_pool_fwd", x, ids, tr.config.pad_token_id, pooled, B, L, d, mode)
         scale = enc.logit_scale_value()
-        feat, hst = _Head.forward(pooled, enc.proj, scale, need_head_grad)
+        feat, hst = _Head.forward(pooled, enc.proj, scale, need_any)
         ctx.enc, ctx.saved, ctx.hst, ctx.scale = enc, saved, hst, scale
         ctx.fin = (mean, rstd, wrow)
+        ctx.pool = (hidden, attn) if (mode == 2 and need_any) else None
         ctx.need_tr_grad = need_tr_grad
-        ctx.n_head = len(head_params)
+        ctx.n_extra, ctx.n_params = n_extra, len(params)
+        ctx.ids = ids
         return feat
 
     @staticmethod
     def backward(ctx, dfeat):
         enc, tr = ctx.enc, ctx.enc.transformer
+        dev = dfeat.device
+        dfeat = dfeat.contiguous()
         dpooled, hgrads = _Head.backward(dfeat, enc.proj, ctx.scale, ctx.hst)
+        extra_grads = []
+        dhidden = None
+        mode = enc.pooling.mode
+        if mode == 2:
+            hidden, attn = ctx.pool
+            B, L, d = hidden.shape
+            dw, db = torch.empty(d, device=dev), torch.empty(1, device=dev)
+            if ctx.need_tr_grad:
+                dhidden = torch.empty(B * L, d, device=dev)
+            hip.call("oneprot_attnpool_bwd", hidden, attn, enc.pooling.layer.weight, dpooled, dw, db, dhidden,
+                     _ws(hip.query("oneprot_attnpool_bwd_workspace", B, d), dev), B, L, d)
+            extra_grads += [dw.view_as(enc.pooling.layer.weight), db]
+        if len(enc.norm) > 1 and enc.norm[1].learnable:
+            # d/d(log s) [s * xhat] = s * xhat = feat  (zero when the clip at max_logit_scale is active)
+            g = torch.zeros(1, device=dev)
+            if not enc.norm[1].is_clipped():
+                hip.call("oneprot_sgemm", dfeat.view(1, -1), ctx.hst["feat"].view(1, -1), g, 1, 1, dfeat.numel(), 0, 0, 1.0, 0)
+            extra_grads.append(g.reshape(()))
         gflat = None
         if ctx.need_tr_grad:
             saved = ctx.saved
             B, L, d = saved["B"], saved["L"], tr.d
-            dev = dfeat.device
             gflat = torch.zeros(tr._total, device=dev)
             mean, rstd, wrow = ctx.fin
             g = torch.empty(B * L, d, device=dev)
             g16 = torch.empty(B * L, d, dtype=torch.bfloat16, device=dev)
-            hip.call("oneprot_layernorm_bwd", dpooled, 2, wrow, L, saved["x_final"], 0, tr.view("encoder.emb_layer_norm_after.weight"), mean, rstd, None, g, g16,
-                     tr.view("encoder.emb_layer_norm_after.weight", gflat), tr.view("encoder.emb_layer_norm_after.bias", gflat),
-                     _ws(hip.query("oneprot_layernorm_bwd_workspace", d), dev), B * L, d, 0)
+            lnw, lnb = tr.view("encoder.emb_layer_norm_after.weight", gflat), tr.view("encoder.emb_layer_norm_after.bias", gflat)
+            ws = _ws(hip.query("oneprot_layernorm_bwd_workspace", d), dev)
+            if mode == 2:
+                hip.call("oneprot_layernorm_bwd", dhidden, 1, None, 0, saved["x_final"], 0, tr.view("encoder.emb_layer_norm_after.weight"), mean, rstd, None, g, g16,
+                         lnw, lnb, ws, B * L, d, 0)
+            else:
+                hip.call("oneprot_layernorm_bwd", dpooled, 2, wrow, L, saved["x_final"], 0, tr.view("encoder.emb_layer_norm_after.weight"), mean, rstd, None, g, g16,
+                         lnw, lnb, ws, B * L, d, 0)
             saved["x_final"] = None
             tr.backward_layers(saved, g, g16, gflat)
             ctx.saved = None
-        hg = list(hgrads) + [None] * (ctx.n_head - len(hgrads))
-        return (None, None, gflat) + tuple(hg)
+        n_head = ctx.n_params - ctx.n_extra
+        hg = list(hgrads) + [None] * (n_head - len(hgrads))
+        eg = list(extra_grads) + [None] * (ctx.n_extra - len(extra_grads))
+        return (None, None, gflat, None) + tuple(eg) + tuple(hg)
 
 
 # ------------------------------------------------------------------------------------------------- BaseEncoder
@@ -269,20 +337,23 @@ class BaseEncoder(nn.Module):
         if pooling_type == 'cls':
             return CLSTokenPooling()
         if pooling_type == 'attention1d':
-            raise NotImplementedError("attention1d pooling is a 'next' row (SURVEY.md section 8f #4); not built in this round")
+            return Attention1dPooling(hidden_size)
         raise NotImplementedError(f"pooling_type={pooling_type!r}: the fused encoder supports 'mean' and 'cls'")
 
     def logit_scale_value(self) -> float:
-        if len(self.norm) > 1:
-            ls = self.norm[1]
-            if ls.learnable:
-                raise NotImplementedError("learnable_logit_scale=True is not on the shipped-config hot path")
-            return ls.scale_value()
-        return 1.0
+        return self.norm[1].scale_value() if len(self.norm) > 1 else 1.0
+
+    def _extra_params(self):
+        """parameters outside the transformer arena that the fused node differentiates: pooling conv (attention1d), learnable logit scale"""
+        ps = list(self.pooling.parameters())
+        if len(self.norm) > 1 and self.norm[1].learnable:
+            ps.append(self.norm[1].log_logit_scale)
+        return ps
 
     def encode(self, input_ids):
+        extra = self._extra_params()
         head_params = [p for p in self.proj.parameters()]
-        return _EncodeFn.apply(self, input_ids, self.transformer.flat, *head_params)
+        return _EncodeFn.apply(self, input_ids, self.transformer.flat, len(extra), *extra, *head_params)
 
 
 class SequenceEncoder(BaseEncoder):

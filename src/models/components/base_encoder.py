@@ -1,2 +1,3 @@
 """ref src/models/components/base_encoder.py surface -> HIP implementation."""
-from oneprot_amd.encoders import BaseEncoder, CLSTokenPooling, LearnableLogitScaling, MeanPooling, Normalize  # noqa: F401
+from oneprot_amd.encoders import (Attention1dPooling, BaseEncoder, CLSTokenPooling, LearnableLogitScaling, MaskedConv1d, MeanPooling,  # noqa: F401
+                                  Normalize)

@@ -304,3 +304,51 @@ def test_mixed_batch_round_robin(golden_dir, tmp_path):
     assert torch.isfinite(module.validation_step(vb, 0))
     out = module.test_step({"text": vb}, 0)
     assert torch.isfinite(out["text"])
+
+
+@pytest.mark.parametrize("frozen", [True, False])
+def test_attention1d_pooling_and_learnable_logit_scale(tmp_path, frozen):
+    """ref configs/experiment/train_ddp_1.yaml:46 shape in miniature: sequence encoder with pooling_type=attention1d (conv width hard-coded
+    1280 in the reference, so the encoder width must be 1280), linear head, learnable logit scale; gradients vs the oracle's autograd."""
+    os.environ.update(RANK="0", WORLD_SIZE="1", ONEPROT_ALLOW_RANDOM_INIT="1")
+    from src.models.components.sequence_encoder import SequenceEncoder
+    cfg = dict(vocab=33, hidden=1280, layers=1, heads=20, ffn=256, pad=1, mask=32, eps=1e-5)
+    p = _write_cfg(str(tmp_path), cfg, "esm1280")
+    torch.manual_seed(5)
+    enc = SequenceEncoder(p, output_dim=64, pooling_type="attention1d", proj_type="linear", use_logit_scale=True, learnable_logit_scale=True, use_lora=False,
+                          frozen=frozen)
+    with torch.no_grad():
+        enc.pooling.layer.weight.normal_(0, 0.05)
+        enc.pooling.layer.bias.fill_(0.3)
+    sd = {k: v.detach().clone() for k, v in enc.state_dict().items()}
+    assert "pooling.layer.weight" in sd and tuple(sd["pooling.layer.weight"].shape) == (1, 1280, 1) and "norm.1.log_logit_scale" in sd
+    gen = torch.Generator().manual_seed(2)
+    B, L = 3, 24
+    ids = torch.randint(4, 24, (B, L), generator=gen)
+    ids[:, 0] = 0
+    for b, n in enumerate([24, 11, 5]):
+        ids[b, n - 1] = 2
+        ids[b, n:] = 1
+    tgt = torch.randn(B, 64, generator=gen)
+    # oracle
+    leaf = {k: v.clone().requires_grad_(v.is_floating_point() and "inv_freq" not in k) for k, v in sd.items()}
+    ref = O.encoder_features("esm", ids, leaf, cfg, "attention1d", "linear", True)
+    (ref * tgt).sum().backward()
+    # HIP
+    enc = enc.to(DEV)
+    got = enc(ids.to(DEV))
+    (got * tgt.to(DEV)).sum().backward()
+    cs = torch.nn.functional.cosine_similarity(got.detach().cpu(), ref.detach(), dim=-1)
+    assert cs.min() > 0.999, cs
+    assert _cos(enc.pooling.layer.weight.grad.cpu(), leaf["pooling.layer.weight"].grad) > 0.99
+    assert abs(enc.pooling.layer.bias.grad.item() - leaf["pooling.layer.bias"].grad.item()) < 2e-2 * (abs(leaf["pooling.layer.bias"].grad.item()) + 1e-3)
+    gs, rs_ = enc.norm[1].log_logit_scale.grad.item(), leaf["norm.1.log_logit_scale"].grad.item()
+    assert abs(gs - rs_) < 2e-2 * abs(rs_) + 1e-3, (gs, rs_)
+    assert _cos(enc.proj[1].weight.grad.cpu(), leaf["proj.1.weight"].grad) > 0.999
+    if frozen:
+        assert enc.transformer.flat.grad is None
+    else:
+        gq = enc.transformer.view("encoder.layer.0.attention.self.value.weight", enc.transformer.flat.grad).cpu()
+        assert _cos(gq, leaf["transformer.encoder.layer.0.attention.self.value.weight"].grad) > 0.99
+        ge = enc.transformer.view("encoder.emb_layer_norm_after.weight", enc.transformer.flat.grad).cpu()
+        assert _cos(ge, leaf["transformer.encoder.emb_layer_norm_after.weight"].grad) > 0.99
