@@ -253,4 +253,27 @@ extern "C" int oneprot_siglip_fwd_bwd(float* logits, float* loss_sum, float* row
   return launch_status();
 }
 
+// Retrieval ranks (ref retrieval_metric.py:83-102): for logits = S @ M^T [N,N], the rank of the matching pair is the number of entries that
+// beat the diagonal -- counted directly (O(N^2)) instead of the reference's full argsort (O(N^2 log N) on the CPU).
+//   rank_row[i] = #{ j : logits[i][j] > logits[i][i] }   (sequence -> modality)      rank_col[i] = #{ j : logits[j][i] > logits[i][i] }
+__global__ void __launch_bounds__(256) k_diag_rank(const float* __restrict__ logits, int* __restrict__ rank_row, int* __restrict__ rank_col, int N) {
+  __shared__ float s4[4];
+  const int i = blockIdx.x;
+  const float dg = logits[(size_t)i * N + i];
+  float cr = 0.f, cc = 0.f;
+  for (int j = threadIdx.x; j < N; j += 256) {
+    cr += logits[(size_t)i * N + j] > dg ? 1.f : 0.f;
+    cc += logits[(size_t)j * N + i] > dg ? 1.f : 0.f;
+  }
+  cr = block_sum_256(cr, s4);
+  __syncthreads();
+  cc = block_sum_256(cc, s4);
+  if (threadIdx.x == 0) { rank_row[i] = (int)cr; rank_col[i] = (int)cc; }
+}
+extern "C" int oneprot_diag_rank(const float* logits, int* rank_row, int* rank_col, int N, void* stream) {
+  if (!logits || !rank_row || !rank_col || N <= 0 || N >= (1 << 24)) return OP_EINVAL;
+  hipLaunchKernelGGL(k_diag_rank, dim3(N), dim3(256), 0, (hipStream_t)stream, logits, rank_row, rank_col, N);
+  return launch_status();
+}
+
 extern "C" int oneprot_abi_version(void) { return 1; }

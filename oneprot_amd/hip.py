@@ -55,6 +55,7 @@ _SIGS = {
     "oneprot_l2norm_bwd": (I, [P, P, P, P, I, I, F, F, P]),
     "oneprot_ce_fwd_bwd": (I, [P, P, P, I, I, I, F, P]),
     "oneprot_siglip_fwd_bwd": (I, [P, P, P, I, F, I, P]),
+    "oneprot_diag_rank": (I, [P, P, P, I, P]),
     "oneprot_abs_sum": (I, [P, P, P, L64, F, P]),
     "oneprot_l1_bwd": (I, [P, P, L64, F, P, I, P]),
     "oneprot_scale_by_device_scalar": (I, [P, L64, P, P]),

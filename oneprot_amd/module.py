@@ -20,6 +20,7 @@ import torch.nn as nn
 
 from . import distributed as D
 from .loss import ClipLoss, SigLipLoss, l1_penalty
+from .metrics import RetrievalMetric
 from .optim import FusedAdam, clip_grad_norm_
 
 try:                                                    # pragma: no cover  (not installed in the build image)
@@ -63,23 +64,6 @@ class _DeviceMin:
 
     def compute(self):
         return self.value if self.value is not None else torch.tensor(float("inf"))
-
-
-class _FeatureBuffer:
-    """placeholder for ref RetrievalMetric (retrieval_metric.py): buffers features; ranking is a 'next' row (SURVEY section 8f #2)."""
-
-    def __init__(self):
-        self.reset()
-
-    def reset(self):
-        self.seq, self.mod = [], []
-
-    def update(self, sequence_features, modality_features):
-        self.seq.append(sequence_features.detach())
-        self.mod.append(modality_features.detach())
-
-    def compute(self):
-        raise NotImplementedError("retrieval metrics are outside the round-1 hot path (SURVEY.md section 8f #2)")
 
 
 class _PlainBase(nn.Module):
@@ -134,7 +118,7 @@ class OneProtLitModule(_Base):
         self.train_loss, self.val_loss, self.test_loss = _DeviceMean(), _DeviceMean(), _DeviceMean()
         self.val_loss_best = _DeviceMin()
         self.use_seqsim = use_seqsim
-        self.metrics = {f"{split}_{modality}": _FeatureBuffer() for split in ["val", "test"]
+        self.metrics = {f"{split}_{modality}": RetrievalMetric() for split in ["val", "test"]
                         for modality in list(self.network.keys()) + ["seqsim"] if modality != 'sequence'}
 
     def l1_regularization(self, features):
@@ -218,6 +202,25 @@ class OneProtLitModule(_Base):
             self.metrics[f"test_{modality}"].update(seq_features, mod_features)
             out[modality] = loss
         return out
+
+    def on_validation_epoch_end(self):
+        """ref oneprot_module.py:123-135"""
+        loss = self.val_loss.compute()
+        self.val_loss_best(loss)
+        self.log("val/loss_best", self.val_loss_best.compute(), sync_dist=True, prog_bar=True)
+        for name, metric in self.metrics.items():
+            if name.startswith("val_") and metric.preds:
+                for key, value in metric.compute().items():
+                    self.log(f"val/{key}/{name}", value, sync_dist=True, prog_bar=True)
+                metric.reset()
+
+    def on_test_epoch_end(self):
+        """ref oneprot_module.py:148-154"""
+        for name, metric in self.metrics.items():
+            if name.startswith("test_") and metric.preds:
+                for key, value in metric.compute().items():
+                    self.log(f"test/{key}/{name}", value, prog_bar=True)
+                metric.reset()
 
     def configure_optimizers(self):
         optimizer = self.hparams.optimizer(params=self.parameters())

@@ -385,6 +385,22 @@ def train_multi_substeps(seq_ids, mod_ids, sd_seq, sd_mod, cfg_seq, cfg_mod, seq
     return losses, {k: v.detach() for k, v in ps.items()}, {k: v.detach() for k, v in pm.items()}
 
 
+def retrieval_metrics(sequence_outputs: Tensor, modality_outputs: Tensor, ks=(1, 10, 100)) -> dict:
+    """ref retrieval_metric.py:76-102: S @ M^T, descending argsort, position of the diagonal; median rank (floor + 1) and R@k both ways.
+    (The reference's own class needs torchmetrics, absent here: this restatement is pinned only by reading those lines.)"""
+    import numpy as np
+    out = {}
+    lps = (sequence_outputs @ modality_outputs.t()).detach().cpu()
+    gt = torch.arange(len(modality_outputs)).view(-1, 1)
+    for name, logit in (("seq_to_mod", lps), ("mod_to_seq", lps.t())):
+        ranking = torch.argsort(logit, descending=True)
+        preds = torch.where(ranking == gt)[1].numpy()
+        out[f"{name}_median_rank"] = float(np.floor(np.median(preds)) + 1)
+        for k in ks:
+            out[f"{name}_R@{k}"] = float(np.mean(preds < k))
+    return out
+
+
 # --------------------------------------------------------------------------------------
 # src/distributed.py:8-38 restated (string logic only)
 # --------------------------------------------------------------------------------------

@@ -427,3 +427,19 @@ def test_siglip_block(negative_only):
     assert abs(loss.item() - ref.item()) < 1e-4 * abs(ref.item())
     assert_close(md.grad.cpu(), mr.grad, 1e-4, 1e-6, "siglip dm")
     assert_close(sd.grad.cpu(), sr.grad, 1e-4, 1e-6, "siglip ds")
+
+
+def test_retrieval_metric_counts_ranks():
+    from oneprot_amd.metrics import RetrievalMetric
+    g = torch.Generator().manual_seed(15)
+    N, D = 300, 32
+    s = torch.nn.functional.normalize(torch.randn(N, D, generator=g), dim=-1)
+    m = torch.nn.functional.normalize(s + 0.6 * torch.randn(N, D, generator=g), dim=-1) * (1 / 0.07)
+    met = RetrievalMetric()
+    for i in range(0, N, 100):
+        met.update(s[i:i + 100].to(DEV), m[i:i + 100].to(DEV))
+    got = met.compute()
+    ref = O.retrieval_metrics(s, m)
+    assert set(got) == set(ref)
+    for k in ref:
+        assert abs(got[k] - ref[k]) <= (1.0 if "median" in k else 0.011), (k, got[k], ref[k])
