@@ -164,8 +164,15 @@ def main():
         gemm_ms = sum(launches_ms) / max(len(launches_ms), 1)
         achieved = gemm_flops / (gemm_ms * 1e-3) / 1e12 if gemm_ms > 0 else 0.0
         fwd = encoder_flops_fwd(dict(hidden=d, ffn=f, layers=seq.transformer.n_layers), L)
-        step_flops = B * (fwd * (2 if not args.train_seq else 1) + 0) + B * fwd * (3 if True else 0)   # seq fwd (+bwd if trained) + struct fwd+bwd
-        step_flops = B * fwd * ((3 if args.train_seq else 1) + 3)
+        step_flops = B * fwd * ((3 if args.train_seq else 1) + 3)      # sequence encoder fwd (+2x bwd if trained) + struct-token encoder fwd + bwd
+        # HBM/fabric bytes per launch of the dominant kernel: PMC passes cannot run inside this process, so the figure measured with
+        # rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE (separate passes, gfx950 x2 correction on FETCH_SIZE) is read from profiles/.
+        traffic = None
+        try:
+            with open(os.path.join(ROOT, "profiles", "r01_pmc_traffic.json")) as f:
+                traffic = json.load(f)["traffic_bytes_per_launch"] / 1e9
+        except Exception:
+            pass
         out = {
             "metric": "protein-pairs/sec/node (seq+struct-token, L=512, ESM-2-150M)", "value": round(value, 2), "unit": "protein-pairs/sec/node",
             "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": round(ms_step, 2), "higher_is_better": True, "scaling": "weak",
@@ -177,7 +184,7 @@ def main():
                        "loss": round(loss_val, 5)},
             "step_tflops_per_gpu": round(step_flops / (ms_step * 1e-3) / 1e12, 1),
             "roofline": {"bound": "mfma", "kernel": "k_gemm_nt<BIAS_GELU> FFN-1 [T,640]x[2560,640]^T", "achieved": round(achieved, 1), "peak": PEAK_BF16_TFLOPS,
-                         "unit": "TFLOP/s", "frac": round(achieved / PEAK_BF16_TFLOPS, 4), "traffic": None, "launches_timed": len(launches_ms),
+                         "unit": "TFLOP/s", "frac": round(achieved / PEAK_BF16_TFLOPS, 4), "traffic": traffic, "traffic_unit": "GB/launch (rocprofv3 PMC, profiles/r01_pmc_traffic.json; algorithmic 1.51)", "launches_timed": len(launches_ms),
                          "avg_launch_ms": round(gemm_ms, 4), "flops_per_launch": gemm_flops},
         }
         if world == 1 and not args.no_cpu_baseline:
