@@ -1,0 +1,53 @@
+"""2-rank data-parallel sub-step on ONE GPU (both ranks on cuda:0, gloo transport for the collectives): used by
+tests/test_multirank_gpu.py to check the N>1 path end to end with the real HIP kernels."""
+import functools
+import json
+import os
+import sys
+import warnings
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+import torch
+
+
+def main():
+    rank, world, port, out_dir, golden = int(sys.argv[1]), int(sys.argv[2]), sys.argv[3], sys.argv[4], sys.argv[5]
+    os.environ.update(RANK=str(rank), WORLD_SIZE=str(world), LOCAL_RANK="0", MASTER_ADDR="127.0.0.1", MASTER_PORT=port, ONEPROT_ALLOW_RANDOM_INIT="1")
+    warnings.filterwarnings("ignore")
+    from oneprot_amd import distributed as D
+    from oneprot_amd.optim import FusedAdam
+    from src.models.components.sequence_encoder import SequenceEncoder
+    from src.models.components.struct_token_encoder import StructTokenEncoder
+    from src.models.oneprot_module import OneProtLitModule
+    if world > 1:
+        D.setup_process_group(backend="gloo")
+    g = torch.load(golden, weights_only=False)
+    cfg = g["cfg"]
+    p = os.path.join(out_dir, f"cfg_rank{rank}")
+    os.makedirs(p, exist_ok=True)
+    with open(os.path.join(p, "config.json"), "w") as f:
+        json.dump(dict(model_type="esm", vocab_size=cfg["vocab"], hidden_size=cfg["hidden"], num_hidden_layers=cfg["layers"], num_attention_heads=cfg["heads"],
+                       intermediate_size=cfg["ffn"], pad_token_id=1, mask_token_id=32, layer_norm_eps=cfg["eps"]), f)
+    seq = SequenceEncoder(p, output_dim=cfg["output_dim"], pooling_type="mean", proj_type="mlp", use_lora=False, frozen=False)
+    st = StructTokenEncoder(p, output_dim=cfg["output_dim"], pooling_type="mean", proj_type="linear", use_logit_scale=True)
+    seq.load_state_dict(g["sd_seq"]); st.load_state_dict(g["sd_st"])
+    module = OneProtLitModule(components={"sequence": seq, "struct_token": st}, optimizer=functools.partial(FusedAdam, lr=1e-3), loss_fn="CLIP",
+                              use_l1_regularization=False, local_loss=True, gather_with_grad=True).to("cuda:0")
+    B = g["seq_ids"].shape[0]
+    per = B // world
+    sl = slice(rank * per, (rank + 1) * per)
+    batch = {"struct_token": (g["seq_ids"][sl].to("cuda:0"), g["st_ids"][sl].to("cuda:0"), "struct_token", None)}
+    loss = module.training_step(batch, 0)
+    torch.cuda.synchronize()
+    out = {"loss": float(loss.detach()), "gnorm": float(module.last_grad_norm),
+           "w": module.network["struct_token"].state_dict()["transformer.encoder.layer.0.output.dense.weight"].cpu(),
+           "emb": module.network["sequence"].state_dict()["transformer.embeddings.word_embeddings.weight"].cpu()}
+    torch.save(out, os.path.join(out_dir, f"w{world}_rank{rank}.pt"))
+    if world > 1:
+        torch.distributed.barrier()
+        torch.distributed.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()
