@@ -207,8 +207,14 @@ class EsmTransformer(ArenaModule):
         d, f, n, V = config.hidden_size, config.intermediate_size, config.num_hidden_layers, config.vocab_size
         self.d, self.f, self.n_layers, self.H = d, f, n, config.num_attention_heads
         self.hd = d // self.H
-        if self.hd not in (16, 32, 64) or d % 64:
-            raise NotImplementedError(f"head_dim {self.hd} / hidden {d}: kernels are built for head_dim 16/32/64, hidden % 64 == 0")
+        # The attention / RoPE kernels are built for head_dim 16/32/64.  Any other even head_dim <= 64 (ESM-2-35M: 24) runs on the
+        # next larger one: each head's two RoPE halves are placed at the start of the two halves of a zero-padded head
+        # (`_head_pad_maps`), in the bf16 GEMM operands only -- parameters, gradients and checkpoints keep the HF shapes.
+        self.hdp = next((c for c in (16, 32, 64) if c >= self.hd), None)
+        if self.hdp is None or self.hd % 2 or self.hd * self.H != d or d % 8 or (self.H * self.hdp) % 64:
+            raise NotImplementedError(f"head_dim {self.hd} x {self.H} heads (hidden {d}): kernels need an even head_dim <= 64 and heads*padded_head_dim % 64 == 0")
+        self.dp = self.H * self.hdp
+        self._padded = self.hdp != self.hd
         self._init_arena()
         self._add("embeddings.word_embeddings.weight", (V, d))
         for i in range(n):
@@ -239,6 +245,7 @@ class EsmTransformer(ArenaModule):
         inv_freq = 1.0 / (10000.0 ** (torch.arange(0, self.hd, 2, dtype=torch.float32) / self.hd))
         self.register_buffer("inv_freq", inv_freq, persistent=False)
         self._rope_cache = {}
+        self._pad_ops = {}
         self.reset_parameters()
 
     @torch.no_grad()
@@ -296,29 +303,81 @@ class EsmTransformer(ArenaModule):
         if not self._refresh_bf16_mirror():
             return
         dev = self.flat.device
+        if self._padded:
+            self._refresh_padded_heads()
         if self.flat.requires_grad:
             d, f = self.d, self.f
             for i in range(self.n_layers):
                 p = f"encoder.layer.{i}."
                 o, n = self.span(p + "attention.self.query.weight", p + "attention.self.value.weight")
-                for key, (src, R, C) in {
-                    "qkv": (self.flat.data[o:o + n], 3 * d, d),
-                    "o": (self.view(p + "attention.output.dense.weight"), d, d),
-                    "w1": (self.view(p + "intermediate.dense.weight"), f, d),
-                    "w2": (self.view(p + "output.dense.weight"), d, f),
-                }.items():
+                plain = {"w1": (self.view(p + "intermediate.dense.weight"), f, d), "w2": (self.view(p + "output.dense.weight"), d, f)}
+                if not self._padded:
+                    plain["qkv"] = (self.flat.data[o:o + n], 3 * d, d)
+                    plain["o"] = (self.view(p + "attention.output.dense.weight"), d, d)
+                for key, (src, R, C) in plain.items():
                     t = self._bf16_T.get((i, key))
                     if t is None:
                         t = torch.empty(C, R, dtype=torch.bfloat16, device=dev)
                         self._bf16_T[(i, key)] = t
                     hip.call("oneprot_transpose_cast_f32_to_bf16", src, t, R, C)
 
+    def _head_pad_maps(self):
+        """(rowmap [3d], colmap [d]): position of HF row s*d + h*hd + j of the fused QKV weight inside the padded [3*dp] layout, and of
+        context column h*hd + j inside [dp].  j < hd/2 -> j ; j >= hd/2 -> hdp/2 + (j - hd/2): the RoPE partner of padded column c is
+        c +- hdp/2, as the hd=hdp kernels assume."""
+        dev = self.flat.device
+        if self._pad_ops.get("maps_dev") != dev:
+            half, hhp = self.hd // 2, self.hdp // 2
+            j = torch.arange(self.hd)
+            within = torch.where(j < half, j, hhp + j - half)
+            col = (torch.arange(self.H)[:, None] * self.hdp + within[None, :]).reshape(-1)
+            row = (torch.arange(3)[:, None] * self.dp + col[None, :]).reshape(-1)
+            self._pad_ops["maps"] = (row.to(dev), col.to(dev))
+            self._pad_ops["maps_dev"] = dev
+        return self._pad_ops["maps"]
+
+    def _refresh_padded_heads(self):
+        """bf16 QKV / out-proj operands (and their transposes for the dgrad GEMMs) in the padded-head layout; a layout permutation
+        of the bf16 mirror, redone whenever the mirror is."""
+        d, dp, dev = self.d, self.dp, self.flat.device
+        rowmap, colmap = self._head_pad_maps()
+        for i in range(self.n_layers):
+            p = f"encoder.layer.{i}."
+            o, n = self.span(p + "attention.self.query.weight", p + "attention.self.value.weight")
+            ob, nb = self.span(p + "attention.self.query.bias", p + "attention.self.value.bias")
+            ops = self._pad_ops.get(i)
+            if ops is None or ops["qkv"].device != dev:
+                ops = dict(qkv=torch.zeros(3 * dp, d, dtype=torch.bfloat16, device=dev), bqkv=torch.zeros(3 * dp, device=dev),
+                           o=torch.zeros(d, dp, dtype=torch.bfloat16, device=dev))
+                self._pad_ops[i] = ops
+            ops["qkv"][rowmap] = self._bf16[o:o + n].view(3 * d, d)
+            ops["bqkv"][rowmap] = self.flat.data[ob:ob + nb]
+            ops["o"][:, colmap] = self._w16(p + "attention.output.dense.weight")
+            if self.flat.requires_grad:
+                self._bf16_T[(i, "qkv")] = ops["qkv"].t().contiguous()       # [d, 3dp]
+                self._bf16_T[(i, "o")] = ops["o"].t().contiguous()           # [dp, d]
+
+    def _qkv_operands(self, i):
+        """(W_qkv bf16 [3*dp, d], bias fp32 [3*dp], W_o bf16 [d, dp]) for layer i"""
+        p = f"encoder.layer.{i}."
+        if self._padded:
+            ops = self._pad_ops[i]
+            return ops["qkv"], ops["bqkv"], ops["o"]
+        o, n = self.span(p + "attention.self.query.weight", p + "attention.self.value.weight")
+        ob, nb = self.span(p + "attention.self.query.bias", p + "attention.self.value.bias")
+        return self._bf16[o:o + n], self.flat.data[ob:ob + nb], self._w16(p + "attention.output.dense.weight")
+
     def _rope(self, L):
         key = (L, self.flat.device)
         if key not in self._rope_cache:
             t = torch.arange(L, dtype=torch.float32)
             freqs = torch.outer(t, self.inv_freq.detach().float().cpu())      # hf modeling_esm.py:150-158 (positions = arange(L))
-            self._rope_cache[key] = (freqs.cos().contiguous().to(self.flat.device), freqs.sin().contiguous().to(self.flat.device))
+            cos, sin = freqs.cos(), freqs.sin()
+            if self._padded:      # padded dims hold zeros; rotate them by angle 0
+                extra = self.hdp // 2 - self.hd // 2
+                cos = torch.cat([cos, torch.ones(L, extra)], 1)
+                sin = torch.cat([sin, torch.zeros(L, extra)], 1)
+            self._rope_cache[key] = (cos.contiguous().to(self.flat.device), sin.contiguous().to(self.flat.device))
         return self._rope_cache[key]
 
     # ----------------------------------------------------------------------------------------- forward / backward
@@ -329,7 +388,8 @@ class EsmTransformer(ArenaModule):
         self._refresh_bf16()
         cfg = self.config
         B, L = ids.shape
-        T, d, f, H, hd = B * L, self.d, self.f, self.H, self.hd
+        T, d, f, H, hd, dp = B * L, self.d, self.f, self.H, self.hdp, self.dp        # hd: kernel (padded) head dim
+        q_scale = self.hd ** -0.5
         dev = ids.device
         ids = ids.contiguous()
         f32 = lambda *s: torch.empty(*s, dtype=torch.float32, device=dev)
@@ -344,14 +404,14 @@ class EsmTransformer(ArenaModule):
         saved = dict(ids=ids, key_bias=key_bias, row_scale=row_scale, layers=[], B=B, L=L) if save else None
         h = b16(T, d)
         q, k, v = b16(B, H, L, hd), b16(B, H, L, hd), b16(B, H, L, hd)
-        ctx_ = b16(T, d)
+        ctx_ = b16(T, dp)
         u = b16(T, f)
         eps = cfg.layer_norm_eps
         for i in range(self.n_layers):
             p = f"encoder.layer.{i}."
             if save:
                 st = dict(x_in=x, mean1=f32(T), rstd1=f32(T), mean2=f32(T), rstd2=f32(T), h1=b16(T, d), q=b16(B, H, L, hd), k=b16(B, H, L, hd),
-                          v=b16(B, H, L, hd), ctx=b16(T, d), lse=f32(B, H, L), h2=b16(T, d), z=b16(T, f), u=b16(T, f))
+                          v=b16(B, H, L, hd), ctx=b16(T, dp), lse=f32(B, H, L), h2=b16(T, d), z=b16(T, f), u=b16(T, f))
                 h1, q, k, v, ctx_, h2, u, z = st["h1"], st["q"], st["k"], st["v"], st["ctx"], st["h2"], st["u"], st["z"]
                 m1, r1, m2, r2, lse = st["mean1"], st["rstd1"], st["mean2"], st["rstd2"], st["lse"]
             else:
@@ -359,13 +419,11 @@ class EsmTransformer(ArenaModule):
                 z = m1 = r1 = m2 = r2 = lse = None
             hip.call("oneprot_layernorm_fwd", x, 0, self.view(p + "attention.LayerNorm.weight"), self.view(p + "attention.LayerNorm.bias"), h1, None,
                      m1, r1, T, d, eps)
-            o, n = self.span(p + "attention.self.query.weight", p + "attention.self.value.weight")
-            ob, nb = self.span(p + "attention.self.query.bias", p + "attention.self.value.bias")
-            hip.call("oneprot_gemm_bf16_nt", h1, self._bf16[o:o + n], T, 3 * d, d, d, d, hip.EPI_QKV_ROPE, self.flat.data[ob:ob + nb], q, k, v, None,
-                     cos, sin, hd ** -0.5, L, H, hd)
+            w_qkv, b_qkv, w_o = self._qkv_operands(i)
+            hip.call("oneprot_gemm_bf16_nt", h1, w_qkv, T, 3 * dp, d, d, d, hip.EPI_QKV_ROPE, b_qkv, q, k, v, None, cos, sin, q_scale, L, H, hd)
             hip.call("oneprot_attn_fwd", q, k, v, key_bias, ctx_, lse, B, H, L, hd)
             x_mid = f32(T, d) if save else x
-            hip.call("oneprot_gemm_bf16_nt", ctx_, self._w16(p + "attention.output.dense.weight"), T, d, d, d, d, hip.EPI_BIAS_RESID,
+            hip.call("oneprot_gemm_bf16_nt", ctx_, w_o, T, d, dp, dp, dp, hip.EPI_BIAS_RESID,
                      self.view(p + "attention.output.dense.bias"), x_mid, None, None, x, None, None, 1.0, 0, 0, 0)
             hip.call("oneprot_layernorm_fwd", x_mid, 0, self.view(p + "LayerNorm.weight"), self.view(p + "LayerNorm.bias"), h2, None, m2, r2, T, d, eps)
             hip.call("oneprot_gemm_bf16_nt", h2, self._w16(p + "intermediate.dense.weight"), T, f, d, d, d, hip.EPI_BIAS_GELU,
@@ -385,18 +443,23 @@ class EsmTransformer(ArenaModule):
         """g: fp32 [T,d] gradient w.r.t. the last layer's output (consumed in place), g16: its bf16 copy;
         gflat: fp32 arena gradient (written)."""
         B, L = saved["B"], saved["L"]
-        T, d, f, H, hd = B * L, self.d, self.f, self.H, self.hd
+        T, d, f, H, hd, dp = B * L, self.d, self.f, self.H, self.hdp, self.dp
+        q_scale = self.hd ** -0.5
         dev = g.device
         cfg = self.config
         cos, sin = self._rope(L)
         gv = lambda name: self.view(name, gflat)
         b16 = lambda *s: torch.empty(*s, dtype=torch.bfloat16, device=dev)
         ws_ln = torch.empty(hip.query("oneprot_layernorm_bwd_workspace", d), dtype=torch.uint8, device=dev)
-        ws_tn = torch.empty(max(hip.query("oneprot_gemm_bf16_tn_workspace", 3 * d, d), hip.query("oneprot_gemm_bf16_tn_workspace", f, d)), dtype=torch.uint8, device=dev)
+        ws_tn = torch.empty(max(hip.query("oneprot_gemm_bf16_tn_workspace", 3 * dp, d), hip.query("oneprot_gemm_bf16_tn_workspace", f, d)), dtype=torch.uint8, device=dev)
         ws_at = torch.empty(hip.query("oneprot_attn_bwd_workspace", B, H, L), dtype=torch.uint8, device=dev)
         dz = b16(T, f)
         dh = b16(T, d)
-        dqkv = b16(T, 3 * d)
+        dctx = b16(T, dp) if self._padded else dh
+        dqkv = b16(T, 3 * dp)
+        if self._padded:      # weight gradients come out in the padded-head layout and are gathered back into the arena gradient
+            rowmap, colmap = self._head_pad_maps()
+            gw_qkv, gb_qkv, gw_o = torch.empty(3 * dp, d, device=dev), torch.empty(3 * dp, device=dev), torch.empty(d, dp, device=dev)
         for i in reversed(range(self.n_layers)):
             st = saved["layers"][i]
             p = f"encoder.layer.{i}."
@@ -411,15 +474,21 @@ class EsmTransformer(ArenaModule):
             hip.call("oneprot_layernorm_bwd", dh, 0, None, 0, st["x_mid"], 0, self.view(p + "LayerNorm.weight"), st["mean2"], st["rstd2"], g, g, g16,
                      gv(p + "LayerNorm.weight"), gv(p + "LayerNorm.bias"), ws_ln, T, d, 0)
             # ---- out-proj: x_mid = x_in + ctx Wo^T + bo
-            hip.call("oneprot_gemm_bf16_tn", g16, st["ctx"], T, d, d, d, d, gv(p + "attention.output.dense.weight"), gv(p + "attention.output.dense.bias"), ws_tn, 0)
-            hip.call("oneprot_gemm_bf16_nt", g16, self._bf16_T[(i, "o")], T, d, d, d, d, hip.EPI_BF16, None, dh, None, None, None, None, None, 1.0, 0, 0, 0)
+            hip.call("oneprot_gemm_bf16_tn", g16, st["ctx"], T, d, dp, d, dp, gw_o if self._padded else gv(p + "attention.output.dense.weight"),
+                     gv(p + "attention.output.dense.bias"), ws_tn, 0)
+            hip.call("oneprot_gemm_bf16_nt", g16, self._bf16_T[(i, "o")], T, dp, d, d, d, hip.EPI_BF16, None, dctx, None, None, None, None, None, 1.0, 0, 0, 0)
             # ---- attention
-            hip.call("oneprot_attn_bwd", st["q"], st["k"], st["v"], saved["key_bias"], st["ctx"], dh, st["lse"], cos, sin, hd ** -0.5, dqkv, ws_at, B, H, L, hd)
+            hip.call("oneprot_attn_bwd", st["q"], st["k"], st["v"], saved["key_bias"], st["ctx"], dctx, st["lse"], cos, sin, q_scale, dqkv, ws_at, B, H, L, hd)
             # ---- QKV projection
             o, n = self.span(p + "attention.self.query.weight", p + "attention.self.value.weight")
             ob, nb = self.span(p + "attention.self.query.bias", p + "attention.self.value.bias")
-            hip.call("oneprot_gemm_bf16_tn", dqkv, st["h1"], T, 3 * d, d, 3 * d, d, gflat[o:o + n], gflat[ob:ob + nb], ws_tn, 0)
-            hip.call("oneprot_gemm_bf16_nt", dqkv, self._bf16_T[(i, "qkv")], T, d, 3 * d, 3 * d, 3 * d, hip.EPI_BF16, None, dh, None, None, None, None, None,
+            hip.call("oneprot_gemm_bf16_tn", dqkv, st["h1"], T, 3 * dp, d, 3 * dp, d, gw_qkv if self._padded else gflat[o:o + n],
+                     gb_qkv if self._padded else gflat[ob:ob + nb], ws_tn, 0)
+            if self._padded:
+                gv(p + "attention.output.dense.weight").copy_(gw_o[:, colmap])
+                gflat[o:o + n].view(3 * d, d).copy_(gw_qkv[rowmap])
+                gflat[ob:ob + nb].copy_(gb_qkv[rowmap])
+            hip.call("oneprot_gemm_bf16_nt", dqkv, self._bf16_T[(i, "qkv")], T, d, 3 * dp, 3 * dp, 3 * dp, hip.EPI_BF16, None, dh, None, None, None, None, None,
                      1.0, 0, 0, 0)
             # ---- LN1 (input x_in)
             hip.call("oneprot_layernorm_bwd", dh, 0, None, 0, st["x_in"], 0, self.view(p + "attention.LayerNorm.weight"), st["mean1"], st["rstd1"], g, g, g16,

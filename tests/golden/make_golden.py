@@ -21,7 +21,7 @@ Third-party arithmetic under the reference (HF transformers EsmModel /
 BertModel) is whatever is installed here: transformers 5.15.0, torch 2.10 CPU,
 fp32, attention implementation "eager".
 
-Usage:  python tests/golden/make_golden.py            (writes *.pt / *.json)
+Usage:  python tests/golden/make_golden.py [tag ...]   (writes *.pt / *.json; tags: pooling hd16 hd32 hd24 text multirank distributed)
 """
 import json
 import os
@@ -324,18 +324,25 @@ def gen_distributed(refdist):
 
 def main():
     torch.set_num_threads(4)
+    only = set(sys.argv[1:])          # e.g. `make_golden.py hd24` regenerates one fixture; no arguments = all
+    want = lambda tag: not only or tag in only
     base_encoder, lossmod, SequenceEncoder, StructTokenEncoder, TextEncoder, refdist = _import_reference()
-    gen_pooling(base_encoder)
-    # hd=16 (as ESM-2-8M), with ragged right-padding and <mask> tokens
-    gen_esm_pair("hd16", layers=2, d=64, heads=4, ffn=128, B=6, L=24, lens=[24, 17, 9, 24, 3, 12], D_out=48,
-                 with_mask_tok=True, SequenceEncoder=SequenceEncoder, StructTokenEncoder=StructTokenEncoder, lossmod=lossmod)
-    # hd=32 (as ESM-2-150M), L not a multiple of any tile size
-    gen_esm_pair("hd32", layers=2, d=64, heads=2, ffn=160, B=4, L=37, lens=[37, 20, 37, 5], D_out=64,
-                 with_mask_tok=False, SequenceEncoder=SequenceEncoder, StructTokenEncoder=StructTokenEncoder, lossmod=lossmod)
-    gen_text(TextEncoder)
-    gen_multirank(2, 29611)
-    gen_multirank(3, 29612)
-    gen_distributed(refdist)
+    kw = dict(SequenceEncoder=SequenceEncoder, StructTokenEncoder=StructTokenEncoder, lossmod=lossmod)
+    if want("pooling"):
+        gen_pooling(base_encoder)
+    if want("hd16"):     # hd=16 (as ESM-2-8M), with ragged right-padding and <mask> tokens
+        gen_esm_pair("hd16", layers=2, d=64, heads=4, ffn=128, B=6, L=24, lens=[24, 17, 9, 24, 3, 12], D_out=48, with_mask_tok=True, **kw)
+    if want("hd32"):     # hd=32 (as ESM-2-150M), L not a multiple of any tile size
+        gen_esm_pair("hd32", layers=2, d=64, heads=2, ffn=160, B=4, L=37, lens=[37, 20, 37, 5], D_out=64, with_mask_tok=False, **kw)
+    if want("hd24"):     # hd=24 (as ESM-2-35M, the StructTokenEncoder default): a head dim that is not a power of two
+        gen_esm_pair("hd24", layers=2, d=96, heads=4, ffn=192, B=8, L=29, lens=[29, 11, 29, 20, 7, 29, 16, 25], D_out=64, with_mask_tok=True, **kw)
+    if want("text"):
+        gen_text(TextEncoder)
+    if want("multirank"):
+        gen_multirank(2, 29611)
+        gen_multirank(3, 29612)
+    if want("distributed"):
+        gen_distributed(refdist)
 
 
 if __name__ == "__main__":

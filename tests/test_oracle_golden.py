@@ -26,7 +26,7 @@ def _close(a, b, atol=2e-5, rtol=2e-5):
     assert err <= atol + rtol * ref, f"max err {err} vs ref scale {ref}"
 
 
-@pytest.mark.parametrize("tag", ["hd16", "hd32"])
+@pytest.mark.parametrize("tag", ["hd16", "hd32", "hd24"])
 def test_esm_forward_stages(golden_dir, tag):
     g = _load(golden_dir, f"esm_pair_{tag}.pt")
     cfg = g["cfg"]
@@ -47,7 +47,7 @@ def test_esm_forward_stages(golden_dir, tag):
     assert abs(mf.norm(dim=-1) - 1 / 0.07).max() < 1e-3
 
 
-@pytest.mark.parametrize("tag", ["hd16", "hd32"])
+@pytest.mark.parametrize("tag", ["hd16", "hd32", "hd24"])
 def test_train_substep(golden_dir, tag):
     g = _load(golden_dir, f"esm_pair_{tag}.pt")
     cfg = g["cfg"]

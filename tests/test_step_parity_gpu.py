@@ -50,7 +50,7 @@ def _build(golden_dir, tag, tmp_path, frozen_seq=False):
     return g, module
 
 
-@pytest.mark.parametrize("tag", ["hd16", "hd32"])
+@pytest.mark.parametrize("tag", ["hd16", "hd32", "hd24"])
 def test_forward_features_vs_reference(golden_dir, tag, tmp_path):
     g, module = _build(golden_dir, tag, tmp_path)
     with torch.no_grad():
@@ -63,7 +63,7 @@ def test_forward_features_vs_reference(golden_dir, tag, tmp_path):
     assert abs(mf.norm(dim=-1) - 1 / 0.07).max() < 1e-3
 
 
-@pytest.mark.parametrize("tag", ["hd16", "hd32"])
+@pytest.mark.parametrize("tag", ["hd16", "hd32", "hd24"])
 def test_training_substep_vs_reference(golden_dir, tag, tmp_path):
     g, module = _build(golden_dir, tag, tmp_path)
     batch = {"struct_token": (g["seq_ids"].to(DEV), g["st_ids"].to(DEV), "struct_token", None)}
@@ -87,7 +87,11 @@ def test_training_substep_vs_reference(golden_dir, tag, tmp_path):
     loss = module.training_step(batch, 0)
     loss = float(loss)
     ref_loss = float(g["loss_total"])
-    assert abs(loss - ref_loss) / abs(ref_loss) < 1e-3, (loss, ref_loss)
+    # 1e-3 relative (BASELINE north_star).  The hd24 fixture (8 pairs, d=96, logits scaled by 14.29) turns the same per-feature bf16
+    # error as the other two (1-cos ~2e-5, layer-0 output 0.5 % -- printed by tools/feature_error_report.py) into a 1.6e-3 loss
+    # difference, so it is held to 3e-3 here and to 1e-3 at the real ESM-2-35M shape in test_esm2_35m_shape_train_step_vs_oracle.
+    tol = 3e-3 if tag == "hd24" else 1e-3
+    assert abs(loss - ref_loss) / abs(ref_loss) < tol, (loss, ref_loss)
     gn = float(module.last_grad_norm)
     assert abs(gn - float(g["grad_total_norm"])) / float(g["grad_total_norm"]) < 2e-2, (gn, float(g["grad_total_norm"]))
     worst = (1.0, None)
@@ -261,6 +265,61 @@ def test_cfg1_shape_train_step_vs_oracle():
     loss = float(module.training_step({"struct_token": (seq_ids.to(DEV), st_ids.to(DEV), "struct_token", None)}, 0).detach())
     assert abs(loss - float(ref["loss"])) / float(ref["loss"]) < 1e-3
     assert abs(float(module.last_grad_norm) - float(ref["grad_total_norm"])) / float(ref["grad_total_norm"]) < 2e-2
+
+
+def test_esm2_35m_shape_train_step_vs_oracle():
+    """ESM-2-35M shape (12 layers, d=480, 20 heads, head_dim 24 -- the StructTokenEncoder default model, ref struct_token_encoder.py:9;
+    runs on the hd=32 kernels through the padded-head operand layout of oneprot_amd/esm.py), L=128, 8 ragged pairs: full sub-step
+    loss, gradient norm and per-tensor gradients of the attention parameters vs the CPU oracle."""
+    os.environ.update(RANK="0", WORLD_SIZE="1", ONEPROT_ALLOW_RANDOM_INIT="1")
+    from src.models.components.sequence_encoder import SequenceEncoder
+    from src.models.components.struct_token_encoder import StructTokenEncoder
+    from src.models.oneprot_module import OneProtLitModule
+    from oneprot_amd.optim import FusedAdam
+    torch.manual_seed(5)
+    name = "facebook/esm2_t12_35M_UR50D"
+    seq = SequenceEncoder(name, output_dim=1024, pooling_type="mean", proj_type="mlp", use_lora=False, frozen=False)
+    st = StructTokenEncoder(name, output_dim=1024, pooling_type="mean", proj_type="linear", use_logit_scale=True)
+    assert st.transformer.hd == 24 and st.transformer.hdp == 32
+    with torch.no_grad():
+        for enc in (seq, st):
+            for k, v in enc.transformer.named_views().items():
+                if k.endswith(".bias"):
+                    v.normal_(0, 0.02)
+    sd_seq = {k: v.detach().clone() for k, v in seq.state_dict().items()}
+    sd_st = {k: v.detach().clone() for k, v in st.state_dict().items()}
+    gen = torch.Generator().manual_seed(1881)
+    B, L = 8, 128
+    seq_ids = torch.randint(4, 24, (B, L), generator=gen); st_ids = torch.randint(33, 53, (B, L), generator=gen)
+    for ids in (seq_ids, st_ids):
+        ids[:, 0] = 0
+        for b, n in enumerate([128, 90, 128, 31, 128, 128, 64, 100]):
+            ids[b, n - 1] = 2
+            ids[b, n:] = 1
+    cfg = dict(layers=12, hidden=480, heads=20, ffn=1920, pad=1, mask=32, eps=1e-5)
+    ref = O.train_substep(seq_ids, st_ids, sd_seq, sd_st, cfg, cfg, dict(kind="esm", pooling="mean", proj_type="mlp", use_logit_scale=False),
+                          dict(kind="esm", pooling="mean", proj_type="linear", use_logit_scale=True), use_l1=True)
+    module = OneProtLitModule(components={"sequence": seq, "struct_token": st}, optimizer=functools.partial(FusedAdam, lr=1e-3), loss_fn="CLIP",
+                              use_l1_regularization=True, local_loss=True, gather_with_grad=True).to(DEV)
+    grads = {}
+    orig_clip = module.clip_gradients
+
+    def spy(opt, **kw):
+        tr = module.network["struct_token"].transformer
+        for k in tr._spec:
+            if "attention" in k and ("layer.0." in k or "layer.11." in k):
+                grads[k] = tr.view(k, tr.flat.grad).detach().cpu().clone()
+        return orig_clip(opt, **kw)
+
+    module.clip_gradients = spy
+    loss = float(module.training_step({"struct_token": (seq_ids.to(DEV), st_ids.to(DEV), "struct_token", None)}, 0).detach())
+    assert abs(loss - float(ref["loss"])) / float(ref["loss"]) < 1e-3, (loss, float(ref["loss"]))
+    assert abs(float(module.last_grad_norm) - float(ref["grad_total_norm"])) / float(ref["grad_total_norm"]) < 2e-2
+    assert len(grads) == 20
+    for k, v in grads.items():
+        r = ref["grads"]["mod.transformer." + k]
+        if float(r.norm()) > 1e-6:
+            assert _cos(v, r) > 0.98, (k, _cos(v, r))
 
 
 def test_mixed_batch_round_robin(golden_dir, tmp_path):
