@@ -350,7 +350,7 @@ __global__ void __launch_bounds__(256, 2) k_attn_bwd_dq(const bf16_t* __restrict
     const int nkeys = min(KC, L - kc0);
     const int nrows = (nkeys + 31) & ~31;
     __syncthreads();
-    load_tile_pair<HD>(sK, kbase + (size_t)kc0 * HD, HD, sV, vbase + (size_t)kc0 * HD, HD, nkeys, nrows);
+    load_tile<HD>(sK, kbase + (size_t)kc0 * HD, HD, nkeys, nrows); load_tile<HD>(sV, vbase + (size_t)kc0 * HD, HD, nkeys, nrows);
     for (int i = threadIdx.x; i < nrows; i += 256)
       sBias[i] = i < nkeys ? (key_bias ? key_bias[(size_t)b * L + kc0 + i] : 0.f) : -INFINITY;
     __syncthreads();
@@ -416,7 +416,7 @@ __global__ void __launch_bounds__(256, 2) k_attn_bwd_dkv(const bf16_t* __restric
     const int nq = min(KC, L - qc0);
     const int nrows = (nq + 31) & ~31;
     __syncthreads();
-    load_tile_pair<HD>(sQ, q + ((size_t)bh * L + qc0) * HD, HD, sdO, dctx + ((size_t)b * L + qc0) * dm + head * HD, dm, nq, nrows);
+    load_tile<HD>(sQ, q + ((size_t)bh * L + qc0) * HD, HD, nq, nrows); load_tile<HD>(sdO, dctx + ((size_t)b * L + qc0) * dm + head * HD, dm, nq, nrows);
     for (int i = threadIdx.x; i < nrows; i += 256) {
       sLse[i] = i < nq ? -lse[(size_t)bh * L + qc0 + i] : -INFINITY;       // negated: added to the S accumulator initialiser
       sDelta[i] = i < nq ? -delta[(size_t)bh * L + qc0 + i] : 0.f;
