@@ -51,6 +51,15 @@ int oneprot_lnpool_fwd(const float* x, const int64_t* ids, int pad_id, const flo
 
 /* pooling of an already-normalised hidden state (BERT): mode 0 masked mean, 1 CLS (ref base_encoder.py:109-126). */
 int oneprot_pool_fwd(const float* x, const int64_t* ids, int pad_id, float* pooled, int B, int L, int d, int mode, void* stream);
+/* its backward: g[b,l,:] = dpooled[b,:]/n_b on non-pad tokens (mode 0) or dpooled[b,:] at l=0 (mode 1), zero elsewhere; optional bf16 copy. */
+int oneprot_pool_bwd(const float* dpooled, const int64_t* ids, int pad_id, float* g, void* g_bf16, int B, int L, int d, int mode, void* stream);
+/* Embedding-table gradient for a large vocabulary (BertEmbeddings.word_embeddings, hf modeling_bert.py:53-108): `perm` = stable argsort of
+ * the token ids, `seg_start[s]` / `seg_row[s]` = first sorted position / token id of run s; rows are added in sorted order (deterministic);
+ * run with id == skip_row (padding_idx) is skipped; untouched rows must have been zeroed by the caller. */
+int oneprot_embed_scatter_sorted(const float* dx, const int64_t* perm, const int64_t* seg_start, const int64_t* seg_row, int64_t n_tokens, int n_seg,
+                                 int d, int skip_row, float* dtable, void* stream);
+/* out[j] = sum_r x[r,j], fp32 [R,n] (position / token-type embedding gradients: sums over batch, then over positions). */
+int oneprot_rowsum_f32(const float* x, float* out, int R, int64_t n, void* stream);
 
 /* Attention1dPooling (ref base_encoder.py:40-103): pooled = sum_l softmax_l(x_l.w + b | padding -> -inf) x_l on an fp32 hidden state [B,L,d];
    attn [B,L] (optional in fwd, required by bwd).  bwd: dw [d], db [1], dx [B,L,d] (optional). */

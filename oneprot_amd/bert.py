@@ -1,7 +1,8 @@
-"""BERT text tower (forward only) on the HIP kernels -- what the reference obtains from `AutoModel.from_pretrained` in
-TextEncoder (ref text_encoder.py:33) i.e. transformers' BertModel in eval mode (hf modeling_bert.py:53-108 embeddings,
-139-204 attention, 354-417 layer; post-LN, 1/sqrt(hd) inside attention, erf-GELU).  The text tower is frozen in every shipped
-OneProt config (configs/model/components/text.yaml:12), so only the forward exists; state-dict keys are BertModel's."""
+"""BERT text tower on the HIP kernels -- what the reference obtains from `AutoModel.from_pretrained` in TextEncoder
+(ref text_encoder.py:33) i.e. transformers' BertModel (hf modeling_bert.py:53-108 embeddings, 139-204 attention, 354-417 layer;
+post-LN, 1/sqrt(hd) inside attention, erf-GELU).  State-dict keys are BertModel's.  Forward and hand-written backward
+(`frozen=False`, the TextEncoder signature default); dropout runs at p = 0 (the reference keeps HF's 0.1 active in train mode even
+for the frozen tower, which makes its outputs non-deterministic -- SURVEY.md section 8 a7; parity is defined against eval mode)."""
 import os
 import warnings
 
@@ -81,13 +82,28 @@ class BertTransformer(ArenaModule):
             self._ones_zeros[key] = (torch.ones(L, self.hd // 2, device=dev), torch.zeros(L, self.hd // 2, device=dev))
         return self._ones_zeros[key]
 
+    def _refresh_bf16(self):
+        if not self._refresh_bf16_mirror():
+            return
+        if self.flat.requires_grad:          # transposed bf16 weights for the dgrad GEMMs
+            d, f, dev = self.d, self.f, self.flat.device
+            for i in range(self.n_layers):
+                p = f"encoder.layer.{i}."
+                o, n = self.span(p + "attention.self.query.weight", p + "attention.self.value.weight")
+                for key, (src, R, C) in {"qkv": (self.flat.data[o:o + n], 3 * d, d), "o": (self.view(p + "attention.output.dense.weight"), d, d),
+                                         "w1": (self.view(p + "intermediate.dense.weight"), f, d), "w2": (self.view(p + "output.dense.weight"), d, f)}.items():
+                    t = self._bf16_T.get((i, key))
+                    if t is None:
+                        t = torch.empty(C, R, dtype=torch.bfloat16, device=dev)
+                        self._bf16_T[(i, key)] = t
+                    hip.call("oneprot_transpose_cast_f32_to_bf16", src, t, R, C)
+
     @torch.no_grad()
     def run_layers(self, ids, save=False):
-        if save:
-            raise NotImplementedError("BERT backward is not built (the text tower is frozen in every shipped config)")
+        """Embeddings + n post-LN layers.  Returns (last hidden state fp32 [T,d], saved-dict or None)."""
         if not ids.is_cuda:
             raise hip.HipKernelError("OneProt HIP path needs CUDA(ROCm) tensors; there is no CPU fallback")
-        self._refresh_bf16_mirror()
+        self._refresh_bf16()
         cfg = self.config
         B, L = ids.shape
         if L > cfg.max_position_embeddings:
@@ -105,30 +121,118 @@ class BertTransformer(ArenaModule):
         hip.call("oneprot_bert_embed_fwd", ids, self.view(e + "word_embeddings.weight"), self.view(e + "position_embeddings.weight"),
                  self.view(e + "token_type_embeddings.weight"), self.view(e + "LayerNorm.weight"), self.view(e + "LayerNorm.bias"), x, h, B, L, d,
                  cfg.vocab_size, cfg.layer_norm_eps)
+        saved = dict(ids=ids, key_bias=key_bias, layers=[], B=B, L=L) if save else None
         q, k, v, ctx, u = b16(B, H, L, hd), b16(B, H, L, hd), b16(B, H, L, hd), b16(T, d), b16(T, f)
+        eps = cfg.layer_norm_eps
         for i in range(self.n_layers):
             p = f"encoder.layer.{i}."
+            if save:     # per layer: input (bf16), attention operands, the two pre-LN sums with their statistics, FFN intermediates
+                st = dict(x16=h, q=b16(B, H, L, hd), k=b16(B, H, L, hd), v=b16(B, H, L, hd), ctx=b16(T, d), lse=f32(B, H, L), s1=f32(T, d), mean1=f32(T), rstd1=f32(T),
+                          y1=f32(T, d), y16=b16(T, d), z=b16(T, f), u=b16(T, f), s2=f32(T, d), mean2=f32(T), rstd2=f32(T))
+                q, k, v, ctx, u, z, lse = st["q"], st["k"], st["v"], st["ctx"], st["u"], st["z"], st["lse"]
+                s1, s2, y1, y16, x_out, h_out = st["s1"], st["s2"], st["y1"], st["y16"], f32(T, d), b16(T, d)
+                m1, r1, m2, r2 = st["mean1"], st["rstd1"], st["mean2"], st["rstd2"]
+            else:
+                z = lse = m1 = r1 = m2 = r2 = None
+                s1 = s2 = tmp
+                y1, y16, x_out, h_out = x, h, x, h
             o, n = self.span(p + "attention.self.query.weight", p + "attention.self.value.weight")
             ob, nb = self.span(p + "attention.self.query.bias", p + "attention.self.value.bias")
             # rotary tables (1, 0) turn the QKV epilogue into "q *= 1/sqrt(hd), head-major q/k/v" (scores scaled inside attention in HF: same product)
             hip.call("oneprot_gemm_bf16_nt", h, self._bf16[o:o + n], T, 3 * d, d, d, d, hip.EPI_QKV_ROPE, self.flat.data[ob:ob + nb], q, k, v, None,
                      one, zero, hd ** -0.5, L, H, hd)
-            hip.call("oneprot_attn_fwd", q, k, v, key_bias, ctx, None, B, H, L, hd)
+            hip.call("oneprot_attn_fwd", q, k, v, key_bias, ctx, lse, B, H, L, hd)
             hip.call("oneprot_gemm_bf16_nt", ctx, self._w16(p + "attention.output.dense.weight"), T, d, d, d, d, hip.EPI_BIAS_RESID,
-                     self.view(p + "attention.output.dense.bias"), tmp, None, None, x, None, None, 1.0, 0, 0, 0)
-            hip.call("oneprot_layernorm_fwd", tmp, 0, self.view(p + "attention.output.LayerNorm.weight"), self.view(p + "attention.output.LayerNorm.bias"), h, x,
-                     None, None, T, d, cfg.layer_norm_eps)
-            hip.call("oneprot_gemm_bf16_nt", h, self._w16(p + "intermediate.dense.weight"), T, f, d, d, d, hip.EPI_BIAS_GELU,
-                     self.view(p + "intermediate.dense.bias"), u, None, None, None, None, None, 1.0, 0, 0, 0)
+                     self.view(p + "attention.output.dense.bias"), s1, None, None, x, None, None, 1.0, 0, 0, 0)
+            hip.call("oneprot_layernorm_fwd", s1, 0, self.view(p + "attention.output.LayerNorm.weight"), self.view(p + "attention.output.LayerNorm.bias"), y16, y1,
+                     m1, r1, T, d, eps)
+            hip.call("oneprot_gemm_bf16_nt", y16, self._w16(p + "intermediate.dense.weight"), T, f, d, d, d, hip.EPI_BIAS_GELU,
+                     self.view(p + "intermediate.dense.bias"), u, z, None, None, None, None, 1.0, 0, 0, 0)
             hip.call("oneprot_gemm_bf16_nt", u, self._w16(p + "output.dense.weight"), T, d, f, f, f, hip.EPI_BIAS_RESID, self.view(p + "output.dense.bias"),
-                     tmp, None, None, x, None, None, 1.0, 0, 0, 0)
-            hip.call("oneprot_layernorm_fwd", tmp, 0, self.view(p + "output.LayerNorm.weight"), self.view(p + "output.LayerNorm.bias"), h, x, None, None, T, d,
-                     cfg.layer_norm_eps)
-        return x, None
+                     s2, None, None, y1, None, None, 1.0, 0, 0, 0)
+            hip.call("oneprot_layernorm_fwd", s2, 0, self.view(p + "output.LayerNorm.weight"), self.view(p + "output.LayerNorm.bias"), h_out, x_out, m2, r2, T, d, eps)
+            if save:
+                saved["layers"].append(st)
+            x, h = x_out, h_out
+        if save:
+            saved["x_final"] = x
+        return x, saved
+
+    def backward_layers(self, saved, g, g16, gflat):
+        """g: fp32 [T,d] gradient w.r.t. the last layer's output (consumed), g16 unused (post-LN layers start with a LayerNorm backward);
+        gflat: fp32 arena gradient (written).  Per layer, backwards (hf modeling_bert.py:354-417):
+          y2 = LN2(s2), s2 = y1 + gelu(y1 W1^T + b1) W2^T + b2 ;  y1 = LN1(s1), s1 = x + attn(x) Wo^T + bo."""
+        B, L = saved["B"], saved["L"]
+        T, d, f, H, hd = B * L, self.d, self.f, self.H, self.hd
+        dev = g.device
+        cfg = self.config
+        gv = lambda name: self.view(name, gflat)
+        f32 = lambda *s: torch.empty(*s, dtype=torch.float32, device=dev)
+        b16 = lambda *s: torch.empty(*s, dtype=torch.bfloat16, device=dev)
+        ws_ln = torch.empty(hip.query("oneprot_layernorm_bwd_workspace", d), dtype=torch.uint8, device=dev)
+        ws_tn = torch.empty(max(hip.query("oneprot_gemm_bf16_tn_workspace", 3 * d, d), hip.query("oneprot_gemm_bf16_tn_workspace", f, d)), dtype=torch.uint8, device=dev)
+        ws_at = torch.empty(hip.query("oneprot_attn_bwd_workspace", B, H, L), dtype=torch.uint8, device=dev)
+        ds, ds16, gy = f32(T, d), b16(T, d), f32(T, d)
+        dz, dctx, dqkv = b16(T, f), b16(T, d), b16(T, 3 * d)
+        for i in reversed(range(self.n_layers)):
+            st = saved["layers"][i]
+            p = f"encoder.layer.{i}."
+            # ---- LN2: ds = LN2'(g)  (fp32 + bf16 copy)
+            hip.call("oneprot_layernorm_bwd", g, 1, None, 0, st["s2"], 0, self.view(p + "output.LayerNorm.weight"), st["mean2"], st["rstd2"], None, ds, ds16,
+                     gv(p + "output.LayerNorm.weight"), gv(p + "output.LayerNorm.bias"), ws_ln, T, d, 0)
+            # ---- FFN2 (weight + bias grads in one TN launch), then du * gelu'(z) in the dgrad epilogue
+            hip.call("oneprot_gemm_bf16_tn", ds16, st["u"], T, d, f, d, f, gv(p + "output.dense.weight"), gv(p + "output.dense.bias"), ws_tn, 0)
+            hip.call("oneprot_gemm_bf16_nt", ds16, self._bf16_T[(i, "w2")], T, f, d, d, d, hip.EPI_GELU_BWD, None, dz, None, None, st["z"], None, None, 1.0, 0, 0, 0)
+            # ---- FFN1; gy = ds (residual branch) + dz W1
+            hip.call("oneprot_gemm_bf16_tn", dz, st["y16"], T, f, d, f, d, gv(p + "intermediate.dense.weight"), gv(p + "intermediate.dense.bias"), ws_tn, 0)
+            hip.call("oneprot_gemm_bf16_nt", dz, self._bf16_T[(i, "w1")], T, d, f, f, f, hip.EPI_BIAS_RESID, None, gy, None, None, ds, None, None, 1.0, 0, 0, 0)
+            # ---- LN1: ds = LN1'(gy)
+            hip.call("oneprot_layernorm_bwd", gy, 1, None, 0, st["s1"], 0, self.view(p + "attention.output.LayerNorm.weight"), st["mean1"], st["rstd1"], None, ds, ds16,
+                     gv(p + "attention.output.LayerNorm.weight"), gv(p + "attention.output.LayerNorm.bias"), ws_ln, T, d, 0)
+            # ---- out-proj
+            hip.call("oneprot_gemm_bf16_tn", ds16, st["ctx"], T, d, d, d, d, gv(p + "attention.output.dense.weight"), gv(p + "attention.output.dense.bias"), ws_tn, 0)
+            hip.call("oneprot_gemm_bf16_nt", ds16, self._bf16_T[(i, "o")], T, d, d, d, d, hip.EPI_BF16, None, dctx, None, None, None, None, None, 1.0, 0, 0, 0)
+            # ---- attention (no rotary: cos/sin = null)
+            hip.call("oneprot_attn_bwd", st["q"], st["k"], st["v"], saved["key_bias"], st["ctx"], dctx, st["lse"], None, None, hd ** -0.5, dqkv, ws_at, B, H, L, hd)
+            # ---- QKV projection; g = ds (residual branch) + dqkv Wqkv
+            o, n = self.span(p + "attention.self.query.weight", p + "attention.self.value.weight")
+            ob, nb = self.span(p + "attention.self.query.bias", p + "attention.self.value.bias")
+            hip.call("oneprot_gemm_bf16_tn", dqkv, st["x16"], T, 3 * d, d, 3 * d, d, gflat[o:o + n], gflat[ob:ob + nb], ws_tn, 0)
+            hip.call("oneprot_gemm_bf16_nt", dqkv, self._bf16_T[(i, "qkv")], T, d, 3 * d, 3 * d, 3 * d, hip.EPI_BIAS_RESID, None, g, None, None, ds, None, None,
+                     1.0, 0, 0, 0)
+            saved["layers"][i] = None
+        self._embedding_backward(saved["ids"], g, gflat)
+
+    def _embedding_backward(self, ids, g, gflat):
+        """x0 = LN(word[id] + pos[l] + type[0]) (hf modeling_bert.py:53-108).  The pre-LN sum is re-gathered (torch indexing: data movement),
+        LayerNorm statistics / backward and the table reductions are HIP kernels; equal token ids are summed in sorted order."""
+        cfg = self.config
+        B, L = ids.shape
+        T, d, dev = B * L, self.d, ids.device
+        e = "embeddings."
+        gv = lambda name: self.view(name, gflat)
+        esum = (self.view(e + "word_embeddings.weight")[ids.reshape(-1)] + self.view(e + "position_embeddings.weight")[:L].repeat(B, 1)
+                + self.view(e + "token_type_embeddings.weight")[0]).contiguous()
+        mean, rstd, y = torch.empty(T, device=dev), torch.empty(T, device=dev), torch.empty(T, d, device=dev)
+        hip.call("oneprot_layernorm_fwd", esum, 0, self.view(e + "LayerNorm.weight"), self.view(e + "LayerNorm.bias"), None, y, mean, rstd, T, d, cfg.layer_norm_eps)
+        de = torch.empty(T, d, device=dev)
+        ws_ln = torch.empty(hip.query("oneprot_layernorm_bwd_workspace", d), dtype=torch.uint8, device=dev)
+        hip.call("oneprot_layernorm_bwd", g, 1, None, 0, esum, 0, self.view(e + "LayerNorm.weight"), mean, rstd, None, de, None,
+                 gv(e + "LayerNorm.weight"), gv(e + "LayerNorm.bias"), ws_ln, T, d, 0)
+        # position rows 0..L-1: sum over the batch; token-type row 0: sum over positions of that
+        dpos = gv(e + "position_embeddings.weight")
+        hip.call("oneprot_rowsum_f32", de, dpos[:L], B, L * d)
+        hip.call("oneprot_rowsum_f32", dpos[:L], gv(e + "token_type_embeddings.weight")[0], L, d)
+        # word rows: stable sort of the ids, one block per run of equal ids (padding_idx row gets no gradient, as nn.Embedding)
+        sorted_ids, perm = torch.sort(ids.reshape(-1), stable=True)
+        rows, counts = torch.unique_consecutive(sorted_ids, return_counts=True)
+        starts = (torch.cumsum(counts, 0) - counts).contiguous()
+        pad = cfg.pad_token_id if cfg.pad_token_id is not None else -1
+        hip.call("oneprot_embed_scatter_sorted", de, perm.contiguous(), starts, rows.contiguous(), T, int(rows.numel()), d, pad, gv(e + "word_embeddings.weight"))
 
     @torch.no_grad()
     def forward(self, input_ids=None, attention_mask=None, **_):
-        x, _ = self.run_layers(input_ids)
+        x, _ = self.run_layers(input_ids, save=False)
         B, L = input_ids.shape
         return _Out(x.view(B, L, self.d))
 

@@ -386,7 +386,6 @@ static int launch_gemm(const GemmArgs& a, hipStream_t s) {
   else if (a.N >= 2048) shape = 4;
   else shape = 1;
   switch (shape) {
-    case 8: return launch_shape<EPI, 2, 2, 8, 8, 64, 2, 32, 1, true>(a, s);       // as 6 with software-pipelined fragments (AGPR accumulators)
     case 7: return launch_shape<EPI, 2, 2, 8, 8, 32, 4, 32, 1, false>(a, s);      // 256x256, 4 waves x (128x128), BK32 x4, one wave per SIMD
     case 6: return launch_shape<EPI, 2, 2, 8, 8, 64, 2, 32, 1, false>(a, s);      // 256x256, 4 waves x (128x128), BK64 x2, one wave per SIMD
     case 5: return launch_shape<EPI, 2, 4, 8, 4, 32, 4, 32, 2, false>(a, s);      // 256x256 without fragment pipelining (A/B runs)

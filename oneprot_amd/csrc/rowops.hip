@@ -515,6 +515,76 @@ extern "C" int oneprot_pool_fwd(const float* x, const int64_t* ids, int pad_id, 
   return launch_status();
 }
 
+// backward of k_pool_fwd: g[b,l,:] = dpooled[b,:] / n_b on non-pad tokens (mean) or dpooled[b,:] at l = 0 (CLS), 0 elsewhere; fp32 + bf16 copy
+__global__ void __launch_bounds__(256) k_pool_bwd(const float* __restrict__ dpooled, const long long* __restrict__ ids, int pad_id, float* __restrict__ g,
+                                                  bf16_t* __restrict__ g16, int L, int d, int mode) {
+  const int b = blockIdx.x;
+  __shared__ float s_n[4];
+  float cnt = 0.f;
+  for (int l = threadIdx.x; l < L; l += 256) cnt += (ids[(size_t)b * L + l] != pad_id);
+  cnt = wave_sum(cnt);
+  if ((threadIdx.x & 63) == 0) s_n[threadIdx.x >> 6] = cnt;
+  __syncthreads();
+  const float inv_n = 1.0f / (s_n[0] + s_n[1] + s_n[2] + s_n[3]);
+  const int nv4 = d >> 2;
+  for (int idx = threadIdx.x; idx < L * nv4; idx += 256) {
+    const int l = idx / nv4, c = idx - l * nv4;
+    float w;
+    if (mode == 1) w = (l == 0) ? 1.0f : 0.0f;
+    else w = (ids[(size_t)b * L + l] != pad_id) ? inv_n : 0.0f;
+    const float4 dp = reinterpret_cast<const float4*>(dpooled + (size_t)b * d)[c];
+    const float4 o = make_float4(dp.x * w, dp.y * w, dp.z * w, dp.w * w);
+    const size_t off = ((size_t)b * L + l) * d + 4 * c;
+    *reinterpret_cast<float4*>(g + off) = o;
+    if (g16) { u32x2 pk; pk.x = pack2bf(o.x, o.y); pk.y = pack2bf(o.z, o.w); *reinterpret_cast<u32x2*>(g16 + off) = pk; }
+  }
+}
+extern "C" int oneprot_pool_bwd(const float* dpooled, const int64_t* ids, int pad_id, float* g, void* g_bf16, int B, int L, int d, int mode, void* stream) {
+  if (!dpooled || !ids || !g || B <= 0 || L <= 0 || d <= 0 || (d & 3) || mode < 0 || mode > 1) return OP_EINVAL;
+  hipLaunchKernelGGL(k_pool_bwd, dim3(B), dim3(256), 0, (hipStream_t)stream, dpooled, (const long long*)ids, pad_id, g, (bf16_t*)g_bf16, L, d, mode);
+  return launch_status();
+}
+
+// --------------------------------------------------------------------------------------------------------
+// Embedding-table gradients for a large vocabulary (BERT: 30522 rows): rows of dx that share a token id are summed in a fixed order.
+// The host sorts the token ids (stable) and passes the permutation plus the start of every run of equal ids; one block per run adds
+// its rows in sorted order -> deterministic, no float atomics.  Rows of the table that no token used are left untouched (caller zeroes).
+// --------------------------------------------------------------------------------------------------------
+__global__ void __launch_bounds__(256) k_embed_scatter_sorted(const float* __restrict__ dx, const long long* __restrict__ perm, const long long* __restrict__ seg_start,
+                                                              const long long* __restrict__ seg_row, long long n_tokens, int n_seg, int d, int skip_row,
+                                                              float* __restrict__ dtable) {
+  const int s = blockIdx.x;
+  const long long row = seg_row[s];
+  if (row == skip_row) return;                      // padding_idx row receives no gradient (nn.Embedding semantics)
+  const long long j0 = seg_start[s], j1 = (s + 1 < n_seg) ? seg_start[s + 1] : n_tokens;
+  for (int c = threadIdx.x; c < d; c += 256) {
+    float acc = 0.f;
+    for (long long j = j0; j < j1; ++j) acc += dx[(size_t)perm[j] * d + c];
+    dtable[(size_t)row * d + c] = acc;
+  }
+}
+extern "C" int oneprot_embed_scatter_sorted(const float* dx, const int64_t* perm, const int64_t* seg_start, const int64_t* seg_row, int64_t n_tokens, int n_seg,
+                                            int d, int skip_row, float* dtable, void* stream) {
+  if (!dx || !perm || !seg_start || !seg_row || !dtable || n_tokens <= 0 || n_seg <= 0 || d <= 0) return OP_EINVAL;
+  hipLaunchKernelGGL(k_embed_scatter_sorted, dim3(n_seg), dim3(256), 0, (hipStream_t)stream, dx, (const long long*)perm, (const long long*)seg_start,
+                     (const long long*)seg_row, (long long)n_tokens, n_seg, d, skip_row, dtable);
+  return launch_status();
+}
+
+// out[j] = sum_r x[r, j] for an fp32 [R, n] matrix (position-embedding gradient = sum over the batch; fixed order, one thread per column)
+__global__ void __launch_bounds__(256) k_rowsum_f32(const float* __restrict__ x, float* __restrict__ out, int R, long long n) {
+  const long long j = (long long)blockIdx.x * 256 + threadIdx.x;
+  if (j >= n) return;
+  float acc = 0.f;
+  for (int r = 0; r < R; ++r) acc += x[(size_t)r * n + j];
+  out[j] = acc;
+}
+extern "C" int oneprot_rowsum_f32(const float* x, float* out, int R, int64_t n, void* stream) {
+  if (!x || !out || R <= 0 || n <= 0) return OP_EINVAL;
+  hipLaunchKernelGGL(k_rowsum_f32, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, (hipStream_t)stream, x, out, R, (long long)n);
+  return launch_status();
+}
+
 // --------------------------------------------------------------------------------------------------------
 // Attention1dPooling (ref base_encoder.py:88-103; MaskedConv1d with kernel 1 = one dot product per token):
 //   s_l = x_l . w + b ; s_l = -inf where the token is padding ; a = softmax_l(s) ; pooled = sum_l a_l x_l

@@ -285,9 +285,16 @@ class _EncodeFn(torch.autograd.Function):
             mean, rstd, wrow = ctx.fin
             g = torch.empty(B * L, d, device=dev)
             g16 = torch.empty(B * L, d, dtype=torch.bfloat16, device=dev)
-            lnw, lnb = tr.view("encoder.emb_layer_norm_after.weight", gflat), tr.view("encoder.emb_layer_norm_after.bias", gflat)
-            ws = _ws(hip.query("oneprot_layernorm_bwd_workspace", d), dev)
-            if mode == 2:
+            final_ln = getattr(tr, "final_layer_norm", True)
+            if final_ln:
+                lnw, lnb = tr.view("encoder.emb_layer_norm_after.weight", gflat), tr.view("encoder.emb_layer_norm_after.bias", gflat)
+                ws = _ws(hip.query("oneprot_layernorm_bwd_workspace", d), dev)
+            if not final_ln:        # BERT: pooling reads the last layer's output directly
+                if mode == 2:
+                    g.copy_(dhidden.view(B * L, d))
+                else:
+                    hip.call("oneprot_pool_bwd", dpooled, ctx.ids, tr.config.pad_token_id, g, g16, B, L, d, mode)
+            elif mode == 2:
                 hip.call("oneprot_layernorm_bwd", dhidden, 1, None, 0, saved["x_final"], 0, tr.view("encoder.emb_layer_norm_after.weight"), mean, rstd, None, g, g16,
                          lnw, lnb, ws, B * L, d, 0)
             else:
@@ -396,7 +403,8 @@ class StructTokenEncoder(BaseEncoder):
 
 
 class TextEncoder(BaseEncoder):
-    """ref text_encoder.py:8-62 (BERT text tower; frozen in every shipped config).  Forward-only BERT on the HIP kernels."""
+    """ref text_encoder.py:8-62: BERT text tower (frozen in every shipped config, text.yaml:12; `frozen=False` -- the signature default --
+    trains it through the hand-written BERT backward of oneprot_amd/bert.py).  Dropout runs at p = 0 (see bert.py)."""
 
     def __init__(self, model_name_or_path: str, output_dim: int, pooling_type: str = "mean", proj_type: str = "linear", use_logit_scale: bool = False,
                  learnable_logit_scale: bool = False, frozen: bool = False, use_lora: bool = False, lora_r: int = 8, lora_alpha: int = 16,
@@ -410,11 +418,9 @@ class TextEncoder(BaseEncoder):
             raise NotImplementedError("LoRA adapters are off in every shipped OneProt config (text.yaml:7); not built (SURVEY.md section 8f #4)")
         self.transformer = BertTransformer.from_pretrained(model_name_or_path)
         self.config = self.transformer.config
-        if not frozen:
-            raise NotImplementedError("a trainable BERT text tower is not on the shipped-config hot path (text.yaml:12 frozen: true); "
-                                      "only the frozen forward is built in this round")
-        for param in self.transformer.parameters():
-            param.requires_grad = False
+        if frozen:                                      # ref text_encoder.py:35-37
+            for param in self.transformer.parameters():
+                param.requires_grad = False
         self.use_lora = use_lora
         self.frozen = frozen
 

@@ -33,6 +33,9 @@ _SIGS = {
     "oneprot_esm_embed_bwd": (I, [P, P, P, P, P, I, I, I, I, I, I, I, I, P]),
     "oneprot_bert_embed_fwd": (I, [P, P, P, P, P, P, P, P, I, I, I, I, F, P]),
     "oneprot_pool_fwd": (I, [P, P, I, P, I, I, I, I, P]),
+    "oneprot_pool_bwd": (I, [P, P, I, P, P, I, I, I, I, P]),
+    "oneprot_embed_scatter_sorted": (I, [P, P, P, P, L64, I, I, I, P, P]),
+    "oneprot_rowsum_f32": (I, [P, P, I, L64, P]),
     "oneprot_attnpool_fwd": (I, [P, P, I, P, P, P, P, I, I, I, P]),
     "oneprot_attnpool_bwd_workspace": (SZ, [I, I]),
     "oneprot_attnpool_bwd": (I, [P, P, P, P, P, P, P, P, I, I, I, P]),

@@ -21,7 +21,7 @@ Third-party arithmetic under the reference (HF transformers EsmModel /
 BertModel) is whatever is installed here: transformers 5.15.0, torch 2.10 CPU,
 fp32, attention implementation "eager".
 
-Usage:  python tests/golden/make_golden.py [tag ...]   (writes *.pt / *.json; tags: pooling hd16 hd32 hd24 text multirank distributed)
+Usage:  python tests/golden/make_golden.py [tag ...]   (writes *.pt / *.json; tags: pooling hd16 hd32 hd24 text text_train multirank distributed)
 """
 import json
 import os
@@ -242,6 +242,45 @@ def gen_text(TextEncoder):
     print("text feats norm", feats.norm(dim=-1))
 
 
+def gen_text_train(TextEncoder, lossmod):
+    """trainable text tower (TextEncoder(frozen=False), text_encoder.py:35): gradients of every BERT / head parameter for a CLIP loss
+    against fixed sequence features.  eval() only switches HF's dropout off (it is stochastic in train mode); gradients are unaffected."""
+    with tempfile.TemporaryDirectory() as tmp:
+        p = _bert_dir(tmp, "bert", layers=2, d=64, heads=4, ffn=128, vocab=120, seed=17)
+        torch.manual_seed(29)
+        enc = TextEncoder(p, output_dim=48, pooling_type="mean", proj_type="linear", use_logit_scale=True,
+                          learnable_logit_scale=False, frozen=False, use_lora=False)
+        enc.transformer.config._attn_implementation = "eager"
+    _perturb_head(enc, 35)
+    with torch.no_grad():       # non-trivial biases / LayerNorm parameters everywhere
+        g0 = torch.Generator().manual_seed(41)
+        for n_, p_ in enc.transformer.named_parameters():
+            if n_.endswith(".bias"):
+                p_.copy_(torch.randn(p_.shape, generator=g0) * 0.05)
+            elif "LayerNorm.weight" in n_:
+                p_.copy_(1.0 + torch.randn(p_.shape, generator=g0) * 0.1)
+    enc.eval()
+    gen = torch.Generator().manual_seed(9)
+    B, T = 6, 18
+    lens = [18, 11, 5, 18, 2, 14]
+    ids = torch.zeros(B, T, dtype=torch.long)
+    for b, n in enumerate(lens):
+        ids[b, 0] = 2
+        if n > 2:
+            ids[b, 1:n - 1] = torch.randint(5, 119, (n - 2,), generator=gen)
+        ids[b, n - 1] = 3
+    ids[3, 4] = ids[3, 9] = ids[0, 7] = 77        # repeated token ids across and inside rows (embedding-gradient accumulation)
+    seq = torch.nn.functional.normalize(torch.randn(B, 48, generator=gen), dim=-1)
+    feats = enc(ids)
+    loss = lossmod.ClipLoss()(seq, feats)          # module call order of oneprot_module.py:100 (sequence first)
+    loss.backward()
+    grads = {k: v.grad.detach().clone() for k, v in enc.named_parameters() if v.grad is not None}
+    torch.save({"cfg": dict(layers=2, hidden=64, heads=4, ffn=128, vocab=120, max_pos=64, pad=0, eps=1e-12, output_dim=48, B=B, T=T, lens=lens),
+                "ids": ids, "sd": _sd(enc), "seq_features": seq, "features": feats.detach().clone(), "loss": loss.detach().clone(), "grads": grads},
+               os.path.join(OUT, "bert_text_train.pt"))
+    print("text train loss", float(loss), "n grads", len(grads))
+
+
 def gen_pooling(base_encoder):
     torch.manual_seed(5)
     x = torch.randn(3, 7, 16)
@@ -338,6 +377,8 @@ def main():
         gen_esm_pair("hd24", layers=2, d=96, heads=4, ffn=192, B=8, L=29, lens=[29, 11, 29, 20, 7, 29, 16, 25], D_out=64, with_mask_tok=True, **kw)
     if want("text"):
         gen_text(TextEncoder)
+    if want("text_train"):
+        gen_text_train(TextEncoder, lossmod)
     if want("multirank"):
         gen_multirank(2, 29611)
         gen_multirank(3, 29612)

@@ -94,6 +94,23 @@ def test_bert_text(golden_dir):
     _close(f, g["features"], atol=5e-5)
 
 
+def test_bert_text_trainable_gradients(golden_dir):
+    """trainable text tower: oracle loss and autograd gradients of every BERT / head parameter vs the reference's (TextEncoder(frozen=False))."""
+    g = _load(golden_dir, "bert_text_train.pt")
+    sd = {k: (v.clone().requires_grad_(True) if v.is_floating_point() and k in g["grads"] else v) for k, v in g["sd"].items()}
+    f = O.encoder_features("bert", g["ids"], sd, g["cfg"], "mean", "linear", True)
+    _close(f, g["features"], atol=5e-5)
+    loss = O.clip_loss(g["seq_features"], f)
+    assert abs(float(loss) - float(g["loss"])) < 1e-5 * abs(float(g["loss"]))
+    loss.backward()
+    for k, ref in g["grads"].items():
+        got = sd[k].grad
+        assert got is not None, k
+        _close(got, ref, atol=2e-5 * max(1.0, float(ref.abs().max())))
+    pad_row = sd["transformer.embeddings.word_embeddings.weight"].grad[g["cfg"]["pad"]]
+    assert float(pad_row.abs().max()) == 0.0 or float(g["grads"]["transformer.embeddings.word_embeddings.weight"][g["cfg"]["pad"]].abs().max()) == 0.0
+
+
 def test_pooling_and_norm(golden_dir):
     g = _load(golden_dir, "pooling.pt")
     x, mask = g["x"], g["mask"]

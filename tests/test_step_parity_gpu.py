@@ -201,6 +201,107 @@ def test_text_encoder_vs_reference(golden_dir, tmp_path):
     assert abs(feats.norm(dim=-1) - 1 / 0.07).max() < 1e-3
 
 
+def test_trainable_text_encoder_gradients_vs_reference(golden_dir, tmp_path):
+    """TextEncoder(frozen=False) (the signature default, ref text_encoder.py:9-37): loss and the gradient of every BERT / head parameter vs the
+    reference's autograd, through the hand-written BERT backward (post-LN layers, embedding LayerNorm, sorted embedding-row reduction)."""
+    os.environ.update(RANK="0", WORLD_SIZE="1", ONEPROT_ALLOW_RANDOM_INIT="1")
+    from src.models.components.text_encoder import TextEncoder
+    from src.models.components.loss import ClipLoss
+    g = torch.load(os.path.join(golden_dir, "bert_text_train.pt"), weights_only=False)
+    cfg = g["cfg"]
+    path = os.path.join(str(tmp_path), "bert")
+    os.makedirs(path)
+    with open(os.path.join(path, "config.json"), "w") as f:
+        json.dump(dict(model_type="bert", vocab_size=cfg["vocab"], hidden_size=cfg["hidden"], num_hidden_layers=cfg["layers"], num_attention_heads=cfg["heads"],
+                       intermediate_size=cfg["ffn"], max_position_embeddings=cfg["max_pos"], pad_token_id=cfg["pad"], layer_norm_eps=cfg["eps"]), f)
+    enc = TextEncoder(path, output_dim=cfg["output_dim"], pooling_type="mean", proj_type="linear", use_logit_scale=True, learnable_logit_scale=False, frozen=False,
+                      use_lora=False)
+    enc.load_state_dict(g["sd"], strict=True)
+    enc = enc.to(DEV)
+    feats = enc(g["ids"].to(DEV))
+    cs = torch.nn.functional.cosine_similarity(feats.detach().cpu(), g["features"], dim=-1)
+    assert cs.min() > 0.999, cs
+    loss = ClipLoss()(g["seq_features"].to(DEV), feats)
+    assert abs(float(loss) - float(g["loss"])) / float(g["loss"]) < 2e-3, (float(loss), float(g["loss"]))      # 6 pairs, d=64 (see the hd24 note above)
+    loss.backward()
+    tr = enc.transformer
+    got = {"transformer." + k: tr.view(k, tr.flat.grad).detach().cpu() for k in tr._spec}
+    got.update({"proj." + k: p_.grad.detach().cpu() for k, p_ in enc.proj.named_parameters()})
+    n = 0
+    for k, ref in g["grads"].items():
+        assert k in got, k
+        if float(ref.norm()) < 1e-6:
+            continue
+        c = _cos(got[k], ref)
+        assert c > 0.98, (k, c)
+        if float(ref.norm()) > 0.05 * max(float(v.norm()) for v in g["grads"].values()):
+            assert c > 0.999, (k, c)
+        n += 1
+    assert n >= 38
+    wg = got["transformer.embeddings.word_embeddings.weight"]
+    assert float(wg[cfg["pad"]].abs().max()) == 0.0                      # padding_idx row
+    unused = [r for r in range(cfg["vocab"]) if r not in set(g["ids"].flatten().tolist())]
+    assert float(wg[unused].abs().max()) == 0.0
+    allg = torch.cat([got[k].flatten() for k in g["grads"]]); allr = torch.cat([v.flatten() for v in g["grads"].values()])
+    assert _cos(allg, allr) > 0.9995
+
+
+def test_bert_base_shape_trainable_substep_vs_oracle():
+    """cfg-4 shape (ESM-2-8M sequence tower <-> BERT-base text tower: 12 layers, d=768, 12 heads of 64, ffn 3072, vocab 30522; cls pooling + mlp head
+    as in text.yaml), both towers trainable, 8 ragged pairs (L=64 / T=48): full sub-step loss and gradient norm vs the CPU oracle."""
+    os.environ.update(RANK="0", WORLD_SIZE="1", ONEPROT_ALLOW_RANDOM_INIT="1")
+    from src.models.components.sequence_encoder import SequenceEncoder
+    from src.models.components.text_encoder import TextEncoder
+    from src.models.oneprot_module import OneProtLitModule
+    from oneprot_amd.optim import FusedAdam
+    torch.manual_seed(11)
+    seq = SequenceEncoder("facebook/esm2_t6_8M_UR50D", output_dim=1024, pooling_type="mean", proj_type="mlp", use_lora=False, frozen=False)
+    tx = TextEncoder("bert-base-uncased", output_dim=1024, pooling_type="cls", proj_type="mlp", use_logit_scale=True, learnable_logit_scale=False, frozen=False,
+                     use_lora=False)
+    with torch.no_grad():
+        for k, v in tx.transformer.named_views().items():
+            if k.endswith(".bias"):
+                v.normal_(0, 0.02)
+    sd_seq = {k: v.detach().clone() for k, v in seq.state_dict().items()}
+    sd_tx = {k: v.detach().clone() for k, v in tx.state_dict().items()}
+    gen = torch.Generator().manual_seed(1881)
+    B, L, T = 8, 64, 48
+    seq_ids = torch.randint(4, 24, (B, L), generator=gen)
+    seq_ids[:, 0] = 0
+    for b, n in enumerate([64, 50, 64, 20, 64, 64, 33, 41]):
+        seq_ids[b, n - 1] = 2
+        seq_ids[b, n:] = 1
+    txt_ids = torch.randint(1000, 30522, (B, T), generator=gen)
+    txt_ids[:, 0] = 101
+    for b, n in enumerate([48, 30, 48, 7, 48, 19, 48, 40]):
+        txt_ids[b, n - 1] = 102
+        txt_ids[b, n:] = 0
+    txt_ids[1, 3] = txt_ids[5, 9] = txt_ids[0, 2]           # the same word in several rows
+    cfg_seq = dict(layers=6, hidden=320, heads=20, ffn=1280, pad=1, mask=32, eps=1e-5)
+    cfg_tx = dict(layers=12, hidden=768, heads=12, ffn=3072, vocab=30522, max_pos=512, pad=0, eps=1e-12)
+    ref = O.train_substep(seq_ids, txt_ids, sd_seq, sd_tx, cfg_seq, cfg_tx, dict(kind="esm", pooling="mean", proj_type="mlp", use_logit_scale=False),
+                          dict(kind="bert", pooling="cls", proj_type="mlp", use_logit_scale=True), use_l1=True)
+    module = OneProtLitModule(components={"sequence": seq, "text": tx}, optimizer=functools.partial(FusedAdam, lr=1e-3), loss_fn="CLIP",
+                              use_l1_regularization=True, local_loss=True, gather_with_grad=True).to(DEV)
+    grads = {}
+    orig_clip = module.clip_gradients
+
+    def spy(opt, **kw):
+        tr = module.network["text"].transformer
+        for k in ("embeddings.word_embeddings.weight", "embeddings.position_embeddings.weight", "embeddings.LayerNorm.weight",
+                  "encoder.layer.0.attention.self.query.weight", "encoder.layer.11.output.dense.weight", "encoder.layer.5.attention.output.LayerNorm.bias"):
+            grads[k] = tr.view(k, tr.flat.grad).detach().cpu().clone()
+        return orig_clip(opt, **kw)
+
+    module.clip_gradients = spy
+    loss = float(module.training_step({"text": (seq_ids.to(DEV), txt_ids.to(DEV), "text", None)}, 0).detach())
+    assert abs(loss - float(ref["loss"])) / float(ref["loss"]) < 1e-3, (loss, float(ref["loss"]))
+    assert abs(float(module.last_grad_norm) - float(ref["grad_total_norm"])) / float(ref["grad_total_norm"]) < 2e-2
+    for k, v in grads.items():
+        r = ref["grads"]["mod.transformer." + k]
+        assert _cos(v, r) > 0.98, (k, _cos(v, r))
+
+
 @pytest.mark.parametrize("frozen_seq", [True, False])
 def test_multi_step_training_tracks_oracle(golden_dir, tmp_path, frozen_seq):
     """4 consecutive sub-steps (optimizer state, bf16 weight-mirror refresh after each step, frozen / trainable sequence encoder):
