@@ -87,7 +87,7 @@ void oneprot_gemm_force_shape(int shape);
 /* dW[N,K] (+)= dY[M,N]^T * X[M,K]  (contraction over the M tokens; split over workgroups, fp32 slabs in workspace);
    dbias[N] (+)= column sums of dY (optional, fused: an all-ones MFMA operand in the k-tile-0 workgroups). */
 size_t oneprot_gemm_bf16_tn_workspace(int N, int K);
-/* test / tuning hook: 0 = 64-token stages x2 (default), 1 = 32-token stages x3. */
+/* test / tuning hook: -1 = auto (default, = 2), 0 = 64-token stages x2 (LDS-DMA ring), 1 = 32-token stages x3, 2 = 64-token stages x2 with register-staged fill. */
 void oneprot_gemm_tn_variant(int v);
 int oneprot_gemm_bf16_tn(const void* dY, const void* X, int64_t M, int N, int K, int ldy, int ldx, float* dW, float* dbias, void* workspace,
                          int accumulate, void* stream);

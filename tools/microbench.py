@@ -74,7 +74,7 @@ def main():
             key = f"{name}[v{variant}]"
             if key not in res or ms < res[key][0]:
                 res[key] = (ms, 2.0 * T * N * K / ms / 1e9)
-        hip.query("oneprot_gemm_tn_variant", 0)
+        hip.query("oneprot_gemm_tn_variant", -1)
         del dY, X
     # ---- attention
     q, k, v = (rnd(B, H, L, hd).to(torch.bfloat16) for _ in range(3))
