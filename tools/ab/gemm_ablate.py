@@ -1,6 +1,7 @@
 #!/usr/bin/env python3
 """Development tool (GPU): where does an NT-GEMM launch spend its time?  Same kernel built three ways (build_attn_variants.sh
-g_base / g_nostore (epilogue runs, global stores never execute) / g_noepi (main loop only)) on the FFN-1 and FFN-2 shapes."""
+g_base / g_small (every store redirected into the first 2 MB of the output: store instructions stay, HBM write traffic goes) /
+g_nostore (epilogue runs, global stores never execute) / g_noepi (main loop only)) on the FFN-1 and FFN-2 shapes."""
 import ctypes, os, sys, statistics
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__)))))
 import torch
@@ -8,7 +9,7 @@ here = os.path.dirname(os.path.abspath(__file__))
 T, d, f = 131072, 640, 2560
 P, I, F, L64 = ctypes.c_void_p, ctypes.c_int, ctypes.c_float, ctypes.c_int64
 libs = {}
-for n in ("g_base", "g_nostore", "g_noepi"):
+for n in ("g_base", "g_small", "g_nostore", "g_noepi"):
     lib = ctypes.CDLL(os.path.join(here, f"libattn_v{n}.so"))
     lib.oneprot_gemm_bf16_nt.argtypes = [P, P, L64, I, I, I, I, I, P, P, P, P, P, P, P, F, I, I, I, P]
     lib.oneprot_gemm_force_shape.argtypes = [I]
