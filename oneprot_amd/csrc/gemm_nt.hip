@@ -62,6 +62,130 @@ template <int BKT> __device__ __forceinline__ int swz(int row, int chunk) {
 
 template <int N> __device__ __forceinline__ void wait_vmcnt() { asm volatile("s_waitcnt vmcnt(%0)" ::"n"(N) : "memory"); }
 
+// ---- epilogue: the wave parks EPH rows x 64 columns of its fp32 accumulators in its own padded LDS tile `et` and re-reads them row-wise,
+// 8 columns per lane -> 16-byte coalesced stores in whatever layout the consumer wants.  FULL = the tile lies entirely inside [M, N] (no masks).
+// (A persistent variant of the kernel -- LDS ring running continuously across tiles, epilogue stores never waited for, bias in LDS, store-count-
+// exact vmcnt -- was built on this function, passed the tests and ran the FFN-1 launch in the same 0.70 ms as the plain form; dropped.)
+template <int EPI, int MT, int NTW, int EPH, bool FULL>
+__device__ __forceinline__ void gemm_epilogue(const GemmArgs& p, const float* bias_src, f32x4 (&acc)[MT][NTW], float* et, int m0, int n0, int wr, int wc, int lane) {
+  const int frow = lane & 15, fq = lane >> 4;
+  const int er = lane >> 3, ec = (lane & 7) * 8;
+#pragma unroll
+  for (int nh = 0; nh < NTW / 4; ++nh) {       // 64-column halves of the wave tile
+  const int gn = n0 + wc * (NTW * 16) + nh * 64 + ec;
+  float bias8[8];
+#pragma unroll
+  for (int e = 0; e < 8; ++e) bias8[e] = 0.f;
+  if (bias_src && (FULL || gn < p.N)) {
+    const float4 b0 = *reinterpret_cast<const float4*>(bias_src + gn), b1 = *reinterpret_cast<const float4*>(bias_src + gn + 4);
+    bias8[0] = b0.x; bias8[1] = b0.y; bias8[2] = b0.z; bias8[3] = b0.w; bias8[4] = b1.x; bias8[5] = b1.y; bias8[6] = b1.z; bias8[7] = b1.w;
+  }
+  // QKV/RoPE constants for this lane's 8 columns
+  int sec = 0, head = 0, j0 = 0, pc = 0; float pbias8[8]; float sgn = 0.f;
+  if (EPI == ONEPROT_EPI_QKV_ROPE && (FULL || gn < p.N)) {
+    const int dm = p.H * p.hd;
+    sec = gn / dm;
+    const int within = gn - sec * dm;
+    head = within / p.hd; j0 = within - head * p.hd;
+    const int half = p.hd >> 1;
+    const bool lo = j0 < half;
+    pc = ec + (lo ? half : -half);          // partner columns inside the wave tile
+    sgn = lo ? -1.f : 1.f;
+#pragma unroll
+    for (int e = 0; e < 8; ++e) pbias8[e] = 0.f;
+    if (bias_src && sec < 2) {
+      const int pg = gn + (lo ? half : -half);
+      const float4 b0 = *reinterpret_cast<const float4*>(bias_src + pg), b1 = *reinterpret_cast<const float4*>(bias_src + pg + 4);
+      pbias8[0] = b0.x; pbias8[1] = b0.y; pbias8[2] = b0.z; pbias8[3] = b0.w; pbias8[4] = b1.x; pbias8[5] = b1.y; pbias8[6] = b1.z; pbias8[7] = b1.w;
+    }
+  }
+#pragma unroll
+  for (int half = 0; half < (MT * 16) / EPH; ++half) {
+#pragma unroll
+    for (int i = 0; i < EPH / 16; ++i)
+#pragma unroll
+      for (int j = 0; j < 4; ++j)
+#pragma unroll
+        for (int r = 0; r < 4; ++r) et[(i * 16 + fq * 4 + r) * EPI_LD + j * 16 + frow] = acc[half * (EPH / 16) + i][nh * 4 + j][r];
+    // same wave writes and reads: LDS operations of one wave complete in order
+    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+    if (FULL || gn < p.N) {
+#pragma unroll 2
+    for (int pass = 0; pass < EPH / 8; ++pass) {
+    const int r = pass * 8 + er;
+    const int gm = m0 + wr * (MT * 16) + half * EPH + r;
+    if (!FULL && gm >= p.M) continue;
+    float v[8];
+    {
+      const float4 v0 = *reinterpret_cast<const float4*>(et + r * EPI_LD + ec), v1 = *reinterpret_cast<const float4*>(et + r * EPI_LD + ec + 4);
+      v[0] = v0.x; v[1] = v0.y; v[2] = v0.z; v[3] = v0.w; v[4] = v1.x; v[5] = v1.y; v[6] = v1.z; v[7] = v1.w;
+    }
+#pragma unroll
+    for (int e = 0; e < 8; ++e) v[e] += bias8[e];
+    const size_t o = (size_t)gm * p.N + gn;
+    if (EPI == ONEPROT_EPI_BF16) {
+      u32x4 w; w.x = pack2bf(v[0], v[1]); w.y = pack2bf(v[2], v[3]); w.z = pack2bf(v[4], v[5]); w.w = pack2bf(v[6], v[7]);
+      *reinterpret_cast<u32x4*>((bf16_t*)p.out0 + o) = w;
+    } else if (EPI == ONEPROT_EPI_F32) {
+      float* c = (float*)p.out0 + o;
+      *reinterpret_cast<float4*>(c) = make_float4(v[0], v[1], v[2], v[3]);
+      *reinterpret_cast<float4*>(c + 4) = make_float4(v[4], v[5], v[6], v[7]);
+    } else if (EPI == ONEPROT_EPI_BIAS_GELU) {
+      float dg[8];
+#pragma unroll
+      for (int e = 0; e < 8; ++e) gelu_fwd_and_grad(v[e], v[e], dg[e]);
+      if (p.out1) {          // gelu'(z), consumed by the GELU_BWD epilogue of the dgrad GEMM
+        u32x4 z; z.x = pack2bf(dg[0], dg[1]); z.y = pack2bf(dg[2], dg[3]); z.z = pack2bf(dg[4], dg[5]); z.w = pack2bf(dg[6], dg[7]);
+        *reinterpret_cast<u32x4*>((bf16_t*)p.out1 + o) = z;
+      }
+      u32x4 w; w.x = pack2bf(v[0], v[1]); w.y = pack2bf(v[2], v[3]); w.z = pack2bf(v[4], v[5]); w.w = pack2bf(v[6], v[7]);
+      *reinterpret_cast<u32x4*>((bf16_t*)p.out0 + o) = w;
+    } else if (EPI == ONEPROT_EPI_BIAS_RESID) {
+      const float* rs = (const float*)p.aux + o;
+      const float4 r0 = *reinterpret_cast<const float4*>(rs), r1 = *reinterpret_cast<const float4*>(rs + 4);
+      v[0] += r0.x; v[1] += r0.y; v[2] += r0.z; v[3] += r0.w; v[4] += r1.x; v[5] += r1.y; v[6] += r1.z; v[7] += r1.w;
+      float* c = (float*)p.out0 + o;
+      *reinterpret_cast<float4*>(c) = make_float4(v[0], v[1], v[2], v[3]);
+      *reinterpret_cast<float4*>(c + 4) = make_float4(v[4], v[5], v[6], v[7]);
+      if (p.out1) {
+        u32x4 w; w.x = pack2bf(v[0], v[1]); w.y = pack2bf(v[2], v[3]); w.z = pack2bf(v[4], v[5]); w.w = pack2bf(v[6], v[7]);
+        *reinterpret_cast<u32x4*>((bf16_t*)p.out1 + o) = w;
+      }
+    } else if (EPI == ONEPROT_EPI_GELU_BWD) {
+      const u32x4 z = *reinterpret_cast<const u32x4*>((const bf16_t*)p.aux + o);     // aux = gelu'(z) saved by the forward epilogue
+      v[0] *= bflo(z.x); v[1] *= bfhi(z.x); v[2] *= bflo(z.y); v[3] *= bfhi(z.y);
+      v[4] *= bflo(z.z); v[5] *= bfhi(z.z); v[6] *= bflo(z.w); v[7] *= bfhi(z.w);
+      u32x4 w; w.x = pack2bf(v[0], v[1]); w.y = pack2bf(v[2], v[3]); w.z = pack2bf(v[4], v[5]); w.w = pack2bf(v[6], v[7]);
+      *reinterpret_cast<u32x4*>((bf16_t*)p.out0 + o) = w;
+    } else if (EPI == ONEPROT_EPI_QKV_ROPE) {
+      const int b = gm / p.L, l = gm - b * p.L;
+      if (sec < 2) {
+        float pv[8];
+        const float4 q0 = *reinterpret_cast<const float4*>(et + r * EPI_LD + pc), q1 = *reinterpret_cast<const float4*>(et + r * EPI_LD + pc + 4);
+        pv[0] = q0.x; pv[1] = q0.y; pv[2] = q0.z; pv[3] = q0.w; pv[4] = q1.x; pv[5] = q1.y; pv[6] = q1.z; pv[7] = q1.w;
+        const int half = p.hd >> 1;
+        const int jj = j0 < half ? j0 : j0 - half;
+        const float* cs = p.cos + (size_t)l * half + jj;
+        const float* sn = p.sin + (size_t)l * half + jj;
+        const float sc = sec == 0 ? p.q_scale : 1.0f;
+#pragma unroll
+        for (int e = 0; e < 8; ++e) {
+          const float x = v[e] * sc, xp = (pv[e] + pbias8[e]) * sc;
+          v[e] = x * cs[e] + sgn * xp * sn[e];
+        }
+      }
+      bf16_t* dst = (bf16_t*)(sec == 0 ? p.out0 : (sec == 1 ? p.out1 : p.out2));
+      const size_t oo = (((size_t)b * p.H + head) * p.L + l) * p.hd + j0;
+      u32x4 w; w.x = pack2bf(v[0], v[1]); w.y = pack2bf(v[2], v[3]); w.z = pack2bf(v[4], v[5]); w.w = pack2bf(v[6], v[7]);
+      *reinterpret_cast<u32x4*>(dst + oo) = w;
+    }
+  }
+    }
+    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");     // reads of this pass done before the next pass overwrites the tile
+  }
+  }
+}
+
 template <int EPI, int WM, int WN, int MT, int NTW, int BKT, int NSTAGE, int EPH, int MINW, bool PIPE>
 __global__ void __launch_bounds__(WM * WN * 64, MINW) k_gemm_nt(const GemmArgs p) {
   typedef Shape<WM, WN, MT, NTW, BKT, NSTAGE, EPH> S;
@@ -233,123 +357,8 @@ __global__ void __launch_bounds__(WM * WN * 64, MINW) k_gemm_nt(const GemmArgs p
   }
   __syncthreads();          // everyone done with the staging ring before it is reused as epilogue tiles
 
-  // ---- epilogue: wave-private EPH x 64 fp32 tile in LDS, (MT*16)/EPH passes
-  float* et = reinterpret_cast<float*>(smem) + wave * EPH * EPI_LD;
-  const int er = lane >> 3, ec = (lane & 7) * 8;
-#pragma unroll
-  for (int nh = 0; nh < NTW / 4; ++nh) {       // 64-column halves of the wave tile
-  const int gn = n0 + wc * (NTW * 16) + nh * 64 + ec;
-  float bias8[8];
-#pragma unroll
-  for (int e = 0; e < 8; ++e) bias8[e] = 0.f;
-  if (p.bias && gn < p.N) {
-    const float4 b0 = *reinterpret_cast<const float4*>(p.bias + gn), b1 = *reinterpret_cast<const float4*>(p.bias + gn + 4);
-    bias8[0] = b0.x; bias8[1] = b0.y; bias8[2] = b0.z; bias8[3] = b0.w; bias8[4] = b1.x; bias8[5] = b1.y; bias8[6] = b1.z; bias8[7] = b1.w;
-  }
-  // QKV/RoPE constants for this lane's 8 columns
-  int sec = 0, head = 0, j0 = 0, pc = 0; float pbias8[8]; float sgn = 0.f;
-  if (EPI == ONEPROT_EPI_QKV_ROPE && gn < p.N) {
-    const int dm = p.H * p.hd;
-    sec = gn / dm;
-    const int within = gn - sec * dm;
-    head = within / p.hd; j0 = within - head * p.hd;
-    const int half = p.hd >> 1;
-    const bool lo = j0 < half;
-    pc = ec + (lo ? half : -half);          // partner columns inside the wave tile
-    sgn = lo ? -1.f : 1.f;
-#pragma unroll
-    for (int e = 0; e < 8; ++e) pbias8[e] = 0.f;
-    if (p.bias && sec < 2) {
-      const int pg = gn + (lo ? half : -half);
-      const float4 b0 = *reinterpret_cast<const float4*>(p.bias + pg), b1 = *reinterpret_cast<const float4*>(p.bias + pg + 4);
-      pbias8[0] = b0.x; pbias8[1] = b0.y; pbias8[2] = b0.z; pbias8[3] = b0.w; pbias8[4] = b1.x; pbias8[5] = b1.y; pbias8[6] = b1.z; pbias8[7] = b1.w;
-    }
-  }
-#pragma unroll
-  for (int half = 0; half < (MT * 16) / EPH; ++half) {
-#pragma unroll
-    for (int i = 0; i < EPH / 16; ++i)
-#pragma unroll
-      for (int j = 0; j < 4; ++j)
-#pragma unroll
-        for (int r = 0; r < 4; ++r) et[(i * 16 + fq * 4 + r) * EPI_LD + j * 16 + frow] = acc[half * (EPH / 16) + i][nh * 4 + j][r];
-    // same wave writes and reads: LDS operations of one wave complete in order
-    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
-    if (gn < p.N) {
-#pragma unroll 2
-    for (int pass = 0; pass < EPH / 8; ++pass) {
-    const int r = pass * 8 + er;
-    const int gm = m0 + wr * (MT * 16) + half * EPH + r;
-    if (gm >= p.M) continue;
-    float v[8];
-    {
-      const float4 v0 = *reinterpret_cast<const float4*>(et + r * EPI_LD + ec), v1 = *reinterpret_cast<const float4*>(et + r * EPI_LD + ec + 4);
-      v[0] = v0.x; v[1] = v0.y; v[2] = v0.z; v[3] = v0.w; v[4] = v1.x; v[5] = v1.y; v[6] = v1.z; v[7] = v1.w;
-    }
-#pragma unroll
-    for (int e = 0; e < 8; ++e) v[e] += bias8[e];
-    const size_t o = (size_t)gm * p.N + gn;
-    if (EPI == ONEPROT_EPI_BF16) {
-      u32x4 w; w.x = pack2bf(v[0], v[1]); w.y = pack2bf(v[2], v[3]); w.z = pack2bf(v[4], v[5]); w.w = pack2bf(v[6], v[7]);
-      *reinterpret_cast<u32x4*>((bf16_t*)p.out0 + o) = w;
-    } else if (EPI == ONEPROT_EPI_F32) {
-      float* c = (float*)p.out0 + o;
-      *reinterpret_cast<float4*>(c) = make_float4(v[0], v[1], v[2], v[3]);
-      *reinterpret_cast<float4*>(c + 4) = make_float4(v[4], v[5], v[6], v[7]);
-    } else if (EPI == ONEPROT_EPI_BIAS_GELU) {
-      float dg[8];
-#pragma unroll
-      for (int e = 0; e < 8; ++e) gelu_fwd_and_grad(v[e], v[e], dg[e]);
-      if (p.out1) {          // gelu'(z), consumed by the GELU_BWD epilogue of the dgrad GEMM
-        u32x4 z; z.x = pack2bf(dg[0], dg[1]); z.y = pack2bf(dg[2], dg[3]); z.z = pack2bf(dg[4], dg[5]); z.w = pack2bf(dg[6], dg[7]);
-        *reinterpret_cast<u32x4*>((bf16_t*)p.out1 + o) = z;
-      }
-      u32x4 w; w.x = pack2bf(v[0], v[1]); w.y = pack2bf(v[2], v[3]); w.z = pack2bf(v[4], v[5]); w.w = pack2bf(v[6], v[7]);
-      *reinterpret_cast<u32x4*>((bf16_t*)p.out0 + o) = w;
-    } else if (EPI == ONEPROT_EPI_BIAS_RESID) {
-      const float* rs = (const float*)p.aux + o;
-      const float4 r0 = *reinterpret_cast<const float4*>(rs), r1 = *reinterpret_cast<const float4*>(rs + 4);
-      v[0] += r0.x; v[1] += r0.y; v[2] += r0.z; v[3] += r0.w; v[4] += r1.x; v[5] += r1.y; v[6] += r1.z; v[7] += r1.w;
-      float* c = (float*)p.out0 + o;
-      *reinterpret_cast<float4*>(c) = make_float4(v[0], v[1], v[2], v[3]);
-      *reinterpret_cast<float4*>(c + 4) = make_float4(v[4], v[5], v[6], v[7]);
-      if (p.out1) {
-        u32x4 w; w.x = pack2bf(v[0], v[1]); w.y = pack2bf(v[2], v[3]); w.z = pack2bf(v[4], v[5]); w.w = pack2bf(v[6], v[7]);
-        *reinterpret_cast<u32x4*>((bf16_t*)p.out1 + o) = w;
-      }
-    } else if (EPI == ONEPROT_EPI_GELU_BWD) {
-      const u32x4 z = *reinterpret_cast<const u32x4*>((const bf16_t*)p.aux + o);     // aux = gelu'(z) saved by the forward epilogue
-      v[0] *= bflo(z.x); v[1] *= bfhi(z.x); v[2] *= bflo(z.y); v[3] *= bfhi(z.y);
-      v[4] *= bflo(z.z); v[5] *= bfhi(z.z); v[6] *= bflo(z.w); v[7] *= bfhi(z.w);
-      u32x4 w; w.x = pack2bf(v[0], v[1]); w.y = pack2bf(v[2], v[3]); w.z = pack2bf(v[4], v[5]); w.w = pack2bf(v[6], v[7]);
-      *reinterpret_cast<u32x4*>((bf16_t*)p.out0 + o) = w;
-    } else if (EPI == ONEPROT_EPI_QKV_ROPE) {
-      const int b = gm / p.L, l = gm - b * p.L;
-      if (sec < 2) {
-        float pv[8];
-        const float4 q0 = *reinterpret_cast<const float4*>(et + r * EPI_LD + pc), q1 = *reinterpret_cast<const float4*>(et + r * EPI_LD + pc + 4);
-        pv[0] = q0.x; pv[1] = q0.y; pv[2] = q0.z; pv[3] = q0.w; pv[4] = q1.x; pv[5] = q1.y; pv[6] = q1.z; pv[7] = q1.w;
-        const int half = p.hd >> 1;
-        const int jj = j0 < half ? j0 : j0 - half;
-        const float* cs = p.cos + (size_t)l * half + jj;
-        const float* sn = p.sin + (size_t)l * half + jj;
-        const float sc = sec == 0 ? p.q_scale : 1.0f;
-#pragma unroll
-        for (int e = 0; e < 8; ++e) {
-          const float x = v[e] * sc, xp = (pv[e] + pbias8[e]) * sc;
-          v[e] = x * cs[e] + sgn * xp * sn[e];
-        }
-      }
-      bf16_t* dst = (bf16_t*)(sec == 0 ? p.out0 : (sec == 1 ? p.out1 : p.out2));
-      const size_t oo = (((size_t)b * p.H + head) * p.L + l) * p.hd + j0;
-      u32x4 w; w.x = pack2bf(v[0], v[1]); w.y = pack2bf(v[2], v[3]); w.z = pack2bf(v[4], v[5]); w.w = pack2bf(v[6], v[7]);
-      *reinterpret_cast<u32x4*>(dst + oo) = w;
-    }
-  }
-    }
-    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");     // reads of this pass done before the next pass overwrites the tile
-  }
-  }
+  // ---- epilogue (staging tiles reuse the ring memory)
+  gemm_epilogue<EPI, MT, NTW, EPH, false>(p, p.bias, acc, reinterpret_cast<float*>(smem) + wave * EPH * EPI_LD, m0, n0, wr, wc, lane);
 }
 
 template <int EPI, int WM, int WN, int MT, int NTW, int BKT, int NSTAGE, int EPH, int MINW, bool PIPE>

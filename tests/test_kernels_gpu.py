@@ -151,7 +151,7 @@ def gemm_shape(request):
     hip.query("oneprot_gemm_force_shape", -1)
 
 
-@pytest.mark.parametrize("M,N,K", [(300, 136, 72), (128, 128, 64), (1024, 640, 640), (257, 2560, 640), (515, 640, 2560), (144, 64, 160), (2304, 1920, 640)])
+@pytest.mark.parametrize("M,N,K", [(300, 136, 72), (128, 128, 64), (1024, 640, 640), (257, 2560, 640), (515, 640, 2560), (144, 64, 160), (2304, 1920, 640), (8192, 512, 160)])
 def test_gemm_nt_epilogues(M, N, K, gemm_shape):
     A, W, bias = _gemm_inputs(M, N, K, 3)
     ref = A.float() @ W.float().t()
@@ -182,7 +182,7 @@ def test_gemm_nt_epilogues(M, N, K, gemm_shape):
     assert_close(dz, ref * z.float(), 2 ** -6, 3e-2, "gelu bwd")
 
 
-@pytest.mark.parametrize("B,L,H,hd", [(3, 24, 4, 16), (2, 37, 2, 32), (2, 130, 20, 32), (2, 50, 2, 64), (5, 512, 20, 32)])
+@pytest.mark.parametrize("B,L,H,hd", [(3, 24, 4, 16), (2, 37, 2, 32), (2, 130, 20, 32), (2, 50, 2, 64), (5, 512, 20, 32), (16, 512, 8, 32)])
 def test_gemm_qkv_rope_epilogue(B, L, H, hd, gemm_shape):
     d = H * hd
     M, N, K = B * L, 3 * d, d
