@@ -158,7 +158,7 @@ class BertTransformer(ArenaModule):
             saved["x_final"] = x
         return x, saved
 
-    def backward_layers(self, saved, g, g16, gflat):
+    def backward_layers(self, saved, g, g16, gflat, on_ready=None):
         """g: fp32 [T,d] gradient w.r.t. the last layer's output (consumed), g16 unused (post-LN layers start with a LayerNorm backward);
         gflat: fp32 arena gradient (written).  Per layer, backwards (hf modeling_bert.py:354-417):
           y2 = LN2(s2), s2 = y1 + gelu(y1 W1^T + b1) W2^T + b2 ;  y1 = LN1(s1), s1 = x + attn(x) Wo^T + bo."""
@@ -202,6 +202,8 @@ class BertTransformer(ArenaModule):
                      1.0, 0, 0, 0)
             saved["layers"][i] = None
         self._embedding_backward(saved["ids"], g, gflat)
+        if on_ready is not None:
+            on_ready(0, self._total)
 
     def _embedding_backward(self, ids, g, gflat):
         """x0 = LN(word[id] + pos[l] + type[0]) (hf modeling_bert.py:53-108).  The pre-LN sum is re-gathered (torch indexing: data movement),

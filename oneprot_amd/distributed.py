@@ -84,6 +84,37 @@ def mkdir(path):
             raise
 
 
+class GradOverlap:
+    """Asynchronous mean-all-reduce of arena-gradient ranges issued from inside an encoder's backward (one RCCL call per ~6 layers), so
+    the reduction of the upper layers runs under the backward of the lower ones.  `allreduce_gradients` waits for the handles of a
+    parameter that was reduced this way instead of reducing it again.  Attach with `attach(encoder.transformer)`."""
+
+    def __init__(self):
+        self.world = get_world_size()
+        self.use_avg = is_dist_avail_and_initialized() and dist.get_backend() == "nccl"
+        self.calls = 0
+
+    def attach(self, transformer):
+        transformer._grad_overlap = self if self.world > 1 else None
+
+    def reduce_range(self, param, gflat, lo, hi):
+        chunk = gflat[lo:hi]
+        self.calls += 1
+        h = None
+        if self.use_avg:
+            try:
+                h = dist.all_reduce(chunk, op=dist.ReduceOp.AVG, async_op=True)
+            except (RuntimeError, ValueError):       # a transport without ncclAvg: divide, then SUM
+                self.use_avg = False
+        if h is None:
+            chunk.div_(self.world)
+            h = dist.all_reduce(chunk, op=dist.ReduceOp.SUM, async_op=True)
+        pend = getattr(param, "_oneprot_pending_reduce", None)
+        if pend is None:
+            pend = param._oneprot_pending_reduce = []
+        pend.append(h)
+
+
 def allreduce_gradients(parameters, bucket_bytes=256 << 20, average=True):
     """Mean-all-reduce the gradients of `parameters` (only those with a .grad) in large flat buckets.
     The encoder arena gradient is already one contiguous tensor, so the 148 M-parameter encoder is reduced in place with a
@@ -95,6 +126,11 @@ def allreduce_gradients(parameters, bucket_bytes=256 << 20, average=True):
     for p in parameters:
         g = p.grad
         if g is None:
+            continue
+        pend = getattr(p, "_oneprot_pending_reduce", None)
+        if pend:                                   # already being reduced (GradOverlap): just collect the handles
+            handles.extend(pend)
+            p._oneprot_pending_reduce = []
             continue
         if g.numel() * g.element_size() >= (1 << 20) and g.is_contiguous():
             flat = g.view(-1)

@@ -214,6 +214,8 @@ class _EncodeFn(torch.autograd.Function):
         # (grad mode is off inside Function.forward; ctx.needs_input_grad already folds in torch.no_grad())
         need_tr_grad = bool(ctx.needs_input_grad[2])
         need_any = need_tr_grad or any(ctx.needs_input_grad[4:])
+        if need_tr_grad:
+            tr._live_apps = getattr(tr, "_live_apps", 0) + 1       # applications awaiting their backward (see backward: overlap guard)
         x, saved = tr.run_layers(ids, save=need_tr_grad)
         B, L = ids.shape
         d = tr.d
@@ -301,7 +303,22 @@ class _EncodeFn(torch.autograd.Function):
                 hip.call("oneprot_layernorm_bwd", dpooled, 2, wrow, L, saved["x_final"], 0, tr.view("encoder.emb_layer_norm_after.weight"), mean, rstd, None, g, g16,
                          lnw, lnb, ws, B * L, d, 0)
             saved["x_final"] = None
-            tr.backward_layers(saved, g, g16, gflat)
+            # Overlapped data-parallel reduction (oneprot_amd.distributed.GradOverlap): only when this is the encoder's single application in
+            # the step and nothing has been accumulated yet -- then the arena gradient is installed as .grad here (autograd gets None for it)
+            # and finished ranges are all-reduced while the lower layers are still in their backward.
+            sync = getattr(tr, "_grad_overlap", None)
+            single = getattr(tr, "_live_apps", 1) == 1 and not getattr(tr, "_multi_app_step", False)
+            if getattr(tr, "_live_apps", 1) > 1:
+                tr._multi_app_step = True
+            tr._live_apps = max(getattr(tr, "_live_apps", 1) - 1, 0)
+            if tr._live_apps == 0 and not single:
+                tr._multi_app_step = False
+            if sync is not None and single and tr.flat.grad is None:
+                tr.backward_layers(saved, g, g16, gflat, on_ready=lambda lo, hi: sync.reduce_range(tr.flat, gflat, lo, hi))
+                tr.flat.grad = gflat
+                gflat = None
+            else:
+                tr.backward_layers(saved, g, g16, gflat)
             ctx.saved = None
         n_head = ctx.n_params - ctx.n_extra
         hg = list(hgrads) + [None] * (n_head - len(hgrads))

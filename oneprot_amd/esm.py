@@ -439,9 +439,13 @@ class EsmTransformer(ArenaModule):
             saved["x_final"] = x
         return x, saved
 
-    def backward_layers(self, saved, g, g16, gflat):
+    GRAD_CHUNK_LAYERS = 6      # arena-gradient ranges are handed to `on_ready` every this many layers (overlapped all-reduce)
+
+    def backward_layers(self, saved, g, g16, gflat, on_ready=None):
         """g: fp32 [T,d] gradient w.r.t. the last layer's output (consumed in place), g16: its bf16 copy;
-        gflat: fp32 arena gradient (written)."""
+        gflat: fp32 arena gradient (written).  on_ready(lo, hi): called as soon as the arena-gradient range [lo, hi) is final
+        (the arena is laid out embeddings | layer 0 .. n-1 | final LayerNorm, and the backward walks the layers downwards), so the
+        data-parallel all-reduce of the upper layers runs under the backward of the lower ones."""
         B, L = saved["B"], saved["L"]
         T, d, f, H, hd, dp = B * L, self.d, self.f, self.H, self.hdp, self.dp
         q_scale = self.hd ** -0.5
@@ -457,6 +461,7 @@ class EsmTransformer(ArenaModule):
         dh = b16(T, d)
         dctx = b16(T, dp) if self._padded else dh
         dqkv = b16(T, 3 * dp)
+        ready_hi = self._total
         if self._padded:      # weight gradients come out in the padded-head layout and are gathered back into the arena gradient
             rowmap, colmap = self._head_pad_maps()
             gw_qkv, gb_qkv, gw_o = torch.empty(3 * dp, d, device=dev), torch.empty(3 * dp, device=dev), torch.empty(d, dp, device=dev)
@@ -494,10 +499,16 @@ class EsmTransformer(ArenaModule):
             hip.call("oneprot_layernorm_bwd", dh, 0, None, 0, st["x_in"], 0, self.view(p + "attention.LayerNorm.weight"), st["mean1"], st["rstd1"], g, g, g16,
                      gv(p + "attention.LayerNorm.weight"), gv(p + "attention.LayerNorm.bias"), ws_ln, T, d, 0)
             saved["layers"][i] = None      # release this layer's activations
+            if on_ready is not None and i > 0 and i % self.GRAD_CHUNK_LAYERS == 0:
+                lo = self._spec[f"encoder.layer.{i}.attention.self.query.weight"][0]
+                on_ready(lo, ready_hi)
+                ready_hi = lo
         V = cfg.vocab_size
         ws_e = torch.empty(hip.query("oneprot_esm_embed_bwd_workspace", T, d, V), dtype=torch.uint8, device=dev)
         hip.call("oneprot_esm_embed_bwd", saved["ids"], g, saved["row_scale"], gv("embeddings.word_embeddings.weight"), ws_e, B, L, d, V,
                  cfg.pad_token_id, cfg.mask_token_id, 1 if cfg.token_dropout else 0, 0)
+        if on_ready is not None:
+            on_ready(0, ready_hi)
 
     @torch.no_grad()
     def forward(self, input_ids=None, attention_mask=None, **_):

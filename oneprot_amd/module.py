@@ -146,6 +146,7 @@ class OneProtLitModule(_Base):
     # ------------------------------------------------------------------------------------------- the hot loop
     def training_step(self, batch, batch_idx=None):
         opt = self.optimizers()
+        self._attach_grad_overlap()
         current_step = self.global_step
         if current_step < self.train_on_all_modalities_after_step:
             modalities_to_train = ["struct_token"]
@@ -174,9 +175,19 @@ class OneProtLitModule(_Base):
 
     def _sync_gradients(self, opt):
         """What Lightning's DDP wrapper does implicitly in the reference (C6 in SURVEY.md section 2.2) -- here explicit, and only
-        over parameters that received a gradient in this sub-step."""
+        over parameters that received a gradient in this sub-step.  The encoder arenas are reduced in ranges from inside their backward
+        (distributed.GradOverlap, attached on first use); this call waits for those and reduces the small head parameters."""
         if getattr(self.loss_fn, "world_size", 1) > 1 and not HAVE_LIGHTNING:
             D.allreduce_gradients([p for g in opt.param_groups for p in g["params"]])
+
+    def _attach_grad_overlap(self):
+        if getattr(self, "_overlap_attached", False) or HAVE_LIGHTNING or getattr(self.loss_fn, "world_size", 1) <= 1:
+            return
+        if D.is_dist_avail_and_initialized():
+            ov = D.GradOverlap()
+            for enc in self.network.values():
+                ov.attach(enc.transformer)
+            self._overlap_attached = True
 
     def validation_step(self, batch, batch_idx=None, dataloader_idx=0):
         sequence_inputs, modality_inputs, modality, _ = batch

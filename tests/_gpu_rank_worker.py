@@ -22,6 +22,8 @@ def main():
     from src.models.oneprot_module import OneProtLitModule
     if world > 1:
         D.setup_process_group(backend="gloo")
+        from oneprot_amd.esm import EsmTransformer
+        EsmTransformer.GRAD_CHUNK_LAYERS = 1          # 2-layer fixture: still two ranges through the overlapped all-reduce
     g = torch.load(golden, weights_only=False)
     cfg = g["cfg"]
     p = os.path.join(out_dir, f"cfg_rank{rank}")
@@ -40,7 +42,8 @@ def main():
     batch = {"struct_token": (g["seq_ids"][sl].to("cuda:0"), g["st_ids"][sl].to("cuda:0"), "struct_token", None)}
     loss = module.training_step(batch, 0)
     torch.cuda.synchronize()
-    out = {"loss": float(loss.detach()), "gnorm": float(module.last_grad_norm),
+    ov = getattr(module.network["struct_token"].transformer, "_grad_overlap", None)
+    out = {"loss": float(loss.detach()), "gnorm": float(module.last_grad_norm), "overlap_calls": (ov.calls if ov is not None else 0),
            "w": module.network["struct_token"].state_dict()["transformer.encoder.layer.0.output.dense.weight"].cpu(),
            "emb": module.network["sequence"].state_dict()["transformer.embeddings.word_embeddings.weight"].cpu()}
     torch.save(out, os.path.join(out_dir, f"w{world}_rank{rank}.pt"))

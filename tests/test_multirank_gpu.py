@@ -27,6 +27,7 @@ def test_two_ranks_equal_single_process(golden_dir, tmp_path):
     one = torch.load(os.path.join(out, "w1_rank0.pt"), weights_only=False)
     r0 = torch.load(os.path.join(out, "w2_rank0.pt"), weights_only=False)
     r1 = torch.load(os.path.join(out, "w2_rank1.pt"), weights_only=False)
+    assert r0["overlap_calls"] >= 2 and one["overlap_calls"] == 0          # arena gradient reduced in ranges from inside the backward
     mean_loss = 0.5 * (r0["loss"] + r1["loss"])
     assert abs(mean_loss - one["loss"]) / one["loss"] < 1e-3, (r0["loss"], r1["loss"], one["loss"])
     assert abs(r0["gnorm"] - one["gnorm"]) / one["gnorm"] < 2e-2 and abs(r0["gnorm"] - r1["gnorm"]) < 1e-5 * one["gnorm"] + 1e-6
