@@ -90,7 +90,7 @@ class BertTransformer(ArenaModule):
             for i in range(self.n_layers):
                 p = f"encoder.layer.{i}."
                 o, n = self.span(p + "attention.self.query.weight", p + "attention.self.value.weight")
-                for key, (src, R, C) in {"qkv": (self.flat.data[o:o + n], 3 * d, d), "o": (self.view(p + "attention.output.dense.weight"), d, d),
+                for key, (src, R, C) in {"qkv": (self._qkv_effective_f32(i), 3 * d, d), "o": (self.view(p + "attention.output.dense.weight"), d, d),
                                          "w1": (self.view(p + "intermediate.dense.weight"), f, d), "w2": (self.view(p + "output.dense.weight"), d, f)}.items():
                     t = self._bf16_T.get((i, key))
                     if t is None:

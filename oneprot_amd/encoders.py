@@ -313,12 +313,15 @@ class _EncodeFn(torch.autograd.Function):
             tr._live_apps = max(getattr(tr, "_live_apps", 1) - 1, 0)
             if tr._live_apps == 0 and not single:
                 tr._multi_app_step = False
-            if sync is not None and single and tr.flat.grad is None:
+            if sync is not None and single and tr.flat.grad is None and not tr._lora:
                 tr.backward_layers(saved, g, g16, gflat, on_ready=lambda lo, hi: sync.reduce_range(tr.flat, gflat, lo, hi))
                 tr.flat.grad = gflat
                 gflat = None
             else:
                 tr.backward_layers(saved, g, g16, gflat)
+                if tr._lora:
+                    dA, dB, gflat = tr.lora_backward(gflat)
+                    extra_grads += [dA, dB]
             ctx.saved = None
         n_head = ctx.n_params - ctx.n_extra
         hg = list(hgrads) + [None] * (n_head - len(hgrads))
@@ -372,6 +375,8 @@ class BaseEncoder(nn.Module):
         ps = list(self.pooling.parameters())
         if len(self.norm) > 1 and self.norm[1].learnable:
             ps.append(self.norm[1].log_logit_scale)
+        if getattr(self.transformer, "_lora", None):
+            ps += [self.transformer.lora_A, self.transformer.lora_B]
         return ps
 
     def encode(self, input_ids):
@@ -387,8 +392,6 @@ class SequenceEncoder(BaseEncoder):
         self.config, _ = resolve_config(model_name_or_path)
         super().__init__(d_model=self.config.hidden_size, output_dim=output_dim, proj_type=proj_type, use_logit_scale=use_logit_scale,
                          learnable_logit_scale=learnable_logit_scale, pooling_type=pooling_type)
-        if use_lora:
-            raise NotImplementedError("LoRA adapters are off in every shipped OneProt config (sequence.yaml:7); not built (SURVEY.md section 8f #4)")
         if pretrained:
             self.transformer = EsmTransformer.from_pretrained(model_name_or_path, add_pooling_layer=False)
         else:
@@ -397,6 +400,8 @@ class SequenceEncoder(BaseEncoder):
         if frozen:
             for param in self.transformer.parameters():
                 param.requires_grad = False
+        if use_lora:                                    # ref sequence_encoder.py:61-74 (peft LoraConfig(..., bias="all"))
+            self.transformer.enable_lora(lora_r, lora_alpha, lora_target_modules, lora_dropout)
 
     def forward(self, x):
         return self.encode(x)
@@ -431,13 +436,13 @@ class TextEncoder(BaseEncoder):
         self.config, _ = resolve_bert_config(model_name_or_path)
         super().__init__(d_model=self.config.hidden_size, output_dim=output_dim, proj_type=proj_type, use_logit_scale=use_logit_scale,
                          learnable_logit_scale=learnable_logit_scale, pooling_type=pooling_type)
-        if use_lora:
-            raise NotImplementedError("LoRA adapters are off in every shipped OneProt config (text.yaml:7); not built (SURVEY.md section 8f #4)")
         self.transformer = BertTransformer.from_pretrained(model_name_or_path)
         self.config = self.transformer.config
         if frozen:                                      # ref text_encoder.py:35-37
             for param in self.transformer.parameters():
                 param.requires_grad = False
+        if use_lora:                                    # ref text_encoder.py:39-52
+            self.transformer.enable_lora(lora_r, lora_alpha, lora_target_modules if lora_target_modules is not None else ["query", "key", "value"], lora_dropout)
         self.use_lora = use_lora
         self.frozen = frozen
 

@@ -141,17 +141,72 @@ class ArenaModule(nn.Module):
     _sd_extra_buffers = ()
     _load_ignore_suffixes = ()
 
+    # ------------------------------------------------------------------------------------------------- LoRA (peft 0.5.0 semantics)
+    # ref sequence_encoder.py:61-74 / text_encoder.py:39-52: get_peft_model(transformer, LoraConfig(r, lora_alpha, lora_dropout,
+    # target_modules=[query,key,value], bias="all")).  peft's lora.Linear computes  y = x W^T + b + (alpha/r) * (dropout(x) A^T) B^T  with
+    # A ~ kaiming_uniform(a=sqrt(5)), B = 0; only lora_A / lora_B and every parameter whose name contains "bias" stay trainable; the wrapped
+    # model's keys gain the prefix "base_model.model." and the adapters are "<linear>.lora_{A,B}.default.weight".
+    # Here: the adapters are two stacked parameters, the bf16 GEMM operand of a target is the merged W + (alpha/r) B A (equal to the
+    # two-branch form at dropout p = 0, which is how every dropout of this path runs), the hand-written backward yields d(W_eff) from
+    # which dA = s B^T dW and dB = s dW A^T follow, and the arena gradient is masked down to its "bias" entries.
+    LORA_TARGETS = ("query", "key", "value")
+    _lora = None
+
+    def enable_lora(self, r, alpha, target_modules, dropout=0.0):
+        targets = [t for t in self.LORA_TARGETS if t in list(target_modules)]
+        if len(targets) != len(list(target_modules)):
+            raise NotImplementedError(f"LoRA target modules {list(target_modules)}: only {list(self.LORA_TARGETS)} (the reference's list) are built")
+        n, d = self.n_layers, self.d
+        A = torch.empty(n, len(targets), r, d)
+        A.uniform_(-1.0 / math.sqrt(d), 1.0 / math.sqrt(d))              # kaiming_uniform_(a=sqrt(5)) on [r, d]
+        self.lora_A = nn.Parameter(A)
+        self.lora_B = nn.Parameter(torch.zeros(n, len(targets), d, r))
+        self._lora = dict(r=r, alpha=alpha, scaling=alpha / r, targets=targets, dropout=dropout)
+        for p in self.parameters():
+            p.requires_grad = False
+        self.lora_A.requires_grad = True
+        self.lora_B.requires_grad = True
+        self.flat.requires_grad = True                                   # bias="all": only the "bias" entries receive a gradient (mask below)
+        idx = torch.cat([torch.arange(off, off + cnt) for name, (off, cnt, _) in self._spec.items() if "bias" in name])
+        self.register_buffer("_lora_bias_index", idx, persistent=False)
+        self._bf16_version = None
+
+    def _lora_key(self, prefix, i, t, which):
+        return f"{prefix}encoder.layer.{i}.attention.self.{t}.lora_{which}.default.weight"
+
     def _sd_hook(self, module, state_dict, prefix, local_metadata):
         flat = state_dict.pop(prefix + "flat")
+        base = prefix + ("base_model.model." if self._lora else "")
         for name in self._spec:
-            state_dict[prefix + name] = self.view(name, flat)
+            state_dict[base + name] = self.view(name, flat)
         for k in list(self._extra):
-            state_dict[prefix + k] = state_dict.pop(prefix + "extra." + k.replace(".", "__"))
+            state_dict[base + k] = state_dict.pop(prefix + "extra." + k.replace(".", "__"))
         for key, fn in self._sd_extra_buffers:
-            state_dict[prefix + key] = fn(self)
+            state_dict[base + key] = fn(self)
+        if self._lora:
+            A, B = state_dict.pop(prefix + "lora_A"), state_dict.pop(prefix + "lora_B")
+            for i in range(self.n_layers):
+                for ti, t in enumerate(self._lora["targets"]):
+                    state_dict[self._lora_key(base, i, t, "A")] = A[i, ti]
+                    state_dict[self._lora_key(base, i, t, "B")] = B[i, ti]
         return state_dict
 
     def _load_hook(self, state_dict, prefix, local_metadata, strict, missing_keys, unexpected_keys, error_msgs):
+        peft = prefix + "base_model.model."
+        for k in [k for k in state_dict if k.startswith(peft)]:          # a PeftModel's keys load into either form
+            state_dict[prefix + k[len(peft):]] = state_dict.pop(k)
+        if self._lora:
+            A, B = self.lora_A.detach().clone(), self.lora_B.detach().clone()
+            for i in range(self.n_layers):
+                for ti, t in enumerate(self._lora["targets"]):
+                    for which, dst in (("A", A), ("B", B)):
+                        key = self._lora_key(prefix, i, t, which)
+                        if key in state_dict:
+                            dst[i, ti] = state_dict.pop(key).to(dst)
+                        elif prefix + "lora_" + which not in state_dict:
+                            missing_keys.append(key)
+            state_dict.setdefault(prefix + "lora_A", A)
+            state_dict.setdefault(prefix + "lora_B", B)
         flat = self.flat.detach().clone()
         for name, (off, n, shape) in self._spec.items():
             key = prefix + name
@@ -174,7 +229,7 @@ class ArenaModule(nn.Module):
 
     def _refresh_bf16_mirror(self):
         """returns True when the mirror was rebuilt"""
-        ver = (self.flat._version, self.flat.data_ptr())
+        ver = (self.flat._version, self.flat.data_ptr()) + ((self.lora_A._version, self.lora_B._version) if self._lora else ())
         if self._bf16_version == ver:
             return False
         dev = self.flat.device
@@ -182,8 +237,44 @@ class ArenaModule(nn.Module):
             self._bf16 = torch.empty(self._total, dtype=torch.bfloat16, device=dev)
             self._bf16_T = {}
         hip.call("oneprot_cast_f32_to_bf16", self.flat.data, self._bf16, self._total)
+        if self._lora:          # merged operands W + (alpha/r) B A for the target projections
+            for i in range(self.n_layers):
+                w = self._qkv_effective_f32(i)
+                o, n = self.span(f"encoder.layer.{i}.attention.self.query.weight", f"encoder.layer.{i}.attention.self.value.weight")
+                hip.call("oneprot_cast_f32_to_bf16", w, self._bf16[o:o + n], n)
         self._bf16_version = ver
         return True
+
+    def _qkv_effective_f32(self, i):
+        """fp32 [3d, d] fused q|k|v weight of layer i as the GEMMs must see it: the arena view, or (LoRA) a scratch copy with (alpha/r) B A
+        added to the target blocks."""
+        o, n = self.span(f"encoder.layer.{i}.attention.self.query.weight", f"encoder.layer.{i}.attention.self.value.weight")
+        w = self.flat.data[o:o + n]
+        if not self._lora:
+            return w
+        d, r = self.d, self._lora["r"]
+        if getattr(self, "_lora_scratch", None) is None or self._lora_scratch.device != w.device:
+            self._lora_scratch = torch.empty(3 * d * d, device=w.device)
+        tmp = self._lora_scratch
+        tmp.copy_(w)
+        for ti, t in enumerate(self._lora["targets"]):
+            blk = self.LORA_TARGETS.index(t)
+            hip.call("oneprot_sgemm", self.lora_B.data[i, ti], self.lora_A.data[i, ti], tmp[blk * d * d:(blk + 1) * d * d], d, d, r, 0, 1, self._lora["scaling"], 1)
+        return tmp
+
+    def lora_backward(self, gflat):
+        """(dA, dB) from the gradient w.r.t. the merged weights left in `gflat`, then `gflat` reduced to its "bias" entries (peft bias="all")."""
+        d, r, s_ = self.d, self._lora["r"], self._lora["scaling"]
+        dA, dB = torch.empty_like(self.lora_A), torch.empty_like(self.lora_B)
+        for i in range(self.n_layers):
+            for ti, t in enumerate(self._lora["targets"]):
+                dW = self.view(f"encoder.layer.{i}.attention.self.{t}.weight", gflat)
+                hip.call("oneprot_sgemm", dW, self.lora_A.data[i, ti], dB[i, ti], d, r, d, 0, 0, s_, 0)        # dB = s dW A^T
+                hip.call("oneprot_sgemm", self.lora_B.data[i, ti], dW, dA[i, ti], r, d, d, 1, 1, s_, 0)        # dA = s B^T dW
+        masked = torch.zeros_like(gflat)
+        idx = self._lora_bias_index
+        masked[idx] = gflat[idx]
+        return dA, dB, masked
 
     def save_pretrained(self, path):
         """HF-style directory (config.json + model.safetensors) -- used by ref peft_checkpoint.py:20."""
@@ -312,7 +403,7 @@ class EsmTransformer(ArenaModule):
                 o, n = self.span(p + "attention.self.query.weight", p + "attention.self.value.weight")
                 plain = {"w1": (self.view(p + "intermediate.dense.weight"), f, d), "w2": (self.view(p + "output.dense.weight"), d, f)}
                 if not self._padded:
-                    plain["qkv"] = (self.flat.data[o:o + n], 3 * d, d)
+                    plain["qkv"] = (self._qkv_effective_f32(i), 3 * d, d)
                     plain["o"] = (self.view(p + "attention.output.dense.weight"), d, d)
                 for key, (src, R, C) in plain.items():
                     t = self._bf16_T.get((i, key))

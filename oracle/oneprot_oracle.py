@@ -14,6 +14,8 @@ same maths).
 Pinning: tests/test_oracle_golden.py checks every function here against
 fixtures produced by running the reference itself (tests/golden/make_golden.py)
 -- the reference's own test-suite holds no numeric vectors for this path.
+One branch is PARITY UNPINNED: `lora_proj` restates peft 0.5.0's LoRA linear
+(ref requirements.txt:8; peft is not installed here, so no fixture could be made).
 
 Weights are passed as a flat dict with the reference's state-dict key names
 ("transformer.encoder.layer.0.attention.self.query.weight", "proj.1.weight",
@@ -46,6 +48,25 @@ def gelu_erf(x: Tensor) -> Tensor:
 def linear(x: Tensor, w: Tensor, b: Optional[Tensor] = None) -> Tensor:
     y = x @ w.t()
     return y if b is None else y + b
+
+
+
+def lora_proj(x: Tensor, sd: Dict[str, Tensor], key: str, scaling: Optional[float]) -> Tensor:
+    """A query/key/value projection, optionally wrapped by a LoRA adapter as peft 0.5.0's `lora.Linear.forward` computes it (ref
+    sequence_encoder.py:61-74, text_encoder.py:39-52 call `get_peft_model`; peft is a third-party dependency pinned at 0.5.0 in ref
+    requirements.txt:8 and ABSENT here, so this branch restates its published algorithm and is *parity unpinned*):
+        y = x W^T + b + (lora_alpha / r) * (dropout(x) A^T) B^T       (dropout p = 0: eval mode)
+    with A = `<key>lora_A.default.weight` [r, d], B = `<key>lora_B.default.weight` [d, r]."""
+    y = linear(x, sd[key + "weight"], sd[key + "bias"])
+    a = sd.get(key + "lora_A.default.weight")
+    if a is not None:
+        y = y + scaling * ((x @ a.t()) @ sd[key + "lora_B.default.weight"].t())
+    return y
+
+
+def strip_peft_prefix(sd: Dict[str, Tensor]) -> Dict[str, Tensor]:
+    """PeftModel state-dict keys ("transformer.base_model.model.<hf key>") -> the plain "transformer.<hf key>" this file indexes by."""
+    return {k.replace("transformer.base_model.model.", "transformer."): v for k, v in sd.items()}
 
 
 def rope_tables(L: int, head_dim: int, base: float = 10000.0):
@@ -97,14 +118,14 @@ def additive_key_mask(attn_mask: Tensor) -> Tensor:
 
 
 def esm_layer(x: Tensor, sd: Dict[str, Tensor], pre: str, heads: int, key_mask: Tensor, cos: Tensor, sin: Tensor,
-              eps: float) -> Tensor:
+              eps: float, lora_scaling: Optional[float] = None) -> Tensor:
     """One pre-LN EsmLayer (hf: modeling_esm.py:340-521)."""
     B, L, d = x.shape
     hd = d // heads
     h = layer_norm(x, sd[pre + "attention.LayerNorm.weight"], sd[pre + "attention.LayerNorm.bias"], eps)
-    q = linear(h, sd[pre + "attention.self.query.weight"], sd[pre + "attention.self.query.bias"])
-    k = linear(h, sd[pre + "attention.self.key.weight"], sd[pre + "attention.self.key.bias"])
-    v = linear(h, sd[pre + "attention.self.value.weight"], sd[pre + "attention.self.value.bias"])
+    q = lora_proj(h, sd, pre + "attention.self.query.", lora_scaling)
+    k = lora_proj(h, sd, pre + "attention.self.key.", lora_scaling)
+    v = lora_proj(h, sd, pre + "attention.self.value.", lora_scaling)
     q = q.view(B, L, heads, hd).transpose(1, 2)
     k = k.view(B, L, heads, hd).transpose(1, 2)
     v = v.view(B, L, heads, hd).transpose(1, 2)
@@ -130,7 +151,7 @@ def esm_forward(ids: Tensor, sd: Dict[str, Tensor], cfg: dict, pre: str = "trans
     cos, sin = rope_tables(L, cfg["hidden"] // cfg["heads"])
     km = additive_key_mask(attn_mask)
     for i in range(cfg["layers"]):
-        x = esm_layer(x, sd, f"{pre}encoder.layer.{i}.", cfg["heads"], km, cos, sin, cfg["eps"])
+        x = esm_layer(x, sd, f"{pre}encoder.layer.{i}.", cfg["heads"], km, cos, sin, cfg["eps"], cfg.get("lora_scaling"))
         if taps is not None:
             taps[f"layer{i}"] = x
     x = layer_norm(x, sd[pre + "encoder.emb_layer_norm_after.weight"], sd[pre + "encoder.emb_layer_norm_after.bias"], cfg["eps"])
@@ -156,9 +177,9 @@ def bert_forward(ids: Tensor, sd: Dict[str, Tensor], cfg: dict, pre: str = "tran
     km = additive_key_mask(attn_mask)
     for i in range(cfg["layers"]):
         p = f"{pre}encoder.layer.{i}."
-        q = linear(x, sd[p + "attention.self.query.weight"], sd[p + "attention.self.query.bias"]).view(B, T, heads, hd).transpose(1, 2)
-        k = linear(x, sd[p + "attention.self.key.weight"], sd[p + "attention.self.key.bias"]).view(B, T, heads, hd).transpose(1, 2)
-        v = linear(x, sd[p + "attention.self.value.weight"], sd[p + "attention.self.value.bias"]).view(B, T, heads, hd).transpose(1, 2)
+        q = lora_proj(x, sd, p + "attention.self.query.", cfg.get("lora_scaling")).view(B, T, heads, hd).transpose(1, 2)
+        k = lora_proj(x, sd, p + "attention.self.key.", cfg.get("lora_scaling")).view(B, T, heads, hd).transpose(1, 2)
+        v = lora_proj(x, sd, p + "attention.self.value.", cfg.get("lora_scaling")).view(B, T, heads, hd).transpose(1, 2)
         s = (q @ k.transpose(-1, -2)) * hd ** -0.5 + km
         a = (torch.softmax(s, -1) @ v).transpose(1, 2).reshape(B, T, d)
         a = linear(a, sd[p + "attention.output.dense.weight"], sd[p + "attention.output.dense.bias"])
@@ -224,6 +245,8 @@ def encoder_features(kind: str, ids: Tensor, sd: Dict[str, Tensor], cfg: dict, p
     """SequenceEncoder/StructTokenEncoder/TextEncoder.forward
     (ref: sequence_encoder.py:76-81, struct_token_encoder.py:29-34, text_encoder.py:57-62)."""
     mask = (ids != cfg["pad"]).long()
+    if any(k.startswith("transformer.base_model.model.") for k in sd):
+        sd = strip_peft_prefix(sd)
     hidden = esm_forward(ids, sd, cfg, taps=taps) if kind == "esm" else bert_forward(ids, sd, cfg, taps=taps)
     if taps is not None:
         taps["last_hidden"] = hidden

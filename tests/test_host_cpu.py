@@ -138,11 +138,17 @@ def test_dropin_paths_signatures_and_state_dict(golden_dir, tmp_path, monkeypatc
         seq(g["seq_ids"])
     with pytest.raises(OSError):
         SequenceEncoder("not/a-model", output_dim=8, use_lora=False)
+    with pytest.raises(NotImplementedError):
+        SequenceEncoder(p, output_dim=48, use_lora=True, lora_target_modules=["query", "dense"])      # only the reference's q/k/v targets are built
+    lora = SequenceEncoder(p, output_dim=48)             # signature defaults: use_lora=True, frozen=True  (ref sequence_encoder.py:23-38)
+    keys = set(lora.state_dict())
+    assert "transformer.base_model.model.encoder.layer.0.attention.self.key.lora_B.default.weight" in keys          # peft's key layout
+    assert "transformer.base_model.model.embeddings.word_embeddings.weight" in keys and not any(k.endswith("flat") for k in keys)
+    assert sorted(n for n, q in lora.transformer.named_parameters() if q.requires_grad) == ["flat", "lora_A", "lora_B"]
+    assert float(lora.transformer.lora_B.abs().max()) == 0.0 and float(lora.transformer.lora_A.abs().max()) <= 1 / 8.0 + 1e-6     # B = 0, A ~ U(-1/sqrt(d), 1/sqrt(d))
     monkeypatch.delenv("ONEPROT_ALLOW_RANDOM_INIT")
     with pytest.raises(OSError):
         StructTokenEncoder(p, output_dim=48)          # config only, no weight file: refuses unless random init is explicitly allowed
-    with pytest.raises(NotImplementedError):
-        SequenceEncoder(p, output_dim=48, use_lora=True)
 
 
 def test_config_composer_own_tree():

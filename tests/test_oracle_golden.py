@@ -111,6 +111,34 @@ def test_bert_text_trainable_gradients(golden_dir):
     assert float(pad_row.abs().max()) == 0.0 or float(g["grads"]["transformer.embeddings.word_embeddings.weight"][g["cfg"]["pad"]].abs().max()) == 0.0
 
 
+def test_lora_restatement_equals_merged_weights(golden_dir):
+    """LoRA branch of the oracle (peft 0.5.0 lora.Linear restated; parity unpinned -- peft is absent here): the two-branch form equals the same
+    encoder with W + (alpha/r) B A merged into the q/k/v weights, and an adapter with B = 0 (peft's initialisation) changes nothing."""
+    g = _load(golden_dir, "esm_pair_hd16.pt")
+    sd, cfg = dict(g["sd_seq"]), dict(g["cfg"], lora_scaling=2.0)
+    base = O.encoder_features("esm", g["seq_ids"], sd, cfg, "mean", "mlp", False)
+    gen = torch.Generator().manual_seed(0)
+    d, r = cfg["hidden"], 8
+    merged = dict(sd)
+    for i in range(cfg["layers"]):
+        for t in ("query", "key", "value"):
+            key = f"transformer.base_model.model.encoder.layer.{i}.attention.self.{t}."
+            A, Bm = torch.randn(r, d, generator=gen) * 0.1, torch.zeros(d, r)
+            sd[key + "lora_A.default.weight"], sd[key + "lora_B.default.weight"] = A, Bm
+    sd = {("transformer.base_model.model." + k[len("transformer."):] if k.startswith("transformer.") and "base_model" not in k else k): v for k, v in sd.items()}
+    _close(O.encoder_features("esm", g["seq_ids"], sd, cfg, "mean", "mlp", False), base, atol=1e-6)
+    for i in range(cfg["layers"]):
+        for t in ("query", "key", "value"):
+            key = f"transformer.base_model.model.encoder.layer.{i}.attention.self.{t}."
+            Bm = torch.randn(d, r, generator=gen) * 0.1
+            sd[key + "lora_B.default.weight"] = Bm
+            merged[f"transformer.encoder.layer.{i}.attention.self.{t}.weight"] = merged[f"transformer.encoder.layer.{i}.attention.self.{t}.weight"] + 2.0 * Bm @ sd[key + "lora_A.default.weight"]
+    two = O.encoder_features("esm", g["seq_ids"], sd, cfg, "mean", "mlp", False)
+    one = O.encoder_features("esm", g["seq_ids"], merged, cfg, "mean", "mlp", False)
+    _close(two, one, atol=2e-5)
+    assert float((two - base).abs().max()) > 1e-3
+
+
 def test_pooling_and_norm(golden_dir):
     g = _load(golden_dir, "pooling.pt")
     x, mask = g["x"], g["mask"]

@@ -423,6 +423,115 @@ def test_esm2_35m_shape_train_step_vs_oracle():
             assert _cos(v, r) > 0.98, (k, _cos(v, r))
 
 
+def test_lora_sequence_encoder_vs_oracle():
+    """SequenceEncoder with its signature defaults (use_lora=True, r=8, alpha=16, targets q/k/v, frozen base; ref sequence_encoder.py:23-74): peft's
+    key layout, features, adapter / bias gradients (peft bias="all") vs the oracle's restatement of peft 0.5.0 lora.Linear (parity unpinned: peft is
+    absent here), and an optimizer step that leaves every non-bias base weight bit-identical."""
+    os.environ.update(RANK="0", WORLD_SIZE="1", ONEPROT_ALLOW_RANDOM_INIT="1")
+    from src.models.components.sequence_encoder import SequenceEncoder
+    from oneprot_amd.optim import FusedAdam
+    torch.manual_seed(21)
+    enc = SequenceEncoder("facebook/esm2_t6_8M_UR50D", output_dim=256, pooling_type="mean", proj_type="mlp")       # use_lora=True, frozen=True by default
+    tr = enc.transformer
+    with torch.no_grad():
+        tr.lora_B.normal_(0, 0.05)                       # peft initialises B = 0 (adapter inactive); make it count
+        for k, v in tr.named_views().items():
+            if k.endswith(".bias"):
+                v.normal_(0, 0.02)
+    sd = {k: v.detach().clone() for k, v in enc.state_dict().items()}
+    assert sd["transformer.base_model.model.encoder.layer.0.attention.self.query.lora_A.default.weight"].shape == (8, 320)
+    assert sd["transformer.base_model.model.encoder.layer.5.attention.self.value.lora_B.default.weight"].shape == (320, 8)
+    assert "transformer.base_model.model.encoder.layer.0.attention.self.query.weight" in sd and "transformer.flat" not in sd
+    trainable = sorted(n for n, p_ in enc.named_parameters() if p_.requires_grad)
+    assert trainable == sorted(["transformer.flat", "transformer.lora_A", "transformer.lora_B"] + ["proj." + n for n, _ in enc.proj.named_parameters()])
+    # a second instance loads the PeftModel-style state dict strictly
+    enc2 = SequenceEncoder("facebook/esm2_t6_8M_UR50D", output_dim=256, pooling_type="mean", proj_type="mlp")
+    enc2.load_state_dict(sd, strict=True)
+    assert torch.equal(enc2.transformer.lora_B, tr.lora_B.cpu()) and torch.equal(enc2.transformer.flat, tr.flat.cpu())
+
+    gen = torch.Generator().manual_seed(1881)
+    B, L = 6, 96
+    ids = torch.randint(4, 24, (B, L), generator=gen)
+    ids[:, 0] = 0
+    for b, n in enumerate([96, 40, 96, 17, 70, 96]):
+        ids[b, n - 1] = 2
+        ids[b, n:] = 1
+    other = torch.nn.functional.normalize(torch.randn(B, 256, generator=gen), dim=-1) * (1 / 0.07)
+    cfg = dict(layers=6, hidden=320, heads=20, ffn=1280, pad=1, mask=32, eps=1e-5, lora_scaling=16 / 8)
+    osd = {k: (v.clone().requires_grad_(True) if v.is_floating_point() and ("lora_" in k or "bias" in k or k.startswith("proj.")) else v) for k, v in sd.items()}
+    rf = O.encoder_features("esm", ids, osd, cfg, "mean", "mlp", False)
+    rloss = O.clip_loss(rf, other)
+    rloss.backward()
+
+    enc = enc.to(DEV)
+    feats = enc(ids.to(DEV))
+    cs = torch.nn.functional.cosine_similarity(feats.detach().cpu(), rf.detach(), dim=-1)
+    assert cs.min() > 0.999, cs
+    from src.models.components.loss import ClipLoss
+    loss = ClipLoss()(feats, other.to(DEV))
+    assert abs(float(loss) - float(rloss)) / float(rloss) < 2e-3, (float(loss), float(rloss))
+    opt = FusedAdam([p_ for p_ in enc.parameters() if p_.requires_grad], lr=1e-3)
+    before = tr.flat.detach().clone()
+    loss.backward()
+    P = "transformer.base_model.model.encoder.layer."
+    for i in (0, 5):
+        for ti, t in enumerate(("query", "key", "value")):
+            for which, got in (("A", tr.lora_A.grad[i, ti]), ("B", tr.lora_B.grad[i, ti])):
+                ref = osd[f"{P}{i}.attention.self.{t}.lora_{which}.default.weight"].grad
+                assert _cos(got.cpu(), ref) > 0.98, (i, t, which, _cos(got.cpu(), ref))
+    gflat = tr.flat.grad
+    idx = tr._lora_bias_index
+    mask = torch.zeros_like(gflat, dtype=torch.bool); mask[idx] = True
+    assert float(gflat[~mask].abs().max()) == 0.0                                   # frozen base weights, LayerNorm gains: no gradient
+    for name in ("encoder.layer.0.attention.self.query.bias", "encoder.layer.3.intermediate.dense.bias", "encoder.layer.5.LayerNorm.bias", "encoder.emb_layer_norm_after.bias"):
+        ref = osd["transformer.base_model.model." + name].grad
+        assert _cos(tr.view(name, gflat).cpu(), ref) > 0.98, name
+    opt.step()
+    after = tr.flat.detach()
+    assert torch.equal(after[~mask], before[~mask]) and not torch.equal(after[mask], before[mask])
+    # the merged bf16 operands follow the adapters: features change after the step and still track the oracle evaluated on the new weights
+    with torch.no_grad():
+        f2 = enc(ids.to(DEV)).cpu()
+    sd2 = {k: v.detach().cpu() for k, v in enc.state_dict().items()}
+    r2 = O.encoder_features("esm", ids, sd2, cfg, "mean", "mlp", False)
+    assert torch.nn.functional.cosine_similarity(f2, r2, dim=-1).min() > 0.999
+    assert not torch.allclose(f2, feats.detach().cpu(), atol=1e-4)
+
+
+def test_lora_text_encoder_vs_oracle(golden_dir, tmp_path):
+    """TextEncoder(use_lora=True, frozen=True) (ref text_encoder.py:39-52): BERT tower with q/k/v adapters -- features and adapter gradients vs the oracle."""
+    os.environ.update(RANK="0", WORLD_SIZE="1", ONEPROT_ALLOW_RANDOM_INIT="1")
+    from src.models.components.text_encoder import TextEncoder
+    from src.models.components.loss import ClipLoss
+    g = torch.load(os.path.join(golden_dir, "bert_text_train.pt"), weights_only=False)
+    cfg = dict(g["cfg"], lora_scaling=16 / 4)
+    path = os.path.join(str(tmp_path), "bert")
+    os.makedirs(path)
+    with open(os.path.join(path, "config.json"), "w") as f:
+        json.dump(dict(model_type="bert", vocab_size=cfg["vocab"], hidden_size=cfg["hidden"], num_hidden_layers=cfg["layers"], num_attention_heads=cfg["heads"],
+                       intermediate_size=cfg["ffn"], max_position_embeddings=cfg["max_pos"], pad_token_id=cfg["pad"], layer_norm_eps=cfg["eps"]), f)
+    enc = TextEncoder(path, output_dim=cfg["output_dim"], pooling_type="mean", proj_type="linear", use_logit_scale=True, frozen=True, use_lora=True, lora_r=4,
+                      lora_alpha=16)
+    enc.load_state_dict(g["sd"], strict=False)           # base weights from the (adapter-free) fixture; adapters stay at their init
+    with torch.no_grad():
+        enc.transformer.lora_B.normal_(0, 0.05)
+    sd = {k: v.detach().clone() for k, v in enc.state_dict().items()}
+    osd = {k: (v.clone().requires_grad_(True) if "lora_" in k else v) for k, v in sd.items()}
+    rf = O.encoder_features("bert", g["ids"], osd, cfg, "mean", "linear", True)
+    rloss = O.clip_loss(g["seq_features"], rf)
+    rloss.backward()
+    enc = enc.to(DEV)
+    feats = enc(g["ids"].to(DEV))
+    assert torch.nn.functional.cosine_similarity(feats.detach().cpu(), rf.detach(), dim=-1).min() > 0.999
+    ClipLoss()(g["seq_features"].to(DEV), feats).backward()
+    tr = enc.transformer
+    for i in range(cfg["layers"]):
+        for ti, t in enumerate(("query", "key", "value")):
+            for which, got in (("A", tr.lora_A.grad[i, ti]), ("B", tr.lora_B.grad[i, ti])):
+                ref = osd[f"transformer.base_model.model.encoder.layer.{i}.attention.self.{t}.lora_{which}.default.weight"].grad
+                assert _cos(got.cpu(), ref) > 0.98, (i, t, which)
+
+
 def test_mixed_batch_round_robin(golden_dir, tmp_path):
     """CombinedLoader('min_size') batches with two modalities (struct_token, text): one optimiser sub-step per modality per batch
     (ref oneprot_module.py:84-92), frozen text tower untouched, warm-up gate `train_on_all_modalities_after_step`."""
