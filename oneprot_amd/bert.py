@@ -181,16 +181,16 @@ class BertTransformer(ArenaModule):
             hip.call("oneprot_layernorm_bwd", g, 1, None, 0, st["s2"], 0, self.view(p + "output.LayerNorm.weight"), st["mean2"], st["rstd2"], None, ds, ds16,
                      gv(p + "output.LayerNorm.weight"), gv(p + "output.LayerNorm.bias"), ws_ln, T, d, 0)
             # ---- FFN2 (weight + bias grads in one TN launch), then du * gelu'(z) in the dgrad epilogue
-            hip.call("oneprot_gemm_bf16_tn", ds16, st["u"], T, d, f, d, f, gv(p + "output.dense.weight"), gv(p + "output.dense.bias"), ws_tn, 0)
+            self._wgrad(ds16, st["u"], T, d, f, d, f, gv(p + "output.dense.weight"), gv(p + "output.dense.bias"), ws_tn)
             hip.call("oneprot_gemm_bf16_nt", ds16, self._bf16_T[(i, "w2")], T, f, d, d, d, hip.EPI_GELU_BWD, None, dz, None, None, st["z"], None, None, 1.0, 0, 0, 0)
             # ---- FFN1; gy = ds (residual branch) + dz W1
-            hip.call("oneprot_gemm_bf16_tn", dz, st["y16"], T, f, d, f, d, gv(p + "intermediate.dense.weight"), gv(p + "intermediate.dense.bias"), ws_tn, 0)
+            self._wgrad(dz, st["y16"], T, f, d, f, d, gv(p + "intermediate.dense.weight"), gv(p + "intermediate.dense.bias"), ws_tn)
             hip.call("oneprot_gemm_bf16_nt", dz, self._bf16_T[(i, "w1")], T, d, f, f, f, hip.EPI_BIAS_RESID, None, gy, None, None, ds, None, None, 1.0, 0, 0, 0)
             # ---- LN1: ds = LN1'(gy)
             hip.call("oneprot_layernorm_bwd", gy, 1, None, 0, st["s1"], 0, self.view(p + "attention.output.LayerNorm.weight"), st["mean1"], st["rstd1"], None, ds, ds16,
                      gv(p + "attention.output.LayerNorm.weight"), gv(p + "attention.output.LayerNorm.bias"), ws_ln, T, d, 0)
             # ---- out-proj
-            hip.call("oneprot_gemm_bf16_tn", ds16, st["ctx"], T, d, d, d, d, gv(p + "attention.output.dense.weight"), gv(p + "attention.output.dense.bias"), ws_tn, 0)
+            self._wgrad(ds16, st["ctx"], T, d, d, d, d, gv(p + "attention.output.dense.weight"), gv(p + "attention.output.dense.bias"), ws_tn)
             hip.call("oneprot_gemm_bf16_nt", ds16, self._bf16_T[(i, "o")], T, d, d, d, d, hip.EPI_BF16, None, dctx, None, None, None, None, None, 1.0, 0, 0, 0)
             # ---- attention (no rotary: cos/sin = null)
             hip.call("oneprot_attn_bwd", st["q"], st["k"], st["v"], saved["key_bias"], st["ctx"], dctx, st["lse"], None, None, hd ** -0.5, dqkv, ws_at, B, H, L, hd)

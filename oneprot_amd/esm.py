@@ -262,6 +262,13 @@ class ArenaModule(nn.Module):
             hip.call("oneprot_sgemm", self.lora_B.data[i, ti], self.lora_A.data[i, ti], tmp[blk * d * d:(blk + 1) * d * d], d, d, r, 0, 1, self._lora["scaling"], 1)
         return tmp
 
+    def _wgrad(self, dY, X, T, N, K, ldy, ldx, dW, db, ws):
+        """weight + bias gradient of one Linear; under LoRA the base weight is frozen, so only the bias gradient (column sums of dY) is formed"""
+        if self._lora:
+            hip.call("oneprot_colsum_bf16", dY, db, ws, T, N, 0)
+        else:
+            hip.call("oneprot_gemm_bf16_tn", dY, X, T, N, K, ldy, ldx, dW, db, ws, 0)
+
     def lora_backward(self, gflat):
         """(dA, dB) from the gradient w.r.t. the merged weights left in `gflat`, then `gflat` reduced to its "bias" entries (peft bias="all")."""
         d, r, s_ = self.d, self._lora["r"], self._lora["scaling"]
@@ -560,11 +567,11 @@ class EsmTransformer(ArenaModule):
             st = saved["layers"][i]
             p = f"encoder.layer.{i}."
             # ---- FFN2: x_out = x_mid + u W2^T + b2        (weight grad + bias grad in one TN launch)
-            hip.call("oneprot_gemm_bf16_tn", g16, st["u"], T, d, f, d, f, gv(p + "output.dense.weight"), gv(p + "output.dense.bias"), ws_tn, 0)
+            self._wgrad(g16, st["u"], T, d, f, d, f, gv(p + "output.dense.weight"), gv(p + "output.dense.bias"), ws_tn)
             hip.call("oneprot_gemm_bf16_nt", g16, self._bf16_T[(i, "w2")], T, f, d, d, d, hip.EPI_GELU_BWD, None, dz, None, None, st["z"], None, None,
                      1.0, 0, 0, 0)
             # ---- FFN1: z = h2 W1^T + b1
-            hip.call("oneprot_gemm_bf16_tn", dz, st["h2"], T, f, d, f, d, gv(p + "intermediate.dense.weight"), gv(p + "intermediate.dense.bias"), ws_tn, 0)
+            self._wgrad(dz, st["h2"], T, f, d, f, d, gv(p + "intermediate.dense.weight"), gv(p + "intermediate.dense.bias"), ws_tn)
             hip.call("oneprot_gemm_bf16_nt", dz, self._bf16_T[(i, "w1")], T, d, f, f, f, hip.EPI_BF16, None, dh, None, None, None, None, None, 1.0, 0, 0, 0)
             # ---- LN2 (input x_mid): g += LN'(dh); also refreshes the bf16 copy g16
             hip.call("oneprot_layernorm_bwd", dh, 0, None, 0, st["x_mid"], 0, self.view(p + "LayerNorm.weight"), st["mean2"], st["rstd2"], g, g, g16,
