@@ -96,11 +96,13 @@ int oneprot_gemm_bf16_tn(const void* dY, const void* X, int64_t M, int N, int K,
 int oneprot_sgemm(const float* A, const float* B, float* C, int M, int N, int K, int transA, int b_is_kn, float alpha, int accumulate, void* stream);
 
 /* ---------------- attention (hf modeling_esm.py:292-317,340-395) ------------------------------------------------- */
-/* q (pre-scaled, rotated), k (rotated), v : bf16 [B,H,L,hd]; key_bias fp32 [B,L] (0 valid, -inf-like for padding);
-   ctx bf16 [B*L, H*hd]; lse fp32 [B,H,L] (natural log of the softmax denominator, incl. max). */
+/* q = rotary(projection * hd^-1/2 * log2(e)) (what the QKV_ROPE epilogue writes when it is given q_scale = hd^-1/2 * log2 e: scores are in
+   log2 units inside the kernels, so the softmax is exp2 without a multiply), k (rotated), v : bf16 [B,H,L,hd]; key_bias fp32 [B,L] (0 valid,
+   -inf-like for padding); ctx bf16 [B*L, H*hd]; lse fp32 [B,H,L] (NATURAL log of the softmax denominator, incl. max). */
 int oneprot_attn_fwd(const void* q, const void* k, const void* v, const float* key_bias, void* ctx, float* lse, int B, int H, int L, int hd,
                      void* stream);
-/* dctx bf16 [B*L, H*hd] -> dqkv bf16 [B*L, 3*H*hd] = gradient w.r.t. the un-rotated, un-scaled q/k/v projections. */
+/* dctx bf16 [B*L, H*hd] -> dqkv bf16 [B*L, 3*H*hd] = gradient w.r.t. the un-rotated, un-scaled q/k/v projections; q_scale here is the
+   natural hd^-1/2 (the log2 e inside the stored q cancels in dq and is divided out of dk). */
 size_t oneprot_attn_bwd_workspace(int B, int H, int L);
 int oneprot_attn_bwd(const void* q, const void* k, const void* v, const float* key_bias, const void* ctx, const void* dctx, const float* lse,
                      const float* rope_cos, const float* rope_sin, float q_scale, void* dqkv, void* workspace, int B, int H, int L, int hd,

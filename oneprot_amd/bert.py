@@ -140,7 +140,7 @@ class BertTransformer(ArenaModule):
             ob, nb = self.span(p + "attention.self.query.bias", p + "attention.self.value.bias")
             # rotary tables (1, 0) turn the QKV epilogue into "q *= 1/sqrt(hd), head-major q/k/v" (scores scaled inside attention in HF: same product)
             hip.call("oneprot_gemm_bf16_nt", h, self._bf16[o:o + n], T, 3 * d, d, d, d, hip.EPI_QKV_ROPE, self.flat.data[ob:ob + nb], q, k, v, None,
-                     one, zero, hd ** -0.5, L, H, hd)
+                     one, zero, hd ** -0.5 * hip.LOG2E, L, H, hd)
             hip.call("oneprot_attn_fwd", q, k, v, key_bias, ctx, lse, B, H, L, hd)
             hip.call("oneprot_gemm_bf16_nt", ctx, self._w16(p + "attention.output.dense.weight"), T, d, d, d, d, hip.EPI_BIAS_RESID,
                      self.view(p + "attention.output.dense.bias"), s1, None, None, x, None, None, 1.0, 0, 0, 0)

@@ -1,7 +1,8 @@
 // Flash-style multi-head attention for the ESM-2 / BERT encoders on gfx950 (hf modeling_esm.py:292-317, 340-395).
 // Scores never touch HBM; the backward recomputes P from q, k and the saved log-sum-exp.
 //
-// Data layout: q (already scaled by hd^-1/2 and rotated), k (rotated), v are bf16 [B, H, L, hd] (head-major, written by
+// Data layout: q (already scaled by hd^-1/2 * log2(e) and rotated -- scores come out in log2 units, so P = exp2(S - m) needs no multiply),
+// k (rotated), v are bf16 [B, H, L, hd] (head-major, written by
 // the QKV GEMM epilogue), so one (b, h) slab is a contiguous L*hd*2-byte run.  ctx / dctx are bf16 [B*L, H*hd]
 // (token-major, the A operand of the out-projection GEMM).  key_bias is the additive key-padding mask [B, L] fp32.
 //
@@ -140,7 +141,7 @@ __global__ void __launch_bounds__(256, 2) k_attn_fwd(const bf16_t* __restrict__ 
   extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
   unsigned char* sK = smem;
   unsigned char* sV = sK + KC * C::ROWB;
-  float* sBias = reinterpret_cast<float*>(sV + KC * C::ROWB);
+  u32x4* sE = reinterpret_cast<u32x4*>(sV + KC * C::ROWB);       // per key: bf16 [1, 1, 1, bias, 0, 0, 0, 0]; slot KC = zeros
   int bh, qb;
   decode_block(nqb, B * H, bh, qb);
   if (bh >= B * H) return;
@@ -155,27 +156,34 @@ __global__ void __launch_bounds__(256, 2) k_attn_fwd(const bf16_t* __restrict__ 
   bf8_t qf[C::KSTEPS];
 #pragma unroll
   for (int st = 0; st < C::KSTEPS; ++st) qf[st] = *reinterpret_cast<const bf8_t*>(qbase + (size_t)qrow * HD + 16 * st + 8 * h);
-  float m = -1e30f, l = 0.f;      // (finite floor: -m*log2e must not overflow; masked scores are -FLT_MAX and still underflow to p = 0)
-  f32x16 acc[C::DBLK];
+  // q arrives pre-multiplied by hd^-1/2 * log2(e): scores are in log2 units.  The running maximum m (log2 units) is subtracted INSIDE
+  // the score MFMA chain by one extra k-step: K side [1, 1, 1, bias_key], Q side [-m split into three bf16, 1]  => p = exp2(S') directly.
+  float m = 0.f, l = 0.f;
+  u32x4 qe = {0u, 0u, 0u, 0u};
+  if (h == 0) { qe.x = 0u; qe.y = 0x3F800000u; }        // -m = 0, slot 3 = 1.0 (picks up the key bias)
+  const u32x4 ones = {0x3F803F80u, 0x3F803F80u, 0x3F803F80u, 0x3F803F80u};
+  f32x16 acc[C::DBLK], lacc = zero16();
 #pragma unroll
   for (int d = 0; d < C::DBLK; ++d) acc[d] = zero16();
+  bool first = true;
 
   for (int kc0 = 0; kc0 < L; kc0 += KC) {
     const int nkeys = min(KC, L - kc0);
     const int nrows = (nkeys + 31) & ~31;
     __syncthreads();
     load_tile_pair<HD>(sK, kbase + (size_t)kc0 * HD, HD, sV, vbase + (size_t)kc0 * HD, HD, nkeys, nrows);
-    for (int i = threadIdx.x; i < nrows; i += 256)
-      sBias[i] = i < nkeys ? (key_bias ? key_bias[(size_t)b * L + kc0 + i] : 0.f) : -INFINITY;
+    for (int i = threadIdx.x; i <= KC; i += 256) {
+      u32x4 e = {0u, 0u, 0u, 0u};
+      if (i < nrows) {
+        const float bv = i < nkeys ? (key_bias ? key_bias[(size_t)b * L + kc0 + i] : 0.f) : -INFINITY;
+        e.x = 0x3F803F80u; e.y = 0x3F80u | (pack2bf(bv, 0.f) << 16);
+      }
+      sE[i] = e;
+    }
     __syncthreads();
     for (int t = 0; t < nrows / 32; ++t) {
-      // the additive key bias rides in as the initial accumulator (costs what zeroing it would)
-      f32x16 s;
-#pragma unroll
-      for (int g = 0; g < 4; ++g) {
-        const float4 bv = *reinterpret_cast<const float4*>(sBias + t * 32 + 8 * g + 4 * h);
-        s[4 * g + 0] = bv.x; s[4 * g + 1] = bv.y; s[4 * g + 2] = bv.z; s[4 * g + 3] = bv.w;
-      }
+      const u32x4 ke = sE[h ? KC : t * 32 + (lane & 31)];
+      f32x16 s = MFMA32(__builtin_bit_cast(bf8_t, ke), __builtin_bit_cast(bf8_t, qe), zero16());
 #pragma unroll
       for (int st = 0; st < C::KSTEPS; ++st) s = MFMA32(rd_row<HD>(sK, t * 32 + (lane & 31), st, h), qf[st], s);
       float mx = fmaxf(fmaxf(s[0], s[1]), s[2]);
@@ -183,31 +191,41 @@ __global__ void __launch_bounds__(256, 2) k_attn_fwd(const bf16_t* __restrict__ 
       for (int r = 3; r < 15; r += 2) mx = fmaxf(fmaxf(mx, s[r]), s[r + 1]);
       mx = fmaxf(mx, s[15]);
       mx = fmaxf(mx, __shfl_xor(mx, 32, 64));
-      // deferred rescale: the running max only moves when a tile exceeds it by more than RESCALE_THR (p stays <= e^THR, fp32 sums)
-      if (__any(mx > m + RESCALE_THR)) {
-        const float mn = fmaxf(m, mx);
-        const float alpha = __builtin_amdgcn_exp2f((m - mn) * LOG2E);
-        l *= alpha;
+      // deferred rescale (s is already relative to m): the running max moves when a tile exceeds it by more than the threshold, and
+      // unconditionally on the very first tile (m starts at 0, not at the row maximum)
+      if (first || __any(mx > RESCALE_THR * LOG2E)) {
+        float dlt = first ? mx : fmaxf(mx, 0.f);
+        if (!(dlt > -1e30f)) dlt = 0.f;                    // fully masked so far: keep m
+        const float alpha = __builtin_amdgcn_exp2f(-dlt);
+        l = (l + lacc[0]) * alpha;
+        lacc = zero16();
 #pragma unroll
         for (int d = 0; d < C::DBLK; ++d)
 #pragma unroll
           for (int r = 0; r < 16; ++r) acc[d][r] *= alpha;
-        m = mn;
-      }
-      const float negm = -m * LOG2E;
-      float ls = 0.f;
 #pragma unroll
-      for (int r = 0; r < 16; ++r) { s[r] = __builtin_amdgcn_exp2f(fmaf(s[r], LOG2E, negm)); ls += s[r]; }
-      l += ls;
+        for (int r = 0; r < 16; ++r) s[r] -= dlt;
+        m += dlt;
+        if (h == 0) {
+          const float nm = -m;
+          const unsigned w0 = pack2bf(nm, 0.f); const float r1 = nm - bflo(w0);
+          const unsigned w1 = pack2bf(r1, 0.f); const float r2 = r1 - bflo(w1);
+          qe.x = (w0 & 0xffffu) | (w1 << 16); qe.y = pack2bf(r2, 1.0f);
+        }
+        first = false;
+      }
+#pragma unroll
+      for (int r = 0; r < 16; ++r) s[r] = __builtin_amdgcn_exp2f(s[r]);
 #pragma unroll
       for (int sb = 0; sb < 2; ++sb) {
         const bf8_t pf = pack8(s, sb);
+        lacc = MFMA32(__builtin_bit_cast(bf8_t, ones), pf, lacc);
 #pragma unroll
         for (int d = 0; d < C::DBLK; ++d) acc[d] = MFMA32(rd_tr<HD>(sV, t * 32, sb, d, lane), pf, acc[d]);
       }
     }
   }
-  const float lt = l + __shfl_xor(l, 32, 64);
+  const float lt = l + lacc[0];
   const float inv = lt > 0.f ? 1.0f / lt : 0.f;
   if (qidx < L) {
     bf16_t* dst = ctx + ((size_t)b * L + qidx) * (H * HD) + head * HD;
@@ -221,11 +239,11 @@ __global__ void __launch_bounds__(256, 2) k_attn_fwd(const bf16_t* __restrict__ 
           *reinterpret_cast<u32x2*>(dst + dd) = w;
         }
       }
-    if (lse_out && h == 0) lse_out[(size_t)bh * L + qidx] = m + __logf(lt);
+    if (lse_out && h == 0) lse_out[(size_t)bh * L + qidx] = (m + __log2f(lt)) * 0.6931471805599453f;
   }
 }
 
-template <int HD> static size_t fwd_lds() { return (size_t)2 * KC * Cfg<HD>::ROWB + KC * sizeof(float); }
+template <int HD> static size_t fwd_lds() { return (size_t)2 * KC * Cfg<HD>::ROWB + (KC + 1) * 16; }
 
 template <int HD>
 static int launch_fwd(const void* q, const void* k, const void* v, const float* key_bias, void* ctx, float* lse, int B, int H, int L, hipStream_t s) {
@@ -342,7 +360,7 @@ __global__ void __launch_bounds__(256, 2) k_attn_bwd_dq(const bf16_t* __restrict
     qf[st] = *reinterpret_cast<const bf8_t*>(q + ((size_t)bh * L + qrow) * HD + 16 * st + 8 * h);
     dof[st] = *reinterpret_cast<const bf8_t*>(dctx + ((size_t)b * L + qrow) * dm + head * HD + 16 * st + 8 * h);
   }
-  const float lse_q = lse[(size_t)bh * L + qrow], delta_q = delta[(size_t)bh * L + qrow];
+  const float lse_q = lse[(size_t)bh * L + qrow] * LOG2E, delta_q = delta[(size_t)bh * L + qrow];      // scores are in log2 units (q stored x log2 e)
   f32x16 acc[C::DBLK];
 #pragma unroll
   for (int d = 0; d < C::DBLK; ++d) acc[d] = zero16();
@@ -370,7 +388,7 @@ __global__ void __launch_bounds__(256, 2) k_attn_bwd_dq(const bf16_t* __restrict
         dp = MFMA32(rd_row<HD>(sV, t * 32 + (lane & 31), st, h), dof[st], dp);
       }
 #pragma unroll
-      for (int r = 0; r < 16; ++r) s[r] = __builtin_amdgcn_exp2f(s[r] * LOG2E) * dp[r];          // dS^T = P * (dP - delta)
+      for (int r = 0; r < 16; ++r) s[r] = __builtin_amdgcn_exp2f(s[r]) * dp[r];          // dS^T = P * (dP - delta)
 #pragma unroll
       for (int sb = 0; sb < 2; ++sb) {
         const bf8_t dsf = pack8(s, sb);
@@ -418,7 +436,7 @@ __global__ void __launch_bounds__(256, 2) k_attn_bwd_dkv(const bf16_t* __restric
     __syncthreads();
     load_tile_pair<HD>(sQ, q + ((size_t)bh * L + qc0) * HD, HD, sdO, dctx + ((size_t)b * L + qc0) * dm + head * HD, dm, nq, nrows);
     for (int i = threadIdx.x; i < nrows; i += 256) {
-      sLse[i] = i < nq ? -lse[(size_t)bh * L + qc0 + i] : -INFINITY;       // negated: added to the S accumulator initialiser
+      sLse[i] = i < nq ? -lse[(size_t)bh * L + qc0 + i] * LOG2E : -INFINITY;       // negated, log2 units: added to the S accumulator initialiser
       sDelta[i] = i < nq ? -delta[(size_t)bh * L + qc0 + i] : 0.f;
     }
     __syncthreads();
@@ -438,7 +456,7 @@ __global__ void __launch_bounds__(256, 2) k_attn_bwd_dkv(const bf16_t* __restric
       }
       f32x16 p;
 #pragma unroll
-      for (int r = 0; r < 16; ++r) { p[r] = __builtin_amdgcn_exp2f(s[r] * LOG2E); s[r] = p[r] * dp[r]; }      // P, dS
+      for (int r = 0; r < 16; ++r) { p[r] = __builtin_amdgcn_exp2f(s[r]); s[r] = p[r] * dp[r]; }      // P, dS
 #pragma unroll
       for (int sb = 0; sb < 2; ++sb) {
         const bf8_t pf = pack8(p, sb), dsf = pack8(s, sb);
@@ -452,7 +470,7 @@ __global__ void __launch_bounds__(256, 2) k_attn_bwd_dkv(const bf16_t* __restric
   }
   if (kidx < L) {
     bf16_t* row = dqkv + ((size_t)b * L + kidx) * (3 * dm) + head * HD;
-    unrope_store<HD>(adk, cosT, sinT, kidx, h, 1.0f, cosT != nullptr, row + dm);
+    unrope_store<HD>(adk, cosT, sinT, kidx, h, 0.6931471805599453f, cosT != nullptr, row + dm);      // q is stored x log2(e): dK = ln2 * dS^T q
     unrope_store<HD>(adv, cosT, sinT, kidx, h, 1.0f, false, row + 2 * dm);
   }
 }

@@ -518,7 +518,7 @@ class EsmTransformer(ArenaModule):
             hip.call("oneprot_layernorm_fwd", x, 0, self.view(p + "attention.LayerNorm.weight"), self.view(p + "attention.LayerNorm.bias"), h1, None,
                      m1, r1, T, d, eps)
             w_qkv, b_qkv, w_o = self._qkv_operands(i)
-            hip.call("oneprot_gemm_bf16_nt", h1, w_qkv, T, 3 * dp, d, d, d, hip.EPI_QKV_ROPE, b_qkv, q, k, v, None, cos, sin, q_scale, L, H, hd)
+            hip.call("oneprot_gemm_bf16_nt", h1, w_qkv, T, 3 * dp, d, d, d, hip.EPI_QKV_ROPE, b_qkv, q, k, v, None, cos, sin, q_scale * hip.LOG2E, L, H, hd)
             hip.call("oneprot_attn_fwd", q, k, v, key_bias, ctx_, lse, B, H, L, hd)
             x_mid = f32(T, d) if save else x
             hip.call("oneprot_gemm_bf16_nt", ctx_, w_o, T, d, dp, dp, dp, hip.EPI_BIAS_RESID,

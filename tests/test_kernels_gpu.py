@@ -252,7 +252,7 @@ def _attn_ref(q, k, v, bias):
 @pytest.mark.parametrize("B,H,L,hd", [(2, 3, 37, 32), (1, 2, 128, 16), (2, 2, 300, 32), (1, 2, 70, 64), (1, 1, 513, 32)])
 def test_attention_fwd_bwd(B, H, L, hd):
     g = torch.Generator().manual_seed(8)
-    q = bf(torch.randn(B, H, L, hd, generator=g) * 0.7).to(DEV)
+    q = bf(torch.randn(B, H, L, hd, generator=g) * 0.7 * hip.LOG2E).to(DEV)          # the kernels take q x log2(e) (scores in log2 units)
     k = bf(torch.randn(B, H, L, hd, generator=g)).to(DEV)
     v = bf(torch.randn(B, H, L, hd, generator=g)).to(DEV)
     bias = torch.zeros(B, L)
@@ -261,11 +261,13 @@ def test_attention_fwd_bwd(B, H, L, hd):
     ctx = torch.empty(B * L, H * hd, dtype=torch.bfloat16, device=DEV)
     lse = torch.empty(B, H, L, device=DEV)
     hip.call("oneprot_attn_fwd", q, k, v, bias, ctx, lse, B, H, L, hd)
-    qr, kr, vr = (t.float().requires_grad_(True) for t in (q, k, v))
+    qr, kr, vr = ((q.float() / hip.LOG2E).requires_grad_(True), k.float().requires_grad_(True), v.float().requires_grad_(True))
     o_ref, lse_ref = _attn_ref(qr, kr, vr, bias)
     o_tok = o_ref.permute(0, 2, 1, 3).reshape(B * L, H * hd)
     assert_close(ctx, o_tok.detach(), 2 ** -7, 1e-2, "attn fwd")
-    assert_close(lse, lse_ref.detach(), 1e-4, 1e-3, "lse")
+    # the row sum is taken by an all-ones MFMA over the bf16-rounded probabilities (the same values the context numerator uses): a row
+    # dominated by one key carries that key's 2^-9 rounding into log(l)
+    assert_close(lse, lse_ref.detach(), 1e-4, 5e-3, "lse")
     # backward (no rope: cos/sin NULL => dqkv is the raw gradient * q_scale)
     dctx = bf(torch.randn(B * L, H * hd, generator=g)).to(DEV)
     o_tok.backward(dctx.float())
@@ -286,7 +288,7 @@ def test_attention_bwd_rope_chain():
     cos, sin = O.rope_tables(L, hd)
     qs = O.apply_rope(ylin[0] * hd ** -0.5, cos, sin)
     ks = O.apply_rope(ylin[1], cos, sin)
-    qb, kb, vb = bf(qs.detach()).to(DEV), bf(ks.detach()).to(DEV), bf(ylin[2].detach()).to(DEV)
+    qb, kb, vb = bf(qs.detach() * hip.LOG2E).to(DEV), bf(ks.detach()).to(DEV), bf(ylin[2].detach()).to(DEV)
     ctx = torch.empty(B * L, H * hd, dtype=torch.bfloat16, device=DEV)
     lse = torch.empty(B, H, L, device=DEV)
     hip.call("oneprot_attn_fwd", qb, kb, vb, None, ctx, lse, B, H, L, hd)

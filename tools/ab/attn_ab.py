@@ -8,7 +8,7 @@ B, H, L, hd = 256, 20, 512, int(os.environ.get("HD", "32"))
 variants = sys.argv[1:] or ["0"]
 g = torch.Generator(device="cuda").manual_seed(0)
 q = (torch.randn(B, H, L, hd, device="cuda", generator=g) * hd ** -0.5).to(torch.bfloat16)
-q2 = (q.float() * 1.4426950408889634).to(torch.bfloat16)      # variants named mf*: q pre-multiplied by log2(e)
+q2 = (q.float() * 1.4426950408889634).to(torch.bfloat16)      # variants named mf* (and the product kernels since round 1): q pre-multiplied by log2(e)
 k = torch.randn(B, H, L, hd, device="cuda", generator=g).to(torch.bfloat16)
 v = torch.randn(B, H, L, hd, device="cuda", generator=g).to(torch.bfloat16)
 bias = torch.zeros(B, L, device="cuda")
@@ -30,8 +30,8 @@ ws = torch.empty(libs[variants[0]].oneprot_attn_bwd_workspace(B, H, L), dtype=to
 st = torch.cuda.current_stream().cuda_stream
 def fwd(lib, qq=None): 
     rc = lib.oneprot_attn_fwd((qq if qq is not None else q).data_ptr(), k.data_ptr(), v.data_ptr(), bias.data_ptr(), ctx.data_ptr(), lse.data_ptr(), B, H, L, hd, st); assert rc == 0, rc
-def bwd(lib):
-    rc = lib.oneprot_attn_bwd(q.data_ptr(), k.data_ptr(), v.data_ptr(), bias.data_ptr(), ctx.data_ptr(), dctx.data_ptr(), lse.data_ptr(), cos.data_ptr(), sin.data_ptr(),
+def bwd(lib, qq=None):
+    rc = lib.oneprot_attn_bwd((qq if qq is not None else q).data_ptr(), k.data_ptr(), v.data_ptr(), bias.data_ptr(), ctx.data_ptr(), dctx.data_ptr(), lse.data_ptr(), cos.data_ptr(), sin.data_ptr(),
                               hd ** -0.5, dqkv.data_ptr(), ws.data_ptr(), B, H, L, hd, st); assert rc == 0, rc
 def timeit(fn, iters=10):
     fn(); torch.cuda.synchronize()
@@ -47,7 +47,7 @@ for name, fn in (("fwd", fwd), ("bwd", bwd)):
     res = {n: [] for n in variants}
     for rep in range(3):
         for n in variants:
-            res[n].append(timeit((lambda: fwd(libs[n], q2)) if (name == "fwd" and n.startswith("mf")) else (lambda: fn(libs[n]))))
+            res[n].append(timeit((lambda: fn(libs[n], q2)) if n.startswith("mf") else (lambda: fn(libs[n]))))
     print(name, "  ".join(f"v{n}:{statistics.median(t):.0f}us" for n, t in res.items()), flush=True)
 # correctness of each variant's forward vs variant 0 (ablations differ by construction)
 fwd(libs[variants[0]]); c0 = ctx.float().clone(); l0 = lse.clone()
