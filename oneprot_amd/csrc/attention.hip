@@ -12,7 +12,7 @@
 //                                     accumulator registers: the softmax row-reduce is in-lane + one lane^32 exchange;
 //     O^T[d][query] += V^T * P       (P straight from the accumulator registers as the B operand -- no LDS round trip;
 //                                     A = V^T gathered with ds_read_b64_tr_b16 from the row-major V tile)
-//   backward dQ kernel mirrors the forward (+ dP^T = V dO^T, dQ^T += K^T dS^T);
+//   backward dQ kernel mirrors the forward (+ dP^T = V dO^T, dQ^T += K^T dS^T) and forms delta = rowsum(dO * O) for both backward kernels;
 //   backward dK/dV kernel puts the key on the lane: S = Q K^T, dP = dO V^T, dV^T += dO^T P, dK^T += Q^T dS.
 // Tiles in LDS are row-major with a 16-byte-chunk XOR swizzle that keeps the ds_read_b128 row reads conflict-free.
 #include "common.h"
@@ -269,25 +269,6 @@ extern "C" int oneprot_attn_fwd(const void* q, const void* k, const void* v, con
 // =========================================================================================================
 // backward
 // =========================================================================================================
-// delta[b,h,l] = sum_d dctx[t, h*hd + d] * ctx[t, h*hd + d]
-template <int HD>
-__global__ void __launch_bounds__(256) k_attn_delta(const bf16_t* __restrict__ ctx, const bf16_t* __restrict__ dctx, float* __restrict__ delta, int B, int H, int L) {
-  const size_t idx = (size_t)blockIdx.x * 256 + threadIdx.x;     // (t, head)
-  if (idx >= (size_t)B * L * H) return;
-  const size_t t = idx / H; const int head = (int)(idx - t * H);
-  const bf16_t* a = ctx + t * (H * HD) + head * HD;
-  const bf16_t* g = dctx + t * (H * HD) + head * HD;
-  float s = 0.f;
-#pragma unroll
-  for (int c = 0; c < HD / 8; ++c) {
-    const u32x4 x = *reinterpret_cast<const u32x4*>(a + c * 8), y = *reinterpret_cast<const u32x4*>(g + c * 8);
-    s += bflo(x.x) * bflo(y.x) + bfhi(x.x) * bfhi(y.x) + bflo(x.y) * bflo(y.y) + bfhi(x.y) * bfhi(y.y) + bflo(x.z) * bflo(y.z) + bfhi(x.z) * bfhi(y.z) +
-         bflo(x.w) * bflo(y.w) + bfhi(x.w) * bfhi(y.w);
-  }
-  const size_t b = t / L; const int l = (int)(t - b * L);
-  delta[((size_t)b * H + head) * L + l] = s;
-}
-
 // inverse rotary on a gradient held as O^T-style accumulators: lane owns position `pos`, registers hold head-dim rows
 // d = 32 db + 8 g + 4 h + e.  dx1 = dy1 c + dy2 s ; dx2 = dy2 c - dy1 s   (transpose of hf modeling_esm.py:48-79), then * scale.
 template <int HD>
@@ -336,8 +317,8 @@ __device__ __forceinline__ void unrope_store(f32x16 (&acc)[Cfg<HD>::DBLK], const
 // ---- dQ: one wave = 32 queries, loops over all keys -------------------------------------------------------------
 template <int HD>
 __global__ void __launch_bounds__(256, 2) k_attn_bwd_dq(const bf16_t* __restrict__ q, const bf16_t* __restrict__ k, const bf16_t* __restrict__ v,
-                                                     const float* __restrict__ key_bias, const bf16_t* __restrict__ dctx, const float* __restrict__ lse,
-                                                     const float* __restrict__ delta, const float* __restrict__ cosT, const float* __restrict__ sinT,
+                                                     const float* __restrict__ key_bias, const bf16_t* __restrict__ ctx, const bf16_t* __restrict__ dctx,
+                                                     const float* __restrict__ lse, float* __restrict__ delta, const float* __restrict__ cosT, const float* __restrict__ sinT,
                                                      float q_scale, bf16_t* __restrict__ dqkv, int B, int H, int L, int nqb) {
   typedef Cfg<HD> C;
   extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
@@ -360,7 +341,18 @@ __global__ void __launch_bounds__(256, 2) k_attn_bwd_dq(const bf16_t* __restrict
     qf[st] = *reinterpret_cast<const bf8_t*>(q + ((size_t)bh * L + qrow) * HD + 16 * st + 8 * h);
     dof[st] = *reinterpret_cast<const bf8_t*>(dctx + ((size_t)b * L + qrow) * dm + head * HD + 16 * st + 8 * h);
   }
-  const float lse_q = lse[(size_t)bh * L + qrow] * LOG2E, delta_q = delta[(size_t)bh * L + qrow];      // scores are in log2 units (q stored x log2 e)
+  const float lse_q = lse[(size_t)bh * L + qrow] * LOG2E;      // scores are in log2 units (q stored x log2 e)
+  // delta[query] = sum_d dO[query, d] * O[query, d]: each lane holds 8 of every 16 head-dim columns of its query's dO; formed here (one
+  // lane^32 exchange) and published for the dK/dV kernel, which runs after this one on the same stream
+  float delta_q = 0.f;
+#pragma unroll
+  for (int st = 0; st < C::KSTEPS; ++st) {
+    const u32x4 x = *reinterpret_cast<const u32x4*>(ctx + ((size_t)b * L + qrow) * dm + head * HD + 16 * st + 8 * h), y = __builtin_bit_cast(u32x4, dof[st]);
+    delta_q += bflo(x.x) * bflo(y.x) + bfhi(x.x) * bfhi(y.x) + bflo(x.y) * bflo(y.y) + bfhi(x.y) * bfhi(y.y) + bflo(x.z) * bflo(y.z) + bfhi(x.z) * bfhi(y.z) +
+               bflo(x.w) * bflo(y.w) + bfhi(x.w) * bfhi(y.w);
+  }
+  delta_q += __shfl_xor(delta_q, 32, 64);
+  if (h == 0 && qidx < L) delta[(size_t)bh * L + qidx] = delta_q;
   f32x16 acc[C::DBLK];
 #pragma unroll
   for (int d = 0; d < C::DBLK; ++d) acc[d] = zero16();
@@ -478,14 +470,12 @@ __global__ void __launch_bounds__(256, 2) k_attn_bwd_dkv(const bf16_t* __restric
 template <int HD>
 static int launch_bwd(const void* q, const void* k, const void* v, const float* key_bias, const void* ctx, const void* dctx, const float* lse, float* delta,
                       const float* cosT, const float* sinT, float q_scale, void* dqkv, int B, int H, int L, hipStream_t s) {
-  const size_t n = (size_t)B * L * H;
-  hipLaunchKernelGGL(k_attn_delta<HD>, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, s, (const bf16_t*)ctx, (const bf16_t*)dctx, delta, B, H, L);
   const int nb = (L + 127) / 128;
   const int nbh8 = ((B * H + 7) / 8) * 8;
   const size_t lds_q = (size_t)2 * KC * Cfg<HD>::ROWB + KC * sizeof(float);
   const size_t lds_kv = (size_t)2 * KC * Cfg<HD>::ROWB + 2 * KC * sizeof(float);
   hipLaunchKernelGGL(k_attn_bwd_dq<HD>, dim3(nbh8 * nb), dim3(256), lds_q, s, (const bf16_t*)q, (const bf16_t*)k, (const bf16_t*)v, key_bias,
-                     (const bf16_t*)dctx, lse, (const float*)delta, cosT, sinT, q_scale, (bf16_t*)dqkv, B, H, L, nb);
+                     (const bf16_t*)ctx, (const bf16_t*)dctx, lse, delta, cosT, sinT, q_scale, (bf16_t*)dqkv, B, H, L, nb);
   hipLaunchKernelGGL(k_attn_bwd_dkv<HD>, dim3(nbh8 * nb), dim3(256), lds_kv, s, (const bf16_t*)q, (const bf16_t*)k, (const bf16_t*)v, key_bias,
                      (const bf16_t*)dctx, lse, (const float*)delta, cosT, sinT, (bf16_t*)dqkv, B, H, L, nb);
   return launch_status();

@@ -297,20 +297,26 @@ __global__ void __launch_bounds__(256) k_layernorm_bwd(const void* __restrict__ 
 extern "C" size_t oneprot_layernorm_bwd_workspace(int d) { return (size_t)LN_BWD_BLOCKS * 2 * d * sizeof(float); }
 
 // dgamma_dbeta: [2][d] laid out as dgamma then dbeta (the two may be non-adjacent: pass both pointers)
-// 16 columns per block, 16 part-slices per column (fixed summation order => deterministic)
-__global__ void __launch_bounds__(256) k_ln_reduce(const float* __restrict__ partial, float* __restrict__ dgamma, float* __restrict__ dbeta, int nparts, int d, int accumulate) {
-  __shared__ float s_sl[16][17];
+// 16 columns per block, 64 part-slices per column (1024 threads: the 2048 x 2d partial matrix is 10 MB and the kernel is bound by loads in
+// flight, not bandwidth; fixed summation order => deterministic)
+__global__ void __launch_bounds__(1024) k_ln_reduce(const float* __restrict__ partial, float* __restrict__ dgamma, float* __restrict__ dbeta, int nparts, int d, int accumulate) {
+  __shared__ float s_sl[64][17];
   const int c = threadIdx.x & 15, sl = threadIdx.x >> 4;
   const int j = blockIdx.x * 16 + c;
   float s = 0.f;
   if (j < 2 * d)
-    for (int p = sl; p < nparts; p += 16) s += partial[(size_t)p * 2 * d + j];
+    for (int p = sl; p < nparts; p += 64) s += partial[(size_t)p * 2 * d + j];
   s_sl[sl][c] = s;
   __syncthreads();
-  if (sl == 0 && j < 2 * d) {
+  if (sl < 4) {                       // 4 x 16 partial sums, then 4 -> 1
     float t = 0.f;
 #pragma unroll
-    for (int q = 0; q < 16; ++q) t += s_sl[q][c];
+    for (int q = 0; q < 16; ++q) t += s_sl[sl * 16 + q][c];
+    s_sl[sl][c] = t;
+  }
+  __syncthreads();
+  if (sl == 0 && j < 2 * d) {
+    const float t = (s_sl[0][c] + s_sl[1][c]) + (s_sl[2][c] + s_sl[3][c]);
     float* out = j < d ? dgamma + j : dbeta + (j - d);
     *out = accumulate ? *out + t : t;
   }
@@ -336,7 +342,7 @@ extern "C" int oneprot_layernorm_bwd(const void* dy, int dy_mode, const float* w
 #undef LNB_NV
 #undef LAUNCH_LNB
   if (dgamma)
-    hipLaunchKernelGGL(k_ln_reduce, dim3((2 * d + 15) / 16), dim3(256), 0, s, (const float*)workspace, dgamma, dbeta, blocks, d, accumulate_param_grads);
+    hipLaunchKernelGGL(k_ln_reduce, dim3((2 * d + 15) / 16), dim3(1024), 0, s, (const float*)workspace, dgamma, dbeta, blocks, d, accumulate_param_grads);
   return launch_status();
 }
 
