@@ -186,7 +186,7 @@ __device__ __forceinline__ void gemm_epilogue(const GemmArgs& p, const float* bi
   }
 }
 
-template <int EPI, int WM, int WN, int MT, int NTW, int BKT, int NSTAGE, int EPH, int MINW, bool PIPE>
+template <int EPI, int WM, int WN, int MT, int NTW, int BKT, int NSTAGE, int EPH, int MINW, bool PIPE, bool FULLT>
 __global__ void __launch_bounds__(WM * WN * 64, MINW) k_gemm_nt(const GemmArgs p) {
   typedef Shape<WM, WN, MT, NTW, BKT, NSTAGE, EPH> S;
   constexpr int CH = BKT / 8;                      // chunks per row
@@ -214,7 +214,8 @@ __global__ void __launch_bounds__(WM * WN * 64, MINW) k_gemm_nt(const GemmArgs p
   const int tn = ng * SUP_N + n_in;
   if (tm >= p.tiles_m) return;
   const int m0 = tm * S::BM_, n0 = tn * S::BN_;
-  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int tid = threadIdx.x, lane = tid & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);      // wave-uniform by construction: keeps LDS-DMA destinations and tile bases on the scalar unit
   const int wr = wave / WN, wc = wave % WN;
 
   // ---- per-lane staging addresses: one global_load_lds instruction covers RPI rows of ROWB bytes (1 KiB, lane-linear)
@@ -240,10 +241,30 @@ __global__ void __launch_bounds__(WM * WN * 64, MINW) k_gemm_nt(const GemmArgs p
   }
   const int nk = (p.K + BKT - 1) / BKT;
 
+  // FULLT (every tile inside [M, N], K a multiple of the K-slice -- chosen by the host): no zero-page selects, and each source address is
+  // a wave-uniform base (tile origin + K offset, kept and advanced on the scalar unit) plus a constant 32-bit per-lane offset, i.e. the
+  // saddr + voffset form of global_load_lds: the main loop's vector ALU work per K-step drops from ~55 instructions to a handful.
+  unsigned a_rel[S::A_IPW], b_rel[S::B_IPW];
+#pragma unroll
+  for (int i = 0; i < S::A_IPW; ++i) a_rel[i] = (unsigned)((wave * S::A_IPW + i) * S::RPI + srow) * (unsigned)p.lda * 2u + (unsigned)a_chunk[i] * 16u;
+#pragma unroll
+  for (int i = 0; i < S::B_IPW; ++i) b_rel[i] = (unsigned)((wave * S::B_IPW + i) * S::RPI + srow) * (unsigned)p.ldb * 2u + (unsigned)b_chunk[i] * 16u;
+  const unsigned char* a_tile = reinterpret_cast<const unsigned char*>(p.A + (size_t)m0 * p.lda);
+  const unsigned char* b_tile = reinterpret_cast<const unsigned char*>(p.B + (size_t)n0 * p.ldb);
+
   auto stage = [&](int t, int buf) {
     unsigned char* sA = smem + buf * S::STAGE;
     unsigned char* sB = sA + S::BM_ * S::ROWB;
     const int k0 = t * BKT;
+    if constexpr (FULLT) {
+      const unsigned char* ak = a_tile + (size_t)k0 * 2;
+      const unsigned char* bk = b_tile + (size_t)k0 * 2;
+#pragma unroll
+      for (int i = 0; i < S::A_IPW; ++i) __builtin_amdgcn_global_load_lds(GLB_PTR(ak + a_rel[i]), LDS_PTR(sA + (wave * S::A_IPW + i) * 1024), 16, 0, 0);
+#pragma unroll
+      for (int i = 0; i < S::B_IPW; ++i) __builtin_amdgcn_global_load_lds(GLB_PTR(bk + b_rel[i]), LDS_PTR(sB + (wave * S::B_IPW + i) * 1024), 16, 0, 0);
+      return;
+    }
 #pragma unroll
     for (int i = 0; i < S::A_IPW; ++i) {
       const unsigned char* ga = (a_ok[i] && (k0 + a_chunk[i] * 8) < p.K) ? a_src[i] + (size_t)k0 * 2 : zero;
@@ -358,15 +379,15 @@ __global__ void __launch_bounds__(WM * WN * 64, MINW) k_gemm_nt(const GemmArgs p
   __syncthreads();          // everyone done with the staging ring before it is reused as epilogue tiles
 
   // ---- epilogue (staging tiles reuse the ring memory)
-  gemm_epilogue<EPI, MT, NTW, EPH, false>(p, p.bias, acc, reinterpret_cast<float*>(smem) + wave * EPH * EPI_LD, m0, n0, wr, wc, lane);
+  gemm_epilogue<EPI, MT, NTW, EPH, FULLT>(p, p.bias, acc, reinterpret_cast<float*>(smem) + wave * EPH * EPI_LD, m0, n0, wr, wc, lane);
 }
 
-template <int EPI, int WM, int WN, int MT, int NTW, int BKT, int NSTAGE, int EPH, int MINW, bool PIPE>
-static int launch_shape(GemmArgs a, hipStream_t s) {
+template <int EPI, int WM, int WN, int MT, int NTW, int BKT, int NSTAGE, int EPH, int MINW, bool PIPE, bool FULLT>
+static int launch_shape_full(GemmArgs a, hipStream_t s) {
   typedef Shape<WM, WN, MT, NTW, BKT, NSTAGE, EPH> S;
   static bool configured = false;
   if (!configured) {
-    if (hipFuncSetAttribute((const void*)k_gemm_nt<EPI, WM, WN, MT, NTW, BKT, NSTAGE, EPH, MINW, PIPE>, hipFuncAttributeMaxDynamicSharedMemorySize, S::LDS) != hipSuccess)
+    if (hipFuncSetAttribute((const void*)k_gemm_nt<EPI, WM, WN, MT, NTW, BKT, NSTAGE, EPH, MINW, PIPE, FULLT>, hipFuncAttributeMaxDynamicSharedMemorySize, S::LDS) != hipSuccess)
       return OP_ELAUNCH;
     configured = true;
   }
@@ -374,8 +395,19 @@ static int launch_shape(GemmArgs a, hipStream_t s) {
   a.tiles_n = (a.N + S::BN_ - 1) / S::BN_;
   const int pm_total = (a.tiles_m + 7) / 8;
   const int grid = ((pm_total + 3) / 4) * (4 * 10 * ((a.tiles_n + 9) / 10)) * 8;       // super-tile slots (SUP_M=4, SUP_N=10); surplus blocks exit at once
-  hipLaunchKernelGGL((k_gemm_nt<EPI, WM, WN, MT, NTW, BKT, NSTAGE, EPH, MINW, PIPE>), dim3(grid), dim3(S::NW * 64), S::LDS, s, a);
+  hipLaunchKernelGGL((k_gemm_nt<EPI, WM, WN, MT, NTW, BKT, NSTAGE, EPH, MINW, PIPE, FULLT>), dim3(grid), dim3(S::NW * 64), S::LDS, s, a);
   return launch_status();
+}
+
+// FULL-tile specialisation only for the shapes the heuristic picks (keeps the number of kernel instantiations down)
+template <int EPI, int WM, int WN, int MT, int NTW, int BKT, int NSTAGE, int EPH, int MINW, bool PIPE, bool TRY_FULL = false>
+static int launch_shape(GemmArgs a, hipStream_t s) {
+  typedef Shape<WM, WN, MT, NTW, BKT, NSTAGE, EPH> S;
+  if constexpr (TRY_FULL) {
+    const bool full = a.M % S::BM_ == 0 && a.N % S::BN_ == 0 && a.K % BKT == 0 && (size_t)S::BM_ * a.lda * 2 < (1ull << 31) && (size_t)S::BN_ * a.ldb * 2 < (1ull << 31);
+    if (full) return launch_shape_full<EPI, WM, WN, MT, NTW, BKT, NSTAGE, EPH, MINW, PIPE, true>(a, s);
+  }
+  return launch_shape_full<EPI, WM, WN, MT, NTW, BKT, NSTAGE, EPH, MINW, PIPE, false>(a, s);
 }
 
 static int g_force_shape = -1;     // test / tuning hook, see launch_gemm
@@ -398,10 +430,10 @@ static int launch_gemm(const GemmArgs& a, hipStream_t s) {
     case 7: return launch_shape<EPI, 2, 2, 8, 8, 32, 4, 32, 1, false>(a, s);      // 256x256, 4 waves x (128x128), BK32 x4, one wave per SIMD
     case 6: return launch_shape<EPI, 2, 2, 8, 8, 64, 2, 32, 1, false>(a, s);      // 256x256, 4 waves x (128x128), BK64 x2, one wave per SIMD
     case 5: return launch_shape<EPI, 2, 4, 8, 4, 32, 4, 32, 2, false>(a, s);      // 256x256 without fragment pipelining (A/B runs)
-    case 4: return launch_shape<EPI, 2, 4, 8, 4, 64, 2, 32, 2, true>(a, s);       // 256x256, BK64, 2 stages, pipelined fragments
-    case 3: return launch_shape<EPI, 2, 2, 4, 4, 64, 2, 64, 2, false>(a, s);
+    case 4: return launch_shape<EPI, 2, 4, 8, 4, 64, 2, 32, 2, true, true>(a, s);       // 256x256, BK64, 2 stages, pipelined fragments
+    case 3: return launch_shape<EPI, 2, 2, 4, 4, 64, 2, 64, 2, false, true>(a, s);
     case 2: return launch_shape<EPI, 2, 4, 8, 4, 32, 4, 32, 2, true>(a, s);
-    case 1: return launch_shape<EPI, 4, 2, 4, 4, 32, 3, 32, 4, false>(a, s);
+    case 1: return launch_shape<EPI, 4, 2, 4, 4, 32, 3, 32, 4, false, true>(a, s);
     default: return launch_shape<EPI, 2, 2, 4, 4, 32, 3, 32, 3, true>(a, s);
   }
 }

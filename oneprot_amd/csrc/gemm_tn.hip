@@ -53,7 +53,8 @@ __global__ void __launch_bounds__(256, MINW) k_gemm_tn(const bf16_t* __restrict_
   const int split = w / tiles_all, tile = w - split * tiles_all;
   const int tn = tile / tiles_k, tk = tile - tn * tiles_k;
   const int n0 = tn * 128, k0 = tk * 128;
-  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int tid = threadIdx.x, lane = tid & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
   const int wr = wave >> 1, wc = wave & 1;
   const int mbeg = split * m_per_split;
   const int mend = min(M, mbeg + m_per_split);
@@ -108,7 +109,30 @@ __global__ void __launch_bounds__(256, MINW) k_gemm_tn(const bf16_t* __restrict_
     // 60-185 issue cycles inside an MFMA phase (MI355X_MICROARCH.md), 8 pieces per 32 MFMAs; the plain pair costs ~20.  Two LDS buffers, the
     // loads of stage t+2 are issued after stage t+1 is committed and land during step t+1.
     u32x4 gy[IPW], gx[IPW];
+    // Fast path (wave-uniform test): the work-group's tile lies inside [N, K] and its token range is whole stages -- every address is then a
+    // uniform base (advanced per stage on the scalar unit) plus a constant 32-bit per-lane offset, no selects, no 64-bit multiplies: the
+    // kernel is bound by instruction issue (32 MFMAs + 32 transpose reads + 16 fill instructions per stage), so this is not cosmetic.
+    const bool fast = (n0 + 128 <= N) && (k0 + 128 <= K) && (mbeg + nsteps * BT <= mend) && ((size_t)BT * ldy * 2 < (1u << 31)) && ((size_t)BT * ldx * 2 < (1u << 31));
+    unsigned yrel[IPW], xrel[IPW];
+#pragma unroll
+    for (int i = 0; i < IPW; ++i) {
+      const int sc = schunk ^ tn_f(rows[i]);
+      yrel[i] = (unsigned)rows[i] * (unsigned)ldy * 2u + (unsigned)sc * 16u;
+      xrel[i] = (unsigned)rows[i] * (unsigned)ldx * 2u + (unsigned)sc * 16u;
+    }
+    const unsigned char* ybase = reinterpret_cast<const unsigned char*>(dY + (size_t)mbeg * ldy + n0);
+    const unsigned char* xbase = reinterpret_cast<const unsigned char*>(X + (size_t)mbeg * ldx + k0);
     auto fetch = [&](int t) {
+      if (fast) {
+        const unsigned char* yt = ybase + (size_t)t * BT * ldy * 2;
+        const unsigned char* xt = xbase + (size_t)t * BT * ldx * 2;
+#pragma unroll
+        for (int i = 0; i < IPW; ++i) {
+          gy[i] = *reinterpret_cast<const u32x4*>(yt + yrel[i]);
+          gx[i] = *reinterpret_cast<const u32x4*>(xt + xrel[i]);
+        }
+        return;
+      }
       const int mb = mbeg + t * BT;
 #pragma unroll
       for (int i = 0; i < IPW; ++i) {
