@@ -56,16 +56,16 @@ __device__ __forceinline__ float gelu_erf_grad(float x) {
 // erf-GELU and its derivative from ONE exponential: erf(y), y = x/sqrt2, by Abramowitz-Stegun 7.1.26 (|err| <= 1.5e-7 on erf,
 // far below the bf16 rounding of the stored results); exp(-y^2) = exp(-x^2/2) is also the Gaussian pdf factor of the derivative.
 __device__ __forceinline__ void gelu_fwd_and_grad(float x, float& g, float& dg) {
-  const float ax = fabsf(x) * 0.70710678118654752f;
-  const float t = __builtin_amdgcn_rcpf(fmaf(0.3275911f, ax, 1.0f));
-  const float e = __expf(-ax * ax);
-  float poly = fmaf(1.061405429f, t, -1.453152027f);
-  poly = fmaf(poly, t, 1.421413741f);
-  poly = fmaf(poly, t, -0.284496736f);
-  poly = fmaf(poly, t, 0.254829592f);
-  const float erf_abs = 1.0f - poly * t * e;
-  const float erfv = copysignf(erf_abs, x);
-  const float cdf = 0.5f * (1.0f + erfv);
+  // written for instruction count (the GEMM epilogues that inline this are issue-bound): constants folded so that |x| and x^2 feed the
+  // rational argument and the exponential directly; h = 0.5 * erfc(|x| / sqrt2) comes out of the polynomial with the 0.5 folded in
+  const float t = __builtin_amdgcn_rcpf(fmaf(0.23164189f, fabsf(x), 1.0f));          // 0.3275911 / sqrt2
+  const float e = __builtin_amdgcn_exp2f(x * x * -0.72134752f);                        // exp(-x^2 / 2) = 2^(-x^2 * log2(e) / 2)
+  float poly = fmaf(0.5307027145f, t, -0.7265760135f);
+  poly = fmaf(poly, t, 0.7107068705f);
+  poly = fmaf(poly, t, -0.142248368f);
+  poly = fmaf(poly, t, 0.127414796f);
+  const float h = poly * t * e;                                                        // 0.5 * erfc(|x|/sqrt2)
+  const float cdf = 0.5f + copysignf(0.5f - h, x);                                     // Phi(x)
   g = x * cdf;
   dg = fmaf(x * e, 0.3989422804014327f, cdf);
 }

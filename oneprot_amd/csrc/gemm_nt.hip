@@ -93,11 +93,25 @@ __device__ __forceinline__ void gemm_epilogue(const GemmArgs& p, const float* bi
     sgn = lo ? -1.f : 1.f;
 #pragma unroll
     for (int e = 0; e < 8; ++e) pbias8[e] = 0.f;
+    sec = __builtin_amdgcn_readfirstlane(sec);          // 64-column groups never straddle the q / k / v sections (H*hd % 64 == 0): scalar branches below
     if (bias_src && sec < 2) {
       const int pg = gn + (lo ? half : -half);
       const float4 b0 = *reinterpret_cast<const float4*>(bias_src + pg), b1 = *reinterpret_cast<const float4*>(bias_src + pg + 4);
       pbias8[0] = b0.x; pbias8[1] = b0.y; pbias8[2] = b0.z; pbias8[3] = b0.w; pbias8[4] = b1.x; pbias8[5] = b1.y; pbias8[6] = b1.z; pbias8[7] = b1.w;
     }
+  }
+  // QKV/RoPE: (sequence b, position l) of this lane's row and the head-major output offset, advanced by 8 rows per pass (no division,
+  // no 32-bit multiplies inside the pass loop)
+  int rp_l = 0; size_t rp_off = 0; const float* rp_cos = nullptr; const float* rp_sin = nullptr;
+  if (EPI == ONEPROT_EPI_QKV_ROPE) {
+    const int gm0 = m0 + wr * (MT * 16) + er;
+    const int b0 = gm0 / p.L;
+    rp_l = gm0 - b0 * p.L;
+    rp_off = (((size_t)b0 * p.H + head) * p.L + rp_l) * p.hd + j0;
+    const int hh = p.hd >> 1;
+    const int jj = j0 < hh ? j0 : j0 - hh;
+    rp_cos = p.cos + (size_t)rp_l * hh + jj;
+    rp_sin = p.sin + (size_t)rp_l * hh + jj;
   }
 #pragma unroll
   for (int half = 0; half < (MT * 16) / EPH; ++half) {
@@ -114,6 +128,13 @@ __device__ __forceinline__ void gemm_epilogue(const GemmArgs& p, const float* bi
     for (int pass = 0; pass < EPH / 8; ++pass) {
     const int r = pass * 8 + er;
     const int gm = m0 + wr * (MT * 16) + half * EPH + r;
+    if (EPI == ONEPROT_EPI_QKV_ROPE) {
+      if (half > 0 || pass > 0) {            // 8 rows further than the previous pass
+        const int hh = p.hd >> 1;
+        rp_l += 8; rp_off += (size_t)8 * p.hd; rp_cos += 8 * hh; rp_sin += 8 * hh;
+        if (rp_l >= p.L) { rp_l -= p.L; rp_off += (size_t)(p.H - 1) * p.L * p.hd; rp_cos -= (size_t)p.L * hh; rp_sin -= (size_t)p.L * hh; }
+      }
+    }
     if (!FULL && gm >= p.M) continue;
     float v[8];
     {
@@ -158,26 +179,21 @@ __device__ __forceinline__ void gemm_epilogue(const GemmArgs& p, const float* bi
       u32x4 w; w.x = pack2bf(v[0], v[1]); w.y = pack2bf(v[2], v[3]); w.z = pack2bf(v[4], v[5]); w.w = pack2bf(v[6], v[7]);
       *reinterpret_cast<u32x4*>((bf16_t*)p.out0 + o) = w;
     } else if (EPI == ONEPROT_EPI_QKV_ROPE) {
-      const int b = gm / p.L, l = gm - b * p.L;
       if (sec < 2) {
         float pv[8];
         const float4 q0 = *reinterpret_cast<const float4*>(et + r * EPI_LD + pc), q1 = *reinterpret_cast<const float4*>(et + r * EPI_LD + pc + 4);
         pv[0] = q0.x; pv[1] = q0.y; pv[2] = q0.z; pv[3] = q0.w; pv[4] = q1.x; pv[5] = q1.y; pv[6] = q1.z; pv[7] = q1.w;
-        const int half = p.hd >> 1;
-        const int jj = j0 < half ? j0 : j0 - half;
-        const float* cs = p.cos + (size_t)l * half + jj;
-        const float* sn = p.sin + (size_t)l * half + jj;
+        const float4 c0 = *reinterpret_cast<const float4*>(rp_cos), c1 = *reinterpret_cast<const float4*>(rp_cos + 4);
+        const float4 s0 = *reinterpret_cast<const float4*>(rp_sin), s1 = *reinterpret_cast<const float4*>(rp_sin + 4);
+        const float cs[8] = {c0.x, c0.y, c0.z, c0.w, c1.x, c1.y, c1.z, c1.w}, sn[8] = {s0.x, s0.y, s0.z, s0.w, s1.x, s1.y, s1.z, s1.w};
         const float sc = sec == 0 ? p.q_scale : 1.0f;
+        const float sp = sgn * sc;
 #pragma unroll
-        for (int e = 0; e < 8; ++e) {
-          const float x = v[e] * sc, xp = (pv[e] + pbias8[e]) * sc;
-          v[e] = x * cs[e] + sgn * xp * sn[e];
-        }
+        for (int e = 0; e < 8; ++e) v[e] = (v[e] * sc) * cs[e] + ((pv[e] + pbias8[e]) * sp) * sn[e];
       }
       bf16_t* dst = (bf16_t*)(sec == 0 ? p.out0 : (sec == 1 ? p.out1 : p.out2));
-      const size_t oo = (((size_t)b * p.H + head) * p.L + l) * p.hd + j0;
       u32x4 w; w.x = pack2bf(v[0], v[1]); w.y = pack2bf(v[2], v[3]); w.z = pack2bf(v[4], v[5]); w.w = pack2bf(v[6], v[7]);
-      *reinterpret_cast<u32x4*>(dst + oo) = w;
+      *reinterpret_cast<u32x4*>(dst + rp_off) = w;
     }
   }
     }

@@ -22,18 +22,25 @@ def timeit(fn, iters=5):
     for _ in range(iters): fn()
     e1.record(); torch.cuda.synchronize()
     return e0.elapsed_time(e1) / iters * 1e3
-for (name, N, K, epi) in (("ffn1 gelu", f, d, 2), ("ffn1 bf16", f, d, 0), ("ffn2 resid", d, f, 3), ("ffn1_dgrad bf16", d, f, 0), ("out resid", d, d, 3), ("qkv_dgrad bf16", d, 3 * d, 0)):
+B_, L_, H_, hd_ = 256, 512, 20, 32
+cos = torch.rand(L_, hd_ // 2, device="cuda"); sin = torch.rand(L_, hd_ // 2, device="cuda")
+for (name, N, K, epi) in (("qkv rope", 3 * d, d, 4), ("ffn1 gelu", f, d, 2), ("ffn1 bf16", f, d, 0), ("ffn2 resid", d, f, 3), ("ffn1_dgrad bf16", d, f, 0), ("out resid", d, d, 3), ("qkv_dgrad bf16", d, 3 * d, 0)):
     A = torch.randn(T, K, device="cuda", generator=g).to(torch.bfloat16)
     W = (torch.randn(N, K, device="cuda", generator=g) * 0.05).to(torch.bfloat16)
     bias = torch.randn(N, device="cuda", generator=g)
     o0 = torch.empty(T, N, dtype=torch.float32 if epi == 3 else torch.bfloat16, device="cuda")
     o1 = torch.empty(T, N, dtype=torch.bfloat16, device="cuda") if epi == 2 else None
+    if epi == 4:
+        o0, o1, o2 = (torch.empty(B_, H_, L_, hd_, dtype=torch.bfloat16, device="cuda") for _ in range(3))
     aux = torch.randn(T, N, device="cuda", generator=g) if epi == 3 else None
     res = {"old": [], "new": []}
     outs = {}
     for rep in range(3):
         for n, lib in (("old", old), ("new", new)):
-            fn = lambda: lib.oneprot_gemm_bf16_nt(ptr(A), ptr(W), T, N, K, K, K, epi, ptr(bias), ptr(o0), ptr(o1), None, ptr(aux), None, None, 1.0, 0, 0, 0, st)
+            if epi == 4:
+                fn = lambda: lib.oneprot_gemm_bf16_nt(ptr(A), ptr(W), T, N, K, K, K, epi, ptr(bias), ptr(o0), ptr(o1), ptr(o2), None, ptr(cos), ptr(sin), hd_ ** -0.5, L_, H_, hd_, st)
+            else:
+                fn = lambda: lib.oneprot_gemm_bf16_nt(ptr(A), ptr(W), T, N, K, K, K, epi, ptr(bias), ptr(o0), ptr(o1), None, ptr(aux), None, None, 1.0, 0, 0, 0, st)
             res[n].append(timeit(fn))
             if epi != 3: outs[n] = o0.clone()
     fl = 2.0 * T * N * K
