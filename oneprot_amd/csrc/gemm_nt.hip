@@ -67,21 +67,14 @@ template <int N> __device__ __forceinline__ void wait_vmcnt() { asm volatile("s_
 // (A persistent variant of the kernel -- LDS ring running continuously across tiles, epilogue stores never waited for, bias in LDS, store-count-
 // exact vmcnt -- was built on this function, passed the tests and ran the FFN-1 launch in the same 0.70 ms as the plain form; dropped.)
 template <int EPI, int MT, int NTW, int EPH, bool FULL>
-__device__ __forceinline__ void gemm_epilogue(const GemmArgs& p, const float* bias_src, f32x4 (&acc)[MT][NTW], float* et, int m0, int n0, int wr, int wc, int lane) {
+__device__ __forceinline__ void gemm_epilogue(const GemmArgs& p, f32x4 (&acc)[MT][NTW], float* et, int m0, int n0, int wr, int wc, int lane) {
   const int frow = lane & 15, fq = lane >> 4;
   const int er = lane >> 3, ec = (lane & 7) * 8;
 #pragma unroll
   for (int nh = 0; nh < NTW / 4; ++nh) {       // 64-column halves of the wave tile
   const int gn = n0 + wc * (NTW * 16) + nh * 64 + ec;
-  float bias8[8];
-#pragma unroll
-  for (int e = 0; e < 8; ++e) bias8[e] = 0.f;
-  if (bias_src && (FULL || gn < p.N)) {
-    const float4 b0 = *reinterpret_cast<const float4*>(bias_src + gn), b1 = *reinterpret_cast<const float4*>(bias_src + gn + 4);
-    bias8[0] = b0.x; bias8[1] = b0.y; bias8[2] = b0.z; bias8[3] = b0.w; bias8[4] = b1.x; bias8[5] = b1.y; bias8[6] = b1.z; bias8[7] = b1.w;
-  }
   // QKV/RoPE constants for this lane's 8 columns
-  int sec = 0, head = 0, j0 = 0, pc = 0; float pbias8[8]; float sgn = 0.f;
+  int sec = 0, head = 0, j0 = 0, pc = 0; float sgn = 0.f;
   if (EPI == ONEPROT_EPI_QKV_ROPE && (FULL || gn < p.N)) {
     const int dm = p.H * p.hd;
     sec = gn / dm;
@@ -91,14 +84,7 @@ __device__ __forceinline__ void gemm_epilogue(const GemmArgs& p, const float* bi
     const bool lo = j0 < half;
     pc = ec + (lo ? half : -half);          // partner columns inside the wave tile
     sgn = lo ? -1.f : 1.f;
-#pragma unroll
-    for (int e = 0; e < 8; ++e) pbias8[e] = 0.f;
     sec = __builtin_amdgcn_readfirstlane(sec);          // 64-column groups never straddle the q / k / v sections (H*hd % 64 == 0): scalar branches below
-    if (bias_src && sec < 2) {
-      const int pg = gn + (lo ? half : -half);
-      const float4 b0 = *reinterpret_cast<const float4*>(bias_src + pg), b1 = *reinterpret_cast<const float4*>(bias_src + pg + 4);
-      pbias8[0] = b0.x; pbias8[1] = b0.y; pbias8[2] = b0.z; pbias8[3] = b0.w; pbias8[4] = b1.x; pbias8[5] = b1.y; pbias8[6] = b1.z; pbias8[7] = b1.w;
-    }
   }
   // QKV/RoPE: (sequence b, position l) of this lane's row and the head-major output offset, advanced by 8 rows per pass (no division,
   // no 32-bit multiplies inside the pass loop)
@@ -141,8 +127,6 @@ __device__ __forceinline__ void gemm_epilogue(const GemmArgs& p, const float* bi
       const float4 v0 = *reinterpret_cast<const float4*>(et + r * EPI_LD + ec), v1 = *reinterpret_cast<const float4*>(et + r * EPI_LD + ec + 4);
       v[0] = v0.x; v[1] = v0.y; v[2] = v0.z; v[3] = v0.w; v[4] = v1.x; v[5] = v1.y; v[6] = v1.z; v[7] = v1.w;
     }
-#pragma unroll
-    for (int e = 0; e < 8; ++e) v[e] += bias8[e];
     const size_t o = (size_t)gm * p.N + gn;
     if (EPI == ONEPROT_EPI_BF16) {
       u32x4 w; w.x = pack2bf(v[0], v[1]); w.y = pack2bf(v[2], v[3]); w.z = pack2bf(v[4], v[5]); w.w = pack2bf(v[6], v[7]);
@@ -189,7 +173,7 @@ __device__ __forceinline__ void gemm_epilogue(const GemmArgs& p, const float* bi
         const float sc = sec == 0 ? p.q_scale : 1.0f;
         const float sp = sgn * sc;
 #pragma unroll
-        for (int e = 0; e < 8; ++e) v[e] = (v[e] * sc) * cs[e] + ((pv[e] + pbias8[e]) * sp) * sn[e];
+        for (int e = 0; e < 8; ++e) v[e] = (v[e] * sc) * cs[e] + (pv[e] * sp) * sn[e];
       }
       bf16_t* dst = (bf16_t*)(sec == 0 ? p.out0 : (sec == 1 ? p.out1 : p.out2));
       u32x4 w; w.x = pack2bf(v[0], v[1]); w.y = pack2bf(v[2], v[3]); w.z = pack2bf(v[4], v[5]); w.w = pack2bf(v[6], v[7]);
@@ -293,11 +277,16 @@ __global__ void __launch_bounds__(WM * WN * 64, MINW) k_gemm_nt(const GemmArgs p
     }
   };
 
+  // accumulators start at the bias of their column (C layout: column = lane & 15 within each 16-wide tile): the epilogues then have no bias
+  // add and, for QKV/RoPE, the rotation partner read back from the staging tile already carries its own bias
   f32x4 acc[MT][NTW];
 #pragma unroll
-  for (int i = 0; i < MT; ++i)
+  for (int j = 0; j < NTW; ++j) {
+    const int gc = n0 + wc * (NTW * 16) + j * 16 + (lane & 15);
+    const float bj = (p.bias && gc < p.N) ? p.bias[gc] : 0.f;
 #pragma unroll
-    for (int j = 0; j < NTW; ++j) acc[i][j] = (f32x4){0.f, 0.f, 0.f, 0.f};
+    for (int i = 0; i < MT; ++i) acc[i][j] = (f32x4){bj, bj, bj, bj};
+  }
 
   // fragment read offsets (bytes within a stage's A or B image) for k-substep 0; substep 1 (BK 64) flips chunk bit 2
   const int frow = lane & 15, fq = lane >> 4;
@@ -395,7 +384,7 @@ __global__ void __launch_bounds__(WM * WN * 64, MINW) k_gemm_nt(const GemmArgs p
   __syncthreads();          // everyone done with the staging ring before it is reused as epilogue tiles
 
   // ---- epilogue (staging tiles reuse the ring memory)
-  gemm_epilogue<EPI, MT, NTW, EPH, FULLT>(p, p.bias, acc, reinterpret_cast<float*>(smem) + wave * EPH * EPI_LD, m0, n0, wr, wc, lane);
+  gemm_epilogue<EPI, MT, NTW, EPH, FULLT>(p, acc, reinterpret_cast<float*>(smem) + wave * EPH * EPI_LD, m0, n0, wr, wc, lane);
 }
 
 template <int EPI, int WM, int WN, int MT, int NTW, int BKT, int NSTAGE, int EPH, int MINW, bool PIPE, bool FULLT>
