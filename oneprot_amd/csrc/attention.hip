@@ -122,6 +122,17 @@ __device__ __forceinline__ f32x16 zero16() {
   return z;
 }
 
+// x ~= bf16(w0) + bf16(w1) + bf16(w2) (24 mantissa bits): row constants enter the score chains through an extra MFMA k-step whose operands
+// are bf16, so they are split.  Returns w0 | w1 << 16 and w2 (low half).  Non-finite x (padding: -inf) stays in w0 alone.
+__device__ __forceinline__ void split3_bf16(float x, unsigned& w01, unsigned& w2) {
+  const unsigned a = pack2bf(x, 0.f) & 0xffffu;
+  const float r1 = (fabsf(x) < 3.0e38f) ? x - bflo(a) : 0.f;
+  const unsigned b = pack2bf(r1, 0.f) & 0xffffu;
+  const float r2 = r1 - bflo(b);
+  w01 = a | (b << 16);
+  w2 = pack2bf(r2, 0.f) & 0xffffu;
+}
+
 // XCD-aware decode: blocks with the same (b,h) land on one XCD (they share K/V through its L2)
 __device__ __forceinline__ void decode_block(int nblk_per_bh, int nbh, int& bh, int& blk) {
   const int id = blockIdx.x, xcd = id & 7, seq = id >> 3;
@@ -324,7 +335,7 @@ __global__ void __launch_bounds__(256, 2) k_attn_bwd_dq(const bf16_t* __restrict
   extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
   unsigned char* sK = smem;
   unsigned char* sV = sK + KC * C::ROWB;
-  float* sBias = reinterpret_cast<float*>(sV + KC * C::ROWB);
+  u32x4* sE = reinterpret_cast<u32x4*>(sV + KC * C::ROWB);       // per key: bf16 [1, 1, 1, bias, 0, 0, 0, 0]; slot KC = zeros (as in the forward)
   int bh, qb;
   decode_block(nqb, B * H, bh, qb);
   if (bh >= B * H) return;
@@ -353,6 +364,15 @@ __global__ void __launch_bounds__(256, 2) k_attn_bwd_dq(const bf16_t* __restrict
   }
   delta_q += __shfl_xor(delta_q, 32, 64);
   if (h == 0 && qidx < L) delta[(size_t)bh * L + qidx] = delta_q;
+  // row constants through one extra MFMA k-step each (no per-element VALU): S' = K Q^T + [1,1,1,bias_key] . [-lse split, 1],
+  // dP' = V dO^T + [1,1,1,0] . [-delta split, 0]
+  u32x4 qe = {0u, 0u, 0u, 0u}, de = {0u, 0u, 0u, 0u}, ones3 = {0u, 0u, 0u, 0u};
+  if (h == 0) {
+    unsigned w01, w2;
+    split3_bf16(-lse_q, w01, w2); qe.x = w01; qe.y = w2 | 0x3F800000u;
+    split3_bf16(-delta_q, w01, w2); de.x = w01; de.y = w2;
+    ones3.x = 0x3F803F80u; ones3.y = 0x00003F80u;
+  }
   f32x16 acc[C::DBLK];
 #pragma unroll
   for (int d = 0; d < C::DBLK; ++d) acc[d] = zero16();
@@ -361,19 +381,19 @@ __global__ void __launch_bounds__(256, 2) k_attn_bwd_dq(const bf16_t* __restrict
     const int nrows = (nkeys + 31) & ~31;
     __syncthreads();
     load_tile_pair<HD>(sK, kbase + (size_t)kc0 * HD, HD, sV, vbase + (size_t)kc0 * HD, HD, nkeys, nrows);
-    for (int i = threadIdx.x; i < nrows; i += 256)
-      sBias[i] = i < nkeys ? (key_bias ? key_bias[(size_t)b * L + kc0 + i] : 0.f) : -INFINITY;
+    for (int i = threadIdx.x; i <= KC; i += 256) {
+      u32x4 e = {0u, 0u, 0u, 0u};
+      if (i < nrows) {
+        const float bv = i < nkeys ? (key_bias ? key_bias[(size_t)b * L + kc0 + i] : 0.f) : -INFINITY;
+        e.x = 0x3F803F80u; e.y = 0x3F80u | (pack2bf(bv, 0.f) << 16);
+      }
+      sE[i] = e;
+    }
     __syncthreads();
     for (int t = 0; t < nrows / 32; ++t) {
-      // accumulator initialisers carry the row constants: S starts at bias[key] - lse[query], dP at -delta[query]
-      f32x16 s, dp;
-#pragma unroll
-      for (int g = 0; g < 4; ++g) {
-        const float4 bv = *reinterpret_cast<const float4*>(sBias + t * 32 + 8 * g + 4 * h);
-        s[4 * g + 0] = bv.x - lse_q; s[4 * g + 1] = bv.y - lse_q; s[4 * g + 2] = bv.z - lse_q; s[4 * g + 3] = bv.w - lse_q;
-      }
-#pragma unroll
-      for (int r = 0; r < 16; ++r) dp[r] = -delta_q;
+      const u32x4 ke = sE[h ? KC : t * 32 + (lane & 31)];
+      f32x16 s = MFMA32(__builtin_bit_cast(bf8_t, ke), __builtin_bit_cast(bf8_t, qe), zero16());          // bias[key] - lse[query]
+      f32x16 dp = MFMA32(__builtin_bit_cast(bf8_t, ones3), __builtin_bit_cast(bf8_t, de), zero16());      // -delta[query]
 #pragma unroll
       for (int st = 0; st < C::KSTEPS; ++st) {
         s = MFMA32(rd_row<HD>(sK, t * 32 + (lane & 31), st, h), qf[st], s);
@@ -402,8 +422,7 @@ __global__ void __launch_bounds__(256, 2) k_attn_bwd_dkv(const bf16_t* __restric
   extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
   unsigned char* sQ = smem;
   unsigned char* sdO = sQ + KC * C::ROWB;
-  float* sLse = reinterpret_cast<float*>(sdO + KC * C::ROWB);
-  float* sDelta = sLse + KC;
+  u32x4* sQE = reinterpret_cast<u32x4*>(sdO + KC * C::ROWB);    // per query: bf16 [-lse split in 3, 1, -delta split in 3, 0]; slot KC = zeros
   int bh, kb;
   decode_block(nkb, B * H, bh, kb);
   if (bh >= B * H) return;
@@ -419,6 +438,9 @@ __global__ void __launch_bounds__(256, 2) k_attn_bwd_dkv(const bf16_t* __restric
     vf[st] = *reinterpret_cast<const bf8_t*>(v + ((size_t)bh * L + krow) * HD + 16 * st + 8 * h);
   }
   const float bias_k = kidx < L ? (key_bias ? key_bias[(size_t)b * L + kidx] : 0.f) : -INFINITY;
+  // key-side operands of the extra k-step: [1,1,1,bias_key,0,0,0,0] picks (-lse + bias) for S, [0,0,0,0,1,1,1,0] picks -delta for dP
+  u32x4 kS = {0u, 0u, 0u, 0u}, kD = {0u, 0u, 0u, 0u};
+  if (h == 0) { kS.x = 0x3F803F80u; kS.y = 0x3F80u | (pack2bf(bias_k, 0.f) << 16); kD.z = 0x3F803F80u; kD.w = 0x00003F80u; }
   f32x16 adk[C::DBLK], adv[C::DBLK];
 #pragma unroll
   for (int d = 0; d < C::DBLK; ++d) { adk[d] = zero16(); adv[d] = zero16(); }
@@ -427,20 +449,22 @@ __global__ void __launch_bounds__(256, 2) k_attn_bwd_dkv(const bf16_t* __restric
     const int nrows = (nq + 31) & ~31;
     __syncthreads();
     load_tile_pair<HD>(sQ, q + ((size_t)bh * L + qc0) * HD, HD, sdO, dctx + ((size_t)b * L + qc0) * dm + head * HD, dm, nq, nrows);
-    for (int i = threadIdx.x; i < nrows; i += 256) {
-      sLse[i] = i < nq ? -lse[(size_t)bh * L + qc0 + i] * LOG2E : -INFINITY;       // negated, log2 units: added to the S accumulator initialiser
-      sDelta[i] = i < nq ? -delta[(size_t)bh * L + qc0 + i] : 0.f;
+    for (int i = threadIdx.x; i <= KC; i += 256) {
+      u32x4 e = {0u, 0u, 0u, 0u};
+      if (i < nrows) {
+        unsigned w01, w2;
+        split3_bf16(i < nq ? -lse[(size_t)bh * L + qc0 + i] * LOG2E : -1.0e30f, w01, w2);       // log2 units; finite for padding rows (-inf x 0 in the dP pick would be NaN)
+        e.x = w01; e.y = w2 | 0x3F800000u;
+        split3_bf16(i < nq ? -delta[(size_t)bh * L + qc0 + i] : 0.f, w01, w2);
+        e.z = w01; e.w = w2;
+      }
+      sQE[i] = e;
     }
     __syncthreads();
     for (int t = 0; t < nrows / 32; ++t) {
-      f32x16 s, dp;
-#pragma unroll
-      for (int g = 0; g < 4; ++g) {
-        const float4 lv = *reinterpret_cast<const float4*>(sLse + t * 32 + 8 * g + 4 * h);       // staged as bias-free -lse
-        const float4 dv = *reinterpret_cast<const float4*>(sDelta + t * 32 + 8 * g + 4 * h);    // staged as -delta
-        s[4 * g + 0] = bias_k + lv.x; s[4 * g + 1] = bias_k + lv.y; s[4 * g + 2] = bias_k + lv.z; s[4 * g + 3] = bias_k + lv.w;
-        dp[4 * g + 0] = dv.x; dp[4 * g + 1] = dv.y; dp[4 * g + 2] = dv.z; dp[4 * g + 3] = dv.w;
-      }
+      const bf8_t qe_row = __builtin_bit_cast(bf8_t, sQE[h ? KC : t * 32 + (lane & 31)]);
+      f32x16 s = MFMA32(qe_row, __builtin_bit_cast(bf8_t, kS), zero16());            // bias[key] - lse[query]
+      f32x16 dp = MFMA32(qe_row, __builtin_bit_cast(bf8_t, kD), zero16());           // -delta[query]
 #pragma unroll
       for (int st = 0; st < C::KSTEPS; ++st) {
         s = MFMA32(rd_row<HD>(sQ, t * 32 + (lane & 31), st, h), kf[st], s);          // S[query][key] + bias - lse
@@ -472,8 +496,8 @@ static int launch_bwd(const void* q, const void* k, const void* v, const float* 
                       const float* cosT, const float* sinT, float q_scale, void* dqkv, int B, int H, int L, hipStream_t s) {
   const int nb = (L + 127) / 128;
   const int nbh8 = ((B * H + 7) / 8) * 8;
-  const size_t lds_q = (size_t)2 * KC * Cfg<HD>::ROWB + KC * sizeof(float);
-  const size_t lds_kv = (size_t)2 * KC * Cfg<HD>::ROWB + 2 * KC * sizeof(float);
+  const size_t lds_q = (size_t)2 * KC * Cfg<HD>::ROWB + (KC + 1) * 16;
+  const size_t lds_kv = (size_t)2 * KC * Cfg<HD>::ROWB + (KC + 1) * 16;
   hipLaunchKernelGGL(k_attn_bwd_dq<HD>, dim3(nbh8 * nb), dim3(256), lds_q, s, (const bf16_t*)q, (const bf16_t*)k, (const bf16_t*)v, key_bias,
                      (const bf16_t*)ctx, (const bf16_t*)dctx, lse, delta, cosT, sinT, q_scale, (bf16_t*)dqkv, B, H, L, nb);
   hipLaunchKernelGGL(k_attn_bwd_dkv<HD>, dim3(nbh8 * nb), dim3(256), lds_kv, s, (const bf16_t*)q, (const bf16_t*)k, (const bf16_t*)v, key_bias,

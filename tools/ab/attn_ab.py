@@ -50,6 +50,6 @@ for name, fn in (("fwd", fwd), ("bwd", bwd)):
             res[n].append(timeit((lambda: fn(libs[n], q2)) if n.startswith("mf") else (lambda: fn(libs[n]))))
     print(name, "  ".join(f"v{n}:{statistics.median(t):.0f}us" for n, t in res.items()), flush=True)
 # correctness of each variant's forward vs variant 0 (ablations differ by construction)
-fwd(libs[variants[0]]); c0 = ctx.float().clone(); l0 = lse.clone()
+fwd(libs[variants[0]], q2 if variants[0].startswith("mf") else None); c0 = ctx.float().clone(); l0 = lse.clone()
 for n in variants[1:]:
     fwd(libs[n], q2 if n.startswith("mf") else None); print(f"v{n} ctx max diff vs v{variants[0]}:", float((ctx.float() - c0).abs().max()), "lse diff", float((lse - l0).abs().max()))
