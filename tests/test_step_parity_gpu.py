@@ -532,6 +532,38 @@ def test_lora_text_encoder_vs_oracle(golden_dir, tmp_path):
                 assert _cos(got.cpu(), ref) > 0.98, (i, t, which)
 
 
+def test_max_length_sequences_vs_oracle():
+    """L = 1026 (ESM-2's max_position_embeddings; five attention key chunks, the last one partial), ragged to 700 / 257 tokens: sub-step loss and
+    gradient norm vs the CPU oracle."""
+    os.environ.update(RANK="0", WORLD_SIZE="1", ONEPROT_ALLOW_RANDOM_INIT="1")
+    from src.models.components.sequence_encoder import SequenceEncoder
+    from src.models.components.struct_token_encoder import StructTokenEncoder
+    from src.models.oneprot_module import OneProtLitModule
+    from oneprot_amd.optim import FusedAdam
+    torch.manual_seed(3)
+    name = "facebook/esm2_t6_8M_UR50D"
+    seq = SequenceEncoder(name, output_dim=1024, pooling_type="mean", proj_type="mlp", use_lora=False, frozen=False)
+    st = StructTokenEncoder(name, output_dim=1024, pooling_type="mean", proj_type="linear", use_logit_scale=True)
+    sd_seq = {k: v.detach().clone() for k, v in seq.state_dict().items()}
+    sd_st = {k: v.detach().clone() for k, v in st.state_dict().items()}
+    gen = torch.Generator().manual_seed(1881)
+    B, L = 3, 1026
+    seq_ids = torch.randint(4, 24, (B, L), generator=gen); st_ids = torch.randint(33, 53, (B, L), generator=gen)
+    for ids in (seq_ids, st_ids):
+        ids[:, 0] = 0
+        for b, n in enumerate([1026, 700, 257]):
+            ids[b, n - 1] = 2
+            ids[b, n:] = 1
+    cfg = dict(layers=6, hidden=320, heads=20, ffn=1280, pad=1, mask=32, eps=1e-5)
+    ref = O.train_substep(seq_ids, st_ids, sd_seq, sd_st, cfg, cfg, dict(kind="esm", pooling="mean", proj_type="mlp", use_logit_scale=False),
+                          dict(kind="esm", pooling="mean", proj_type="linear", use_logit_scale=True), use_l1=True)
+    module = OneProtLitModule(components={"sequence": seq, "struct_token": st}, optimizer=functools.partial(FusedAdam, lr=1e-3), loss_fn="CLIP",
+                              use_l1_regularization=True).to(DEV)
+    loss = float(module.training_step({"struct_token": (seq_ids.to(DEV), st_ids.to(DEV), "struct_token", None)}, 0).detach())
+    assert abs(loss - float(ref["loss"])) / float(ref["loss"]) < 1e-3, (loss, float(ref["loss"]))
+    assert abs(float(module.last_grad_norm) - float(ref["grad_total_norm"])) / float(ref["grad_total_norm"]) < 2e-2
+
+
 def test_mixed_batch_round_robin(golden_dir, tmp_path):
     """CombinedLoader('min_size') batches with two modalities (struct_token, text): one optimiser sub-step per modality per batch
     (ref oneprot_module.py:84-92), frozen text tower untouched, warm-up gate `train_on_all_modalities_after_step`."""
