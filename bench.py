@@ -1,107 +1,267 @@
 #!/usr/bin/env python3
-"""bench.py -- OneProt contrastive-alignment training sub-step on MI355X.
+"""bench.py -- OneProt contrastive-alignment training step on MI355X.
 
 Metric (BASELINE.json): protein-pairs/sec/node, seq + struct-token, L=512, ESM-2-150M, at 1/2/4/8 GPUs.
-One "step" = one iteration of the loop body of OneProtLitModule.training_step (ref oneprot_module.py:92-107) for the
-seq<->struct_token pair: forward sequence encoder, forward struct-token encoder, zero_grad, CLIP loss (+0.01*L1),
-backward, (gradient all-reduce when N>1), clip-norm 1.0, Adam step -- on synthetic ids resident in HBM.
+One "step" = one call of OneProtLitModule.training_step on one CombinedLoader batch, i.e. one iteration of the loop body
+ref oneprot_module.py:92-107 per modality in the batch: forward sequence encoder, forward modality encoder, zero_grad,
+CLIP loss (+0.01*L1), backward, (gradient all-reduce when N>1), clip-norm 1.0, Adam step -- on synthetic ids resident in HBM.
 
-  python bench.py [--gpus N] [--steps K] [--warmup W]             (N>1: launched by torch.distributed.run, one rank/GPU)
+  python bench.py [--gpus N] [--steps K] [--warmup W] [--pair struct_token|text|roundrobin]
 
-Workload at every N: cfg-2 per GPU (B=256 pairs, L=512, ESM-2-150M x2, output_dim 1024, random-init weights, reference
-default model flags: sequence encoder frozen, struct-token encoder trainable, loss CLIP local_loss+gather_with_grad,
-use_l1_regularization) => weak scaling, global batch 256*N (cfg-3 at N=8).
+N>1: bench.py starts its N ranks itself (`python -m torch.distributed.run --nnodes=1 --nproc-per-node N ...`, one rank per GPU over
+RCCL) before anything touches the GPU, or runs as one of them when a launcher has already set RANK / WORLD_SIZE.
+
+Workloads (all weak-scaling: `--batch` pairs per GPU per modality, default 256; reference default model flags):
+  struct_token (default)  cfg-2 (N=1) / cfg-3 (N=8): ESM-2-150M x2, L=512; sequence encoder frozen, struct-token encoder trainable
+  text                    cfg-4: ESM-2-150M (L=512, frozen) <-> BERT-base text tower (T=256, frozen: text.yaml), heads train
+  roundrobin              cfg-5 without the pocket/ProNet modality: ESM-2-650M anchor (attention1d pooling, linear head, frozen,
+                          train_ddp_1.yaml:45-49) against struct_token (ESM-2-35M, trainable) and text (BERT-base, frozen) in one
+                          mixed batch -> two optimiser sub-steps per step
 
 Extra objects on the JSON line:
-  roofline     dominant kernel = the bf16 MFMA NT GEMM (k_gemm_nt, FFN-1 launch [T x 640] x [2560 x 640]^T + bias + GELU):
-               algorithmic FLOPs per launch (2*T*N*K) / mean launch duration measured with HIP events on the launch stream
-               inside the timed region; peak = 2.5 PFLOP/s dense bf16 (MI355X_MICROARCH.md).
-  cpu_baseline the CPU oracle (oracle/oneprot_oracle.py, fp32 torch restatement of the reference) timed on this box's host
-               cores on a bounded sample of the same workload (reduced batch), rank 0 at N=1 only.
+  roofline     dominant kernel = the bf16 MFMA NT GEMM with the bias+erf-GELU epilogue (FFN-1 launches): algorithmic FLOPs (2*M*N*K of every
+               timed launch) / their summed durations, measured with HIP events on the launch stream inside the timed region;
+               peak = 2.5 PFLOP/s dense bf16 (MI355X_MICROARCH.md); traffic = HBM bytes per launch from the committed rocprofv3 PMC passes.
+  encoder_fwd  the north_star figure: ESM-2 sequence-encoder forward (frozen tower, embedding + all layers) in TFLOP/s and as a fraction of
+               the MFMA peak, timed with events after the timed region; MFMA-busy % from the committed PMC pass.
+  kernels      per-kernel-family rates from one extra, event-bracketed step after the timed region: MFMA kernels in TFLOP/s, LayerNorm / Adam
+               in HBM GB/s against 8 TB/s.
+  cpu_baseline the CPU oracle (oracle/oneprot_oracle.py, fp32 torch restatement of the reference) timed on this box's host cores on a
+               bounded sample of the same workload (reduced batch; 1 warm-up + 5 timed runs, median), plus the cfg-1 CPU headline point
+               (ESM-2-8M x2, L=128, batch 32); rank 0 at N=1 only.
 """
 import argparse
 import functools
 import json
 import os
+import statistics
+import subprocess
 import sys
 import time
 
 ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, ROOT)
 
-import torch  # noqa: E402
-
-CFG150 = dict(layers=30, hidden=640, heads=20, ffn=2560, pad=1, mask=32, eps=1e-5)
 PEAK_BF16_TFLOPS = 2500.0
+PEAK_HBM_GBS = 8000.0
+ESM = {"8M": "facebook/esm2_t6_8M_UR50D", "35M": "facebook/esm2_t12_35M_UR50D", "150M": "facebook/esm2_t30_150M_UR50D", "650M": "facebook/esm2_t33_650M_UR50D"}
 
 
-def synth_ids(B, L, lo, hi, gen, device):
-    ids = torch.randint(lo, hi + 1, (B, L), generator=gen)
-    ids[:, 0] = 0
-    ids[:, -1] = 2
-    return ids.to(device)
-
-
-def encoder_flops_fwd(cfg, L):
-    d, f, n = cfg["hidden"], cfg["ffn"], cfg["layers"]
-    return n * (8 * L * d * d + 4 * L * d * f + 4 * L * L * d)
-
-
-def cpu_baseline(sample_pairs, L, threads):
-    """Time the CPU oracle's training sub-step (same arithmetic, fp32, torch CPU) on `sample_pairs` pairs."""
-    from oracle import oneprot_oracle as O
-    torch.set_num_threads(threads)
-    gen = torch.Generator().manual_seed(1881)
-
-    def rand_sd(vocab, head):
-        d, f, n = CFG150["hidden"], CFG150["ffn"], CFG150["layers"]
-        sd = {"transformer.embeddings.word_embeddings.weight": torch.randn(vocab, d, generator=gen) * 0.02}
-        for i in range(n):
-            p = f"transformer.encoder.layer.{i}."
-            for nm, shp in (("attention.self.query", (d, d)), ("attention.self.key", (d, d)), ("attention.self.value", (d, d)), ("attention.output.dense", (d, d)),
-                            ("intermediate.dense", (f, d)), ("output.dense", (d, f))):
-                sd[p + nm + ".weight"] = torch.randn(*shp, generator=gen) * 0.02
-                sd[p + nm + ".bias"] = torch.zeros(shp[0])
-            for nm in ("attention.LayerNorm", "LayerNorm"):
-                sd[p + nm + ".weight"], sd[p + nm + ".bias"] = torch.ones(d), torch.zeros(d)
-        sd["transformer.encoder.emb_layer_norm_after.weight"], sd["transformer.encoder.emb_layer_norm_after.bias"] = torch.ones(d), torch.zeros(d)
-        sd["proj.0.weight"], sd["proj.0.bias"] = torch.ones(d), torch.zeros(d)
-        if head == "linear":
-            sd["proj.1.weight"] = torch.randn(1024, d, generator=gen) * 0.03
-            sd["norm.1.log_logit_scale"] = torch.log(torch.tensor(1 / 0.07))
-        else:
-            h = (d + 1024) // 2
-            sd["proj.1.weight"] = torch.randn(h, d, generator=gen) * 0.03
-            sd["proj.3.weight"], sd["proj.3.bias"] = torch.ones(h), torch.zeros(h)
-            sd["proj.4.weight"] = torch.randn(1024, h, generator=gen) * 0.03
-        return sd
-
-    sd_seq, sd_st = rand_sd(33, "mlp"), rand_sd(54, "linear")
-    seq_ids = synth_ids(sample_pairs, L, 4, 23, gen, "cpu")
-    st_ids = synth_ids(sample_pairs, L, 33, 52, gen, "cpu")
-    spec_seq = dict(kind="esm", pooling="mean", proj_type="mlp", use_logit_scale=False)
-    spec_st = dict(kind="esm", pooling="mean", proj_type="linear", use_logit_scale=True)
-    run = lambda: O.train_substep(seq_ids, st_ids, sd_seq, sd_st, CFG150, CFG150, spec_seq, spec_st, use_l1=True, frozen_seq=True)
-    t0 = time.perf_counter(); run(); t_first = time.perf_counter() - t0
-    t0 = time.perf_counter(); run(); t = time.perf_counter() - t0
-    return dict(value=round(sample_pairs / t, 4), unit="protein-pairs/sec", cores=threads, kind="port",
-                sample=f"oracle train sub-step (fp32 torch CPU), ESM-2-150M x2, L={L}, batch {sample_pairs} pairs, frozen sequence encoder; "
-                       f"1 warm-up ({t_first:.1f}s) + 1 timed run ({t:.1f}s)")
-
-
-def main():
+def parse_args():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=5)
     ap.add_argument("--warmup", type=int, default=2)
-    ap.add_argument("--batch", type=int, default=256, help="pairs per GPU")
+    ap.add_argument("--pair", default="struct_token", choices=["struct_token", "text", "roundrobin"])
+    ap.add_argument("--batch", type=int, default=256, help="pairs per GPU (per modality)")
     ap.add_argument("--seq-len", type=int, default=512)
-    ap.add_argument("--model", default="facebook/esm2_t30_150M_UR50D")
+    ap.add_argument("--text-len", type=int, default=256)
+    ap.add_argument("--model-seq", default=None, help="sequence encoder (default: ESM-2-150M; roundrobin: ESM-2-650M)")
+    ap.add_argument("--model-mod", default=None, help="struct-token encoder (default: ESM-2-150M; roundrobin: ESM-2-35M)")
+    ap.add_argument("--model", default=None, help="shorthand: the same ESM-2 model for both towers")
     ap.add_argument("--train-seq", action="store_true", help="also train the sequence encoder (reference default: frozen)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-extras", action="store_true", help="skip the encoder_fwd / kernels measurements after the timed region")
     ap.add_argument("--cpu-sample-pairs", type=int, default=4)
-    args = ap.parse_args()
+    return ap.parse_args()
 
+
+def launch_ranks(args):
+    """N>1 and no launcher environment: become the launcher.  Nothing in this process has touched the GPU."""
+    import socket
+    with socket.socket() as s:
+        s.bind(("127.0.0.1", 0))
+        port = s.getsockname()[1]
+    env = dict(os.environ)
+    env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")        # dmabuf IPC for RCCL (see oneprot_amd/distributed.py)
+    env.setdefault("OMP_NUM_THREADS", "4")
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", f"--nproc-per-node={args.gpus}", "--master-addr", "127.0.0.1",
+           "--master-port", str(port), os.path.abspath(__file__)] + sys.argv[1:]
+    return subprocess.run(cmd, env=env).returncode              # rank 0 prints the JSON line on the inherited stdout
+
+
+def synth_ids(B, L, lo, hi, gen, device, cls=0, eos=2):
+    import torch
+    ids = torch.randint(lo, hi + 1, (B, L), generator=gen)
+    ids[:, 0] = cls
+    ids[:, -1] = eos
+    return ids.to(device)
+
+
+def tower_fwd_flops(tr, L):
+    """algorithmic forward FLOPs per sequence: n * (8 L d^2 + 4 L d f + 4 L^2 d)"""
+    d, f, n = tr.d, tr.f, tr.n_layers
+    return n * (8 * L * d * d + 4 * L * d * f + 4 * L * L * d)
+
+
+def tower_cfg(tr):
+    c = tr.config
+    cfg = dict(layers=tr.n_layers, hidden=tr.d, heads=tr.H, ffn=tr.f, pad=c.pad_token_id, eps=c.layer_norm_eps)
+    if getattr(c, "model_type", "esm") == "bert":
+        cfg.update(vocab=c.vocab_size, max_pos=c.max_position_embeddings)
+    else:
+        cfg.update(mask=c.mask_token_id)
+    return cfg
+
+
+def build_workload(args, dev, rank):
+    """-> dict(module, batch, subs=[(modality, seq_ids, mod_ids)], specs, names, desc, metric)"""
+    import torch
+    from src.models.components.sequence_encoder import SequenceEncoder
+    from src.models.components.struct_token_encoder import StructTokenEncoder
+    from src.models.components.text_encoder import TextEncoder
+    from src.models.oneprot_module import OneProtLitModule
+    from oneprot_amd.optim import FusedAdam
+    B, L, T = args.batch, args.seq_len, args.text_len
+    rr = args.pair == "roundrobin"
+    name_seq = args.model_seq or args.model or (ESM["650M"] if rr else ESM["150M"])
+    name_mod = args.model_mod or args.model or (ESM["35M"] if rr else ESM["150M"])
+    torch.manual_seed(1881)        # identical weights on every rank
+    if rr:      # train_ddp_1.yaml:45-49
+        seq = SequenceEncoder(name_seq, output_dim=1024, pooling_type="attention1d", proj_type="linear", use_lora=False, frozen=not args.train_seq)
+        spec_seq = dict(kind="esm", pooling="attention1d", proj_type="linear", use_logit_scale=False)
+    else:       # sequence.yaml
+        seq = SequenceEncoder(name_seq, output_dim=1024, pooling_type="mean", proj_type="mlp", use_lora=False, frozen=not args.train_seq)
+        spec_seq = dict(kind="esm", pooling="mean", proj_type="mlp", use_logit_scale=False)
+    comps, specs = {"sequence": seq}, {"sequence": spec_seq}
+    if args.pair in ("struct_token", "roundrobin"):
+        comps["struct_token"] = StructTokenEncoder(name_mod, output_dim=1024, pooling_type="mean", proj_type="linear", use_logit_scale=True, learnable_logit_scale=False)
+        specs["struct_token"] = dict(kind="esm", pooling="mean", proj_type="linear", use_logit_scale=True)
+    if args.pair in ("text", "roundrobin"):
+        comps["text"] = TextEncoder("microsoft/BiomedNLP-BiomedBERT-base-uncased-abstract-fulltext", output_dim=1024, pooling_type="cls", proj_type="mlp",
+                                    use_logit_scale=True, learnable_logit_scale=False, frozen=True, use_lora=False)
+        specs["text"] = dict(kind="bert", pooling="cls", proj_type="mlp", use_logit_scale=True)
+    module = OneProtLitModule(components=comps, optimizer=functools.partial(FusedAdam, lr=1e-3, weight_decay=0.0), loss_fn="CLIP",
+                              use_l1_regularization=True, local_loss=True, gather_with_grad=True).to(dev)
+    module.train()
+    gen = torch.Generator().manual_seed(1881 + rank)
+    subs = []
+    for m in comps:
+        if m == "sequence":
+            continue
+        seq_ids = synth_ids(B, L, 4, 23, gen, dev)
+        if m == "text":
+            mod_ids = synth_ids(B, T, 5, 30521, gen, dev, cls=2, eos=3)
+        else:
+            mod_ids = synth_ids(B, L, 33, 52, gen, dev)
+        subs.append((m, seq_ids, mod_ids))
+    batch = {m: (s, x, m, None) for m, s, x in subs}
+    short = lambda n: n.split("/")[-1]
+    if args.pair == "struct_token":
+        desc = f"seq<->struct_token sub-step, {name_seq} / {name_mod}, L={L}"
+        metric = f"protein-pairs/sec/node (seq+struct-token, L={L}, {short(name_seq).split('_')[2] if 'esm2' in name_seq else short(name_seq)})"
+        if (name_seq, name_mod, L) == (ESM["150M"], ESM["150M"], 512):
+            metric = "protein-pairs/sec/node (seq+struct-token, L=512, ESM-2-150M)"
+    elif args.pair == "text":
+        desc = f"seq<->text sub-step, {name_seq} (L={L}) / BERT-base text tower (T={T}), both transformers frozen (sequence.yaml:12, text.yaml:12)"
+        metric = f"protein-pairs/sec/node (seq+text, L={L}/T={T}, {short(name_seq)} + BERT-base)"
+    else:
+        desc = (f"mixed-batch round-robin step = 2 sub-steps (struct_token, text), anchor {name_seq} attention1d+linear frozen, struct_token {name_mod}, "
+                f"text BERT-base frozen, L={L}/T={T}; pocket (ProNet) modality not built")
+        metric = f"protein-pairs/sec/node (round-robin seq+struct-token / seq+text, anchor {short(name_seq)})"
+    return dict(module=module, batch=batch, subs=subs, specs=specs, names=dict(seq=name_seq, mod=name_mod), desc=desc, metric=metric)
+
+
+def step_flops(module, subs, L_of):
+    """algorithmic FLOPs of one step: per sub-step, each tower's forward (+2x for its backward when its transformer is trainable)"""
+    total = 0
+    for m, seq_ids, mod_ids in subs:
+        for name, ids in (("sequence", seq_ids), (m, mod_ids)):
+            tr = module.network[name].transformer
+            mult = 3 if tr.flat.requires_grad else 1
+            total += ids.shape[0] * tower_fwd_flops(tr, ids.shape[1]) * mult
+    return total
+
+
+def summarise_kernels(prof):
+    """per-kernel-family rates from hip.profile_end() of one step: [(ms, scalar args)] per entry point"""
+    out = []
+
+    def add(kernel, items, work, unit, peak):
+        if not items:
+            return
+        t = sum(ms for ms, _ in items) * 1e-3
+        rate = work / t / (1e12 if unit == "TFLOP/s" else 1e9)
+        out.append({"kernel": kernel, "launches": len(items), "avg_ms": round(t / len(items) * 1e3, 4), "rate": round(rate, 1), "unit": unit,
+                    "frac_of_peak": round(rate / peak, 4)})
+    epi_names = {0: "bf16 (dgrad)", 1: "f32", 2: "bias+GELU (FFN-1)", 3: "bias+residual (out-proj / FFN-2)", 4: "QKV+RoPE", 5: "GELU' (FFN-2 dgrad)"}
+    groups = {}
+    for ms, sc in prof.get("oneprot_gemm_bf16_nt", []):
+        M, N, K, epi = sc[0], sc[1], sc[2], sc[5]
+        groups.setdefault((epi, N, K), []).append((ms, 2.0 * M * N * K))
+    for (epi, N, K), items in sorted(groups.items()):
+        add(f"k_gemm_nt {epi_names.get(epi, epi)} N={N} K={K}", items, sum(w for _, w in items), "TFLOP/s", PEAK_BF16_TFLOPS)
+    tn = [(ms, 2.0 * sc[0] * sc[1] * sc[2]) for ms, sc in prof.get("oneprot_gemm_bf16_tn", [])]
+    add("k_gemm_tn (weight gradients, incl. slab reduce)", tn, sum(w for _, w in tn), "TFLOP/s", PEAK_BF16_TFLOPS)
+    af = [(ms, 4.0 * sc[-4] * sc[-3] * sc[-2] * sc[-2] * sc[-1]) for ms, sc in prof.get("oneprot_attn_fwd", [])]
+    add("k_attn_fwd", af, sum(w for _, w in af), "TFLOP/s", PEAK_BF16_TFLOPS)
+    ab = [(ms, 8.0 * sc[-4] * sc[-3] * sc[-2] * sc[-2] * sc[-1]) for ms, sc in prof.get("oneprot_attn_bwd", [])]
+    add("k_attn_bwd (dq + dkv kernels; algorithmic 2x forward)", ab, sum(w for _, w in ab), "TFLOP/s", PEAK_BF16_TFLOPS)
+    big = lambda items, idx: [(ms, sc) for ms, sc in items if sc[idx] >= 4096]          # the [T, d] launches, not the [B, d] head ones
+    lf = [(ms, 6.0 * sc[-3] * sc[-2]) for ms, sc in big(prof.get("oneprot_layernorm_fwd", []), -3)]
+    add("k_layernorm_fwd (fp32 in, bf16 out: 6 B/elem)", lf, sum(w for _, w in lf), "GB/s", PEAK_HBM_GBS)
+    lb = [(ms, 14.0 * sc[-3] * sc[-2]) for ms, sc in big(prof.get("oneprot_layernorm_bwd", []), -3)]
+    add("k_layernorm_bwd (14 B/elem)", lb, sum(w for _, w in lb), "GB/s", PEAK_HBM_GBS)
+    ad = [(ms, 28.0 * sc[0]) for ms, sc in prof.get("oneprot_adam_step", []) if sc[0] >= (1 << 20)]
+    add("k_adam (28 B/param)", ad, sum(w for _, w in ad), "GB/s", PEAK_HBM_GBS)
+    return out
+
+
+def cpu_baseline(work, sample_pairs, threads):
+    """Time the CPU oracle (same arithmetic, fp32, torch CPU) on `sample_pairs` pairs of this workload: 1 warm-up + 5 timed, median."""
+    import torch
+    from oracle import oneprot_oracle as O
+    torch.set_num_threads(threads)
+    module, subs, specs = work["module"], work["subs"], work["specs"]
+    sds = {k: {n: v.detach().cpu() for n, v in enc.state_dict().items()} for k, enc in module.network.items()}
+    cfgs = {k: tower_cfg(enc.transformer) for k, enc in module.network.items()}
+    frozen = tuple(k for k, enc in module.network.items() if not enc.transformer.flat.requires_grad)
+    n = sample_pairs
+    batches = [{m: (s[:n].cpu(), x[:n].cpu()) for m, s, x in subs}]
+    run = lambda: O.train_round_robin(batches, sds, cfgs, specs, use_l1=True, frozen=frozen)      # one sub-step per modality, clip 1.0, Adam
+    t0 = time.perf_counter(); run(); t_first = time.perf_counter() - t0
+    times = []
+    for _ in range(5):
+        t0 = time.perf_counter(); run(); times.append(time.perf_counter() - t0)
+    med = statistics.median(times)
+    out = dict(value=round(n * len(subs) / med, 4), unit="protein-pairs/sec", cores=threads, kind="port",
+               sample=f"oracle training step (fp32 torch CPU) of this workload at batch {n} pairs per modality; 1 warm-up ({t_first:.1f}s) + 5 timed runs, "
+                      f"median {med:.2f}s (min {min(times):.2f}, max {max(times):.2f})")
+    return out
+
+
+def cpu_cfg1(threads):
+    """BASELINE cfg-1, the reference's own CPU-runnable case: ESM-2-8M x2, L=128, batch 32, full training sub-step on the host cores."""
+    import torch
+    from oracle import oneprot_oracle as O
+    from src.models.components.sequence_encoder import SequenceEncoder
+    from src.models.components.struct_token_encoder import StructTokenEncoder
+    torch.set_num_threads(threads)
+    torch.manual_seed(1881)
+    seq = SequenceEncoder(ESM["8M"], output_dim=1024, pooling_type="mean", proj_type="mlp", use_lora=False, frozen=True)
+    st = StructTokenEncoder(ESM["8M"], output_dim=1024, pooling_type="mean", proj_type="linear", use_logit_scale=True)
+    sd_seq, sd_st = ({k: v.detach().clone() for k, v in e.state_dict().items()} for e in (seq, st))
+    cfg = tower_cfg(seq.transformer)
+    gen = torch.Generator().manual_seed(1881)
+    a, b = synth_ids(32, 128, 4, 23, gen, "cpu"), synth_ids(32, 128, 33, 52, gen, "cpu")
+    run = lambda: O.train_substep(a, b, sd_seq, sd_st, cfg, cfg, dict(kind="esm", pooling="mean", proj_type="mlp", use_logit_scale=False),
+                                  dict(kind="esm", pooling="mean", proj_type="linear", use_logit_scale=True), use_l1=True, frozen_seq=True)
+    for _ in range(3):
+        run()
+    times = []
+    for _ in range(5):
+        t0 = time.perf_counter(); run(); times.append(time.perf_counter() - t0)
+    med = statistics.median(times)
+    return dict(value=round(32 / med, 2), unit="protein-pairs/sec", cores=threads, kind="port",
+                sample=f"cfg-1: ESM-2-8M x2, L=128, batch 32, frozen sequence encoder, oracle training sub-step; 3 warm-up + 5 timed, median {med:.3f}s")
+
+
+def main():
+    args = parse_args()
+    if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
+        sys.exit(launch_ranks(args))
+
+    import torch
     os.environ.setdefault("RANK", "0")
     os.environ.setdefault("WORLD_SIZE", "1")
     os.environ.setdefault("ONEPROT_ALLOW_RANDOM_INIT", "1")
@@ -109,28 +269,16 @@ def main():
     from oneprot_amd import hip
     rank, world, local = D.setup_process_group()
     if world != args.gpus:
-        raise SystemExit(f"--gpus {args.gpus} but WORLD_SIZE={world}: for N>1 launch with python -m torch.distributed.run --nproc-per-node N bench.py --gpus N ...")
+        raise SystemExit(f"--gpus {args.gpus} but the launcher set WORLD_SIZE={world}")
     dev = torch.device("cuda", torch.cuda.current_device())
     hip.lib()      # fail loudly if the HIP library is missing
 
     import warnings
     warnings.filterwarnings("ignore", message=".*no weight file.*")
-    from src.models.components.sequence_encoder import SequenceEncoder
-    from src.models.components.struct_token_encoder import StructTokenEncoder
-    from src.models.oneprot_module import OneProtLitModule
-    from oneprot_amd.optim import FusedAdam
-
-    torch.manual_seed(1881)        # identical weights on every rank
-    seq = SequenceEncoder(args.model, output_dim=1024, pooling_type="mean", proj_type="mlp", use_lora=False, frozen=not args.train_seq)
-    st = StructTokenEncoder(args.model, output_dim=1024, pooling_type="mean", proj_type="linear", use_logit_scale=True, learnable_logit_scale=False)
-    module = OneProtLitModule(components={"sequence": seq, "struct_token": st}, optimizer=functools.partial(FusedAdam, lr=1e-3, weight_decay=0.0),
-                              loss_fn="CLIP", use_l1_regularization=True, local_loss=True, gather_with_grad=True).to(dev)
-    module.train()
-    B, L = args.batch, args.seq_len
-    gen = torch.Generator().manual_seed(1881 + rank)
-    seq_ids = synth_ids(B, L, 4, 23, gen, dev)
-    st_ids = synth_ids(B, L, 33, 52, gen, dev)
-    batch = {"struct_token": (seq_ids, st_ids, "struct_token", None)}
+    warnings.filterwarnings("ignore", message=".*requires_grad=True to a scalar.*")
+    work = build_workload(args, dev, rank)
+    module, batch, subs = work["module"], work["batch"], work["subs"]
+    B = args.batch
 
     def barrier():
         if world > 1:
@@ -141,55 +289,95 @@ def main():
         module.training_step(batch, 0)
     barrier()
     # live per-launch timing of the dominant kernel (FFN-1 GEMM, bias+GELU epilogue) with events on the launch stream
-    hip.profile_begin("oneprot_gemm_bf16_nt", epilogue=hip.EPI_BIAS_GELU)
+    hip.profile_begin({"oneprot_gemm_bf16_nt": hip.EPI_BIAS_GELU})
     t0 = time.perf_counter()
     for _ in range(args.steps):
         loss = module.training_step(batch, 0)
     barrier()
     elapsed = time.perf_counter() - t0
-    launches_ms = hip.profile_end()
+    launches = hip.profile_end()["oneprot_gemm_bf16_nt"]
     el = torch.tensor([elapsed], device=dev, dtype=torch.float64)
     if world > 1:
         torch.distributed.all_reduce(el, op=torch.distributed.ReduceOp.MAX)
     elapsed = float(el)
-    loss_val = float(loss)
+    loss_val = float(loss.detach())
+
+    extras = {}
+    if rank == 0 and not args.no_extras:
+        # ---- north_star figure: ESM-2 encoder forward (the frozen sequence tower: embedding + every layer), events on the launch stream
+        seq_tr = module.network["sequence"].transformer
+        seq_ids = subs[0][1]
+        with torch.no_grad():
+            seq_tr.run_layers(seq_ids, save=False)
+            e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+            reps = 3
+            e0.record()
+            for _ in range(reps):
+                seq_tr.run_layers(seq_ids, save=False)
+            e1.record()
+            torch.cuda.synchronize()
+        fwd_ms = e0.elapsed_time(e1) / reps
+        fwd_tf = seq_ids.shape[0] * tower_fwd_flops(seq_tr, seq_ids.shape[1]) / (fwd_ms * 1e-3) / 1e12
+        mfma_busy = None
+        try:
+            with open(os.path.join(ROOT, "profiles", "r02_encoder_fwd_mfma_busy.json")) as f:
+                mfma_busy = json.load(f)["mfma_busy_pct"]
+        except Exception:
+            pass
+        extras["encoder_fwd"] = {"what": f"{work['names']['seq']} forward, {seq_ids.shape[0]} x L={seq_ids.shape[1]} (embedding + {seq_tr.n_layers} layers, no pooling head)",
+                                 "ms": round(fwd_ms, 3), "achieved": round(fwd_tf, 1), "unit": "TFLOP/s", "peak": PEAK_BF16_TFLOPS,
+                                 "frac": round(fwd_tf / PEAK_BF16_TFLOPS, 4), "mfma_busy_pct": mfma_busy, "target_frac": 0.40}
+    if not args.no_extras:
+        # ---- one extra step with every kernel family bracketed by events (outside the timed region: the brackets cost launch time)
+        hip.profile_begin({k: None for k in ("oneprot_gemm_bf16_nt", "oneprot_gemm_bf16_tn", "oneprot_attn_fwd", "oneprot_attn_bwd", "oneprot_layernorm_fwd",
+                                             "oneprot_layernorm_bwd", "oneprot_adam_step")})
+        module.training_step(batch, 0)
+        barrier()
+        prof = hip.profile_end()
+        if rank == 0:
+            extras["kernels"] = summarise_kernels(prof)
 
     if rank == 0:
         ms_step = elapsed / args.steps * 1e3
-        value = world * B * args.steps / elapsed
-        T = B * L
-        cfg = dict(CFG150) if "150M" in args.model else None
-        d, f = seq.transformer.d, seq.transformer.f
-        gemm_flops = 2.0 * T * f * d
-        gemm_ms = sum(launches_ms) / max(len(launches_ms), 1)
-        achieved = gemm_flops / (gemm_ms * 1e-3) / 1e12 if gemm_ms > 0 else 0.0
-        fwd = encoder_flops_fwd(dict(hidden=d, ffn=f, layers=seq.transformer.n_layers), L)
-        step_flops = B * fwd * ((3 if args.train_seq else 1) + 3)      # sequence encoder fwd (+2x bwd if trained) + struct-token encoder fwd + bwd
+        pairs_per_step = B * len(subs)
+        value = world * pairs_per_step * args.steps / elapsed
+        gemm_flops = sum(2.0 * sc[0] * sc[1] * sc[2] for _, sc in launches)
+        gemm_s = sum(ms for ms, _ in launches) * 1e-3
+        achieved = gemm_flops / gemm_s / 1e12 if gemm_s > 0 else 0.0
+        shapes = sorted({(sc[0], sc[1], sc[2]) for _, sc in launches})
+        flops = step_flops(module, subs, None)
         # HBM/fabric bytes per launch of the dominant kernel: PMC passes cannot run inside this process, so the figure measured with
         # rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE (separate passes, gfx950 x2 correction on FETCH_SIZE) is read from profiles/.
-        traffic = None
-        try:
-            with open(os.path.join(ROOT, "profiles", "r01_pmc_traffic.json")) as f:
-                traffic = json.load(f)["traffic_bytes_per_launch"] / 1e9
-        except Exception:
-            pass
+        traffic, traffic_src = None, None
+        if args.pair == "struct_token" and shapes == [(B * args.seq_len, 2560, 640)]:
+            for name in ("r02_pmc_traffic.json", "r01_pmc_traffic.json"):
+                try:
+                    with open(os.path.join(ROOT, "profiles", name)) as f:
+                        traffic, traffic_src = json.load(f)["traffic_bytes_per_launch"] / 1e9, name
+                    break
+                except Exception:
+                    pass
+        cfg_tag = {"struct_token": "cfg-2" if world == 1 else "cfg-3-shaped", "text": "cfg-4-shaped", "roundrobin": "cfg-5-shaped"}[args.pair]
         out = {
-            "metric": "protein-pairs/sec/node (seq+struct-token, L=512, ESM-2-150M)", "value": round(value, 2), "unit": "protein-pairs/sec/node",
+            "metric": work["metric"], "value": round(value, 2), "unit": "protein-pairs/sec/node",
             "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": round(ms_step, 2), "higher_is_better": True, "scaling": "weak",
             "vs_baseline": None, "dtype": "bf16", "data": "synthetic",
-            "config": {"workload": f"cfg-{'2' if world == 1 else '3-shaped'}: seq<->struct_token sub-step, {args.model} x2, L={L}, {B} pairs/GPU, global batch {B * world}, "
-                                   f"output_dim 1024, CLIP local_loss+gather_with_grad, L1 0.01, Adam 1e-3, clip 1.0, "
-                                   f"sequence encoder {'trainable' if args.train_seq else 'frozen (reference default)'}, random-init weights",
-                       "global_batch": B * world, "seq_len": L, "parallelism": f"dp{world}", "frozen_sequence_encoder": not args.train_seq,
-                       "loss": round(loss_val, 5)},
-            "step_tflops_per_gpu": round(step_flops / (ms_step * 1e-3) / 1e12, 1),
-            "roofline": {"bound": "mfma", "kernel": "k_gemm_nt<BIAS_GELU> FFN-1 [T,640]x[2560,640]^T", "achieved": round(achieved, 1), "peak": PEAK_BF16_TFLOPS,
-                         "unit": "TFLOP/s", "frac": round(achieved / PEAK_BF16_TFLOPS, 4), "traffic": traffic, "traffic_unit": "GB/launch (rocprofv3 PMC, profiles/r01_pmc_traffic.json; algorithmic 1.51)", "launches_timed": len(launches_ms),
-                         "avg_launch_ms": round(gemm_ms, 4), "flops_per_launch": gemm_flops},
+            "config": {"workload": f"{cfg_tag}: {work['desc']}, {B} pairs/GPU per modality, global batch {B * world}, output_dim 1024, CLIP local_loss+gather_with_grad, "
+                                   f"L1 0.01, Adam 1e-3, clip 1.0, sequence encoder {'trainable' if args.train_seq else 'frozen (reference default)'}, random-init weights",
+                       "global_batch": B * world, "seq_len": args.seq_len, "parallelism": f"dp{world}", "frozen_sequence_encoder": not args.train_seq,
+                       "sub_steps_per_step": len(subs), "loss": round(loss_val, 5)},
+            "step_tflops_per_gpu": round(flops / (ms_step * 1e-3) / 1e12, 1),
+            "roofline": {"bound": "mfma", "kernel": "k_gemm_nt<BIAS_GELU> FFN-1 launches " + ", ".join(f"[{m}x{k}]x[{n}x{k}]^T" for m, n, k in shapes),
+                         "achieved": round(achieved, 1), "peak": PEAK_BF16_TFLOPS, "unit": "TFLOP/s", "frac": round(achieved / PEAK_BF16_TFLOPS, 4),
+                         "traffic": traffic, "traffic_unit": f"GB/launch (rocprofv3 PMC, profiles/{traffic_src}; algorithmic 1.51 with two bf16 outputs, 0.84 with one)" if traffic else None,
+                         "launches_timed": len(launches), "avg_launch_ms": round(gemm_s / max(len(launches), 1) * 1e3, 4),
+                         "flops_per_launch": gemm_flops / max(len(launches), 1)},
         }
+        out.update(extras)
         if world == 1 and not args.no_cpu_baseline:
             threads = min(len(os.sched_getaffinity(0)), 16)
-            out["cpu_baseline"] = cpu_baseline(args.cpu_sample_pairs, L, threads)
+            out["cpu_baseline"] = cpu_baseline(work, args.cpu_sample_pairs, threads)
+            out["cpu_baseline"]["cfg1"] = cpu_cfg1(threads)
         print(json.dumps(out), flush=True)
     if world > 1:
         torch.distributed.barrier()

@@ -86,11 +86,13 @@ int oneprot_gemm_bf16_nt(const void* A, const void* Bw, int64_t M, int N, int K,
 void oneprot_gemm_force_shape(int shape);
 /* dW[N,K] (+)= dY[M,N]^T * X[M,K]  (contraction over the M tokens; split over workgroups, fp32 slabs in workspace);
    dbias[N] (+)= column sums of dY (optional, fused: an all-ones MFMA operand in the k-tile-0 workgroups). */
+/* workspace bytes for an (N, K) weight gradient, for any M (the split count is capped by M inside the call, never raised). */
 size_t oneprot_gemm_bf16_tn_workspace(int N, int K);
 /* test / tuning hook: -1 = auto (default, = 2), 0 = 64-token stages x2 (LDS-DMA ring), 1 = 32-token stages x3, 2 = 64-token stages x2 with register-staged fill. */
 void oneprot_gemm_tn_variant(int v);
+/* workspace_bytes = size of `workspace`; -1 (invalid argument) when it is smaller than oneprot_gemm_bf16_tn_workspace(N, K). */
 int oneprot_gemm_bf16_tn(const void* dY, const void* X, int64_t M, int N, int K, int ldy, int ldx, float* dW, float* dbias, void* workspace,
-                         int accumulate, void* stream);
+                         size_t workspace_bytes, int accumulate, void* stream);
 /* fp32 GEMM for the small head / logits contractions (ref base_encoder.py:155,159,164; loss.py:91-99):
    C[M,N] = alpha * op(A) * op(B) (+ C if accumulate);  transA: A stored [K,M]; transB: B stored [K,N] else [N,K]. */
 int oneprot_sgemm(const float* A, const float* B, float* C, int M, int N, int K, int transA, int b_is_kn, float alpha, int accumulate, void* stream);

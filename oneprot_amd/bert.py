@@ -170,7 +170,7 @@ class BertTransformer(ArenaModule):
         f32 = lambda *s: torch.empty(*s, dtype=torch.float32, device=dev)
         b16 = lambda *s: torch.empty(*s, dtype=torch.bfloat16, device=dev)
         ws_ln = torch.empty(hip.query("oneprot_layernorm_bwd_workspace", d), dtype=torch.uint8, device=dev)
-        ws_tn = torch.empty(max(hip.query("oneprot_gemm_bf16_tn_workspace", 3 * d, d), hip.query("oneprot_gemm_bf16_tn_workspace", f, d)), dtype=torch.uint8, device=dev)
+        ws_tn = self._tn_workspace(((3 * d, d), (f, d), (d, f), (d, d)), dev)
         ws_at = torch.empty(hip.query("oneprot_attn_bwd_workspace", B, H, L), dtype=torch.uint8, device=dev)
         ds, ds16, gy = f32(T, d), b16(T, d), f32(T, d)
         dz, dctx, dqkv = b16(T, f), b16(T, d), b16(T, 3 * d)
@@ -197,7 +197,7 @@ class BertTransformer(ArenaModule):
             # ---- QKV projection; g = ds (residual branch) + dqkv Wqkv
             o, n = self.span(p + "attention.self.query.weight", p + "attention.self.value.weight")
             ob, nb = self.span(p + "attention.self.query.bias", p + "attention.self.value.bias")
-            hip.call("oneprot_gemm_bf16_tn", dqkv, st["x16"], T, 3 * d, d, 3 * d, d, gflat[o:o + n], gflat[ob:ob + nb], ws_tn, 0)
+            hip.call("oneprot_gemm_bf16_tn", dqkv, st["x16"], T, 3 * d, d, 3 * d, d, gflat[o:o + n], gflat[ob:ob + nb], ws_tn, ws_tn.numel(), 0)
             hip.call("oneprot_gemm_bf16_nt", dqkv, self._bf16_T[(i, "qkv")], T, d, 3 * d, 3 * d, 3 * d, hip.EPI_BIAS_RESID, None, g, None, None, ds, None, None,
                      1.0, 0, 0, 0)
             saved["layers"][i] = None

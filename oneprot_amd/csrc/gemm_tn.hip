@@ -282,13 +282,14 @@ extern "C" size_t oneprot_gemm_bf16_tn_workspace(int N, int K) {
 }
 
 extern "C" int oneprot_gemm_bf16_tn(const void* dY, const void* X, int64_t M, int N, int K, int ldy, int ldx, float* dW, float* dbias, void* workspace,
-                                    int accumulate, void* stream) {
+                                    size_t workspace_bytes, int accumulate, void* stream) {
   if (!dY || !X || !dW || !workspace || M <= 0 || N <= 0 || K <= 0 || M > 0x7fffffff) return OP_EINVAL;
   if ((N & 7) || (K & 7) || (ldy & 7) || (ldx & 7) || ldy < N || ldx < K || ((N * (int64_t)K) & 3)) return OP_EINVAL;
   if (((uintptr_t)dY | (uintptr_t)X | (uintptr_t)dW | (uintptr_t)workspace) & 15) return OP_EINVAL;
   const int variant = g_tn_variant >= 0 ? g_tn_variant : 2;
   const int tiles_n = (N + 127) / 128, tiles_k = (K + 127) / 128, tiles = tiles_n * tiles_k;
   const int S = tn_splits(M, tiles);
+  if (workspace_bytes < (size_t)S * N * K * sizeof(float) + (dbias ? (size_t)S * N * sizeof(float) : 0)) return OP_EINVAL;      // slabs would overrun
   hipStream_t s = (hipStream_t)stream;
   float* bias_slab = dbias ? (float*)workspace + (size_t)S * N * K : nullptr;
   // variant 0: 64-token stages, 2-stage LDS-DMA ring (64 KB, 2 workgroups/CU); 1: 32-token stages, 3-stage ring (48 KB, 3 workgroups/CU);

@@ -41,6 +41,10 @@ def init_distributed_mode(port=12354):
 
 def setup_process_group(backend=None):
     """One process per GPU.  Returns (rank, world_size, local_rank); initialises torch.distributed when world_size > 1."""
+    # the host driver of this pool only supports dmabuf IPC (RCCL / cross-process tensor sharing fail with hipIpcGetMemHandle otherwise);
+    # must be in the environment BEFORE the first call that initialises the HIP runtime, so it is the first thing done here (launchers
+    # -- bench.py's parent process, torchrun -- export it as well)
+    os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
     rank, world = int(os.environ.get("RANK", 0)), int(os.environ.get("WORLD_SIZE", 1))
     local = int(os.environ.get("LOCAL_RANK", 0))
     if torch.cuda.is_available():
@@ -48,7 +52,6 @@ def setup_process_group(backend=None):
     if world > 1 and not dist.is_initialized():
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         os.environ.setdefault("MASTER_PORT", "29500")
-        os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
         if backend is None:       # "nccl" is RCCL on ROCm; ONEPROT_DIST_BACKEND=gloo lets several ranks share one GPU (rehearsals, tests)
             backend = os.environ.get("ONEPROT_DIST_BACKEND") or ("nccl" if torch.cuda.is_available() else "gloo")
         dist.init_process_group(backend=backend, rank=rank, world_size=world)
@@ -100,13 +103,11 @@ class GradOverlap:
     def reduce_range(self, param, gflat, lo, hi):
         chunk = gflat[lo:hi]
         self.calls += 1
-        h = None
+        # the reduction operator is chosen once from the backend (RCCL has ncclAvg; gloo does not): an asynchronous collective reports
+        # its errors at wait(), so there is nothing to catch and fall back from here
         if self.use_avg:
-            try:
-                h = dist.all_reduce(chunk, op=dist.ReduceOp.AVG, async_op=True)
-            except (RuntimeError, ValueError):       # a transport without ncclAvg: divide, then SUM
-                self.use_avg = False
-        if h is None:
+            h = dist.all_reduce(chunk, op=dist.ReduceOp.AVG, async_op=True)
+        else:
             chunk.div_(self.world)
             h = dist.all_reduce(chunk, op=dist.ReduceOp.SUM, async_op=True)
         pend = getattr(param, "_oneprot_pending_reduce", None)
@@ -122,6 +123,8 @@ def allreduce_gradients(parameters, bucket_bytes=256 << 20, average=True):
     if not is_dist_avail_and_initialized() or get_world_size() == 1:
         return
     world = get_world_size()
+    use_avg = average and dist.get_backend() == "nccl"           # RCCL: ncclAvg inside the collective; gloo: divide, then SUM
+    op = dist.ReduceOp.AVG if use_avg else dist.ReduceOp.SUM
     handles, small = [], []
     for p in parameters:
         g = p.grad
@@ -137,16 +140,16 @@ def allreduce_gradients(parameters, bucket_bytes=256 << 20, average=True):
             step = max(bucket_bytes // g.element_size(), 1)
             for o in range(0, flat.numel(), step):
                 chunk = flat[o:o + step]
-                if average:
+                if average and not use_avg:
                     chunk.div_(world)
-                handles.append(dist.all_reduce(chunk, op=dist.ReduceOp.SUM, async_op=True))
+                handles.append(dist.all_reduce(chunk, op=op, async_op=True))
         else:
             small.append(g)
     if small:
         buf = torch.cat([g.reshape(-1) for g in small])
-        if average:
+        if average and not use_avg:
             buf.div_(world)
-        dist.all_reduce(buf, op=dist.ReduceOp.SUM)
+        dist.all_reduce(buf, op=op)
         o = 0
         for g in small:
             g.copy_(buf[o:o + g.numel()].view_as(g))

@@ -29,6 +29,10 @@ class Normalize(nn.Module):
         self.dim = dim
 
     def forward(self, x):
+        """F.normalize(x, dim=self.dim, p=2) (ref base_encoder.py:6-12) on the row-normalise kernel"""
+        dim = self.dim if self.dim >= 0 else x.dim() + self.dim
+        if dim != x.dim() - 1:
+            return _L2NormFn.apply(x.transpose(dim, -1), 1.0).transpose(dim, -1)
         return _L2NormFn.apply(x, 1.0)
 
 
@@ -47,27 +51,64 @@ class LearnableLogitScaling(nn.Module):
             self.register_buffer("log_logit_scale", log_logit_scale)
 
     def scale_value(self) -> float:
-        """clip(exp(log_logit_scale), max) as a host float; cached on the tensor's version so the hot loop does not synchronise."""
+        """clip(exp(log_logit_scale), max) as a host float (fixed scale: read once, cached on the tensor's version).  The learnable scale
+        never comes through here on the hot path -- it changes every step, so the fused encoder keeps it on the device (`scale_device`)."""
         key = (self.log_logit_scale._version, self.log_logit_scale.data_ptr())
         if getattr(self, "_cached", (None, None))[0] != key:
             self._cached = (key, min(math.exp(float(self.log_logit_scale.detach())), self.max_logit_scale))
         return self._cached[1]
 
-    def is_clipped(self) -> bool:
-        return math.exp(float(self.log_logit_scale.detach())) >= self.max_logit_scale
+    def scale_device(self):
+        """(clip(exp(l), max), d/dl of it) as 1-element device tensors: no host synchronisation"""
+        e = self.log_logit_scale.detach().float().exp().reshape(1)
+        return torch.clamp(e, max=self.max_logit_scale), e * (e < self.max_logit_scale).float()
 
     def forward(self, x):
-        return x * self.scale_value()
+        return torch.clip(self.log_logit_scale.exp(), max=self.max_logit_scale) * x
 
     def extra_repr(self):
         return f"logit_scale_init={self.logit_scale_init},learnable={self.learnable}, max_logit_scale={self.max_logit_scale}"
 
 
+def _mask_as_ids(features, input_mask):
+    """the pooling kernels take token ids + pad id; a 0/1 mask is the same thing with pad id 0"""
+    B, L = features.shape[0], features.shape[1]
+    if input_mask is None:
+        return torch.ones(B, L, dtype=torch.int64, device=features.device)
+    return (input_mask != 0).to(torch.int64).contiguous()
+
+
+class _PoolFn(torch.autograd.Function):
+    """stand-alone pooling of a [B,L,d] fp32 tensor (inside the encoders pooling is fused into the final LayerNorm kernel; this is what a
+    caller reaching into `encoder.pooling` gets): mode 0 masked mean, 1 CLS"""
+
+    @staticmethod
+    def forward(ctx, features, mask_ids, mode):
+        if not features.is_cuda:
+            raise hip.HipKernelError("OneProt HIP path needs CUDA(ROCm) tensors; there is no CPU fallback")
+        x = features.contiguous().float()
+        B, L, d = x.shape
+        pooled = torch.empty(B, d, device=x.device)
+        hip.call("oneprot_pool_fwd", x, mask_ids, 0, pooled, B, L, d, mode)
+        ctx.save_for_backward(mask_ids)
+        ctx.shape, ctx.mode = (B, L, d), mode
+        return pooled
+
+    @staticmethod
+    def backward(ctx, dpooled):
+        (mask_ids,) = ctx.saved_tensors
+        B, L, d = ctx.shape
+        g = torch.empty(B, L, d, device=dpooled.device)
+        hip.call("oneprot_pool_bwd", dpooled.contiguous().float(), mask_ids, 0, g, None, B, L, d, ctx.mode)
+        return g, None, None
+
+
 class MeanPooling(nn.Module):
+    """ref base_encoder.py:105-118: sum(x * m) / sum(m) over all non-pad positions (CLS / EOS included)"""
     mode = 0
 
     def forward(self, features, input_mask=None):
-        raise RuntimeError("pooling is fused into the encoder's final LayerNorm kernel; call the encoder, not the pooling module")
+        return _PoolFn.apply(features, _mask_as_ids(features, input_mask), 0)
 
 
 class CLSTokenPooling(nn.Module):
@@ -95,7 +136,33 @@ class Attention1dPooling(nn.Module):
         self.layer = MaskedConv1d(hidden_size, 1, 1)
 
     def forward(self, x, input_mask=None):
-        raise RuntimeError("pooling is fused into the encoder node; call the encoder, not the pooling module")
+        return _AttnPoolFn.apply(x, _mask_as_ids(x, input_mask), self.layer.weight, self.layer.bias)
+
+
+class _AttnPoolFn(torch.autograd.Function):
+    """stand-alone Attention1dPooling.forward (ref base_encoder.py:95-103) on the attnpool kernels"""
+
+    @staticmethod
+    def forward(ctx, x, mask_ids, w, b):
+        if not x.is_cuda:
+            raise hip.HipKernelError("OneProt HIP path needs CUDA(ROCm) tensors; there is no CPU fallback")
+        x = x.contiguous().float()
+        B, L, d = x.shape
+        if w.numel() != d:
+            raise RuntimeError(f"Attention1dPooling was built for hidden size {w.numel()} but the input width is {d}")
+        pooled, attn = torch.empty(B, d, device=x.device), torch.empty(B, L, device=x.device)
+        hip.call("oneprot_attnpool_fwd", x, mask_ids, 0, w, b, pooled, attn, B, L, d)
+        ctx.save_for_backward(x, attn, w)
+        return pooled
+
+    @staticmethod
+    def backward(ctx, dpooled):
+        x, attn, w = ctx.saved_tensors
+        B, L, d = x.shape
+        dev = x.device
+        dw, db, dx = torch.empty(d, device=dev), torch.empty(1, device=dev), torch.empty(B, L, d, device=dev)
+        hip.call("oneprot_attnpool_bwd", x, attn, w, dpooled.contiguous().float(), dw, db, dx, _ws(hip.query("oneprot_attnpool_bwd_workspace", B, d), dev), B, L, d)
+        return dx, None, dw.view_as(w), db
 
 
 def _ws(nbytes, dev):
@@ -108,7 +175,9 @@ class _Head:
     (ref base_encoder.py:147-178).  Forward keeps what backward needs."""
 
     @staticmethod
-    def forward(pooled, proj, scale, save):
+    def forward(pooled, proj, scale, save, scale_t=None):
+        """scale: host float (fixed logit scale, or 1.0); scale_t: 1-element device tensor (learnable logit scale: applied by a second tiny
+        launch so that the value never visits the host)"""
         B, d = pooled.shape
         dev = pooled.device
         f32 = lambda *s: torch.empty(*s, dtype=torch.float32, device=dev)
@@ -141,11 +210,19 @@ class _Head:
         feat, inv = f32(B, D), f32(B)
         hip.call("oneprot_l2norm_fwd", y, feat, inv, B, D, scale)
         st.update(inv=inv, feat=feat, pooled=pooled)
+        if scale_t is not None:
+            out = feat.clone()
+            hip.call("oneprot_scale_by_device_scalar", out, out.numel(), scale_t)
+            st.update(feat_scaled=out)
+            feat = out
         return feat, (st if save else None)
 
     @staticmethod
-    def backward(dfeat, proj, scale, st):
-        """returns (dpooled, [grads of proj parameters in proj.parameters() order])"""
+    def backward(dfeat, proj, scale, st, scale_t=None):
+        """returns (dpooled, [grads of proj parameters in proj.parameters() order]); with a device-side scale `dfeat` is first multiplied by it"""
+        if scale_t is not None:
+            dfeat = dfeat.clone()
+            hip.call("oneprot_scale_by_device_scalar", dfeat, dfeat.numel(), scale_t)
         dev = dfeat.device
         B, D = dfeat.shape
         f32 = lambda *s: torch.empty(*s, dtype=torch.float32, device=dev)
@@ -190,20 +267,23 @@ class _L2NormFn(torch.autograd.Function):
 
     @staticmethod
     def forward(ctx, x, scale):
-        x = x.contiguous()
+        if not x.is_cuda:
+            raise hip.HipKernelError("OneProt HIP path needs CUDA(ROCm) tensors; there is no CPU fallback")
+        shape = x.shape
+        x = x.contiguous().float().view(-1, shape[-1])
         B, D = x.shape
         y, inv = torch.empty_like(x), torch.empty(B, device=x.device)
         hip.call("oneprot_l2norm_fwd", x, y, inv, B, D, scale)
         ctx.save_for_backward(y, inv)
         ctx.scale = scale
-        return y
+        return y.view(shape)
 
     @staticmethod
     def backward(ctx, dy):
         y, inv = ctx.saved_tensors
         dx = torch.empty_like(y)
-        hip.call("oneprot_l2norm_bwd", y, dy.contiguous(), inv, dx, y.shape[0], y.shape[1], ctx.scale, 0.0)
-        return dx, None
+        hip.call("oneprot_l2norm_bwd", y, dy.contiguous().float().view(y.shape), inv, dx, y.shape[0], y.shape[1], ctx.scale, 0.0)
+        return dx.view(dy.shape), None
 
 
 # ------------------------------------------------------------------------------------------------- whole-encoder node
@@ -245,9 +325,12 @@ class _EncodeFn(torch.autograd.Function):
                      tr.view("encoder.emb_layer_norm_after.bias"), pooled, mean, rstd, wrow, None, None, B, L, d, tr.config.layer_norm_eps, mode)
         else:       # BERT: the last layer's output is already post-LN
             hip.call("oneprot_pool_fwd", x, ids, tr.config.pad_token_id, pooled, B, L, d, mode)
-        scale = enc.logit_scale_value()
-        feat, hst = _Head.forward(pooled, enc.proj, scale, need_any)
+        learn = len(enc.norm) > 1 and enc.norm[1].learnable
+        scale_t, dscale_t = enc.norm[1].scale_device() if learn else (None, None)
+        scale = 1.0 if learn else enc.logit_scale_value()
+        feat, hst = _Head.forward(pooled, enc.proj, scale, need_any, scale_t)
         ctx.enc, ctx.saved, ctx.hst, ctx.scale = enc, saved, hst, scale
+        ctx.scale_t, ctx.dscale_t = scale_t, dscale_t
         ctx.fin = (mean, rstd, wrow)
         ctx.pool = (hidden, attn) if (mode == 2 and need_any) else None
         ctx.need_tr_grad = need_tr_grad
@@ -260,7 +343,7 @@ class _EncodeFn(torch.autograd.Function):
         enc, tr = ctx.enc, ctx.enc.transformer
         dev = dfeat.device
         dfeat = dfeat.contiguous()
-        dpooled, hgrads = _Head.backward(dfeat, enc.proj, ctx.scale, ctx.hst)
+        dpooled, hgrads = _Head.backward(dfeat, enc.proj, ctx.scale, ctx.hst, ctx.scale_t)
         extra_grads = []
         dhidden = None
         mode = enc.pooling.mode
@@ -274,10 +357,10 @@ class _EncodeFn(torch.autograd.Function):
                      _ws(hip.query("oneprot_attnpool_bwd_workspace", B, d), dev), B, L, d)
             extra_grads += [dw.view_as(enc.pooling.layer.weight), db]
         if len(enc.norm) > 1 and enc.norm[1].learnable:
-            # d/d(log s) [s * xhat] = s * xhat = feat  (zero when the clip at max_logit_scale is active)
+            # d/d(log s) [clip(e^l) * xhat] = (dfeat . xhat) * d clip(e^l)/dl, the last factor e^l or 0 (clip active): all on the device
             g = torch.zeros(1, device=dev)
-            if not enc.norm[1].is_clipped():
-                hip.call("oneprot_sgemm", dfeat.view(1, -1), ctx.hst["feat"].view(1, -1), g, 1, 1, dfeat.numel(), 0, 0, 1.0, 0)
+            hip.call("oneprot_sgemm", dfeat.view(1, -1), ctx.hst["feat"].view(1, -1), g, 1, 1, dfeat.numel(), 0, 0, 1.0, 0)
+            hip.call("oneprot_scale_by_device_scalar", g, 1, ctx.dscale_t)
             extra_grads.append(g.reshape(()))
         gflat = None
         if ctx.need_tr_grad:

@@ -267,7 +267,12 @@ class ArenaModule(nn.Module):
         if self._lora:
             hip.call("oneprot_colsum_bf16", dY, db, ws, T, N, 0)
         else:
-            hip.call("oneprot_gemm_bf16_tn", dY, X, T, N, K, ldy, ldx, dW, db, ws, 0)
+            hip.call("oneprot_gemm_bf16_tn", dY, X, T, N, K, ldy, ldx, dW, db, ws, ws.numel(), 0)
+
+    @staticmethod
+    def _tn_workspace(shapes, dev):
+        """one workspace large enough for every (N, K) weight gradient of a backward pass (the split count, hence the slab size, differs per shape)"""
+        return torch.empty(max(hip.query("oneprot_gemm_bf16_tn_workspace", N, K) for N, K in shapes), dtype=torch.uint8, device=dev)
 
     def lora_backward(self, gflat):
         """(dA, dB) from the gradient w.r.t. the merged weights left in `gflat`, then `gflat` reduced to its "bias" entries (peft bias="all")."""
@@ -553,7 +558,7 @@ class EsmTransformer(ArenaModule):
         gv = lambda name: self.view(name, gflat)
         b16 = lambda *s: torch.empty(*s, dtype=torch.bfloat16, device=dev)
         ws_ln = torch.empty(hip.query("oneprot_layernorm_bwd_workspace", d), dtype=torch.uint8, device=dev)
-        ws_tn = torch.empty(max(hip.query("oneprot_gemm_bf16_tn_workspace", 3 * dp, d), hip.query("oneprot_gemm_bf16_tn_workspace", f, d)), dtype=torch.uint8, device=dev)
+        ws_tn = self._tn_workspace(((3 * dp, d), (f, d), (d, f), (d, dp)), dev)
         ws_at = torch.empty(hip.query("oneprot_attn_bwd_workspace", B, H, L), dtype=torch.uint8, device=dev)
         dz = b16(T, f)
         dh = b16(T, d)
@@ -578,7 +583,7 @@ class EsmTransformer(ArenaModule):
                      gv(p + "LayerNorm.weight"), gv(p + "LayerNorm.bias"), ws_ln, T, d, 0)
             # ---- out-proj: x_mid = x_in + ctx Wo^T + bo
             hip.call("oneprot_gemm_bf16_tn", g16, st["ctx"], T, d, dp, d, dp, gw_o if self._padded else gv(p + "attention.output.dense.weight"),
-                     gv(p + "attention.output.dense.bias"), ws_tn, 0)
+                     gv(p + "attention.output.dense.bias"), ws_tn, ws_tn.numel(), 0)
             hip.call("oneprot_gemm_bf16_nt", g16, self._bf16_T[(i, "o")], T, dp, d, d, d, hip.EPI_BF16, None, dctx, None, None, None, None, None, 1.0, 0, 0, 0)
             # ---- attention
             hip.call("oneprot_attn_bwd", st["q"], st["k"], st["v"], saved["key_bias"], st["ctx"], dctx, st["lse"], cos, sin, q_scale, dqkv, ws_at, B, H, L, hd)
@@ -586,7 +591,7 @@ class EsmTransformer(ArenaModule):
             o, n = self.span(p + "attention.self.query.weight", p + "attention.self.value.weight")
             ob, nb = self.span(p + "attention.self.query.bias", p + "attention.self.value.bias")
             hip.call("oneprot_gemm_bf16_tn", dqkv, st["h1"], T, 3 * dp, d, 3 * dp, d, gw_qkv if self._padded else gflat[o:o + n],
-                     gb_qkv if self._padded else gflat[ob:ob + nb], ws_tn, 0)
+                     gb_qkv if self._padded else gflat[ob:ob + nb], ws_tn, ws_tn.numel(), 0)
             if self._padded:
                 gv(p + "attention.output.dense.weight").copy_(gw_o[:, colmap])
                 gflat[o:o + n].view(3 * d, d).copy_(gw_qkv[rowmap])

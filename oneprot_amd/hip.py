@@ -12,6 +12,7 @@ import torch
 _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.path.join(_HERE, "liboneprot_hip.so")
 
+ABI_VERSION = 2
 EPI_BF16, EPI_F32, EPI_BIAS_GELU, EPI_BIAS_RESID, EPI_QKV_ROPE, EPI_GELU_BWD = range(6)
 LOG2E = 1.4426950408889634      # the attention kernels take q pre-multiplied by hd^-1/2 * log2(e) (include/oneprot_hip.h)
 
@@ -48,7 +49,7 @@ _SIGS = {
     "oneprot_gemm_force_shape": (None, [I]),
     "oneprot_gemm_bf16_tn_workspace": (SZ, [I, I]),
     "oneprot_gemm_tn_variant": (None, [I]),
-    "oneprot_gemm_bf16_tn": (I, [P, P, L64, I, I, I, I, P, P, P, I, P]),
+    "oneprot_gemm_bf16_tn": (I, [P, P, L64, I, I, I, I, P, P, P, SZ, I, P]),
     "oneprot_sgemm": (I, [P, P, P, I, I, I, I, I, F, I, P]),
     "oneprot_attn_fwd": (I, [P, P, P, P, P, P, I, I, I, I, P]),
     "oneprot_attn_bwd_workspace": (SZ, [I, I, I]),
@@ -93,6 +94,8 @@ def lib():
         for name, (res, args) in _SIGS.items():
             fn = getattr(h, name)          # AttributeError here = header/library mismatch: fail loudly
             fn.restype, fn.argtypes = res, args
+        if h.oneprot_abi_version() != ABI_VERSION:
+            raise HipLibraryMissing(f"{LIB_PATH} has ABI version {h.oneprot_abi_version()}, this binding needs {ABI_VERSION}: rebuild it (oneprot_amd/csrc/build.sh)")
         _lib = h
     return _lib
 
@@ -109,14 +112,17 @@ def stream():
     return torch.cuda.current_stream().cuda_stream
 
 
-_prof = None     # (entry point, epilogue or None, [(start_event, end_event), ...])
+_prof = None     # {entry point: (epilogue or None, [(start_event, end_event, scalar args), ...])}
 
 
 def profile_begin(name, epilogue=None):
     """Bracket every subsequent launch of `name` (optionally: only with this GEMM epilogue id) with HIP events recorded on the
-    launch stream; profile_end() returns the per-launch durations in ms.  Used by bench.py for the live roofline figure."""
+    launch stream; profile_end() returns the per-launch durations in ms.  Used by bench.py for the live roofline figure.
+    `name` may be a dict {entry point: epilogue or None} to watch several entry points at once (profile_end then returns a dict of
+    [(ms, scalar args), ...] lists)."""
     global _prof
-    _prof = (name, epilogue, [])
+    _prof = {k: (v, []) for k, v in name.items()} if isinstance(name, dict) else {name: (epilogue, [])}
+    _prof["__single__"] = None if isinstance(name, dict) else name
 
 
 def profile_end():
@@ -124,21 +130,23 @@ def profile_end():
     if _prof is None:
         return []
     torch.cuda.synchronize()
-    out = [a.elapsed_time(b) for a, b in _prof[2]]
+    single = _prof.pop("__single__")
+    out = {k: [(a.elapsed_time(b), sc) for a, b, sc in v[1]] for k, v in _prof.items()}
     _prof = None
-    return out
+    return [ms for ms, _ in out[single]] if single is not None else out
 
 
 def call(name, *args):
     """Invoke an int-returning entry point on the current torch stream; raise on a non-zero status."""
     fn = getattr(lib(), name)
     cargs = [ptr(a) if isinstance(a, torch.Tensor) or a is None else a for a in args]
-    if _prof is not None and _prof[0] == name and (_prof[1] is None or args[7] == _prof[1]):
+    watch = _prof.get(name) if _prof is not None else None
+    if watch is not None and (watch[0] is None or args[7] == watch[0]):
         e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
         e0.record()
         rc = fn(*cargs, stream())
         e1.record()
-        _prof[2].append((e0, e1))
+        watch[1].append((e0, e1, tuple(a for a in args if isinstance(a, (int, float)))))
     else:
         rc = fn(*cargs, stream())
     if rc != 0:

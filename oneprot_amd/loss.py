@@ -36,13 +36,12 @@ class _PackedAllGather(torch.autograd.Function):
         W = ctx.world_size
         grad_out = grad_out.contiguous()
         flat = grad_out.view((W * grad_out.shape[1],) + tuple(grad_out.shape[2:]))
-        grad_in = torch.empty(grad_out.shape[1:], dtype=grad_out.dtype, device=grad_out.device)
-        try:
-            dist.reduce_scatter_tensor(grad_in, flat, op=dist.ReduceOp.SUM, group=ctx.group)
-        except RuntimeError:      # backends without reduce_scatter (gloo): all-reduce, keep the own slice
+        if dist.get_backend(ctx.group) == "gloo":      # gloo has no reduce_scatter: all-reduce, keep the own slice (CPU tests / rehearsals only)
             buf = grad_out.clone()
             dist.all_reduce(buf, op=dist.ReduceOp.SUM, group=ctx.group)
-            grad_in = buf[ctx.rank].clone()
+            return buf[ctx.rank].clone(), None, None
+        grad_in = torch.empty(grad_out.shape[1:], dtype=grad_out.dtype, device=grad_out.device)
+        dist.reduce_scatter_tensor(grad_in, flat, op=dist.ReduceOp.SUM, group=ctx.group)      # RCCL: errors propagate, no silent 2x-larger fallback
         return grad_in, None, None
 
 
@@ -88,14 +87,25 @@ class _ClipLossFn(torch.autograd.Function):
         dev = rows_m.device
         lm = torch.empty(R, C, device=dev)
         ls = torch.empty(R, C, device=dev)
-        hip.call("oneprot_sgemm", rows_m, cols_s, lm, R, C, D, 0, 0, float(logit_scale), 0)
-        hip.call("oneprot_sgemm", rows_s, cols_m, ls, R, C, D, 0, 0, float(logit_scale), 0)
+        # a python-number scale is folded into the GEMM's alpha; a tensor scale (e.g. `log_logit_scale.exp()`, ref oneprot_module.py:142) stays on
+        # the device -- one extra pass over the tiny logit blocks instead of a host synchronisation -- and receives its gradient
+        scale_t = logit_scale.detach().reshape(1).float().to(dev).contiguous() if isinstance(logit_scale, torch.Tensor) else None
+        alpha = 1.0 if scale_t is not None else float(logit_scale)
+        hip.call("oneprot_sgemm", rows_m, cols_s, lm, R, C, D, 0, 0, alpha, 0)
+        hip.call("oneprot_sgemm", rows_s, cols_m, ls, R, C, D, 0, 0, alpha, 0)
+        keep = None
+        if scale_t is not None:
+            hip.call("oneprot_scale_by_device_scalar", lm, lm.numel(), scale_t)
+            hip.call("oneprot_scale_by_device_scalar", ls, ls.numel(), scale_t)
+            if ctx.needs_input_grad[4]:
+                keep = (lm.clone(), ls.clone())          # scaled logits, for d(scale) = sum(dlogits * logits) / scale
         loss = torch.zeros(1, device=dev)
         rw = torch.empty(R, device=dev)
         hip.call("oneprot_ce_fwd_bwd", lm, loss, rw, R, C, int(label_offset), 0.5 / R)
         hip.call("oneprot_ce_fwd_bwd", ls, loss, rw, R, C, int(label_offset), 0.5 / R)
         ctx.save_for_backward(rows_m, cols_s, rows_s, cols_m, lm, ls)      # lm/ls now hold dlogits
-        ctx.logit_scale = float(logit_scale)
+        ctx.alpha, ctx.scale_t, ctx.keep = alpha, scale_t, keep
+        ctx.scale_shape = logit_scale.shape if scale_t is not None else None
         return loss.reshape(())
 
     @staticmethod
@@ -103,7 +113,7 @@ class _ClipLossFn(torch.autograd.Function):
         rows_m, cols_s, rows_s, cols_m, dlm, dls = ctx.saved_tensors
         R, D = rows_m.shape
         C = cols_s.shape[0]
-        a = ctx.logit_scale
+        a = ctx.alpha
         d_rows_m, d_rows_s = torch.empty_like(rows_m), torch.empty_like(rows_s)
         d_cols_s, d_cols_m = torch.empty_like(cols_s), torch.empty_like(cols_m)
         hip.call("oneprot_sgemm", dlm, cols_s, d_rows_m, R, D, C, 0, 1, a, 0)      # dA_m = dL_m  B_s
@@ -113,7 +123,16 @@ class _ClipLossFn(torch.autograd.Function):
         g = gout.reshape(1).float().contiguous()
         for t in (d_rows_m, d_cols_s, d_rows_s, d_cols_m):
             hip.call("oneprot_scale_by_device_scalar", t, t.numel(), g)
-        return d_rows_m, d_cols_s, d_rows_s, d_cols_m, None, None
+            if ctx.scale_t is not None:
+                hip.call("oneprot_scale_by_device_scalar", t, t.numel(), ctx.scale_t)
+        d_scale = None
+        if ctx.keep is not None:
+            acc = torch.zeros(1, device=rows_m.device)
+            hip.call("oneprot_sgemm", dlm.view(1, -1), ctx.keep[0].view(1, -1), acc, 1, 1, dlm.numel(), 0, 0, 1.0, 0)
+            hip.call("oneprot_sgemm", dls.view(1, -1), ctx.keep[1].view(1, -1), acc, 1, 1, dls.numel(), 0, 0, 1.0, 1)
+            hip.call("oneprot_scale_by_device_scalar", acc, 1, g)
+            d_scale = (acc / ctx.scale_t).reshape(ctx.scale_shape)
+        return d_rows_m, d_cols_s, d_rows_s, d_cols_m, d_scale, None
 
 
 class ClipLoss(nn.Module):
@@ -136,8 +155,6 @@ class ClipLoss(nn.Module):
         return labels
 
     def forward(self, modality_features, sequence_features, logit_scale=1.0, output_dict=False):
-        if isinstance(logit_scale, torch.Tensor):
-            logit_scale = float(logit_scale)
         if self.world_size > 1:
             all_m, all_s = gather_features(modality_features, sequence_features, self.local_loss, self.gather_with_grad, self.rank, self.world_size,
                                            self.use_horovod)

@@ -20,13 +20,54 @@ class RetrievalMetric:
         self.preds.append(preds.detach().float())
         self.target.append(target.detach().float())
 
-    def _gathered(self):
-        s, m = torch.cat(self.preds), torch.cat(self.target)
-        if torch.distributed.is_available() and torch.distributed.is_initialized() and torch.distributed.get_world_size() > 1:   # dist_reduce_fx="cat"
-            W = torch.distributed.get_world_size()
-            outs = [torch.empty_like(s) for _ in range(W)], [torch.empty_like(m) for _ in range(W)]
-            torch.distributed.all_gather(outs[0], s.contiguous()); torch.distributed.all_gather(outs[1], m.contiguous())
-            s, m = torch.cat(outs[0]), torch.cat(outs[1])
+    @staticmethod
+    def _dist():
+        d = torch.distributed
+        return d if (d.is_available() and d.is_initialized() and d.get_world_size() > 1) else None
+
+    def global_count(self, device=None):
+        """number of accumulated pairs over ALL ranks (collective when distributed): the decision to enter compute() must be the same on
+        every rank, a rank-local `if metric.preds` would dead-lock the gather below when one rank saw no batch of a modality"""
+        n = sum(int(p.shape[0]) for p in self.preds)
+        d = self._dist()
+        if d is None:
+            return n
+        dev = self.preds[0].device if self.preds else (device or (torch.device("cuda", torch.cuda.current_device()) if d.get_backend() == "nccl" else torch.device("cpu")))
+        t = torch.tensor([n], dtype=torch.int64, device=dev)
+        d.all_reduce(t)
+        return int(t)
+
+    def _gathered(self, device=None, width=None):
+        """torchmetrics dist_reduce_fx="cat" semantics: rank-major concatenation, ranks may hold different numbers of rows (even none):
+        the counts travel first, every rank pads to the maximum, the padding is trimmed after the gather"""
+        d = self._dist()
+        if self.preds:
+            s, m = torch.cat(self.preds).contiguous(), torch.cat(self.target).contiguous()
+        else:
+            s = m = None
+        if d is None:
+            return s, m
+        W = d.get_world_size()
+        if s is None:       # this rank saw no batch: learn the feature width / device from the others
+            dev = device or (torch.device("cuda", torch.cuda.current_device()) if d.get_backend() == "nccl" else torch.device("cpu"))
+            meta = torch.zeros(2, dtype=torch.int64, device=dev)
+        else:
+            dev = s.device
+            meta = torch.tensor([s.shape[0], s.shape[1]], dtype=torch.int64, device=dev)
+        metas = [torch.zeros_like(meta) for _ in range(W)]
+        d.all_gather(metas, meta)
+        counts = [int(x[0]) for x in metas]
+        D = max(int(x[1]) for x in metas)
+        nmax = max(counts)
+        def padded(t):
+            buf = torch.zeros(nmax, D, device=dev)
+            if t is not None:
+                buf[:t.shape[0]] = t
+            return buf
+        outs_s, outs_m = [torch.empty(nmax, D, device=dev) for _ in range(W)], [torch.empty(nmax, D, device=dev) for _ in range(W)]
+        d.all_gather(outs_s, padded(s)); d.all_gather(outs_m, padded(m))
+        s = torch.cat([o[:c] for o, c in zip(outs_s, counts)])
+        m = torch.cat([o[:c] for o, c in zip(outs_m, counts)])
         return s.contiguous(), m.contiguous()
 
     def compute(self):

@@ -66,38 +66,79 @@ class _DeviceMin:
         return self.value if self.value is not None else torch.tensor(float("inf"))
 
 
-class _PlainBase(nn.Module):
-    """The slice of LightningModule that OneProtLitModule.training_step relies on."""
+class _PlainServices:
+    """The slice of LightningModule that OneProtLitModule.training_step relies on, without a Trainer: used as the whole base when Lightning is
+    absent, and as the fallback of a real LightningModule that is driven without a Trainer (fit_steps / bench.py)."""
 
+    def _plain_optimizers(self):
+        if getattr(self, "_optimizer", None) is None:
+            cfg = self.configure_optimizers()
+            self._optimizer = cfg["optimizer"]
+            self._lr_scheduler = cfg.get("lr_scheduler")            # {"scheduler", "monitor", "interval", "frequency"} or None
+        return self._optimizer
+
+    def _plain_lr_schedulers(self):
+        self._plain_optimizers()
+        return self._lr_scheduler["scheduler"] if self._lr_scheduler else None
+
+    def _plain_clip_gradients(self, optimizer, gradient_clip_val=None, gradient_clip_algorithm="norm"):
+        assert gradient_clip_algorithm == "norm"
+        params = [p for g in optimizer.param_groups for p in g["params"]]
+        self.last_grad_norm = clip_grad_norm_(params, gradient_clip_val, optimizer)
+
+    def _plain_log(self, name, value, **kw):
+        if not hasattr(self, "logged"):
+            self.logged = {}
+        self.logged[name] = value
+
+
+class _PlainBase(nn.Module, _PlainServices):
     def __init__(self):
         super().__init__()
         self.automatic_optimization = True
         self.hparams = SimpleNamespace()
         self.global_step = 0
         self._optimizer = None
+        self._lr_scheduler = None
         self.logged = {}
 
     def save_hyperparameters(self, logger=False, **kw):
         pass   # hparams are filled explicitly by the subclass
 
-    def optimizers(self):
-        if self._optimizer is None:
-            self._optimizer = self.configure_optimizers()["optimizer"]
-        return self._optimizer
+    optimizers = _PlainServices._plain_optimizers
+    lr_schedulers = _PlainServices._plain_lr_schedulers
+    clip_gradients = _PlainServices._plain_clip_gradients
+    log = _PlainServices._plain_log
 
     def manual_backward(self, loss):
         loss.backward()
 
-    def clip_gradients(self, optimizer, gradient_clip_val=None, gradient_clip_algorithm="norm"):
-        assert gradient_clip_algorithm == "norm"
-        params = [p for g in optimizer.param_groups for p in g["params"]]
-        self.last_grad_norm = clip_grad_norm_(params, gradient_clip_val, optimizer)
 
-    def log(self, name, value, **kw):
-        self.logged[name] = value
+if HAVE_LIGHTNING:                                      # pragma: no cover  (not installed in the build image)
+    class _Base(_LightningBase, _PlainServices):
+        """LightningModule whose Trainer-backed services fall back to the plain ones while no Trainer is attached"""
 
+        def _has_trainer(self):
+            return getattr(self, "_trainer", None) is not None
 
-_Base = _LightningBase if HAVE_LIGHTNING else _PlainBase
+        def optimizers(self, *a, **kw):
+            return super().optimizers(*a, **kw) if self._has_trainer() else self._plain_optimizers()
+
+        def lr_schedulers(self):
+            return super().lr_schedulers() if self._has_trainer() else self._plain_lr_schedulers()
+
+        def manual_backward(self, loss, *a, **kw):
+            return super().manual_backward(loss, *a, **kw) if self._has_trainer() else loss.backward()
+
+        def clip_gradients(self, optimizer, gradient_clip_val=None, gradient_clip_algorithm=None):
+            if self._has_trainer():
+                return super().clip_gradients(optimizer, gradient_clip_val=gradient_clip_val, gradient_clip_algorithm=gradient_clip_algorithm)
+            return self._plain_clip_gradients(optimizer, gradient_clip_val, gradient_clip_algorithm or "norm")
+
+        def log(self, name, value, *a, **kw):
+            return super().log(name, value, *a, **kw) if self._has_trainer() else self._plain_log(name, value)
+else:
+    _Base = _PlainBase
 
 
 class OneProtLitModule(_Base):
@@ -147,7 +188,7 @@ class OneProtLitModule(_Base):
     def training_step(self, batch, batch_idx=None):
         opt = self.optimizers()
         self._attach_grad_overlap()
-        current_step = self.global_step
+        current_step = self.global_step if not (HAVE_LIGHTNING and self._owns_gradient_sync()) else getattr(self, "_standalone_step", 0)
         if current_step < self.train_on_all_modalities_after_step:
             modalities_to_train = ["struct_token"]
         else:
@@ -169,19 +210,30 @@ class OneProtLitModule(_Base):
             self.clip_gradients(opt, gradient_clip_val=1.0, gradient_clip_algorithm="norm")
             opt.step()
             self.log("train/loss", self.train_loss, on_step=True, on_epoch=True, prog_bar=True, sync_dist=True)
-            if not HAVE_LIGHTNING:
-                self.global_step += 1
+            if self._owns_gradient_sync():
+                self._bump_global_step()
         return loss
+
+    def _bump_global_step(self):
+        if HAVE_LIGHTNING:                               # pragma: no cover  (global_step is a Trainer-backed property there)
+            self._standalone_step = getattr(self, "_standalone_step", 0) + 1
+        else:
+            self.global_step += 1
 
     def _sync_gradients(self, opt):
         """What Lightning's DDP wrapper does implicitly in the reference (C6 in SURVEY.md section 2.2) -- here explicit, and only
         over parameters that received a gradient in this sub-step.  The encoder arenas are reduced in ranges from inside their backward
         (distributed.GradOverlap, attached on first use); this call waits for those and reduces the small head parameters."""
-        if getattr(self.loss_fn, "world_size", 1) > 1 and not HAVE_LIGHTNING:
+        if getattr(self.loss_fn, "world_size", 1) > 1 and self._owns_gradient_sync():
             D.allreduce_gradients([p for g in opt.param_groups for p in g["params"]])
 
+    def _owns_gradient_sync(self):
+        """True when nothing else reduces the gradients: no Lightning, or a LightningModule that is driven without a Trainer (fit_steps /
+        bench.py).  Under a Trainer the DDP strategy wraps the module and does it (configs/trainer/ddp.yaml)."""
+        return (not HAVE_LIGHTNING) or getattr(self, "_trainer", None) is None
+
     def _attach_grad_overlap(self):
-        if getattr(self, "_overlap_attached", False) or HAVE_LIGHTNING or getattr(self.loss_fn, "world_size", 1) <= 1:
+        if getattr(self, "_overlap_attached", False) or not self._owns_gradient_sync() or getattr(self.loss_fn, "world_size", 1) <= 1:
             return
         if D.is_dist_avail_and_initialized():
             ov = D.GradOverlap()
@@ -220,15 +272,22 @@ class OneProtLitModule(_Base):
         self.val_loss_best(loss)
         self.log("val/loss_best", self.val_loss_best.compute(), sync_dist=True, prog_bar=True)
         for name, metric in self.metrics.items():
-            if name.startswith("val_") and metric.preds:
+            if name.startswith("val_") and metric.global_count() > 0:       # collective decision: every rank enters compute() or none does
                 for key, value in metric.compute().items():
                     self.log(f"val/{key}/{name}", value, sync_dist=True, prog_bar=True)
                 metric.reset()
+        sched = getattr(self, "_lr_scheduler", None)
+        if sched and self._owns_gradient_sync():        # what Lightning does for {"interval": "epoch", "monitor": "val/loss_best"} (ref oneprot_module.py:161-169)
+            s = sched["scheduler"]
+            if "metrics" in s.step.__code__.co_varnames:
+                s.step(self.val_loss_best.compute())
+            else:
+                s.step()
 
     def on_test_epoch_end(self):
         """ref oneprot_module.py:148-154"""
         for name, metric in self.metrics.items():
-            if name.startswith("test_") and metric.preds:
+            if name.startswith("test_") and metric.global_count() > 0:
                 for key, value in metric.compute().items():
                     self.log(f"test/{key}/{name}", value, prog_bar=True)
                 metric.reset()

@@ -408,9 +408,73 @@ def train_multi_substeps(seq_ids, mod_ids, sd_seq, sd_mod, cfg_seq, cfg_mod, seq
     return losses, {k: v.detach() for k, v in ps.items()}, {k: v.detach() for k, v in pm.items()}
 
 
+def _features(spec: dict, ids: Tensor, sd: Dict[str, Tensor], cfg: dict) -> Tensor:
+    return encoder_features(spec["kind"], ids, sd, cfg, spec["pooling"], spec["proj_type"], spec["use_logit_scale"])
+
+
+def validation_substep(seq_ids, mod_ids, sd_seq, sd_mod, cfg_seq, cfg_mod, seq_spec, mod_spec):
+    """OneProtLitModule.validation_step (ref oneprot_module.py:110-121): forward both encoders, plain CLIP loss (no L1 term, logit_scale 1.0).
+    Returns (loss, sequence_features, modality_features)."""
+    with torch.no_grad():
+        sf, mf = _features(seq_spec, seq_ids, sd_seq, cfg_seq), _features(mod_spec, mod_ids, sd_mod, cfg_mod)
+        return clip_loss(sf, mf), sf, mf
+
+
+def test_substep(seq_ids, mod_ids, sd_seq, sd_mod, cfg_seq, cfg_mod, seq_spec, mod_spec):
+    """OneProtLitModule.test_step (ref oneprot_module.py:137-146).  NB line 142 hands `network[modality].norm[1].log_logit_scale.exp()` to
+    the loss although the modality features already carry that factor: the logits are scaled twice (14.29^2 = 204x).  Restated as written."""
+    with torch.no_grad():
+        sf, mf = _features(seq_spec, seq_ids, sd_seq, cfg_seq), _features(mod_spec, mod_ids, sd_mod, cfg_mod)
+        return clip_loss(sf, mf, float(sd_mod["norm.1.log_logit_scale"].exp())), sf, mf
+
+
+test_substep.__test__ = False        # not a pytest test
+
+
+def train_round_robin(batches, sds, cfgs, specs, use_l1=True, frozen=(), train_on_all_modalities_after_step=0, lr=1e-3):
+    """The mixed-batch loop (ref oneprot_module.py:80-108 driven by CombinedLoader("min_size") batches, oneprot_datamodule.py:75): ONE
+    torch.optim.Adam over every trainable tensor of every component (configure_optimizers :157-170); per batch, per modality in dict order:
+    fwd sequence, fwd modality, zero_grad, loss (+L1), backward, clip-norm 1.0 over the parameters that received a gradient, step (Adam skips
+    parameters whose grad is None -- the inactive modalities').  While global_step < train_on_all_modalities_after_step only "struct_token"
+    trains (:84-86; global_step counts optimiser steps under manual optimisation).
+    batches: list of {modality: (seq_ids, mod_ids)}; sds/cfgs/specs: {"sequence": ..., modality: ...}; frozen: component names whose
+    `transformer.*` tensors are not trained.  Returns [(modality, loss), ...] in execution order and the final parameter dicts."""
+    params = {}
+    for name, sd in sds.items():
+        out = {}
+        for k, v in sd.items():
+            t = v.detach().clone()
+            trainable = t.is_floating_point() and k != "norm.1.log_logit_scale" and "inv_freq" not in k and not k.startswith("transformer.pooler") \
+                and not k.startswith("transformer.contact_head") and not (name in frozen and k.startswith("transformer."))
+            if trainable:
+                t.requires_grad_(True)
+            out[k] = t
+        params[name] = out
+    leaves = [t for d in params.values() for t in d.values() if t.requires_grad]
+    opt = torch.optim.Adam(leaves, lr=lr, weight_decay=0.0)
+    log, global_step = [], 0
+    for batch in batches:
+        mods = ["struct_token"] if global_step < train_on_all_modalities_after_step else [m for m in batch if m != "seqsim"]
+        for m in mods:
+            seq_ids, mod_ids = batch[m]
+            sf = _features(specs["sequence"], seq_ids, params["sequence"], cfgs["sequence"])
+            mf = _features(specs[m], mod_ids, params[m], cfgs[m])
+            opt.zero_grad()
+            loss = clip_loss(sf, mf)
+            if use_l1:
+                loss = loss + 0.01 * (sf.abs().mean() + mf.abs().mean())
+            loss.backward()
+            torch.nn.utils.clip_grad_norm_([t for t in leaves if t.grad is not None], 1.0)
+            opt.step()
+            global_step += 1
+            log.append((m, float(loss)))
+    return log, {n: {k: v.detach() for k, v in d.items()} for n, d in params.items()}
+
+
 def retrieval_metrics(sequence_outputs: Tensor, modality_outputs: Tensor, ks=(1, 10, 100)) -> dict:
     """ref retrieval_metric.py:76-102: S @ M^T, descending argsort, position of the diagonal; median rank (floor + 1) and R@k both ways.
-    (The reference's own class needs torchmetrics, absent here: this restatement is pinned only by reading those lines.)"""
+    Pinned by tests/golden/retrieval.pt: the reference's RetrievalMetric.compute itself, run by make_golden.py (its torchmetrics base class
+    replaced by an import-time placeholder; the arithmetic is the reference's own lines), on features whose similarities are exact in fp32."""
     import numpy as np
     out = {}
     lps = (sequence_outputs @ modality_outputs.t()).detach().cpu()

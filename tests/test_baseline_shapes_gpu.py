@@ -1,0 +1,247 @@
+"""Parity at the BASELINE.json model shapes: the drop-in classes driven through OneProtLitModule.training_step vs the CPU
+oracle on the same seeded inputs, at the shapes the bench quotes -- only the batch is reduced so that the oracle finishes in seconds:
+
+  cfg-2/3  ESM-2-150M x2 (30 layers, d=640, 20 heads of 32), L=512           frozen (reference default) and trainable sequence encoder
+  cfg-4    ESM-2-150M (L=512) <-> BERT-base text tower (12 layers, d=768, T=256)   text tower frozen (text.yaml:12) and trainable
+  cfg-5    ESM-2-650M width (d=1280, 20 heads of 64, ffn 5120; 4 of the 33 layers), attention1d pooling + linear head, frozen anchor
+           (ref configs/experiment/train_ddp_1.yaml:45-49) <-> ESM-2-35M struct-token encoder, L=512
+
+Gates (north_star: loss 1e-3 rel): loss rel <= 1e-3, gradient norm <= 2e-2, whole-gradient cosine > 0.9999, feature cosine > 0.999."""
+import functools
+import json
+import os
+
+import pytest
+import torch
+
+pytestmark = pytest.mark.gpu
+
+from oracle import oneprot_oracle as O  # noqa: E402
+
+DEV = "cuda"
+CFG150 = dict(layers=30, hidden=640, heads=20, ffn=2560, pad=1, mask=32, eps=1e-5)
+CFG35 = dict(layers=12, hidden=480, heads=20, ffn=1920, pad=1, mask=32, eps=1e-5)
+CFG_BERT = dict(layers=12, hidden=768, heads=12, ffn=3072, vocab=30522, max_pos=512, pad=0, eps=1e-12)
+SPEC_SEQ = dict(kind="esm", pooling="mean", proj_type="mlp", use_logit_scale=False)
+SPEC_ST = dict(kind="esm", pooling="mean", proj_type="linear", use_logit_scale=True)
+SPEC_TXT = dict(kind="bert", pooling="cls", proj_type="mlp", use_logit_scale=True)
+
+
+def _cos(a, b):
+    a, b = a.double().flatten(), b.double().flatten()
+    return float((a @ b) / (a.norm() * b.norm() + 1e-30))
+
+
+def _env():
+    os.environ.update(RANK="0", WORLD_SIZE="1", ONEPROT_ALLOW_RANDOM_INIT="1")
+
+
+def _ragged_ids(B, L, lo, hi, lens, gen, cls=0, eos=2, pad=1):
+    ids = torch.randint(lo, hi + 1, (B, L), generator=gen)
+    ids[:, 0] = cls
+    for b, n in enumerate(lens):
+        ids[b, n - 1] = eos
+        ids[b, n:] = pad
+    return ids
+
+
+def _randomise_biases(*encoders):
+    """random-init ESM/BERT biases are zero and LayerNorm gains one: perturb them so that a wrong bias / gain path cannot hide"""
+    with torch.no_grad():
+        for enc in encoders:
+            for k, v in enc.transformer.named_views().items():
+                if k.endswith(".bias"):
+                    v.normal_(0, 0.02)
+                elif k.endswith("LayerNorm.weight") or k.endswith("layer_norm_after.weight"):
+                    v.add_(torch.randn_like(v) * 0.05)
+
+
+def _run_substep(module, mod_key, seq_ids, mod_ids, grab):
+    """training_step with a spy that copies the arena gradients of the encoders named in `grab` before the optimizer consumes them"""
+    grads = {}
+    orig_clip = module.clip_gradients
+
+    def spy(opt, **kw):
+        for name in grab:
+            tr = module.network[name].transformer
+            if tr.flat.grad is not None:
+                grads[name] = {k: tr.view(k, tr.flat.grad).detach().cpu().clone() for k in tr._spec}
+        return orig_clip(opt, **kw)
+
+    module.clip_gradients = spy
+    loss = float(module.training_step({mod_key: (seq_ids.to(DEV), mod_ids.to(DEV), mod_key, None)}, 0).detach())
+    return loss, float(module.last_grad_norm), grads
+
+
+def _check_arena_grads(got, ref_grads, pref):
+    keys = [k for k in got if pref + "transformer." + k in ref_grads and float(ref_grads[pref + "transformer." + k].abs().max()) > 1e-9]
+    assert len(keys) > 50, len(keys)
+    allg = torch.cat([got[k].flatten() for k in keys])
+    allr = torch.cat([ref_grads[pref + "transformer." + k].flatten() for k in keys])
+    c = _cos(allg, allr)
+    assert c > 0.9999, f"whole-gradient cosine {c}"
+    big = max(float(ref_grads[pref + "transformer." + k].norm()) for k in keys)
+    for k in keys:
+        r = ref_grads[pref + "transformer." + k]
+        if float(r.norm()) >= 0.01 * big:
+            assert _cos(got[k], r) > 0.999, (k, _cos(got[k], r))
+    return c
+
+
+@pytest.mark.parametrize("frozen_seq", [True, False], ids=["frozen_seq", "trainable_seq"])
+def test_cfg2_shape_150m_substep_vs_oracle(frozen_seq):
+    """The headline shape: ESM-2-150M x2 at L=512 (30 layers deep, 512 keys per softmax row), 4 pairs (two full-length, two ragged)."""
+    _env()
+    from src.models.components.sequence_encoder import SequenceEncoder
+    from src.models.components.struct_token_encoder import StructTokenEncoder
+    from src.models.oneprot_module import OneProtLitModule
+    from oneprot_amd.optim import FusedAdam
+    torch.manual_seed(150)
+    name = "facebook/esm2_t30_150M_UR50D"
+    seq = SequenceEncoder(name, output_dim=1024, pooling_type="mean", proj_type="mlp", use_lora=False, frozen=frozen_seq)
+    st = StructTokenEncoder(name, output_dim=1024, pooling_type="mean", proj_type="linear", use_logit_scale=True, learnable_logit_scale=False)
+    assert (seq.transformer.n_layers, seq.transformer.d, seq.transformer.hd, seq.transformer.f) == (30, 640, 32, 2560)
+    _randomise_biases(seq, st)
+    sd_seq = {k: v.detach().clone() for k, v in seq.state_dict().items()}
+    sd_st = {k: v.detach().clone() for k, v in st.state_dict().items()}
+    gen = torch.Generator().manual_seed(1881)
+    B, L = 4, 512
+    lens = [512, 389, 512, 131]
+    seq_ids = _ragged_ids(B, L, 4, 23, lens, gen)
+    st_ids = _ragged_ids(B, L, 33, 52, lens, gen)
+    seq_ids[1, 7] = 32                                        # one <mask> token (token-dropout rescale path)
+    ref = O.train_substep(seq_ids, st_ids, sd_seq, sd_st, CFG150, CFG150, SPEC_SEQ, SPEC_ST, use_l1=True, frozen_seq=frozen_seq)
+    module = OneProtLitModule(components={"sequence": seq, "struct_token": st}, optimizer=functools.partial(FusedAdam, lr=1e-3), loss_fn="CLIP",
+                              use_l1_regularization=True, local_loss=True, gather_with_grad=True).to(DEV)
+    with torch.no_grad():
+        sf = module(seq_ids.to(DEV), "sequence").cpu()
+        mf = module(st_ids.to(DEV), "struct_token").cpu()
+    assert torch.nn.functional.cosine_similarity(sf, ref["sequence_features"], dim=-1).min() > 0.999
+    assert torch.nn.functional.cosine_similarity(mf, ref["modality_features"], dim=-1).min() > 0.999
+    loss, gn, grads = _run_substep(module, "struct_token", seq_ids, st_ids, ["sequence", "struct_token"])
+    rl, rg = float(ref["loss"]), float(ref["grad_total_norm"])
+    assert abs(loss - rl) / rl < 1e-3, (loss, rl)
+    assert abs(gn - rg) / rg < 2e-2, (gn, rg)
+    _check_arena_grads(grads["struct_token"], ref["grads"], "mod.")
+    if frozen_seq:
+        assert "sequence" not in grads
+    else:
+        _check_arena_grads(grads["sequence"], ref["grads"], "seq.")
+
+
+@pytest.mark.parametrize("frozen_text", [True, False], ids=["frozen_text", "trainable_text"])
+def test_cfg4_shape_150m_vs_bert_base_substep_vs_oracle(frozen_text):
+    """cfg-4: ESM-2-150M sequence tower (L=512, frozen) <-> BERT-base text tower (T=256; cls pooling, mlp head, logit scale: text.yaml)."""
+    _env()
+    from src.models.components.sequence_encoder import SequenceEncoder
+    from src.models.components.text_encoder import TextEncoder
+    from src.models.oneprot_module import OneProtLitModule
+    from oneprot_amd.optim import FusedAdam
+    torch.manual_seed(44)
+    seq = SequenceEncoder("facebook/esm2_t30_150M_UR50D", output_dim=1024, pooling_type="mean", proj_type="mlp", use_lora=False, frozen=True)
+    tx = TextEncoder("bert-base-uncased", output_dim=1024, pooling_type="cls", proj_type="mlp", use_logit_scale=True, learnable_logit_scale=False,
+                     frozen=frozen_text, use_lora=False)
+    assert (tx.transformer.n_layers, tx.transformer.d) == (12, 768)
+    _randomise_biases(seq, tx)
+    sd_seq = {k: v.detach().clone() for k, v in seq.state_dict().items()}
+    sd_tx = {k: v.detach().clone() for k, v in tx.state_dict().items()}
+    gen = torch.Generator().manual_seed(1881)
+    B, L, T = 4, 512, 256
+    seq_ids = _ragged_ids(B, L, 4, 23, [512, 300, 512, 77], gen)
+    txt_ids = _ragged_ids(B, T, 1000, 30521, [256, 140, 256, 19], gen, cls=101, eos=102, pad=0)
+    txt_ids[1, 3] = txt_ids[2, 9] = txt_ids[0, 2]           # the same word in several rows (embedding-row reduction)
+    if frozen_text:
+        # oracle: only the heads (and nothing of either transformer) are leaves
+        sd_tx_o = dict(sd_tx)
+        ref = _train_substep_frozen_mod(seq_ids, txt_ids, sd_seq, sd_tx_o, CFG150, CFG_BERT, SPEC_SEQ, SPEC_TXT)
+    else:
+        ref = O.train_substep(seq_ids, txt_ids, sd_seq, sd_tx, CFG150, CFG_BERT, SPEC_SEQ, SPEC_TXT, use_l1=True, frozen_seq=True)
+    module = OneProtLitModule(components={"sequence": seq, "text": tx}, optimizer=functools.partial(FusedAdam, lr=1e-3), loss_fn="CLIP",
+                              use_l1_regularization=True, local_loss=True, gather_with_grad=True).to(DEV)
+    with torch.no_grad():
+        mf = module(txt_ids.to(DEV), "text").cpu()
+    assert torch.nn.functional.cosine_similarity(mf, ref["modality_features"], dim=-1).min() > 0.999
+    loss, gn, grads = _run_substep(module, "text", seq_ids, txt_ids, ["text"])
+    rl, rg = float(ref["loss"]), float(ref["grad_total_norm"])
+    assert abs(loss - rl) / rl < 1e-3, (loss, rl)
+    assert abs(gn - rg) / rg < 2e-2, (gn, rg)
+    if frozen_text:
+        assert "text" not in grads
+        # head gradients of both towers vs the oracle
+        for name, pref in (("sequence", "seq."), ("text", "mod.")):
+            for k, p_ in module.network[name].proj.named_parameters():
+                r = ref["grads"][pref + "proj." + k]
+                assert _cos(p_.grad.cpu(), r) > 0.999, (name, k)
+    else:
+        _check_arena_grads(grads["text"], ref["grads"], "mod.")
+
+
+def _train_substep_frozen_mod(seq_ids, mod_ids, sd_seq, sd_mod, cfg_seq, cfg_mod, seq_spec, mod_spec):
+    """O.train_substep with BOTH transformers frozen (shipped cfg-4: sequence.yaml:12 and text.yaml:12): the oracle's own pieces composed in the
+    reference's order (oneprot_module.py:92-107), only the projection heads are leaves."""
+    def leaves(sd):
+        out = {}
+        for k, v in sd.items():
+            t = v.detach().clone()
+            if k.startswith("proj.") and t.is_floating_point():
+                t.requires_grad_(True)
+            out[k] = t
+        return out
+    ps, pm = leaves(sd_seq), leaves(sd_mod)
+    sf = O.encoder_features(seq_spec["kind"], seq_ids, ps, cfg_seq, seq_spec["pooling"], seq_spec["proj_type"], seq_spec["use_logit_scale"])
+    mf = O.encoder_features(mod_spec["kind"], mod_ids, pm, cfg_mod, mod_spec["pooling"], mod_spec["proj_type"], mod_spec["use_logit_scale"])
+    loss = O.clip_loss(sf, mf) + 0.01 * (sf.abs().mean() + mf.abs().mean())
+    loss.backward()
+    grads = {}
+    for pref, d in (("seq.", ps), ("mod.", pm)):
+        for k, t in d.items():
+            if t.requires_grad and t.grad is not None:
+                grads[pref + k] = t.grad
+    total, _ = O.clip_grad_norm(grads, 1.0)
+    return dict(sequence_features=sf.detach(), modality_features=mf.detach(), loss=loss.detach(), grads=grads, grad_total_norm=total)
+
+
+def test_cfg5_shape_650m_width_anchor_vs_oracle(tmp_path):
+    """cfg-5 anchor: ESM-2-650M width (d=1280, 20 heads of 64, ffn 5120; 4 layers instead of 33 so the oracle stays in seconds), attention1d
+    pooling + linear head, frozen (train_ddp_1.yaml:45-49), L=512, against the ESM-2-35M struct-token encoder (struct_token.yaml:3)."""
+    _env()
+    from src.models.components.sequence_encoder import SequenceEncoder
+    from src.models.components.struct_token_encoder import StructTokenEncoder
+    from src.models.oneprot_module import OneProtLitModule
+    from oneprot_amd.optim import FusedAdam
+    torch.manual_seed(650)
+    cfg650 = dict(layers=4, hidden=1280, heads=20, ffn=5120, pad=1, mask=32, eps=1e-5)
+    path = os.path.join(str(tmp_path), "esm650w")
+    os.makedirs(path)
+    with open(os.path.join(path, "config.json"), "w") as f:
+        json.dump(dict(model_type="esm", vocab_size=33, hidden_size=1280, num_hidden_layers=4, num_attention_heads=20, intermediate_size=5120, pad_token_id=1,
+                       mask_token_id=32, layer_norm_eps=1e-5, token_dropout=True, position_embedding_type="rotary", emb_layer_norm_before=False), f)
+    seq = SequenceEncoder(path, output_dim=1024, pooling_type="attention1d", proj_type="linear", use_lora=False, frozen=True, use_logit_scale=False)
+    st = StructTokenEncoder("facebook/esm2_t12_35M_UR50D", output_dim=1024, pooling_type="mean", proj_type="linear", use_logit_scale=True)
+    assert (seq.transformer.d, seq.transformer.hd) == (1280, 64)
+    _randomise_biases(seq, st)
+    with torch.no_grad():
+        seq.pooling.layer.weight.normal_(0, 0.05)
+        seq.pooling.layer.bias.fill_(0.1)
+    sd_seq = {k: v.detach().clone() for k, v in seq.state_dict().items()}
+    sd_st = {k: v.detach().clone() for k, v in st.state_dict().items()}
+    gen = torch.Generator().manual_seed(1881)
+    B, L = 4, 512
+    lens = [512, 201, 512, 350]
+    seq_ids = _ragged_ids(B, L, 4, 23, lens, gen)
+    st_ids = _ragged_ids(B, L, 33, 52, lens, gen)
+    spec_seq = dict(kind="esm", pooling="attention1d", proj_type="linear", use_logit_scale=False)
+    ref = O.train_substep(seq_ids, st_ids, sd_seq, sd_st, cfg650, CFG35, spec_seq, SPEC_ST, use_l1=True, frozen_seq=True)
+    module = OneProtLitModule(components={"sequence": seq, "struct_token": st}, optimizer=functools.partial(FusedAdam, lr=1e-3), loss_fn="CLIP",
+                              use_l1_regularization=True, local_loss=True, gather_with_grad=True).to(DEV)
+    with torch.no_grad():
+        sf = module(seq_ids.to(DEV), "sequence").cpu()
+    assert torch.nn.functional.cosine_similarity(sf, ref["sequence_features"], dim=-1).min() > 0.999
+    loss, gn, grads = _run_substep(module, "struct_token", seq_ids, st_ids, ["struct_token"])
+    rl, rg = float(ref["loss"]), float(ref["grad_total_norm"])
+    assert abs(loss - rl) / rl < 1e-3, (loss, rl)
+    assert abs(gn - rg) / rg < 2e-2, (gn, rg)
+    _check_arena_grads(grads["struct_token"], ref["grads"], "mod.")
+    # the pooling convolution is a trainable leaf outside the frozen transformer (reference: only `transformer` is frozen, sequence_encoder.py:57-59)
+    r = ref["grads"]["seq.pooling.layer.weight"]
+    assert _cos(seq.pooling.layer.weight.grad.cpu(), r) > 0.999

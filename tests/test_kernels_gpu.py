@@ -38,7 +38,7 @@ def ws(nbytes):
 
 # ------------------------------------------------------------------------------------------------------
 def test_library_loads():
-    assert hip.query("oneprot_abi_version") == 1
+    assert hip.query("oneprot_abi_version") == 2
 
 
 @pytest.mark.parametrize("B,L,d,vocab", [(3, 17, 64, 33), (4, 130, 640, 54)])
@@ -215,16 +215,38 @@ def test_gemm_tn(M, N, K, tn_variant):
     dW = torch.full((N, K), 3.0, device=DEV)
     w = ws(hip.query("oneprot_gemm_bf16_tn_workspace", N, K))
     db = torch.full((N,), 5.0, device=DEV)
-    hip.call("oneprot_gemm_bf16_tn", dY, X, M, N, K, N, K, dW, db, w, 0)
+    hip.call("oneprot_gemm_bf16_tn", dY, X, M, N, K, N, K, dW, db, w, w.numel(), 0)
     assert_close(dW, ref, 1e-4, 2e-3 * math.sqrt(M / 64), "tn")
     assert_close(db, dY.float().sum(0), 1e-4, 1e-2, "tn fused bias grad")
-    hip.call("oneprot_gemm_bf16_tn", dY, X, M, N, K, N, K, dW, None, w, 1)
+    hip.call("oneprot_gemm_bf16_tn", dY, X, M, N, K, N, K, dW, None, w, w.numel(), 1)
     assert_close(dW, 2 * ref, 1e-4, 4e-3 * math.sqrt(M / 64), "tn accumulate")
     # strided views: columns [N0:N0+n) of a wider matrix
     cs = torch.full((N,), -1.0, device=DEV)
     w2 = ws(hip.query("oneprot_colsum_workspace", N))
     hip.call("oneprot_colsum_bf16", dY, cs, w2, M, N, 0)
     assert_close(cs, dY.float().sum(0), 1e-4, 1e-2, "colsum")
+
+
+@pytest.mark.parametrize("M,N,K", [(8192, 1280, 1280), (8192, 1280, 5120), (8448, 480, 640), (6400, 1920, 480), (8320, 768, 768), (8320, 768, 3072)])
+def test_gemm_tn_large_m_every_width(M, N, K):
+    """Weight-gradient shapes of the ESM-2-650M, ESM-2-35M (padded heads) and BERT-base widths at token counts where the split count is no
+    longer capped by M (a workspace sized for another (N, K) was overrun there).  The call must also refuse a workspace that is
+    too small instead of writing past it."""
+    g = torch.Generator().manual_seed(16)
+    dY = bf(torch.randn(M, N, generator=g) * 0.5).to(DEV)
+    X = bf(torch.randn(M, K, generator=g) * 0.5).to(DEV)
+    need = hip.query("oneprot_gemm_bf16_tn_workspace", N, K)
+    guard = 4096
+    w = torch.zeros(need + guard, dtype=torch.uint8, device=DEV)
+    w[need:] = 0xA5
+    dW, db = torch.empty(N, K, device=DEV), torch.empty(N, device=DEV)
+    hip.call("oneprot_gemm_bf16_tn", dY, X, M, N, K, N, K, dW, db, w, need, 0)
+    assert bool((w[need:] == 0xA5).all()), "wrote past the workspace"
+    ref = dY.float().t() @ X.float()
+    assert_close(dW, ref, 1e-4, 2e-3 * math.sqrt(M / 64), "tn large M")
+    assert_close(db, dY.float().sum(0), 1e-4, 2e-2, "tn large M bias")
+    with pytest.raises(hip.HipKernelError):
+        hip.call("oneprot_gemm_bf16_tn", dY, X, M, N, K, N, K, dW, db, w, need // 2, 0)
 
 
 @pytest.mark.parametrize("tA,bkn", [(0, 0), (0, 1), (1, 1), (1, 0)])
@@ -438,6 +460,25 @@ def test_siglip_block(negative_only):
     assert_close(sd.grad.cpu(), sr.grad, 1e-4, 1e-6, "siglip ds")
 
 
+def test_retrieval_metric_vs_reference_golden(golden_dir):
+    """device-side RetrievalMetric (SGEMM + rank-counting kernel) vs the numbers the reference's RetrievalMetric.compute produced
+    (tests/golden/retrieval.pt: exact fp32 similarities, no ties with the diagonal): equal, not close; updates arrive in several batches."""
+    import os
+    from oneprot_amd.metrics import RetrievalMetric
+    cases = torch.load(os.path.join(golden_dir, "retrieval.pt"), weights_only=False)
+    for name, c in cases.items():
+        met = RetrievalMetric()
+        o = 0
+        for n in c["cuts"]:
+            met.update(c["s"][o:o + n].to(DEV), c["m"][o:o + n].to(DEV))
+            o += n
+        assert met.global_count() == c["s"].shape[0]
+        got = met.compute()
+        assert set(got) == set(c["expected"]), name
+        for k, v in c["expected"].items():
+            assert got[k] == v, (name, k, got[k], v)
+
+
 def test_retrieval_metric_counts_ranks():
     from oneprot_amd.metrics import RetrievalMetric
     g = torch.Generator().manual_seed(15)
@@ -452,3 +493,75 @@ def test_retrieval_metric_counts_ranks():
     assert set(got) == set(ref)
     for k in ref:
         assert abs(got[k] - ref[k]) <= (1.0 if "median" in k else 0.011), (k, got[k], ref[k])
+
+
+def test_clip_loss_tensor_logit_scale_stays_on_device_and_gets_a_gradient():
+    """ClipLoss.forward(m, s, logit_scale=<tensor>) (what ref oneprot_module.py:142 passes): same value as the python-number path and as the
+    oracle, no host read of the scale, and d loss / d scale when the scale requires grad (a CLIP-style learnable temperature handed in)."""
+    from src.models.components.loss import ClipLoss
+    g = torch.Generator().manual_seed(21)
+    B, D = 9, 40
+    m = torch.nn.functional.normalize(torch.randn(B, D, generator=g), dim=-1)
+    s = torch.nn.functional.normalize(m + 0.5 * torch.randn(B, D, generator=g), dim=-1)
+    mr, sr = m.clone().requires_grad_(True), s.clone().requires_grad_(True)
+    log_scale_ref = torch.tensor(1.7, requires_grad=True)
+    ref = O.clip_loss(mr, sr, 1.0) * 0 + torch.nn.functional.cross_entropy(log_scale_ref.exp() * mr @ sr.t(), torch.arange(B)) / 2 \
+        + torch.nn.functional.cross_entropy(log_scale_ref.exp() * sr @ mr.t(), torch.arange(B)) / 2
+    ref.backward()
+    md, sd = m.to(DEV).requires_grad_(True), s.to(DEV).requires_grad_(True)
+    log_scale = torch.tensor(1.7, device=DEV, requires_grad=True)
+    fn = ClipLoss()
+    loss = fn(md, sd, log_scale.exp())
+    loss.backward()
+    assert abs(loss.item() - ref.item()) < 1e-5 * abs(ref.item())
+    assert_close(md.grad.cpu(), mr.grad, 1e-4, 1e-6, "dm (tensor scale)")
+    assert_close(sd.grad.cpu(), sr.grad, 1e-4, 1e-6, "ds (tensor scale)")
+    assert abs(log_scale.grad.item() - log_scale_ref.grad.item()) < 1e-4 * abs(log_scale_ref.grad.item()) + 1e-6
+    with torch.no_grad():
+        assert abs(fn(md, sd, log_scale.exp()).item() - fn(md, sd, float(log_scale.exp())).item()) < 1e-6
+
+
+def test_public_pooling_and_normalize_modules():
+    """`encoder.pooling` / `encoder.norm` are attributes other code reaches into: their forward must work stand-alone, with autograd
+    (inside the encoders the same arithmetic is fused into the final-LayerNorm kernel).  ref base_encoder.py:6-12, 88-126."""
+    from src.models.components.base_encoder import MeanPooling, Attention1dPooling, Normalize, CLSTokenPooling
+    g = torch.Generator().manual_seed(22)
+    B, L, d = 3, 19, 1280
+    x = torch.randn(B, L, d, generator=g)
+    mask = torch.ones(B, L)
+    mask[1, 11:] = 0
+    mask[2, 3:] = 0
+    tgt = torch.randn(B, d, generator=g)
+    # mean
+    xr = x.clone().requires_grad_(True)
+    ref = O.mean_pool(xr, mask)
+    (ref * tgt).sum().backward()
+    xd = x.to(DEV).requires_grad_(True)
+    got = MeanPooling()(xd, mask.to(DEV))
+    (got * tgt.to(DEV)).sum().backward()
+    assert_close(got.detach().cpu(), ref.detach(), 1e-5, 1e-6, "mean pool")
+    assert_close(xd.grad.cpu(), xr.grad, 1e-5, 1e-7, "mean pool dx")
+    assert_close(MeanPooling()(xd.detach()).cpu(), x.mean(1), 1e-5, 1e-6, "mean pool without mask")
+    assert torch.equal(CLSTokenPooling()(xd.detach()), xd.detach()[:, 0])
+    # attention1d
+    pool = Attention1dPooling(d)
+    with torch.no_grad():
+        pool.layer.weight.normal_(0, 0.05, generator=g)
+        pool.layer.bias.fill_(0.2)
+    w_ref, b_ref = pool.layer.weight.detach().clone().requires_grad_(True), pool.layer.bias.detach().clone().requires_grad_(True)
+    xr = x.clone().requires_grad_(True)
+    ref = O.attention1d_pool(xr, w_ref, b_ref, mask)
+    (ref * tgt).sum().backward()
+    pool = pool.to(DEV)
+    xd = x.to(DEV).requires_grad_(True)
+    got = pool(xd, mask.to(DEV))
+    (got * tgt.to(DEV)).sum().backward()
+    assert_close(got.detach().cpu(), ref.detach(), 1e-4, 1e-5, "attention1d pool")
+    assert_close(xd.grad.cpu(), xr.grad, 1e-3, 1e-5, "attention1d dx")
+    assert_close(pool.layer.weight.grad.cpu(), w_ref.grad, 1e-3, 1e-4, "attention1d dw")
+    # Normalize over the last and over another dimension
+    y = torch.randn(5, 7, generator=g)
+    assert_close(Normalize(dim=-1)(y.to(DEV)).cpu(), torch.nn.functional.normalize(y, dim=-1), 1e-5, 1e-6, "normalize -1")
+    assert_close(Normalize(dim=0)(y.to(DEV)).cpu(), torch.nn.functional.normalize(y, dim=0), 1e-5, 1e-6, "normalize 0")
+    with pytest.raises(hip.HipKernelError):
+        MeanPooling()(x, mask)                       # CPU tensors: no fallback

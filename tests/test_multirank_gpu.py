@@ -1,4 +1,5 @@
-"""N>1 path on real kernels: two ranks (both on the one GPU of the test box, gloo transport) each take half of the batch; with
+"""N>1 path on real kernels.  (a) RCCL itself: the collectives the product issues on backend "nccl", on one GPU (world 1) and -- when the box
+has them -- across two GPUs.  (b) Two ranks (both on the one GPU of the test box, gloo transport) each take half of the batch; with
 local_loss + gather_with_grad and mean gradient all-reduce the result must equal the single-process run on the whole batch
 (mean over ranks of the per-rank losses == global loss; reduced gradient == global gradient)."""
 import os
@@ -17,6 +18,25 @@ def _run(world, out_dir, golden, port):
              for r in range(world)]
     for p in procs:
         assert p.wait(timeout=300) == 0
+
+
+def _run_rccl(world, port):
+    env = dict(os.environ, HSA_ENABLE_IPC_MODE_LEGACY="0")
+    procs = [subprocess.Popen([sys.executable, os.path.join(ROOT, "tests", "_rccl_rank_worker.py"), str(r), str(world), str(port)], env=env) for r in range(world)]
+    for p in procs:
+        assert p.wait(timeout=300) == 0
+
+
+def test_rccl_collectives_single_gpu():
+    """backend "nccl" (= RCCL) on the one GPU of the test box, world size 1: the product's reduce_scatter_tensor / all_gather_into_tensor /
+    asynchronous ReduceOp.AVG calls go through RCCL itself (gloo has none of them and runs fallbacks instead)."""
+    _run_rccl(1, 29751)
+
+
+@pytest.mark.skipif(torch.cuda.device_count() < 2, reason="needs two GPUs: RCCL refuses two ranks on one device")
+def test_rccl_collectives_two_gpus():
+    """the same calls across two GPUs over xGMI, plus the SigLIP neighbour ring; expectations are asserted inside the rank workers"""
+    _run_rccl(2, 29752)
 
 
 def test_two_ranks_equal_single_process(golden_dir, tmp_path):

@@ -207,3 +207,15 @@ def test_first_node_and_env(golden_dir):
         cases = json.load(f)
     for c in cases["first_node"]:
         assert O.first_node(c["nodelist"]) == c["first"], c
+
+
+def test_retrieval_metrics_vs_reference(golden_dir):
+    """O.retrieval_metrics vs RetrievalMetric.compute of the reference (retrieval_metric.py:76-102), run by make_golden.py on grid-valued
+    features whose similarities are exact in fp32 and tie-free on the diagonal: every number must be equal, not close."""
+    cases = _load(golden_dir, "retrieval.pt")
+    assert set(cases) == {"n257", "n64", "n130_three_updates", "n200_noisy"}
+    for name, c in cases.items():
+        got = O.retrieval_metrics(c["s"], c["m"])
+        assert set(got) == set(c["expected"]), name
+        for k, v in c["expected"].items():
+            assert got[k] == v, (name, k, got[k], v)

@@ -87,11 +87,8 @@ def test_training_substep_vs_reference(golden_dir, tag, tmp_path):
     loss = module.training_step(batch, 0)
     loss = float(loss)
     ref_loss = float(g["loss_total"])
-    # 1e-3 relative (BASELINE north_star).  The hd24 fixture (8 pairs, d=96, logits scaled by 14.29) turns the same per-feature bf16
-    # error as the other two (1-cos ~2e-5, layer-0 output 0.5 % -- printed by tools/feature_error_report.py) into a 1.6e-3 loss
-    # difference, so it is held to 3e-3 here and to 1e-3 at the real ESM-2-35M shape in test_esm2_35m_shape_train_step_vs_oracle.
-    tol = 3e-3 if tag == "hd24" else 1e-3
-    assert abs(loss - ref_loss) / abs(ref_loss) < tol, (loss, ref_loss)
+    # 1e-3 relative (BASELINE north_star) against the reference's own output, every fixture
+    assert abs(loss - ref_loss) / abs(ref_loss) < 1e-3, (loss, ref_loss)
     gn = float(module.last_grad_norm)
     assert abs(gn - float(g["grad_total_norm"])) / float(g["grad_total_norm"]) < 2e-2, (gn, float(g["grad_total_norm"]))
     worst = (1.0, None)
@@ -593,6 +590,15 @@ def test_mixed_batch_round_robin(golden_dir, tmp_path):
     text_before = module.network["text"].transformer.flat.detach().clone()
     text_head_before = module.network["text"].proj[1].weight.detach().clone()
     st_before = module.network["struct_token"].transformer.flat.detach().clone()
+    sds0 = {k: {n: v.detach().cpu().clone() for n, v in module.network[k].state_dict().items()} for k in ("sequence", "struct_token", "text")}
+    per_substep = []
+
+    class _Recorder(type(module.train_loss)):           # the module's running-mean metric, additionally keeping every sub-step's value
+        def __call__(self, value):
+            per_substep.append(value.detach().clone())
+            super().__call__(value)
+
+    module.train_loss = _Recorder()
     loss = module.fit_steps(loader)
     # batch 0: warm-up gate -> struct_token only (1 sub-step); batches 1, 2: both modalities (2 sub-steps each)
     assert module.global_step == 5
@@ -600,11 +606,43 @@ def test_mixed_batch_round_robin(golden_dir, tmp_path):
     assert torch.equal(text_before, module.network["text"].transformer.flat.detach())            # frozen tower
     assert not torch.equal(text_head_before, module.network["text"].proj[1].weight.detach())      # its projection head trains
     assert not torch.equal(st_before, module.network["struct_token"].transformer.flat.detach())
-    # validation / test hooks run forward-only
-    vb = next(iter(SyntheticPairs("text", 6, 24, mod_len=20, device=DEV, text_vocab=c["vocab"])))
-    assert torch.isfinite(module.validation_step(vb, 0))
+    # ---- value level: every sub-step's loss vs the oracle's round-robin loop (one Adam over all components, per-modality sub-steps, warm-up gate)
+    cfg_b = dict(layers=c["layers"], hidden=c["hidden"], heads=c["heads"], ffn=c["ffn"], vocab=c["vocab"], max_pos=c["max_pos"], pad=0, eps=c["eps"])
+    cfgs = {"sequence": g["cfg"], "struct_token": g["cfg"], "text": cfg_b}
+    specs = {"sequence": dict(kind="esm", pooling="mean", proj_type="mlp", use_logit_scale=False),
+             "struct_token": dict(kind="esm", pooling="mean", proj_type="linear", use_logit_scale=True),
+             "text": dict(kind="bert", pooling="cls", proj_type="mlp", use_logit_scale=True)}
+    batches = [{m: (b[0].cpu(), b[1].cpu()) for m, b in batch.items()} for batch in loader]
+    ref_log, ref_params = O.train_round_robin(batches, sds0, cfgs, specs, use_l1=True, frozen=("sequence", "text"), train_on_all_modalities_after_step=1)
+    assert [m for m, _ in ref_log] == ["struct_token", "struct_token", "text", "struct_token", "text"]
+    got = [float(v) for v in per_substep]
+    assert len(got) == len(ref_log) == 5
+    # sub-steps 0 and 2 are the first time their modality's loss is evaluated (pure functions of the start point up to the shared sequence
+    # head): 1e-3; later ones follow Adam updates that are ~lr*sign(g), where bf16-noise sign flips on tiny gradients separate the two
+    # trajectories slowly (same gate as test_multi_step_training_tracks_oracle)
+    for i, ((m, r), v) in enumerate(zip(ref_log, got)):
+        assert abs(v - r) / r < (1e-3 if i == 0 else 2e-2), (i, m, v, r)
+    # ---- validation / test hooks: VALUES vs the oracle evaluated on the module's current weights (ref oneprot_module.py:110-121, 137-146)
+    sd_now = {k: {n: v.detach().cpu() for n, v in module.network[k].state_dict().items()} for k in ("sequence", "text", "struct_token")}
+    vb = next(iter(SyntheticPairs("text", 6, 24, mod_len=20, device=DEV, text_vocab=c["vocab"], seed=77, ragged=True)))
+    v_ref, sf_ref, mf_ref = O.validation_substep(vb[0].cpu(), vb[1].cpu(), sd_now["sequence"], sd_now["text"], cfgs["sequence"], cfgs["text"], specs["sequence"], specs["text"])
+    v_got = module.validation_step(vb, 0)
+    assert abs(float(v_got) - float(v_ref)) / float(v_ref) < 1e-3, (float(v_got), float(v_ref))
+    assert abs(float(module.val_loss.compute()) - float(v_ref)) / float(v_ref) < 1e-3
+    met = module.metrics["val_text"].compute()
+    ref_met = O.retrieval_metrics(sf_ref, mf_ref)
+    assert set(met) == set(ref_met)
+    t_ref, _, _ = O.test_substep(vb[0].cpu(), vb[1].cpu(), sd_now["sequence"], sd_now["text"], cfgs["sequence"], cfgs["text"], specs["sequence"], specs["text"])
     out = module.test_step({"text": vb}, 0)
-    assert torch.isfinite(out["text"])
+    # the reference's double logit scale (14.29^2 on the logits) makes this loss ~20x more sensitive to feature rounding than the training loss
+    assert float(t_ref) > 2 * float(v_ref)
+    assert abs(float(out["text"]) - float(t_ref)) / float(t_ref) < 2e-2, (float(out["text"]), float(t_ref))
+    sb = next(iter(SyntheticPairs("struct_token", 6, 24, device=DEV, seed=78, ragged=True)))
+    t2_ref, _, _ = O.test_substep(sb[0].cpu(), sb[1].cpu(), sd_now["sequence"], sd_now["struct_token"], cfgs["sequence"], cfgs["struct_token"], specs["sequence"], specs["struct_token"])
+    out2 = module.test_step({"struct_token": sb}, 1)
+    assert abs(float(out2["struct_token"]) - float(t2_ref)) / float(t2_ref) < 2e-2
+    module.on_validation_epoch_end(); module.on_test_epoch_end()
+    assert "val/seq_to_mod_R@1/val_text" in module.logged and "test/mod_to_seq_median_rank/test_struct_token" in module.logged
 
 
 @pytest.mark.parametrize("frozen", [True, False])

@@ -70,7 +70,7 @@ def main():
         w = torch.empty(hip.query("oneprot_gemm_bf16_tn_workspace", N, K), dtype=torch.uint8, device=DEV)
         for variant in (0, 1, 0, 1):
             hip.query("oneprot_gemm_tn_variant", variant)
-            ms = timeit(lambda: hip.call("oneprot_gemm_bf16_tn", dY, X, T, N, K, N, K, dW, None, w, 0))
+            ms = timeit(lambda: hip.call("oneprot_gemm_bf16_tn", dY, X, T, N, K, N, K, dW, None, w, w.numel(), 0))
             key = f"{name}[v{variant}]"
             if key not in res or ms < res[key][0]:
                 res[key] = (ms, 2.0 * T * N * K / ms / 1e9)

@@ -19,7 +19,7 @@ for name, N, K in (("qkv  dW[1920,640]", 3 * d, d), ("out  dW[640,640]", d, d), 
     X = torch.randn(T, K, device="cuda", generator=g).to(torch.bfloat16)
     dW, db = torch.empty(N, K, device="cuda"), torch.empty(N, device="cuda")
     ws = torch.empty(hip.query("oneprot_gemm_bf16_tn_workspace", N, K), dtype=torch.uint8, device="cuda")
-    fn = lambda: hip.call("oneprot_gemm_bf16_tn", dY, X, T, N, K, N, K, dW, db, ws, 0)
+    fn = lambda: hip.call("oneprot_gemm_bf16_tn", dY, X, T, N, K, N, K, dW, db, ws, ws.numel(), 0)
     res, outs = {v: [] for v in variants}, {}
     for rep in range(3):
         for v in variants:
