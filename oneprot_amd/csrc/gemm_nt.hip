@@ -21,6 +21,7 @@
 #include "common.h"
 #include "../../include/oneprot_hip.h"
 #include <type_traits>
+#include <utility>
 
 #define EPI_LD 68                                   // fp32 row pitch of a wave's epilogue tile (64 columns + pad)
 
@@ -186,8 +187,135 @@ __device__ __forceinline__ void gemm_epilogue(const GemmArgs& p, f32x4 (&acc)[MT
   }
 }
 
-template <int EPI, int WM, int WN, int MT, int NTW, int BKT, int NSTAGE, int EPH, int MINW, bool PIPE, bool FULLT>
+// ---- DIRECT form (full tiles only).  The MFMA is issued with the operand roles swapped -- a = weight fragment, b = activation fragment -- so
+// the accumulator of lane (c = lane & 15, q = lane >> 4) is C[token c][feature slot q*4 + r]: four consecutive slots of ONE token row per
+// register quad.  Which logical column a slot is, is decided when the weight tile is staged: LDS row slot s of the tile receives global weight
+// row nmap(s) (the LDS-DMA source address is per lane, so the permutation costs nothing in the loop and leaves the bank pattern of the fragment
+// reads untouched).  bf16 outputs use the PAIR map (slots of tiles 2p / 2p+1 interleaved in runs of four: a lane owns 8 consecutive columns
+// = one 16-byte store, four lanes cover 64 contiguous bytes of a row); fp32 outputs and QKV/RoPE use the NATURAL map (4 consecutive fp32 = 16 bytes
+// per lane; the RoPE partner column +-hd/2 is the same register of tile j^1 (hd 32) / j^2 (hd 64) of the SAME lane).  No LDS staging of the
+// accumulators, no waits on the LDS queue, no reuse of the operand ring: 1 ds_write_b32 + 1/4 ds_read_b128 per element less than the staged form.
+template <int EPI> struct DirectMap { static constexpr bool PAIR = (EPI == ONEPROT_EPI_BF16 || EPI == ONEPROT_EPI_BIAS_GELU || EPI == ONEPROT_EPI_GELU_BWD); };
+// logical column (within the wave's NTW*16-column block) of slot rho of 16-slot tile j
+template <bool PAIR> __device__ __forceinline__ constexpr int direct_nmap(int j, int rho) {
+  return PAIR ? ((j >> 1) * 32 + (rho >> 2) * 8 + (j & 1) * 4 + (rho & 3)) : (j * 16 + rho);
+}
+
+__device__ __forceinline__ float gelu_fwd_only(float x) {
+  const float t = __builtin_amdgcn_rcpf(fmaf(0.23164189f, fabsf(x), 1.0f));
+  const float e = __builtin_amdgcn_exp2f(x * x * -0.72134752f);
+  float poly = fmaf(0.5307027145f, t, -0.7265760135f);
+  poly = fmaf(poly, t, 0.7107068705f);
+  poly = fmaf(poly, t, -0.142248368f);
+  poly = fmaf(poly, t, 0.127414796f);
+  const float h = poly * t * e;
+  return x * (0.5f + copysignf(0.5f - h, x));
+}
+
+// QKV/RoPE tail of the direct epilogue (natural map: lane owns columns [j*16 + q*4, +4) of tile j).  H*hd is a multiple of 64 = the wave's
+// column block, so the whole wave sits in one section (q / k / v); with HD in {32, 64} a head is 2 or 4 tiles of the block, the position of
+// tile j inside its head and its rotation partner (tile j ^ (HD/32)) are compile-time constants -- the partner value is a register of the SAME lane.
+template <int HD, int MT, int NTW>
+__device__ __forceinline__ void rope_store_direct(const GemmArgs& p, f32x4 (&acc)[MT][NTW], int mrow0, int ncol0, int q) {
+  static_assert((NTW * 16) % HD == 0, "a head must not straddle the wave's column block");
+  constexpr int HALF = HD / 2, JP = HALF / 16;
+  const int dm = p.H * HD;
+  const int sec = __builtin_amdgcn_readfirstlane(ncol0 / dm);
+  const int head0 = (ncol0 - sec * dm) / HD;
+  bf16_t* dst = (bf16_t*)(sec == 0 ? p.out0 : (sec == 1 ? p.out1 : p.out2));
+  const float sc = sec == 0 ? p.q_scale : 1.0f;
+#pragma unroll
+  for (int i = 0; i < MT; ++i) {
+    const int gm = mrow0 + i * 16;
+    const int b = gm / p.L, l = gm - b * p.L;
+    const float* cs_row = p.cos + (size_t)l * HALF + q * 4;
+    const float* sn_row = p.sin + (size_t)l * HALF + q * 4;
+#pragma unroll
+    for (int j = 0; j < NTW; ++j) {
+      const int jt = (j * 16) % HD;                    // column of the tile inside its head (compile-time after unrolling)
+      const bool lo = jt < HALF;
+      const int head = head0 + (j * 16) / HD;
+      float v[4] = {acc[i][j][0], acc[i][j][1], acc[i][j][2], acc[i][j][3]};
+      if (sec < 2) {
+        const f32x4 pv = acc[i][lo ? j + JP : j - JP];
+        const int jj = lo ? jt : jt - HALF;
+        const float4 cs = *reinterpret_cast<const float4*>(cs_row + jj);
+        const float4 sn = *reinterpret_cast<const float4*>(sn_row + jj);
+        const float sp = lo ? -sc : sc;
+        v[0] = (v[0] * sc) * cs.x + (pv[0] * sp) * sn.x; v[1] = (v[1] * sc) * cs.y + (pv[1] * sp) * sn.y;
+        v[2] = (v[2] * sc) * cs.z + (pv[2] * sp) * sn.z; v[3] = (v[3] * sc) * cs.w + (pv[3] * sp) * sn.w;
+      }
+      u32x2 w; w.x = pack2bf(v[0], v[1]); w.y = pack2bf(v[2], v[3]);
+      *reinterpret_cast<u32x2*>(dst + (((size_t)b * p.H + head) * p.L + l) * HD + jt + q * 4) = w;
+    }
+  }
+}
+
+template <int EPI, int MT, int NTW>
+__device__ __forceinline__ void gemm_epilogue_direct(const GemmArgs& p, f32x4 (&acc)[MT][NTW], int m0, int n0, int wr, int wc, int lane) {
+  const int c = lane & 15, q = lane >> 4;
+  const int mrow0 = m0 + wr * (MT * 16) + c;                 // + i*16
+  const int ncol0 = n0 + wc * (NTW * 16);
+  if constexpr (DirectMap<EPI>::PAIR) {
+    const bool with_grad = (EPI == ONEPROT_EPI_BIAS_GELU) && p.out1 != nullptr;      // wave-uniform
+#pragma unroll
+    for (int i = 0; i < MT; ++i) {
+      const size_t rowoff = (size_t)(mrow0 + i * 16) * p.N + ncol0 + q * 8;
+#pragma unroll
+      for (int pp = 0; pp < NTW / 2; ++pp) {
+        const size_t o = rowoff + pp * 32;
+        float v[8];
+#pragma unroll
+        for (int r = 0; r < 4; ++r) { v[r] = acc[i][2 * pp][r]; v[4 + r] = acc[i][2 * pp + 1][r]; }
+        if (EPI == ONEPROT_EPI_BIAS_GELU) {
+          if (with_grad) {
+            float dg[8];
+#pragma unroll
+            for (int e = 0; e < 8; ++e) gelu_fwd_and_grad(v[e], v[e], dg[e]);
+            u32x4 z; z.x = pack2bf(dg[0], dg[1]); z.y = pack2bf(dg[2], dg[3]); z.z = pack2bf(dg[4], dg[5]); z.w = pack2bf(dg[6], dg[7]);
+            *reinterpret_cast<u32x4*>((bf16_t*)p.out1 + o) = z;
+          } else {
+#pragma unroll
+            for (int e = 0; e < 8; ++e) v[e] = gelu_fwd_only(v[e]);
+          }
+        } else if (EPI == ONEPROT_EPI_GELU_BWD) {
+          const u32x4 z = *reinterpret_cast<const u32x4*>((const bf16_t*)p.aux + o);
+          v[0] *= bflo(z.x); v[1] *= bfhi(z.x); v[2] *= bflo(z.y); v[3] *= bfhi(z.y);
+          v[4] *= bflo(z.z); v[5] *= bfhi(z.z); v[6] *= bflo(z.w); v[7] *= bfhi(z.w);
+        }
+        u32x4 w; w.x = pack2bf(v[0], v[1]); w.y = pack2bf(v[2], v[3]); w.z = pack2bf(v[4], v[5]); w.w = pack2bf(v[6], v[7]);
+        *reinterpret_cast<u32x4*>((bf16_t*)p.out0 + o) = w;
+      }
+    }
+  } else if constexpr (EPI == ONEPROT_EPI_QKV_ROPE) {
+    if (p.hd == 32) rope_store_direct<32, MT, NTW>(p, acc, mrow0, ncol0, q); else rope_store_direct<64, MT, NTW>(p, acc, mrow0, ncol0, q);
+  } else {      // fp32 outputs: ONEPROT_EPI_F32, ONEPROT_EPI_BIAS_RESID (natural map, 16 bytes per lane per tile)
+#pragma unroll
+    for (int i = 0; i < MT; ++i) {
+      const size_t rowoff = (size_t)(mrow0 + i * 16) * p.N + ncol0 + q * 4;
+      float4 rs[NTW];
+      if (EPI == ONEPROT_EPI_BIAS_RESID) {
+#pragma unroll
+        for (int j = 0; j < NTW; ++j) rs[j] = *reinterpret_cast<const float4*>((const float*)p.aux + rowoff + j * 16);
+      }
+#pragma unroll
+      for (int j = 0; j < NTW; ++j) {
+        float4 v = make_float4(acc[i][j][0], acc[i][j][1], acc[i][j][2], acc[i][j][3]);
+        if (EPI == ONEPROT_EPI_BIAS_RESID) { v.x += rs[j].x; v.y += rs[j].y; v.z += rs[j].z; v.w += rs[j].w; }
+        *reinterpret_cast<float4*>((float*)p.out0 + rowoff + j * 16) = v;
+        if (EPI == ONEPROT_EPI_BIAS_RESID && p.out1) {
+          u32x2 w; w.x = pack2bf(v.x, v.y); w.y = pack2bf(v.z, v.w);
+          *reinterpret_cast<u32x2*>((bf16_t*)p.out1 + rowoff + j * 16) = w;
+        }
+      }
+    }
+  }
+}
+
+template <int EPI, int WM, int WN, int MT, int NTW, int BKT, int NSTAGE, int EPH, int MINW, bool PIPE, bool FULLT, bool DIRECT = false>
 __global__ void __launch_bounds__(WM * WN * 64, MINW) k_gemm_nt(const GemmArgs p) {
+  static_assert(!DIRECT || FULLT, "the direct-store form is built for full tiles only");
+  static_assert(!DIRECT || NTW % 2 == 0, "pair map needs an even number of column tiles per wave");
   typedef Shape<WM, WN, MT, NTW, BKT, NSTAGE, EPH> S;
   constexpr int CH = BKT / 8;                      // chunks per row
   constexpr int KK = BKT / 32;                     // MFMA k-substeps per stage
@@ -248,7 +376,15 @@ __global__ void __launch_bounds__(WM * WN * 64, MINW) k_gemm_nt(const GemmArgs p
 #pragma unroll
   for (int i = 0; i < S::A_IPW; ++i) a_rel[i] = (unsigned)((wave * S::A_IPW + i) * S::RPI + srow) * (unsigned)p.lda * 2u + (unsigned)a_chunk[i] * 16u;
 #pragma unroll
-  for (int i = 0; i < S::B_IPW; ++i) b_rel[i] = (unsigned)((wave * S::B_IPW + i) * S::RPI + srow) * (unsigned)p.ldb * 2u + (unsigned)b_chunk[i] * 16u;
+  for (int i = 0; i < S::B_IPW; ++i) {
+    const int slot = (wave * S::B_IPW + i) * S::RPI + srow;          // LDS row slot of the weight tile this lane fills
+    int grow = slot;                                                 // global weight row (relative to the tile) that goes there
+    if constexpr (DIRECT) {
+      const int blk = slot / (NTW * 16), in = slot - blk * (NTW * 16);
+      grow = blk * (NTW * 16) + direct_nmap<DirectMap<EPI>::PAIR>(in >> 4, in & 15);
+    }
+    b_rel[i] = (unsigned)grow * (unsigned)p.ldb * 2u + (unsigned)b_chunk[i] * 16u;
+  }
   const unsigned char* a_tile = reinterpret_cast<const unsigned char*>(p.A + (size_t)m0 * p.lda);
   const unsigned char* b_tile = reinterpret_cast<const unsigned char*>(p.B + (size_t)n0 * p.ldb);
 
@@ -280,12 +416,23 @@ __global__ void __launch_bounds__(WM * WN * 64, MINW) k_gemm_nt(const GemmArgs p
   // accumulators start at the bias of their column (C layout: column = lane & 15 within each 16-wide tile): the epilogues then have no bias
   // add and, for QKV/RoPE, the rotation partner read back from the staging tile already carries its own bias
   f32x4 acc[MT][NTW];
+  if constexpr (DIRECT) {          // lane (c, q) holds 4 consecutive columns of its token row in every tile: the bias is a float4 per tile
+#pragma unroll
+    for (int j = 0; j < NTW; ++j) {
+      const int gc = n0 + wc * (NTW * 16) + direct_nmap<DirectMap<EPI>::PAIR>(j, (lane >> 4) * 4);
+      f32x4 bj = {0.f, 0.f, 0.f, 0.f};
+      if (p.bias) { const float4 t = *reinterpret_cast<const float4*>(p.bias + gc); bj = (f32x4){t.x, t.y, t.z, t.w}; }
+#pragma unroll
+      for (int i = 0; i < MT; ++i) acc[i][j] = bj;
+    }
+  } else {
 #pragma unroll
   for (int j = 0; j < NTW; ++j) {
     const int gc = n0 + wc * (NTW * 16) + j * 16 + (lane & 15);
     const float bj = (p.bias && gc < p.N) ? p.bias[gc] : 0.f;
 #pragma unroll
     for (int i = 0; i < MT; ++i) acc[i][j] = (f32x4){bj, bj, bj, bj};
+  }
   }
 
   // fragment read offsets (bytes within a stage's A or B image) for k-substep 0; substep 1 (BK 64) flips chunk bit 2
@@ -344,7 +491,9 @@ __global__ void __launch_bounds__(WM * WN * 64, MINW) k_gemm_nt(const GemmArgs p
   #pragma unroll
         for (int i = 0; i < MT; ++i)
   #pragma unroll
-          for (int j = 0; j < NTW; ++j) acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(fa[cur][i], fb[cur][j], acc[i][j], 0, 0, 0);
+          for (int j = 0; j < NTW; ++j)
+            acc[i][j] = DIRECT ? __builtin_amdgcn_mfma_f32_16x16x32_bf16(fb[cur][j], fa[cur][i], acc[i][j], 0, 0, 0)
+                               : __builtin_amdgcn_mfma_f32_16x16x32_bf16(fa[cur][i], fb[cur][j], acc[i][j], 0, 0, 0);
       }
       buf = (buf + 1 == NSTAGE) ? 0 : buf + 1;
     };
@@ -375,24 +524,28 @@ __global__ void __launch_bounds__(WM * WN * 64, MINW) k_gemm_nt(const GemmArgs p
   #pragma unroll
         for (int i = 0; i < MT; ++i)
   #pragma unroll
-          for (int j = 0; j < NTW; ++j) acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a[i], b[j], acc[i][j], 0, 0, 0);
+          for (int j = 0; j < NTW; ++j)
+            acc[i][j] = DIRECT ? __builtin_amdgcn_mfma_f32_16x16x32_bf16(b[j], a[i], acc[i][j], 0, 0, 0) : __builtin_amdgcn_mfma_f32_16x16x32_bf16(a[i], b[j], acc[i][j], 0, 0, 0);
       }
       buf = (buf + 1 == NSTAGE) ? 0 : buf + 1;
       nbuf = (nbuf + 1 == NSTAGE) ? 0 : nbuf + 1;
     }
   }
-  __syncthreads();          // everyone done with the staging ring before it is reused as epilogue tiles
-
-  // ---- epilogue (staging tiles reuse the ring memory)
-  gemm_epilogue<EPI, MT, NTW, EPH, FULLT>(p, acc, reinterpret_cast<float*>(smem) + wave * EPH * EPI_LD, m0, n0, wr, wc, lane);
+  if constexpr (DIRECT) {
+    gemm_epilogue_direct<EPI, MT, NTW>(p, acc, m0, n0, wr, wc, lane);      // straight from the accumulators: the LDS ring is not touched again
+  } else {
+    __syncthreads();          // everyone done with the staging ring before it is reused as epilogue tiles
+    // ---- epilogue (staging tiles reuse the ring memory)
+    gemm_epilogue<EPI, MT, NTW, EPH, FULLT>(p, acc, reinterpret_cast<float*>(smem) + wave * EPH * EPI_LD, m0, n0, wr, wc, lane);
+  }
 }
 
-template <int EPI, int WM, int WN, int MT, int NTW, int BKT, int NSTAGE, int EPH, int MINW, bool PIPE, bool FULLT>
+template <int EPI, int WM, int WN, int MT, int NTW, int BKT, int NSTAGE, int EPH, int MINW, bool PIPE, bool FULLT, bool DIRECT = false>
 static int launch_shape_full(GemmArgs a, hipStream_t s) {
   typedef Shape<WM, WN, MT, NTW, BKT, NSTAGE, EPH> S;
   static bool configured = false;
   if (!configured) {
-    if (hipFuncSetAttribute((const void*)k_gemm_nt<EPI, WM, WN, MT, NTW, BKT, NSTAGE, EPH, MINW, PIPE, FULLT>, hipFuncAttributeMaxDynamicSharedMemorySize, S::LDS) != hipSuccess)
+    if (hipFuncSetAttribute((const void*)k_gemm_nt<EPI, WM, WN, MT, NTW, BKT, NSTAGE, EPH, MINW, PIPE, FULLT, DIRECT>, hipFuncAttributeMaxDynamicSharedMemorySize, S::LDS) != hipSuccess)
       return OP_ELAUNCH;
     configured = true;
   }
@@ -400,19 +553,371 @@ static int launch_shape_full(GemmArgs a, hipStream_t s) {
   a.tiles_n = (a.N + S::BN_ - 1) / S::BN_;
   const int pm_total = (a.tiles_m + 7) / 8;
   const int grid = ((pm_total + 3) / 4) * (4 * 10 * ((a.tiles_n + 9) / 10)) * 8;       // super-tile slots (SUP_M=4, SUP_N=10); surplus blocks exit at once
-  hipLaunchKernelGGL((k_gemm_nt<EPI, WM, WN, MT, NTW, BKT, NSTAGE, EPH, MINW, PIPE, FULLT>), dim3(grid), dim3(S::NW * 64), S::LDS, s, a);
+  hipLaunchKernelGGL((k_gemm_nt<EPI, WM, WN, MT, NTW, BKT, NSTAGE, EPH, MINW, PIPE, FULLT, DIRECT>), dim3(grid), dim3(S::NW * 64), S::LDS, s, a);
   return launch_status();
 }
 
 // FULL-tile specialisation only for the shapes the heuristic picks (keeps the number of kernel instantiations down)
-template <int EPI, int WM, int WN, int MT, int NTW, int BKT, int NSTAGE, int EPH, int MINW, bool PIPE, bool TRY_FULL = false>
+template <int EPI, int WM, int WN, int MT, int NTW, int BKT, int NSTAGE, int EPH, int MINW, bool PIPE, bool TRY_FULL = false, bool TRY_DIRECT = false>
 static int launch_shape(GemmArgs a, hipStream_t s) {
   typedef Shape<WM, WN, MT, NTW, BKT, NSTAGE, EPH> S;
   if constexpr (TRY_FULL) {
     const bool full = a.M % S::BM_ == 0 && a.N % S::BN_ == 0 && a.K % BKT == 0 && (size_t)S::BM_ * a.lda * 2 < (1ull << 31) && (size_t)S::BN_ * a.ldb * 2 < (1ull << 31);
+    if constexpr (TRY_DIRECT) {
+      // direct-store form: additionally every row of the tile lies in one sequence-aligned 16-row group for QKV/RoPE (L % 16 == 0) and the head
+      // dim has the RoPE partner in the same lane (32 / 64); anything else takes the staged epilogue
+      const bool rope_ok = EPI != ONEPROT_EPI_QKV_ROPE || (a.hd == 32 || a.hd == 64);
+      if (full && rope_ok) return launch_shape_full<EPI, WM, WN, MT, NTW, BKT, NSTAGE, EPH, MINW, PIPE, true, true>(a, s);
+    }
     if (full) return launch_shape_full<EPI, WM, WN, MT, NTW, BKT, NSTAGE, EPH, MINW, PIPE, true>(a, s);
   }
   return launch_shape_full<EPI, WM, WN, MT, NTW, BKT, NSTAGE, EPH, MINW, PIPE, false>(a, s);
+}
+
+// =====================================================================================================================================
+// Ping-pong form: ONE 512-thread work-group per CU, persistent over tiles, made of two 4-wave groups (one wave of each per SIMD) that run in
+// ANTI-PHASE on different 256 x 128 output tiles: while group g issues the MFMAs of its tile's K loop, group g^1 runs the epilogue of the tile
+// it has just finished (GELU / RoPE arithmetic, the fp32 residual read-modify-write, the stores) and then stages the first K-slices of its next
+// tile.  Measured on gfx950 (tools/ab/coissue2.hip, profiles/r02_coissue_probe.txt): an MFMA-only wave and a GELU-arithmetic wave on the same SIMD
+// overlap almost completely (MFMA stream unimpeded, the VALU stream at 88 % of its stand-alone rate), whereas two waves that are both in their
+// epilogue gain nothing from each other (the VALU pipe is already full) -- so with every wave of a work-group in the same phase the epilogue time
+// simply ADDS to the main loop (the round-1 finding), and de-phasing independent work-groups cannot be enforced.  Here the phase relation is
+// enforced by construction: the work-group barrier is the common clock, every "slot" (one 32-deep K-step of the main-loop group) contains exactly
+// one s_barrier in both roles, a main-loop phase is NK = K/32 slots, and the epilogue role spreads its chunks (8 output elements per lane each)
+// over the first NK-3 slots of the partner's main loop and issues its own next tile's first three K-slices in the remaining ones.
+//   * per group: wave tile 128 x 64 (8 x 4 accumulator tiles), private 3-buffer LDS ring of 24 KB stages (2 x 72 KB per work-group), LDS-DMA
+//     fills with counted vmcnt; the operand fragments of K-step t+1 are read while the MFMAs of step t issue (two register sets), so a stage's
+//     buffer is free one slot earlier and 3 buffers keep two K-slices in flight;
+//   * direct-store epilogue (operand roles swapped, weight rows permuted at staging: see gemm_epilogue_direct);
+//   * tiles are dealt per XCD (work-groups b, b+8, ... share an XCD: they walk that XCD's row panels, n fastest), two per work-group per round.
+// Built for whole tiles with K % 64 == 0 and K >= 128; everything else takes the per-tile kernels above.
+// One epilogue chunk of the ping-pong kernel.  Addresses are formed as (wave-uniform row/column base, on the scalar unit) + ONE 32-bit per-lane
+// byte offset (row-in-tile * N + column-in-quad): per-lane 64-bit addresses per chunk would be hoisted by the compiler and pin ~50 VGPRs for the
+// whole kernel (the register file is the scarce resource here: 128 accumulators + 64 fragment registers).
+template <int EPI, int C, int MT, int NTW>
+__device__ __forceinline__ void pp_chunk(const GemmArgs& p, f32x4 (&acc)[MT][NTW], int um0, int un0, unsigned lane_off, const u32x4& aux16, const float4& res4) {
+  static_assert(C >= 0 && C < (DirectMap<EPI>::PAIR ? MT * NTW / 2 : MT * NTW), "chunk index");
+  if constexpr (DirectMap<EPI>::PAIR) {
+    constexpr int i = C / (NTW / 2), pp = C % (NTW / 2);
+    const size_t uo = (size_t)(um0 + i * 16) * p.N + un0 + pp * 32;          // uniform element offset of the chunk's row group / column block
+    float v[8];
+#pragma unroll
+    for (int r = 0; r < 4; ++r) { v[r] = acc[i][2 * pp][r]; v[4 + r] = acc[i][2 * pp + 1][r]; }
+    if (EPI == ONEPROT_EPI_BIAS_GELU) {
+      if (p.out1 != nullptr) {
+        float dg[8];
+#pragma unroll
+        for (int e = 0; e < 8; ++e) gelu_fwd_and_grad(v[e], v[e], dg[e]);
+        u32x4 z; z.x = pack2bf(dg[0], dg[1]); z.y = pack2bf(dg[2], dg[3]); z.z = pack2bf(dg[4], dg[5]); z.w = pack2bf(dg[6], dg[7]);
+        *reinterpret_cast<u32x4*>(reinterpret_cast<unsigned char*>((bf16_t*)p.out1 + uo) + lane_off) = z;
+      } else {
+#pragma unroll
+        for (int e = 0; e < 8; ++e) v[e] = gelu_fwd_only(v[e]);
+      }
+    } else if (EPI == ONEPROT_EPI_GELU_BWD) {
+      v[0] *= bflo(aux16.x); v[1] *= bfhi(aux16.x); v[2] *= bflo(aux16.y); v[3] *= bfhi(aux16.y);
+      v[4] *= bflo(aux16.z); v[5] *= bfhi(aux16.z); v[6] *= bflo(aux16.w); v[7] *= bfhi(aux16.w);
+    }
+    u32x4 w; w.x = pack2bf(v[0], v[1]); w.y = pack2bf(v[2], v[3]); w.z = pack2bf(v[4], v[5]); w.w = pack2bf(v[6], v[7]);
+    *reinterpret_cast<u32x4*>(reinterpret_cast<unsigned char*>((bf16_t*)p.out0 + uo) + lane_off) = w;
+  } else {
+    constexpr int i = C / NTW, j = C % NTW;
+    const size_t uo = (size_t)(um0 + i * 16) * p.N + un0 + j * 16;
+    float4 v = make_float4(acc[i][j][0], acc[i][j][1], acc[i][j][2], acc[i][j][3]);
+    if (EPI == ONEPROT_EPI_BIAS_RESID) { v.x += res4.x; v.y += res4.y; v.z += res4.z; v.w += res4.w; }
+    *reinterpret_cast<float4*>(reinterpret_cast<unsigned char*>((float*)p.out0 + uo) + lane_off) = v;
+    if (EPI == ONEPROT_EPI_BIAS_RESID && p.out1) {
+      u32x2 w; w.x = pack2bf(v.x, v.y); w.y = pack2bf(v.z, v.w);
+      *reinterpret_cast<u32x2*>(reinterpret_cast<unsigned char*>((bf16_t*)p.out1 + uo) + (lane_off >> 1)) = w;
+    }
+  }
+}
+
+// one (i, j) tile of the QKV / RoPE epilogue (natural map; see rope_store_direct)
+template <int HD, int C, int MT, int NTW>
+__device__ __forceinline__ void pp_chunk_rope(const GemmArgs& p, f32x4 (&acc)[MT][NTW], int ncol0, int q, int b, int l) {
+  constexpr int i = C / NTW, j = C % NTW;
+  constexpr int HALF = HD / 2, JP = HALF / 16;
+  constexpr int jt = (j * 16) % HD;
+  constexpr bool lo = jt < HALF;
+  const int dm = p.H * HD;
+  const int sec = __builtin_amdgcn_readfirstlane(ncol0 / dm);
+  const int head = (ncol0 - sec * dm) / HD + (j * 16) / HD;
+  bf16_t* dst = (bf16_t*)(sec == 0 ? p.out0 : (sec == 1 ? p.out1 : p.out2));
+  const float sc = sec == 0 ? p.q_scale : 1.0f;
+  float v[4] = {acc[i][j][0], acc[i][j][1], acc[i][j][2], acc[i][j][3]};
+  if (sec < 2) {
+    const f32x4 pv = acc[i][lo ? j + JP : j - JP];
+    constexpr int jj = lo ? jt : jt - HALF;
+    const float4 cs = *reinterpret_cast<const float4*>(p.cos + (size_t)l * HALF + q * 4 + jj);
+    const float4 sn = *reinterpret_cast<const float4*>(p.sin + (size_t)l * HALF + q * 4 + jj);
+    const float sp = lo ? -sc : sc;
+    v[0] = (v[0] * sc) * cs.x + (pv[0] * sp) * sn.x; v[1] = (v[1] * sc) * cs.y + (pv[1] * sp) * sn.y;
+    v[2] = (v[2] * sc) * cs.z + (pv[2] * sp) * sn.z; v[3] = (v[3] * sc) * cs.w + (pv[3] * sp) * sn.w;
+  }
+  u32x2 w; w.x = pack2bf(v[0], v[1]); w.y = pack2bf(v[2], v[3]);
+  *reinterpret_cast<u32x2*>(dst + (((size_t)b * p.H + head) * p.L + l) * HD + jt + q * 4) = w;
+}
+
+#define PP_BARRIER() asm volatile("s_barrier" ::: "memory")
+template <class F, int... Cs> __device__ __forceinline__ void pp_unroll(F&& f, std::integer_sequence<int, Cs...>) { (f(std::integral_constant<int, Cs>{}), ...); }
+
+// Roles per phase q (= one tile's K loop, NK slots of one 32-deep K-step each; every slot opens with the work-group barrier):
+//   consumer = group q & 1, on tile q:   barrier -> ds_read the operand fragments of K-step t+1 -> 32 MFMAs of K-step t.  No vector-memory
+//              instruction at all: an LDS-DMA piece costs its issuing wave 60-180 cycles in order, which a lone wave per SIMD cannot hide
+//              (first version of this kernel: 1500 cycles per slot against 576 of MFMA work).
+//   loader   = the other group = owner of tiles q-1 and q+1:  barrier -> one sixteenth of the epilogue of tile q-1 (slots 0..15) -> the six
+//              LDS-DMA pieces of the stage four K-steps ahead of the consumer (crossing into tile q+1, its own next tile, at the end of the
+//              phase) -> counted vmcnt that leaves exactly its two youngest stages in flight.
+// ONE ring of five 24 KB stage buffers is shared: global stage G = q * NK + t lives in buffer G % 5; the loader writes stage G+4 into the buffer
+// whose fragments the consumer fetched two slots earlier.  A stage is published by its issuing wave's vmcnt wait followed by the next slot's
+// barrier; the four stages that the new consumer issued itself while it was still loader are covered by its own waits in slots 0 and 1.
+// wait until at most `stages` of this wave's youngest LDS-DMA stages (LPS pieces each) are still in flight
+template <int LPS> __device__ __forceinline__ void pp_wait_stages(int stages) {
+  if (stages >= 4) wait_vmcnt<4 * LPS>(); else if (stages == 3) wait_vmcnt<3 * LPS>(); else if (stages == 2) wait_vmcnt<2 * LPS>();
+  else if (stages == 1) wait_vmcnt<LPS>(); else wait_vmcnt<0>();
+}
+
+// NB ring buffers; the loader runs LA = NB-1 K-steps ahead of the consumer, i.e. up to NB-3 stages (24 KB each) are in flight while the consumer
+// fetches the fragments of one more: the fill rate of a CU is (bytes in flight) / (~1 us of loaded L2 / fabric latency), measured 42-46 GB/s with
+// 48-64 KB in flight (this kernel at NB 5 / LA 4 and the per-tile kernels alike) against the 55-80 GB/s the MFMA pipe can consume.
+template <int EPI, bool GRAD, int NB>
+__global__ void __launch_bounds__(512, 2) k_gemm_nt_pp(const GemmArgs p, int g8) {
+  // LA = NB - 1: the buffer refilled in slot G held stage G-1, whose last fragment reads were issued a whole slot earlier (the consumer fetches
+  // the second half of its activation fragments at the END of a slot and does not wait for them before the barrier: with LA = NB those reads
+  // could still be in flight when the refill lands)
+  constexpr int MT = 8, NTW = 4, BKT = 32, LA = NB - 1, CSLOTS = 16;
+  typedef Shape<2, 2, MT, NTW, BKT, NB, 32> S;          // per GROUP: 4 waves, 256 x 128 tile, 64-byte LDS rows, 24 KB per stage
+  constexpr bool PAIR = DirectMap<EPI>::PAIR;
+  constexpr int NCH = PAIR ? MT * NTW / 2 : MT * NTW;   // epilogue chunks per wave tile (8 resp. 4 elements per lane each)
+  constexpr int CPS = NCH / CSLOTS;                     // chunks per chunk-carrying slot
+  constexpr int ST_PER_CHUNK = (EPI == ONEPROT_EPI_BIAS_GELU && GRAD) ? 2 : 1;      // global stores per chunk
+  constexpr int LPS = S::LPS;                           // LDS-DMA instructions per wave per stage (6)
+  extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+  const int tid = threadIdx.x, lane = tid & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int group = wave >> 2, gw = wave & 3;
+  const int wr = gw >> 1, wc = gw & 1;
+  const int NK = p.K / BKT;
+
+  // ---- this work-group's tile sequence (per XCD: row panels x, x+8, ...; n fastest)
+  const int x = blockIdx.x & 7, w = blockIdx.x >> 3;
+  const int panels_x = p.tiles_m > x ? (p.tiles_m - x + 7) >> 3 : 0;
+  const int Tx = panels_x * p.tiles_n;
+  const int Q = Tx > w ? (Tx - w + g8 - 1) / g8 : 0;
+  if (Q == 0) return;
+  auto tile_origin = [&](int qi, int& m0, int& n0) {
+    const int u = qi * g8 + w;
+    const int pl = u / p.tiles_n, tn = u - pl * p.tiles_n;
+    m0 = (pl * 8 + x) * S::BM_; n0 = tn * S::BN_;
+  };
+
+  // ---- staging constants (lane-linear 1 KB pieces = 16 rows of 64 B; XOR swizzle on the source chunk; weight rows permuted for the direct map).
+  // The swizzle of a row depends on (row >> 2) & 3 only, i.e. on the lane, not on the piece: every A piece of a wave has the same per-lane offset.
+  constexpr int CH = BKT / 8;
+  const int srow = lane / CH, schunk = lane % CH;
+  const unsigned a_rel0 = (unsigned)srow * (unsigned)p.lda * 2u + (unsigned)swz<BKT>(srow, schunk) * 16u;
+  unsigned b_rel[S::B_IPW];
+#pragma unroll
+  for (int i = 0; i < S::B_IPW; ++i) {
+    const int slot = (gw * S::B_IPW + i) * S::RPI + srow;
+    const int blk = slot / (NTW * 16), in = slot - blk * (NTW * 16);
+    const int grow = blk * (NTW * 16) + direct_nmap<PAIR>(in >> 4, in & 15);
+    b_rel[i] = (unsigned)grow * (unsigned)p.ldb * 2u + (unsigned)swz<BKT>(slot, schunk) * 16u;
+  }
+  const size_t a_piece = (size_t)S::RPI * p.lda * 2;          // bytes between consecutive A pieces (wave-uniform)
+  auto issue = [&](const unsigned char* a_tile, const unsigned char* b_tile, int t, int buf) {
+    unsigned char* sA = smem + buf * S::STAGE;
+    unsigned char* sB = sA + S::BM_ * S::ROWB;
+    const unsigned char* ak = a_tile + (size_t)t * (BKT * 2) + (size_t)(gw * S::A_IPW) * a_piece;
+    const unsigned char* bk = b_tile + (size_t)t * (BKT * 2);
+#pragma unroll
+    for (int i = 0; i < S::A_IPW; ++i) __builtin_amdgcn_global_load_lds(GLB_PTR(ak + i * a_piece + a_rel0), LDS_PTR(sA + (gw * S::A_IPW + i) * 1024), 16, 0, 0);
+#pragma unroll
+    for (int i = 0; i < S::B_IPW; ++i) __builtin_amdgcn_global_load_lds(GLB_PTR(bk + b_rel[i]), LDS_PTR(sB + (gw * S::B_IPW + i) * 1024), 16, 0, 0);
+  };
+
+  // ---- fragment read offsets inside a stage image (tile i / j is a constant 1 KB step = an immediate offset)
+  const int frow = lane & 15, fq = lane >> 4;
+  const int a_off0 = (wr * (MT * 16) + frow) * S::ROWB + (swz<BKT>(frow, fq) << 4);
+  const int b_off0 = S::BM_ * S::ROWB + (wc * (NTW * 16) + frow) * S::ROWB + (swz<BKT>(frow, fq) << 4);
+
+  // Register plan (256 per lane at two waves per SIMD): 128 accumulators + ONE set of activation fragments (32) + two sets of weight fragments
+  // (32) = 192.  The activation fragments of K-step t+1 are fetched in two halves, each right after the MFMAs that consumed the registers it
+  // overwrites (stage t+1 is already published by the barrier that opened slot t), so the reads still run one half-step ahead of their use.
+  f32x4 acc[MT][NTW];
+  bf8_t fa[MT], fb[2][NTW];
+  auto load_fa = [&](auto halfc, int buf) {
+    constexpr int half = decltype(halfc)::value;
+    const unsigned char* sa = smem + buf * S::STAGE + a_off0;
+#pragma unroll
+    for (int i = half * (MT / 2); i < (half + 1) * (MT / 2); ++i) fa[i] = *reinterpret_cast<const bf8_t*>(sa + i * (16 * S::ROWB));
+  };
+  auto load_fb = [&](auto setc, int buf) {
+    constexpr int set = decltype(setc)::value;
+    const unsigned char* sb = smem + buf * S::STAGE + b_off0;
+#pragma unroll
+    for (int j = 0; j < NTW; ++j) fb[set][j] = *reinterpret_cast<const bf8_t*>(sb + j * (16 * S::ROWB));
+  };
+  auto init_acc = [&](int n0) {          // accumulators start at the bias of their columns (4 consecutive columns per lane and tile)
+#pragma unroll
+    for (int j = 0; j < NTW; ++j) {
+      f32x4 bj = {0.f, 0.f, 0.f, 0.f};
+      if (p.bias) { const float4 t = *reinterpret_cast<const float4*>(p.bias + n0 + wc * (NTW * 16) + direct_nmap<PAIR>(j, fq * 4)); bj = (f32x4){t.x, t.y, t.z, t.w}; }
+#pragma unroll
+      for (int i = 0; i < MT; ++i) acc[i][j] = bj;
+    }
+  };
+
+  // ---- the stage to be issued next (global stage cursor, the same in both groups whoever is loader), and the consumer's read cursor
+  int iq = 0, it = 0, ibuf = 0;                 // tile / K-step / ring buffer of the next stage to issue
+  const unsigned char *ia_tile, *ib_tile;
+  { int m0, n0; tile_origin(0, m0, n0); ia_tile = reinterpret_cast<const unsigned char*>(p.A + (size_t)m0 * p.lda); ib_tile = reinterpret_cast<const unsigned char*>(p.B + (size_t)n0 * p.ldb); }
+  auto advance_issue = [&]() {
+    ibuf = ibuf + 1 == NB ? 0 : ibuf + 1;
+    if (++it == NK) {
+      it = 0; ++iq;
+      if (iq < Q) { int m0, n0; tile_origin(iq, m0, n0); ia_tile = reinterpret_cast<const unsigned char*>(p.A + (size_t)m0 * p.lda); ib_tile = reinterpret_cast<const unsigned char*>(p.B + (size_t)n0 * p.ldb); }
+    }
+  };
+  int rbuf = 0;                                 // ring buffer of the stage whose MFMAs run in the current slot
+  // per-lane byte offset of this lane's first output element inside a chunk's (row group, column block): see pp_chunk
+  const unsigned lane_off = PAIR ? ((unsigned)frow * (unsigned)p.N + fq * 8u) * 2u : ((unsigned)frow * (unsigned)p.N + fq * 4u) * 4u;
+
+  // ---- start-up: the first consumer (group 0) stages K-steps 0..3 of tile 0 itself
+  if (group == 0) {
+    int m0, n0; tile_origin(0, m0, n0);
+    init_acc(n0);
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+  }
+#pragma unroll
+  for (int k = 0; k < LA; ++k) { if (group == 0) issue(ia_tile, ib_tile, it, ibuf); advance_issue(); }
+  if (group == 0) pp_wait_stages<LPS>(LA - 2);    // stages 0 and 1 landed (published by the barrier that opens slot 0)
+
+  for (int ph = 0; ph < Q; ++ph) {
+    if ((ph & 1) == group) {
+      // ================= consumer of tile ph
+      auto slot = [&](int t, auto parity) {
+        constexpr int P = decltype(parity)::value;
+        if (t != 0) PP_BARRIER();                  // (slot 0's barrier and fragment reads sit in front of the loop)
+        const int nxt = rbuf + 1 == NB ? 0 : rbuf + 1;
+#pragma unroll
+        for (int i = 0; i < MT / 2; ++i)
+#pragma unroll
+          for (int j = 0; j < NTW; ++j) acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(fb[P][j], fa[i], acc[i][j], 0, 0, 0);
+        if (t + 1 < NK) { load_fb(std::integral_constant<int, P ^ 1>{}, nxt); load_fa(std::integral_constant<int, 0>{}, nxt); }
+#pragma unroll
+        for (int i = MT / 2; i < MT; ++i)
+#pragma unroll
+          for (int j = 0; j < NTW; ++j) acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(fb[P][j], fa[i], acc[i][j], 0, 0, 0);
+        if (t + 1 < NK) load_fa(std::integral_constant<int, 1>{}, nxt);
+        rbuf = nxt;
+        advance_issue();                           // (cursor only: the loader issues)
+        // Every fragment read of stage t+1 is consumed by the MFMAs of slot t+1, i.e. retired before this wave reaches the barrier that lets
+        // the loader refill that buffer (slot t+2 at the earliest).  The stages this group issued while it was loader (0 .. LA-1 of this tile):
+        // stage t+2 is fetched in the next slot, so stages t+3 .. LA-1 may still be in flight at the end of slot t.
+        if (t < LA - 3) pp_wait_stages<LPS>(LA - 3 - t); else wait_vmcnt<0>();
+      };
+      // first K-step of the tile: nothing was prefetched across the role change (defined HERE, in front of the loop, so that the fragment
+      // registers are provably dead throughout the loader role)
+      PP_BARRIER();
+      load_fb(std::integral_constant<int, 0>{}, rbuf);
+      load_fa(std::integral_constant<int, 0>{}, rbuf);
+      load_fa(std::integral_constant<int, 1>{}, rbuf);
+      for (int t = 0; t < NK; t += 2) {
+        slot(t, std::integral_constant<int, 0>{});
+        slot(t + 1, std::integral_constant<int, 1>{});
+      }
+    } else {
+      // ================= loader for tile ph's K loop + epilogue of this group's previous tile (ph-1) + first stages of its next tile (ph+1)
+      const bool has_prev = ph >= 1;
+      int em0 = 0, en0 = 0;
+      if (has_prev) tile_origin(ph - 1, em0, en0);
+      const int um0 = em0 + wr * (MT * 16), un0 = en0 + wc * (NTW * 16);
+      const u32x4 no16 = {0, 0, 0, 0}; const float4 no4 = make_float4(0.f, 0.f, 0.f, 0.f);
+      // end of a loader slot: issue the stage LA K-steps ahead of the consumer, then make sure that every stage the consumer fetches in the NEXT
+      // slot has landed: in steady state the two youngest stages (this slot's and the previous one's) may stay in flight -- this slot's stores
+      // are older than its DMA pieces, so they never count among the youngest.  When the stage sequence has run out, fewer may stay.
+      int since_issue = 0;                         // slots since this wave last issued a stage (0 = this slot)
+      auto loader_tail = [&]() {
+        if (iq < Q) { issue(ia_tile, ib_tile, it, ibuf); since_issue = 0; } else ++since_issue;
+        advance_issue();
+        pp_wait_stages<LPS>(LA - 2 - since_issue);      // steady state: stages G+3 .. G+LA stay in flight, G+2 (fetched next slot) has landed
+      };
+      auto cslot = [&](auto sc) {                  // slots 0..15: CPS epilogue chunks each
+        constexpr int sidx = decltype(sc)::value;
+        PP_BARRIER();
+        if (has_prev) {
+          pp_unroll([&](auto cc) { pp_chunk<EPI, sidx * CPS + decltype(cc)::value, MT, NTW>(p, acc, um0, un0, lane_off, no16, no4); }, std::make_integer_sequence<int, CPS>{});
+        }
+        if (sidx == CSLOTS - 1) {                  // accumulators are free: the next tile's bias goes in now (an ordinary load: drains the queue once per tile).
+          // Unconditional on purpose (a tile that does not exist re-reads the bias of the last one): a conditional re-definition keeps the
+          // old accumulator values alive beside the new ones and costs 50 VGPRs of spills
+          int m0, n0; tile_origin(ph + 1 < Q ? ph + 1 : Q - 1, m0, n0);
+          init_acc(n0);
+        }
+        loader_tail();
+      };
+      pp_unroll(cslot, std::make_integer_sequence<int, CSLOTS>{});
+      for (int t = CSLOTS; t < NK; ++t) {
+        PP_BARRIER();
+        loader_tail();
+      }
+    }
+  }
+  // ================= closing phase: the owner of the last tile finishes its epilogue (no partner K loop left: no barriers)
+  if (((Q - 1) & 1) == group) {
+    int em0, en0; tile_origin(Q - 1, em0, en0);
+    const int um0 = em0 + wr * (MT * 16), un0 = en0 + wc * (NTW * 16);
+    const u32x4 no16 = {0, 0, 0, 0}; const float4 no4 = make_float4(0.f, 0.f, 0.f, 0.f);
+    pp_unroll([&](auto cc) { pp_chunk<EPI, decltype(cc)::value, MT, NTW>(p, acc, um0, un0, lane_off, no16, no4); }, std::make_integer_sequence<int, NCH>{});
+  }
+}
+
+static int g_pp_ring = 6;            // tuning hook (oneprot_gemm_force_shape(32 + 64 * ring))
+template <int EPI, bool GRAD, int NB>
+static int launch_pp3(GemmArgs a, hipStream_t s) {
+  constexpr int LDS = NB * (256 + 128) * 64;
+  static bool configured = false;
+  static int n_cu = 0;
+  if (!configured) {
+    if (hipFuncSetAttribute((const void*)k_gemm_nt_pp<EPI, GRAD, NB>, hipFuncAttributeMaxDynamicSharedMemorySize, LDS) != hipSuccess) return OP_ELAUNCH;
+    int dev = 0; hipDeviceProp_t prop;
+    if (hipGetDevice(&dev) != hipSuccess || hipGetDeviceProperties(&prop, dev) != hipSuccess) return OP_ELAUNCH;
+    n_cu = prop.multiProcessorCount;
+    configured = true;
+  }
+  a.tiles_m = a.M / 256; a.tiles_n = a.N / 128;
+  const long tiles = (long)a.tiles_m * a.tiles_n;
+  int g8 = n_cu / 8;                                   // work-groups per XCD
+  const long per_xcd = (tiles + 7) / 8;
+  if (g8 > per_xcd) g8 = (int)per_xcd;
+  if (g8 < 1) g8 = 1;
+  hipLaunchKernelGGL((k_gemm_nt_pp<EPI, GRAD, NB>), dim3(g8 * 8), dim3(512), LDS, s, a, g8);
+  return launch_status();
+}
+template <int EPI, bool GRAD>
+static int launch_pp2(GemmArgs a, hipStream_t s) {
+  switch (g_pp_ring) {
+    case 4: return launch_pp3<EPI, GRAD, 4>(a, s);
+    case 5: return launch_pp3<EPI, GRAD, 5>(a, s);
+    default: return launch_pp3<EPI, GRAD, 6>(a, s);
+  }
+}
+template <int EPI>
+static int launch_pp(GemmArgs a, hipStream_t s) {
+  if (EPI == ONEPROT_EPI_BIAS_GELU && a.out1 != nullptr) return launch_pp2<EPI, true>(a, s);
+  return launch_pp2<EPI, false>(a, s);
+}
+
+// whole 256 x 128 tiles, K a multiple of 64 and at least 16 K-steps (the epilogue is spread over 16 slots of the partner's K loop), 31-bit
+// tile-relative byte offsets; epilogues that read operands from memory (residual, GELU', RoPE tables) are not built in this form yet
+template <int EPI>
+static bool pp_eligible(const GemmArgs& a) {
+  if (EPI != ONEPROT_EPI_BF16 && EPI != ONEPROT_EPI_F32 && EPI != ONEPROT_EPI_BIAS_GELU) return false;
+  if (a.M % 256 || a.N % 128 || a.K % 64 || a.K < 512) return false;
+  if ((size_t)256 * a.lda * 2 >= (1ull << 31) || (size_t)128 * a.ldb * 2 >= (1ull << 31)) return false;
+  return true;
 }
 
 static int g_force_shape = -1;     // test / tuning hook, see launch_gemm
@@ -431,7 +936,19 @@ static int launch_gemm(const GemmArgs& a, hipStream_t s) {
   else if (a.K >= 1024) shape = 3;
   else if (a.N >= 2048) shape = 4;
   else shape = 1;
+  if (shape >= 32 && (shape & 63) == 32) {            // ping-pong form; 32 + 64 * ring selects the ring depth (4..6) for A/B runs
+    if (shape >> 6) g_pp_ring = shape >> 6;
+    shape = 32;
+  }
+  if (shape == 32) {            // ping-pong form (falls back to the direct-store 256 x 128 form when the problem is not made of whole tiles)
+    if (pp_eligible<EPI>(a)) return launch_pp<EPI>(a, s);
+    shape = 17;
+  }
   switch (shape) {
+    // 16 + s: shape s with the direct-store epilogue (full tiles; falls back to s otherwise)
+    case 20: return launch_shape<EPI, 2, 4, 8, 4, 64, 2, 32, 2, true, true, true>(a, s);
+    case 19: return launch_shape<EPI, 2, 2, 4, 4, 64, 2, 64, 2, false, true, true>(a, s);
+    case 17: return launch_shape<EPI, 4, 2, 4, 4, 32, 3, 32, 4, false, true, true>(a, s);
     case 7: return launch_shape<EPI, 2, 2, 8, 8, 32, 4, 32, 1, false>(a, s);      // 256x256, 4 waves x (128x128), BK32 x4, one wave per SIMD
     case 6: return launch_shape<EPI, 2, 2, 8, 8, 64, 2, 32, 1, false>(a, s);      // 256x256, 4 waves x (128x128), BK64 x2, one wave per SIMD
     case 5: return launch_shape<EPI, 2, 4, 8, 4, 32, 4, 32, 2, false>(a, s);      // 256x256 without fragment pipelining (A/B runs)

@@ -144,14 +144,19 @@ def _gemm_inputs(M, N, K, seed):
     return A, W, bias
 
 
-@pytest.fixture(params=[-1, 0, 1, 2, 3, 4, 5, 6, 7], ids=["auto", "128x128", "256x128", "256x256", "128x128bk64", "256x256bk64", "256x256nopipe", "4w128x128bk64", "4w128x128bk32"])
+@pytest.fixture(params=[-1, 0, 1, 2, 3, 4, 5, 6, 7, 17, 19, 20, 32], ids=["auto", "128x128", "256x128", "256x256", "128x128bk64", "256x256bk64", "256x256nopipe", "4w128x128bk64",
+                                                                          "4w128x128bk32", "direct256x128", "direct128x128bk64", "direct256x256bk64", "pingpong"])
 def gemm_shape(request):
     hip.query("oneprot_gemm_force_shape", request.param)
     yield request.param
     hip.query("oneprot_gemm_force_shape", -1)
 
 
-@pytest.mark.parametrize("M,N,K", [(300, 136, 72), (128, 128, 64), (1024, 640, 640), (257, 2560, 640), (515, 640, 2560), (144, 64, 160), (2304, 1920, 640), (8192, 512, 160)])
+@pytest.mark.parametrize("M,N,K", [(300, 136, 72), (128, 128, 64), (1024, 640, 640), (257, 2560, 640), (515, 640, 2560), (144, 64, 160), (2304, 1920, 640), (8192, 512, 160),
+                                   (1024, 1280, 640), (512, 768, 2560), (8192, 640, 640), (4096, 2560, 128), (16384, 128, 192),
+                                   (4096, 256, 512), (2048, 384, 576), (256, 128, 1024), (768, 256, 640)])
+# (1024, 1280, 640) onwards are whole tiles in every block shape (direct-store and ping-pong forms).  For the persistent ping-pong kernel (K >= 512):
+# several tiles per work-group, K = 512 (16 K-steps: every slot carries an epilogue chunk) and 576, a single tile, and XCDs without any tile.
 def test_gemm_nt_epilogues(M, N, K, gemm_shape):
     A, W, bias = _gemm_inputs(M, N, K, 3)
     ref = A.float() @ W.float().t()
@@ -170,19 +175,26 @@ def test_gemm_nt_epilogues(M, N, K, gemm_shape):
     gz.sum().backward()
     assert_close(u, gz.detach(), 2 ** -7, 2e-2, "gelu(z)")
     assert_close(z, zr.grad, 2 ** -7, 1e-2, "gelu'(z)")
+    u2 = torch.empty(M, N, dtype=torch.bfloat16, device=DEV)            # forward-only form (frozen tower): no derivative output
+    hip.call("oneprot_gemm_bf16_nt", A, W, M, N, K, K, K, hip.EPI_BIAS_GELU, bias, u2, None, None, None, None, None, 1.0, 0, 0, 0)
+    assert_close(u2, gz.detach(), 2 ** -7, 2e-2, "gelu(z), no derivative")
     # bias + fp32 residual, in place
     g = torch.Generator().manual_seed(4)
     resid = torch.randn(M, N, generator=g).to(DEV)
     x = resid.clone()
     hip.call("oneprot_gemm_bf16_nt", A, W, M, N, K, K, K, hip.EPI_BIAS_RESID, bias, x, None, None, x, None, None, 1.0, 0, 0, 0)
     assert_close(x, ref + bias + resid, 1e-4, 1e-3 * math.sqrt(K / 64), "bias+resid")
+    x2, x2h = torch.empty(M, N, device=DEV), torch.empty(M, N, dtype=torch.bfloat16, device=DEV)      # out of place, with the bf16 copy
+    hip.call("oneprot_gemm_bf16_nt", A, W, M, N, K, K, K, hip.EPI_BIAS_RESID, bias, x2, x2h, None, resid, None, None, 1.0, 0, 0, 0)
+    assert_close(x2, ref + bias + resid, 1e-4, 1e-3 * math.sqrt(K / 64), "bias+resid out of place")
+    assert_close(x2h, ref + bias + resid, 2 ** -7, 2e-2, "bias+resid bf16 copy")
     # gelu backward epilogue
     dz = torch.empty(M, N, dtype=torch.bfloat16, device=DEV)
     hip.call("oneprot_gemm_bf16_nt", A, W, M, N, K, K, K, hip.EPI_GELU_BWD, None, dz, None, None, z, None, None, 1.0, 0, 0, 0)
     assert_close(dz, ref * z.float(), 2 ** -6, 3e-2, "gelu bwd")
 
 
-@pytest.mark.parametrize("B,L,H,hd", [(3, 24, 4, 16), (2, 37, 2, 32), (2, 130, 20, 32), (2, 50, 2, 64), (5, 512, 20, 32), (16, 512, 8, 32)])
+@pytest.mark.parametrize("B,L,H,hd", [(3, 24, 4, 16), (2, 37, 2, 32), (2, 130, 20, 32), (2, 50, 2, 64), (5, 512, 20, 32), (16, 512, 8, 32), (4, 128, 4, 64), (8, 96, 8, 32)])
 def test_gemm_qkv_rope_epilogue(B, L, H, hd, gemm_shape):
     d = H * hd
     M, N, K = B * L, 3 * d, d
