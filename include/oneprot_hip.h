@@ -84,6 +84,8 @@ int oneprot_gemm_bf16_nt(const void* A, const void* Bw, int64_t M, int N, int K,
                          int L, int H, int hd, void* stream);
 /* test / tuning hook: force the block shape of oneprot_gemm_bf16_nt (0..5, see csrc/gemm_nt.hip; -1 = heuristic). */
 void oneprot_gemm_force_shape(int shape);
+/* test / tuning hook: L2 super-tile of the per-tile kernels (sup_m row panels x sup_n column tiles per XCD at a time; <= 0 keeps a value). */
+void oneprot_gemm_tune(int sup_m, int sup_n);
 /* dW[N,K] (+)= dY[M,N]^T * X[M,K]  (contraction over the M tokens; split over workgroups, fp32 slabs in workspace);
    dbias[N] (+)= column sums of dY (optional, fused: an all-ones MFMA operand in the k-tile-0 workgroups). */
 /* workspace bytes for an (N, K) weight gradient, for any M (the split count is capped by M inside the call, never raised). */

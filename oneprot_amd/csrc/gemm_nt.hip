@@ -37,6 +37,7 @@ struct GemmArgs {
   float q_scale;
   int L, H, hd;
   int tiles_m, tiles_n;
+  int sup_m, sup_n;             // L2 super-tile of the per-tile kernels: sup_m row panels x sup_n column tiles per XCD at a time
 };
 
 // WM x WN waves, MT x NTW 16x16 accumulator tiles per wave (wave tile = MT*16 x NTW*16), BKT = K-slice per LDS stage (32 or 64), NSTAGE ring depth,
@@ -62,6 +63,9 @@ template <int BKT> __device__ __forceinline__ int swz(int row, int chunk) {
 }
 
 template <int N> __device__ __forceinline__ void wait_vmcnt() { asm volatile("s_waitcnt vmcnt(%0)" ::"n"(N) : "memory"); }
+
+static int g_sup_m = 4, g_sup_n = 10;      // L2 super-tile (tuning hook oneprot_gemm_tune)
+extern "C" void oneprot_gemm_tune(int sup_m, int sup_n) { if (sup_m > 0) g_sup_m = sup_m; if (sup_n > 0) g_sup_n = sup_n; }
 
 // ---- epilogue: the wave parks EPH rows x 64 columns of its fp32 accumulators in its own padded LDS tile `et` and re-reads them row-wise,
 // 8 columns per lane -> 16-byte coalesced stores in whatever layout the consumer wants.  FULL = the tile lies entirely inside [M, N] (no masks).
@@ -326,7 +330,7 @@ __global__ void __launch_bounds__(WM * WN * 64, MINW) k_gemm_nt(const GemmArgs p
   // 1.65 GB -> 1.1 GB of fabric reads for the FFN-1 launch, whose operand set is 171 MB).
   const int bid = blockIdx.x;
   const int xcd = bid & 7, seq = bid >> 3;
-  constexpr int SUP_M = 4, SUP_N = 10;
+  const int SUP_M = p.sup_m, SUP_N = p.sup_n;
   const int pm_total = (p.tiles_m + 7) >> 3;
   const int per_mgroup = SUP_M * SUP_N * ((p.tiles_n + SUP_N - 1) / SUP_N);      // slots per m-group (partial groups leave idle slots)
   const int mg = seq / per_mgroup;
@@ -552,7 +556,8 @@ static int launch_shape_full(GemmArgs a, hipStream_t s) {
   a.tiles_m = (a.M + S::BM_ - 1) / S::BM_;
   a.tiles_n = (a.N + S::BN_ - 1) / S::BN_;
   const int pm_total = (a.tiles_m + 7) / 8;
-  const int grid = ((pm_total + 3) / 4) * (4 * 10 * ((a.tiles_n + 9) / 10)) * 8;       // super-tile slots (SUP_M=4, SUP_N=10); surplus blocks exit at once
+  a.sup_m = g_sup_m; a.sup_n = g_sup_n;
+  const int grid = ((pm_total + a.sup_m - 1) / a.sup_m) * (a.sup_m * a.sup_n * ((a.tiles_n + a.sup_n - 1) / a.sup_n)) * 8;       // super-tile slots; surplus blocks exit at once
   hipLaunchKernelGGL((k_gemm_nt<EPI, WM, WN, MT, NTW, BKT, NSTAGE, EPH, MINW, PIPE, FULLT, DIRECT>), dim3(grid), dim3(S::NW * 64), S::LDS, s, a);
   return launch_status();
 }
@@ -672,33 +677,41 @@ template <class F, int... Cs> __device__ __forceinline__ void pp_unroll(F&& f, s
 // ONE ring of five 24 KB stage buffers is shared: global stage G = q * NK + t lives in buffer G % 5; the loader writes stage G+4 into the buffer
 // whose fragments the consumer fetched two slots earlier.  A stage is published by its issuing wave's vmcnt wait followed by the next slot's
 // barrier; the four stages that the new consumer issued itself while it was still loader are covered by its own waits in slots 0 and 1.
-// wait until at most `stages` of this wave's youngest LDS-DMA stages (LPS pieces each) are still in flight
-template <int LPS> __device__ __forceinline__ void pp_wait_stages(int stages) {
-  if (stages >= 4) wait_vmcnt<4 * LPS>(); else if (stages == 3) wait_vmcnt<3 * LPS>(); else if (stages == 2) wait_vmcnt<2 * LPS>();
-  else if (stages == 1) wait_vmcnt<LPS>(); else wait_vmcnt<0>();
+// wait until at most `halves` of this wave's youngest half-stage issues (HP LDS-DMA pieces each) are still in flight
+template <int HP> __device__ __forceinline__ void pp_wait_halves(int halves) {
+  if (halves >= 2) wait_vmcnt<2 * HP>(); else if (halves == 1) wait_vmcnt<HP>(); else wait_vmcnt<0>();
 }
 
-// NB ring buffers; the loader runs LA = NB-1 K-steps ahead of the consumer, i.e. up to NB-3 stages (24 KB each) are in flight while the consumer
-// fetches the fragments of one more: the fill rate of a CU is (bytes in flight) / (~1 us of loaded L2 / fabric latency), measured 42-46 GB/s with
-// 48-64 KB in flight (this kernel at NB 5 / LA 4 and the per-tile kernels alike) against the 55-80 GB/s the MFMA pipe can consume.
-template <int EPI, bool GRAD, int NB>
+// Geometry of the ping-pong kernel.  A STAGE is a 64-deep K-slice of the group tile (256 activation rows + 128 weight rows, 128-byte LDS rows:
+// every 1 KB LDS-DMA piece covers 8 rows x one whole 128-byte line -- measured (tools/ab/fill_probe.hip, profiles/r02_fill_probe.txt) 93-100 GB/s
+// per CU against 59 GB/s for pieces of 16 half lines (32-deep slices), which capped the first version of this kernel at 22 B/clk); the ring
+// holds three stages (144 KB).  TIME is counted in SUB-SLOTS of one 32-deep K-step (= 32 MFMAs per consumer wave), each opened by the
+// work-group barrier.  Sub-slot U = 2t + kk works on half kk of stage t.
+//   consumer: MFMAs of (t, kk) from registers; fetches the fragments of the next sub-step -- (t, 1) from the same buffer, or (t+1, 0) from the
+//             next one -- in two halves behind the MFMAs that free the registers (one activation set, two weight sets: 192 + 64 registers).
+//   loader:   one sixteenth of its previous tile's epilogue (sub-slots 0..15), then HALF a stage (6 of the 12 pieces per wave): at U = 2t+1 the
+//             first half of stage t+3 into the buffer of stage t (its last fragments were fetched during sub-slot 2t, and the consumer retires
+//             its LDS reads before the barrier that opens 2t+1), at U = 2t+2 the second half.  I.e. half-stage h = U + 5 is issued in sub-slot
+//             U; afterwards the wave waits until at most its two youngest half-stages are in flight, so that at the END of sub-slot U every
+//             half-stage <= U + 3 has landed -- the consumer touches stage t+1 = halves 2t+2, 2t+3 first in sub-slot 2t+1.
+//   role change: the new consumer issued half-stages up to U'+4 itself (U' = its first sub-slot); U'+3 must have landed at the end of U'
+//             (vmcnt(6)), U'+4 at the end of U'+1 (vmcnt(0)); afterwards its queue is empty.
+template <int EPI, bool GRAD, int NBX>
 __global__ void __launch_bounds__(512, 2) k_gemm_nt_pp(const GemmArgs p, int g8) {
-  // LA = NB - 1: the buffer refilled in slot G held stage G-1, whose last fragment reads were issued a whole slot earlier (the consumer fetches
-  // the second half of its activation fragments at the END of a slot and does not wait for them before the barrier: with LA = NB those reads
-  // could still be in flight when the refill lands)
-  constexpr int MT = 8, NTW = 4, BKT = 32, LA = NB - 1, CSLOTS = 16;
-  typedef Shape<2, 2, MT, NTW, BKT, NB, 32> S;          // per GROUP: 4 waves, 256 x 128 tile, 64-byte LDS rows, 24 KB per stage
+  constexpr int MT = 8, NTW = 4, BKT = 64, NB = 3, CSLOTS = 16, HLA = 5;
+  typedef Shape<2, 2, MT, NTW, BKT, NB, 32> S;          // per GROUP: 4 waves, 256 x 128 tile, 128-byte LDS rows, 48 KB per stage
   constexpr bool PAIR = DirectMap<EPI>::PAIR;
   constexpr int NCH = PAIR ? MT * NTW / 2 : MT * NTW;   // epilogue chunks per wave tile (8 resp. 4 elements per lane each)
-  constexpr int CPS = NCH / CSLOTS;                     // chunks per chunk-carrying slot
-  constexpr int ST_PER_CHUNK = (EPI == ONEPROT_EPI_BIAS_GELU && GRAD) ? 2 : 1;      // global stores per chunk
-  constexpr int LPS = S::LPS;                           // LDS-DMA instructions per wave per stage (6)
+  constexpr int CPS = NCH / CSLOTS;                     // chunks per chunk-carrying sub-slot
+  constexpr int HP = S::LPS / 2;                        // LDS-DMA pieces per wave per half-stage (6)
+  static_assert(S::A_IPW == 8 && S::B_IPW == 4 && HP == 6, "half-stage split below assumes 8 + 4 pieces per wave");
   extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
   const int tid = threadIdx.x, lane = tid & 63;
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
   const int group = wave >> 2, gw = wave & 3;
   const int wr = gw >> 1, wc = gw & 1;
-  const int NK = p.K / BKT;
+  const int NK = p.K / BKT;                             // stages per tile
+  const int NU = 2 * NK;                                // sub-slots per phase
 
   // ---- this work-group's tile sequence (per XCD: row panels x, x+8, ...; n fastest)
   const int x = blockIdx.x & 7, w = blockIdx.x >> 3;
@@ -712,50 +725,78 @@ __global__ void __launch_bounds__(512, 2) k_gemm_nt_pp(const GemmArgs p, int g8)
     m0 = (pl * 8 + x) * S::BM_; n0 = tn * S::BN_;
   };
 
-  // ---- staging constants (lane-linear 1 KB pieces = 16 rows of 64 B; XOR swizzle on the source chunk; weight rows permuted for the direct map).
-  // The swizzle of a row depends on (row >> 2) & 3 only, i.e. on the lane, not on the piece: every A piece of a wave has the same per-lane offset.
-  constexpr int CH = BKT / 8;
-  const int srow = lane / CH, schunk = lane % CH;
-  const unsigned a_rel0 = (unsigned)srow * (unsigned)p.lda * 2u + (unsigned)swz<BKT>(srow, schunk) * 16u;
-  unsigned b_rel[S::B_IPW];
+  // ---- staging constants.  Piece = 8 rows x 128 B, lane (srow, schunk); the source chunk carries the XOR swizzle chunk ^ ((row >> 1) & 7), which
+  // for row = 8 * piece + srow is ((piece & 1) * 4 + (srow >> 1)): even and odd pieces differ by chunk bit 2 = byte offset bit 6.
+  // (These per-lane constants are only needed by the loader role and the fragment offsets below only by the consumer role: with 192 registers
+  // in accumulators and fragments there is no room to keep both sets alive, so each role recomputes its own from the lane id at phase entry --
+  // `role_lane()` hides the lane id behind an empty asm so that the compiler does not hoist the results out of the phase loop and spill them.)
+  auto role_lane = [&]() { int l = lane; asm volatile("" : "+v"(l)); return l; };
+  unsigned a_rel_e = 0, b_rel[S::B_IPW] = {0, 0, 0, 0};
+  auto loader_consts = [&]() {
+    const int l = role_lane();
+    const int srow = l >> 3, schunk = l & 7;
+    a_rel_e = (unsigned)srow * (unsigned)p.lda * 2u + (unsigned)(schunk ^ (srow >> 1)) * 16u;      // even pieces; odd: ^ 64
 #pragma unroll
-  for (int i = 0; i < S::B_IPW; ++i) {
-    const int slot = (gw * S::B_IPW + i) * S::RPI + srow;
-    const int blk = slot / (NTW * 16), in = slot - blk * (NTW * 16);
-    const int grow = blk * (NTW * 16) + direct_nmap<PAIR>(in >> 4, in & 15);
-    b_rel[i] = (unsigned)grow * (unsigned)p.ldb * 2u + (unsigned)swz<BKT>(slot, schunk) * 16u;
-  }
+    for (int i = 0; i < S::B_IPW; ++i) {
+      const int slot = (gw * S::B_IPW + i) * S::RPI + srow;
+      const int blk = slot / (NTW * 16), in = slot - blk * (NTW * 16);
+      const int grow = blk * (NTW * 16) + direct_nmap<PAIR>(in >> 4, in & 15);
+      b_rel[i] = (unsigned)grow * (unsigned)p.ldb * 2u + (unsigned)swz<BKT>(slot, schunk) * 16u;
+    }
+  };
   const size_t a_piece = (size_t)S::RPI * p.lda * 2;          // bytes between consecutive A pieces (wave-uniform)
-  auto issue = [&](const unsigned char* a_tile, const unsigned char* b_tile, int t, int buf) {
+  // half 0: A pieces 0..5 of this wave; half 1: A pieces 6, 7 and the four W pieces
+  auto issue_half = [&](const unsigned char* a_tile, const unsigned char* b_tile, int t, int half, int buf) {
+#if defined(PP_ABL_NODMA)
+    return;
+#endif
     unsigned char* sA = smem + buf * S::STAGE;
     unsigned char* sB = sA + S::BM_ * S::ROWB;
     const unsigned char* ak = a_tile + (size_t)t * (BKT * 2) + (size_t)(gw * S::A_IPW) * a_piece;
     const unsigned char* bk = b_tile + (size_t)t * (BKT * 2);
+    if (half == 0) {
 #pragma unroll
-    for (int i = 0; i < S::A_IPW; ++i) __builtin_amdgcn_global_load_lds(GLB_PTR(ak + i * a_piece + a_rel0), LDS_PTR(sA + (gw * S::A_IPW + i) * 1024), 16, 0, 0);
+      for (int i = 0; i < 6; ++i)
+        __builtin_amdgcn_global_load_lds(GLB_PTR(ak + i * a_piece + (a_rel_e ^ ((i & 1) << 6))), LDS_PTR(sA + (gw * S::A_IPW + i) * 1024), 16, 0, 0);
+    } else {
 #pragma unroll
-    for (int i = 0; i < S::B_IPW; ++i) __builtin_amdgcn_global_load_lds(GLB_PTR(bk + b_rel[i]), LDS_PTR(sB + (gw * S::B_IPW + i) * 1024), 16, 0, 0);
+      for (int i = 6; i < 8; ++i)
+        __builtin_amdgcn_global_load_lds(GLB_PTR(ak + i * a_piece + (a_rel_e ^ ((i & 1) << 6))), LDS_PTR(sA + (gw * S::A_IPW + i) * 1024), 16, 0, 0);
+#pragma unroll
+      for (int i = 0; i < S::B_IPW; ++i) __builtin_amdgcn_global_load_lds(GLB_PTR(bk + b_rel[i]), LDS_PTR(sB + (gw * S::B_IPW + i) * 1024), 16, 0, 0);
+    }
   };
 
-  // ---- fragment read offsets inside a stage image (tile i / j is a constant 1 KB step = an immediate offset)
+  // ---- fragment read offsets inside a stage image for k-half 0 (k-half 1: ^ 64); tile i / j is a constant 2 KB step = an immediate offset
   const int frow = lane & 15, fq = lane >> 4;
-  const int a_off0 = (wr * (MT * 16) + frow) * S::ROWB + (swz<BKT>(frow, fq) << 4);
-  const int b_off0 = S::BM_ * S::ROWB + (wc * (NTW * 16) + frow) * S::ROWB + (swz<BKT>(frow, fq) << 4);
+  int a_off0 = 0, b_off0 = 0;
+  auto consumer_consts = [&]() {
+    const int l = role_lane();
+    const int fr = l & 15, fqq = l >> 4;
+    a_off0 = (wr * (MT * 16) + fr) * S::ROWB + (swz<BKT>(fr, fqq) << 4);
+    b_off0 = S::BM_ * S::ROWB + (wc * (NTW * 16) + fr) * S::ROWB + (swz<BKT>(fr, fqq) << 4);
+  };
 
   // Register plan (256 per lane at two waves per SIMD): 128 accumulators + ONE set of activation fragments (32) + two sets of weight fragments
-  // (32) = 192.  The activation fragments of K-step t+1 are fetched in two halves, each right after the MFMAs that consumed the registers it
-  // overwrites (stage t+1 is already published by the barrier that opened slot t), so the reads still run one half-step ahead of their use.
+  // (32) = 192.  The activation fragments of the next sub-step are fetched in two halves, each right after the MFMAs that consumed the registers
+  // it overwrites, so the reads still run half a sub-step ahead of their use.
   f32x4 acc[MT][NTW];
   bf8_t fa[MT], fb[2][NTW];
-  auto load_fa = [&](auto halfc, int buf) {
+  auto load_fa = [&](auto halfc, int buf, int kk) {
     constexpr int half = decltype(halfc)::value;
-    const unsigned char* sa = smem + buf * S::STAGE + a_off0;
+#if defined(PP_ABL_NOREAD)
+    return;
+#endif
+    const unsigned char* sa = smem + buf * S::STAGE + (a_off0 ^ (kk << 6));
 #pragma unroll
     for (int i = half * (MT / 2); i < (half + 1) * (MT / 2); ++i) fa[i] = *reinterpret_cast<const bf8_t*>(sa + i * (16 * S::ROWB));
   };
-  auto load_fb = [&](auto setc, int buf) {
+  auto load_fb = [&](auto setc, int buf, int kk) {
     constexpr int set = decltype(setc)::value;
-    const unsigned char* sb = smem + buf * S::STAGE + b_off0;
+#if defined(PP_ABL_NOREAD)
+    return;
+#endif
+    const unsigned char* sb = smem + buf * S::STAGE + (b_off0 ^ (kk << 6));
 #pragma unroll
     for (int j = 0; j < NTW; ++j) fb[set][j] = *reinterpret_cast<const bf8_t*>(sb + j * (16 * S::ROWB));
   };
@@ -769,82 +810,94 @@ __global__ void __launch_bounds__(512, 2) k_gemm_nt_pp(const GemmArgs p, int g8)
     }
   };
 
-  // ---- the stage to be issued next (global stage cursor, the same in both groups whoever is loader), and the consumer's read cursor
-  int iq = 0, it = 0, ibuf = 0;                 // tile / K-step / ring buffer of the next stage to issue
+  // ---- cursor of the next half-stage to issue (the same in both groups, whoever is loader), and the consumer's stage buffer
+  int iq = 0, it = 0, ih = 0, ibuf = 0;         // tile / stage / half / ring buffer of the next half-stage to issue
   const unsigned char *ia_tile, *ib_tile;
   { int m0, n0; tile_origin(0, m0, n0); ia_tile = reinterpret_cast<const unsigned char*>(p.A + (size_t)m0 * p.lda); ib_tile = reinterpret_cast<const unsigned char*>(p.B + (size_t)n0 * p.ldb); }
   auto advance_issue = [&]() {
+    if (ih == 0) { ih = 1; return; }
+    ih = 0;
     ibuf = ibuf + 1 == NB ? 0 : ibuf + 1;
     if (++it == NK) {
       it = 0; ++iq;
       if (iq < Q) { int m0, n0; tile_origin(iq, m0, n0); ia_tile = reinterpret_cast<const unsigned char*>(p.A + (size_t)m0 * p.lda); ib_tile = reinterpret_cast<const unsigned char*>(p.B + (size_t)n0 * p.ldb); }
     }
   };
-  int rbuf = 0;                                 // ring buffer of the stage whose MFMAs run in the current slot
+  int rbuf = 0;                                 // ring buffer of the stage whose MFMAs run in the current sub-slot
   // per-lane byte offset of this lane's first output element inside a chunk's (row group, column block): see pp_chunk
   const unsigned lane_off = PAIR ? ((unsigned)frow * (unsigned)p.N + fq * 8u) * 2u : ((unsigned)frow * (unsigned)p.N + fq * 4u) * 4u;
 
-  // ---- start-up: the first consumer (group 0) stages K-steps 0..3 of tile 0 itself
+  // ---- start-up: the first consumer (group 0) issues half-stages 0..4 of tile 0 itself; 0..2 must have landed when sub-slot 0 opens
   if (group == 0) {
     int m0, n0; tile_origin(0, m0, n0);
     init_acc(n0);
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    loader_consts();
   }
 #pragma unroll
-  for (int k = 0; k < LA; ++k) { if (group == 0) issue(ia_tile, ib_tile, it, ibuf); advance_issue(); }
-  if (group == 0) pp_wait_stages<LPS>(LA - 2);    // stages 0 and 1 landed (published by the barrier that opens slot 0)
+  for (int k = 0; k < HLA; ++k) { if (group == 0) issue_half(ia_tile, ib_tile, it, ih, ibuf); advance_issue(); }
+  if (group == 0) pp_wait_halves<HP>(2);
 
+#if defined(PP_ABL_NOMFMA)
+#define PP_MFMA(d, a, b) asm volatile("" :: "v"(a), "v"(b))
+#else
+#define PP_MFMA(d, a, b) d = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a, b, d, 0, 0, 0)
+#endif
   for (int ph = 0; ph < Q; ++ph) {
     if ((ph & 1) == group) {
       // ================= consumer of tile ph
-      auto slot = [&](int t, auto parity) {
-        constexpr int P = decltype(parity)::value;
-        if (t != 0) PP_BARRIER();                  // (slot 0's barrier and fragment reads sit in front of the loop)
+      // sub(t, kk, P): P = weight-fragment set in use (alternates every sub-slot)
+      auto sub = [&](int t, auto kkc, auto parity) {
+        constexpr int kk = decltype(kkc)::value, P = decltype(parity)::value;
+        if (!(t == 0 && kk == 0)) PP_BARRIER();   // (the first sub-slot's barrier and fragment reads sit in front of the loop)
         const int nxt = rbuf + 1 == NB ? 0 : rbuf + 1;
+        const bool more = kk == 0 || t + 1 < NK;  // is there a next sub-step in this tile?
+        const int nbuf = kk == 0 ? rbuf : nxt;    // ... it lives in the same stage (k-half 1) or in the next one (k-half 0)
 #pragma unroll
         for (int i = 0; i < MT / 2; ++i)
 #pragma unroll
-          for (int j = 0; j < NTW; ++j) acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(fb[P][j], fa[i], acc[i][j], 0, 0, 0);
-        if (t + 1 < NK) { load_fb(std::integral_constant<int, P ^ 1>{}, nxt); load_fa(std::integral_constant<int, 0>{}, nxt); }
+          for (int j = 0; j < NTW; ++j) PP_MFMA(acc[i][j], fb[P][j], fa[i]);
+        if (more) { load_fb(std::integral_constant<int, P ^ 1>{}, nbuf, kk ^ 1); load_fa(std::integral_constant<int, 0>{}, nbuf, kk ^ 1); }
 #pragma unroll
         for (int i = MT / 2; i < MT; ++i)
 #pragma unroll
-          for (int j = 0; j < NTW; ++j) acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(fb[P][j], fa[i], acc[i][j], 0, 0, 0);
-        if (t + 1 < NK) load_fa(std::integral_constant<int, 1>{}, nxt);
-        rbuf = nxt;
+          for (int j = 0; j < NTW; ++j) PP_MFMA(acc[i][j], fb[P][j], fa[i]);
+        if (more) load_fa(std::integral_constant<int, 1>{}, nbuf, kk ^ 1);
+        if (kk == 1) rbuf = nxt;
         advance_issue();                           // (cursor only: the loader issues)
-        // Every fragment read of stage t+1 is consumed by the MFMAs of slot t+1, i.e. retired before this wave reaches the barrier that lets
-        // the loader refill that buffer (slot t+2 at the earliest).  The stages this group issued while it was loader (0 .. LA-1 of this tile):
-        // stage t+2 is fetched in the next slot, so stages t+3 .. LA-1 may still be in flight at the end of slot t.
-        if (t < LA - 3) pp_wait_stages<LPS>(LA - 3 - t); else wait_vmcnt<0>();
+        // kk == 0: the reads just issued are the LAST ones of this stage, whose buffer the loader refills right after the next barrier
+        if (kk == 0) asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+        // half-stages this group issued while it was loader: U'+3 lands by the end of its first sub-slot, U'+4 by the end of the second
+        if (t == 0 && kk == 0) wait_vmcnt<HP>(); else wait_vmcnt<0>();
       };
-      // first K-step of the tile: nothing was prefetched across the role change (defined HERE, in front of the loop, so that the fragment
-      // registers are provably dead throughout the loader role)
+      consumer_consts();
       PP_BARRIER();
-      load_fb(std::integral_constant<int, 0>{}, rbuf);
-      load_fa(std::integral_constant<int, 0>{}, rbuf);
-      load_fa(std::integral_constant<int, 1>{}, rbuf);
-      for (int t = 0; t < NK; t += 2) {
-        slot(t, std::integral_constant<int, 0>{});
-        slot(t + 1, std::integral_constant<int, 1>{});
+      load_fb(std::integral_constant<int, 0>{}, rbuf, 0);
+      load_fa(std::integral_constant<int, 0>{}, rbuf, 0);
+      load_fa(std::integral_constant<int, 1>{}, rbuf, 0);
+      for (int t = 0; t < NK; ++t) {
+        sub(t, std::integral_constant<int, 0>{}, std::integral_constant<int, 0>{});
+        sub(t, std::integral_constant<int, 1>{}, std::integral_constant<int, 1>{});
       }
     } else {
       // ================= loader for tile ph's K loop + epilogue of this group's previous tile (ph-1) + first stages of its next tile (ph+1)
       const bool has_prev = ph >= 1;
+      loader_consts();
       int em0 = 0, en0 = 0;
       if (has_prev) tile_origin(ph - 1, em0, en0);
       const int um0 = em0 + wr * (MT * 16), un0 = en0 + wc * (NTW * 16);
       const u32x4 no16 = {0, 0, 0, 0}; const float4 no4 = make_float4(0.f, 0.f, 0.f, 0.f);
-      // end of a loader slot: issue the stage LA K-steps ahead of the consumer, then make sure that every stage the consumer fetches in the NEXT
-      // slot has landed: in steady state the two youngest stages (this slot's and the previous one's) may stay in flight -- this slot's stores
-      // are older than its DMA pieces, so they never count among the youngest.  When the stage sequence has run out, fewer may stay.
-      int since_issue = 0;                         // slots since this wave last issued a stage (0 = this slot)
-      auto loader_tail = [&]() {
-        if (iq < Q) { issue(ia_tile, ib_tile, it, ibuf); since_issue = 0; } else ++since_issue;
+      // end of a loader sub-slot: issue the half-stage HLA sub-steps ahead of the consumer, then wait until at most the two youngest half-stages
+      // are in flight (this sub-slot's stores are older than its DMA pieces, so they never count among the youngest).  When the sequence has
+      // run out, fewer may stay.
+      int since_issue = 0;
+      auto loader_tail = [&](int u) {
+        if (iq < Q) { issue_half(ia_tile, ib_tile, it, ih, ibuf); since_issue = 0; } else ++since_issue;
         advance_issue();
-        pp_wait_stages<LPS>(LA - 2 - since_issue);      // steady state: stages G+3 .. G+LA stay in flight, G+2 (fetched next slot) has landed
+        if (u & 1) rbuf = rbuf + 1 == NB ? 0 : rbuf + 1;      // the consumer's stage cursor advances in BOTH groups
+        pp_wait_halves<HP>(2 - since_issue);
       };
-      auto cslot = [&](auto sc) {                  // slots 0..15: CPS epilogue chunks each
+      auto cslot = [&](auto sc) {                  // sub-slots 0..15: CPS epilogue chunks each
         constexpr int sidx = decltype(sc)::value;
         PP_BARRIER();
         if (has_prev) {
@@ -856,12 +909,12 @@ __global__ void __launch_bounds__(512, 2) k_gemm_nt_pp(const GemmArgs p, int g8)
           int m0, n0; tile_origin(ph + 1 < Q ? ph + 1 : Q - 1, m0, n0);
           init_acc(n0);
         }
-        loader_tail();
+        loader_tail(sidx);
       };
       pp_unroll(cslot, std::make_integer_sequence<int, CSLOTS>{});
-      for (int t = CSLOTS; t < NK; ++t) {
+      for (int u = CSLOTS; u < NU; ++u) {
         PP_BARRIER();
-        loader_tail();
+        loader_tail(u);
       }
     }
   }
@@ -877,7 +930,7 @@ __global__ void __launch_bounds__(512, 2) k_gemm_nt_pp(const GemmArgs p, int g8)
 static int g_pp_ring = 6;            // tuning hook (oneprot_gemm_force_shape(32 + 64 * ring))
 template <int EPI, bool GRAD, int NB>
 static int launch_pp3(GemmArgs a, hipStream_t s) {
-  constexpr int LDS = NB * (256 + 128) * 64;
+  constexpr int LDS = 3 * (256 + 128) * 128;       // three 48 KB stage buffers (NB is a spare template slot for A/B variants)
   static bool configured = false;
   static int n_cu = 0;
   if (!configured) {
@@ -898,11 +951,7 @@ static int launch_pp3(GemmArgs a, hipStream_t s) {
 }
 template <int EPI, bool GRAD>
 static int launch_pp2(GemmArgs a, hipStream_t s) {
-  switch (g_pp_ring) {
-    case 4: return launch_pp3<EPI, GRAD, 4>(a, s);
-    case 5: return launch_pp3<EPI, GRAD, 5>(a, s);
-    default: return launch_pp3<EPI, GRAD, 6>(a, s);
-  }
+  return launch_pp3<EPI, GRAD, 3>(a, s);
 }
 template <int EPI>
 static int launch_pp(GemmArgs a, hipStream_t s) {
@@ -915,7 +964,7 @@ static int launch_pp(GemmArgs a, hipStream_t s) {
 template <int EPI>
 static bool pp_eligible(const GemmArgs& a) {
   if (EPI != ONEPROT_EPI_BF16 && EPI != ONEPROT_EPI_F32 && EPI != ONEPROT_EPI_BIAS_GELU) return false;
-  if (a.M % 256 || a.N % 128 || a.K % 64 || a.K < 512) return false;
+  if (a.M % 256 || a.N % 128 || a.K % 64 || a.K < 512 || a.lda % 64) return false;      // (lda: odd LDS-DMA pieces address their rows as even ^ 64 bytes)
   if ((size_t)256 * a.lda * 2 >= (1ull << 31) || (size_t)128 * a.ldb * 2 >= (1ull << 31)) return false;
   return true;
 }
@@ -926,15 +975,18 @@ extern "C" void oneprot_gemm_force_shape(int shape) { g_force_shape = shape; }
 // shapes: 0 = 128x128 (BK32, 3 stages, pipelined fragments, 48 KB LDS -> 3 blocks/CU)     1 = 256x128 (BK32, 3 stages, 72 KB -> 2 blocks/CU)
 //         2 = 256x256 (BK32, 4 stages, pipelined fragments, 128 KB)   3 = 128x128 BK64 2 stages (first version; still the best for long K)
 //         4 = 256x256 BK64 2 stages, pipelined fragments               5 = 256x256 BK32 4 stages, plain loop
+//         16 + s = shape s with the direct-store epilogue (17, 19, 20);  32 = persistent ping-pong form (opt-in: see k_gemm_nt_pp)
 // Heuristic from in-process A/B on the training shapes (tools/gemm_ab.py; all shapes lie within ~10 % of each other, vendor hipBLASLt
-// runs the same plain shapes at 650-1030 TFLOP/s): long K -> 3, wide N with short K -> 4, otherwise 1; small problems -> 0.
+// runs the same plain shapes at 650-1030 TFLOP/s): long K -> 3, wide N with short K -> 4 (20 for the single-output GELU), otherwise 1; small
+// problems -> 0.  The direct-store and ping-pong forms tie with these elsewhere (round-2 A/B: every form is bound by the same L2 -> LDS fill
+// latency), so they are only selected where they measured faster.
 template <int EPI>
 static int launch_gemm(const GemmArgs& a, hipStream_t s) {
   int shape;
   if (g_force_shape >= 0) shape = g_force_shape;
   else if (a.M < 2048) shape = 0;
   else if (a.K >= 1024) shape = 3;
-  else if (a.N >= 2048) shape = 4;
+  else if (a.N >= 2048) shape = (EPI == ONEPROT_EPI_BIAS_GELU && a.out1 == nullptr) ? 20 : 4;      // forward-only GELU (frozen tower): direct-store form, -6 %
   else shape = 1;
   if (shape >= 32 && (shape & 63) == 32) {            // ping-pong form; 32 + 64 * ring selects the ring depth (4..6) for A/B runs
     if (shape >> 6) g_pp_ring = shape >> 6;
@@ -969,7 +1021,7 @@ extern "C" int oneprot_gemm_bf16_nt(const void* A, const void* Bw, int64_t M, in
   GemmArgs a;
   a.A = (const bf16_t*)A; a.B = (const bf16_t*)Bw; a.M = (int)M; a.N = N; a.K = K; a.lda = lda; a.ldb = ldb; a.bias = bias;
   a.out0 = out0; a.out1 = out1; a.out2 = out2; a.aux = aux; a.cos = rope_cos; a.sin = rope_sin; a.q_scale = q_scale; a.L = L; a.H = H; a.hd = hd;
-  a.tiles_m = 0; a.tiles_n = 0;
+  a.tiles_m = 0; a.tiles_n = 0; a.sup_m = g_sup_m; a.sup_n = g_sup_n;
   hipStream_t s = (hipStream_t)stream;
   switch (epilogue) {
     case ONEPROT_EPI_BF16: return launch_gemm<ONEPROT_EPI_BF16>(a, s);

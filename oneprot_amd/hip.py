@@ -47,6 +47,7 @@ _SIGS = {
     "oneprot_lnpool_fwd": (I, [P, P, I, P, P, P, P, P, P, P, P, I, I, I, F, I, P]),
     "oneprot_gemm_bf16_nt": (I, [P, P, L64, I, I, I, I, I, P, P, P, P, P, P, P, F, I, I, I, P]),
     "oneprot_gemm_force_shape": (None, [I]),
+    "oneprot_gemm_tune": (None, [I, I]),
     "oneprot_gemm_bf16_tn_workspace": (SZ, [I, I]),
     "oneprot_gemm_tn_variant": (None, [I]),
     "oneprot_gemm_bf16_tn": (I, [P, P, L64, I, I, I, I, P, P, P, SZ, I, P]),
