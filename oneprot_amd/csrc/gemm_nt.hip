@@ -580,6 +580,179 @@ static int launch_shape(GemmArgs a, hipStream_t s) {
 }
 
 // =====================================================================================================================================
+// Register-staged form (whole 256 x 256 tiles, direct-store epilogue).  Every NT-GEMM form above is bound by the same thing (round-2 probes,
+// DESIGN.md section 6): a K-slice can only be requested once an LDS buffer is free, 160 KB of LDS hold at most two 64 KB slices of a 256 x 256
+// tile, so ONE slice is in flight and a K-step costs max(MFMA time, fill latency + transfer) = ~3200 cycles against 2304 of MFMA work.  Here the
+// slices travel through REGISTERS instead: each wave loads its 8 KB share of a slice with eight plain global_load_dwordx4 (32 VGPRs), keeps TWO
+// slices in flight that way (64 VGPRs: a load now has two K-steps to arrive, 128 KB in flight per CU on top of the 128 KB resident in LDS), and
+// commits a slice to its LDS buffer (ds_write_b128, lane-linear = the same image the LDS-DMA form builds) one K-step before it is consumed.
+// The loads are inline asm with hand-counted vmcnt waits: hipcc's waitcnt pass loses the count of the OTHER register set's loads across the loop
+// back edge and drains the queue (vmcnt 7..0) before every commit, which puts one slice in flight again.  rs_wait<N>() is also what tells
+// the compiler that a register set is (re)defined at that point and not at the load.
+__device__ __forceinline__ void rs_load16(u32x4& d, const unsigned char* sbase, unsigned voff) {
+  asm volatile("global_load_dwordx4 %0, %1, %2" : "=v"(d) : "v"(voff), "s"(sbase) : "memory");
+}
+template <int N> __device__ __forceinline__ void rs_wait(u32x4 (&r)[8]) {
+  asm volatile("s_waitcnt vmcnt(%8)" : "+v"(r[0]), "+v"(r[1]), "+v"(r[2]), "+v"(r[3]), "+v"(r[4]), "+v"(r[5]), "+v"(r[6]), "+v"(r[7]) : "n"(N) : "memory");
+}
+template <int EPI>
+__global__ void __launch_bounds__(512, 2) k_gemm_nt_rs(const GemmArgs p) {
+  constexpr int WM = 2, WN = 4, MT = 8, NTW = 4, BKT = 64, KK = 2;
+  typedef Shape<WM, WN, MT, NTW, BKT, 2, 32> S;        // 256 x 256 tile, 128-byte LDS rows, 64 KB per stage, 2 buffers
+  static_assert(S::A_IPW == 4 && S::B_IPW == 4, "eight 1 KB pieces per wave and stage");
+  constexpr bool PAIR = DirectMap<EPI>::PAIR;
+  extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+  // ---- XCD-aware, L2-blocked tile assignment (as k_gemm_nt)
+  const int bid = blockIdx.x;
+  const int xcd = bid & 7, seq = bid >> 3;
+  const int SUP_M = p.sup_m, SUP_N = p.sup_n;
+  const int pm_total = (p.tiles_m + 7) >> 3;
+  const int per_mgroup = SUP_M * SUP_N * ((p.tiles_n + SUP_N - 1) / SUP_N);
+  const int mg = seq / per_mgroup;
+  int r_ = seq - mg * per_mgroup;
+  const int mb_here = min(SUP_M, pm_total - mg * SUP_M);
+  if (mb_here <= 0) return;
+  const int ng = r_ / (mb_here * SUP_N);
+  r_ -= ng * mb_here * SUP_N;
+  const int nb_here = min(SUP_N, p.tiles_n - ng * SUP_N);
+  if (nb_here <= 0 || r_ >= mb_here * nb_here) return;
+  const int m_in = r_ / nb_here, n_in = r_ - m_in * nb_here;
+  const int tm = (mg * SUP_M + m_in) * 8 + xcd;
+  const int tn = ng * SUP_N + n_in;
+  if (tm >= p.tiles_m) return;
+  const int m0 = tm * S::BM_, n0 = tn * S::BN_;
+  const int tid = threadIdx.x, lane = tid & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int wr = wave / WN, wc = wave % WN;
+  const int nk = p.K / BKT;
+
+  // ---- source offsets.  Piece = 8 rows x 128 B; swizzled source chunk = chunk ^ ((row >> 1) & 7) = (chunk ^ (srow >> 1)) ^ ((piece & 1) << 2)
+  const int srow = lane >> 3, schunk = lane & 7;
+  const unsigned a_rel_e = (unsigned)srow * (unsigned)p.lda * 2u + (unsigned)(schunk ^ (srow >> 1)) * 16u;      // even pieces; odd: ^ 64
+  unsigned b_rel[S::B_IPW];
+#pragma unroll
+  for (int i = 0; i < S::B_IPW; ++i) {
+    const int slot = (wave * S::B_IPW + i) * S::RPI + srow;
+    const int blk = slot / (NTW * 16), in = slot - blk * (NTW * 16);
+    const int grow = blk * (NTW * 16) + direct_nmap<PAIR>(in >> 4, in & 15);
+    b_rel[i] = (unsigned)grow * (unsigned)p.ldb * 2u + (unsigned)swz<BKT>(slot, schunk) * 16u;
+  }
+  const size_t a_piece = (size_t)S::RPI * p.lda * 2;
+  const unsigned char* a_tile = reinterpret_cast<const unsigned char*>(p.A + (size_t)m0 * p.lda) + (size_t)(wave * S::A_IPW) * a_piece;
+  const unsigned char* b_tile = reinterpret_cast<const unsigned char*>(p.B + (size_t)n0 * p.ldb);
+  const int lane16 = lane * 16;
+
+  u32x4 st[2][8];                                   // two K-slices in flight in registers
+  auto gload = [&](int t, auto setc) {
+    constexpr int set = decltype(setc)::value;
+    const unsigned char* ak = a_tile + (size_t)t * (BKT * 2);
+    const unsigned char* bk = b_tile + (size_t)t * (BKT * 2);
+#pragma unroll
+    for (int i = 0; i < S::A_IPW; ++i) st[set][i] = *reinterpret_cast<const u32x4*>(ak + i * a_piece + (a_rel_e ^ ((i & 1) << 6)));
+#pragma unroll
+    for (int i = 0; i < S::B_IPW; ++i) st[set][S::A_IPW + i] = *reinterpret_cast<const u32x4*>(bk + b_rel[i]);
+  };
+  auto commit = [&](int buf, auto setc) {
+    constexpr int set = decltype(setc)::value;
+    unsigned char* sA = smem + buf * S::STAGE + lane16;
+    unsigned char* sB = sA + S::BM_ * S::ROWB;
+#pragma unroll
+    for (int i = 0; i < S::A_IPW; ++i) *reinterpret_cast<u32x4*>(sA + (wave * S::A_IPW + i) * 1024) = st[set][i];
+#pragma unroll
+    for (int i = 0; i < S::B_IPW; ++i) *reinterpret_cast<u32x4*>(sB + (wave * S::B_IPW + i) * 1024) = st[set][S::A_IPW + i];
+  };
+
+  // accumulators start at the bias of their columns
+  f32x4 acc[MT][NTW];
+#pragma unroll
+  for (int j = 0; j < NTW; ++j) {
+    const int gc = n0 + wc * (NTW * 16) + direct_nmap<PAIR>(j, (lane >> 4) * 4);
+    f32x4 bj = {0.f, 0.f, 0.f, 0.f};
+    if (p.bias) { const float4 t = *reinterpret_cast<const float4*>(p.bias + gc); bj = (f32x4){t.x, t.y, t.z, t.w}; }
+#pragma unroll
+    for (int i = 0; i < MT; ++i) acc[i][j] = bj;
+  }
+  const int frow = lane & 15, fq = lane >> 4;
+  const int a_off0 = (wr * (MT * 16) + frow) * S::ROWB + (swz<BKT>(frow, fq) << 4);
+  const int b_off0 = S::BM_ * S::ROWB + (wc * (NTW * 16) + frow) * S::ROWB + (swz<BKT>(frow, fq) << 4);
+
+  // ---- prologue: slices 0 and 1 requested, slice 0 committed, slice 2 requested into the freed registers
+  gload(0, std::integral_constant<int, 0>{});
+  if (nk > 1) gload(1, std::integral_constant<int, 1>{});
+  commit(0, std::integral_constant<int, 0>{});
+  if (nk > 2) gload(2, std::integral_constant<int, 0>{});
+  asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+  asm volatile("s_barrier" ::: "memory");
+
+  // STEADY: slices t+1 and t+3 exist, nothing is conditional -- hipcc's waitcnt pass then counts the eight younger loads of the other register
+  // set exactly (vmcnt(8) before the commit); with the guards inside the loop it merges the paths and drains the queue (vmcnt 7..0), which puts
+  // one slice in flight again.  The guarded form only runs the last K-steps of a tile.
+  auto kstep = [&](int t, auto parity, auto steadyc) {
+    constexpr int P = decltype(parity)::value;      // slice t+1 sits in register set P ^ 1 (slice s uses set s & 1)
+    constexpr bool STEADY = decltype(steadyc)::value;
+    const unsigned char* base = smem + (t & 1) * S::STAGE;
+#pragma unroll
+    for (int kk = 0; kk < KK; ++kk) {
+      const unsigned char* sa = base + (a_off0 ^ (kk << 6));
+      const unsigned char* sb = base + (b_off0 ^ (kk << 6));
+      bf8_t b[NTW];
+#pragma unroll
+      for (int j = 0; j < NTW; ++j) b[j] = *reinterpret_cast<const bf8_t*>(sb + j * (16 * S::ROWB));
+#pragma unroll
+      for (int h = 0; h < 2; ++h) {               // activation fragments in two batches of four (register budget)
+        bf8_t a[MT / 2];
+#pragma unroll
+        for (int i = 0; i < MT / 2; ++i) a[i] = *reinterpret_cast<const bf8_t*>(sa + (h * (MT / 2) + i) * (16 * S::ROWB));
+#pragma unroll
+        for (int i = 0; i < MT / 2; ++i)
+#pragma unroll
+          for (int j = 0; j < NTW; ++j) acc[h * (MT / 2) + i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(b[j], a[i], acc[h * (MT / 2) + i][j], 0, 0, 0);
+      }
+      if (kk == 0) {
+        // slice t+1 (requested two K-steps ago) goes into the buffer that slice t-1 vacated at the last barrier; its registers then take slice t+3
+        if (STEADY || t + 1 < nk) commit((t + 1) & 1, std::integral_constant<int, P ^ 1>{});
+        if (STEADY || t + 3 < nk) gload(t + 3, std::integral_constant<int, P ^ 1>{});
+      }
+    }
+    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+    asm volatile("s_barrier" ::: "memory");
+  };
+  int t = 0;
+  for (; t + 4 < nk; t += 2) {
+    kstep(t, std::integral_constant<int, 0>{}, std::true_type{});
+    kstep(t + 1, std::integral_constant<int, 1>{}, std::true_type{});
+  }
+  for (; t < nk; t += 2) {
+    kstep(t, std::integral_constant<int, 0>{}, std::false_type{});
+    if (t + 1 < nk) kstep(t + 1, std::integral_constant<int, 1>{}, std::false_type{});
+  }
+  gemm_epilogue_direct<EPI, MT, NTW>(p, acc, m0, n0, wr, wc, lane);
+}
+
+template <int EPI>
+static int launch_rs(GemmArgs a, hipStream_t s) {
+  constexpr int LDS = 2 * 512 * 128;
+  static bool configured = false;
+  if (!configured) {
+    if (hipFuncSetAttribute((const void*)k_gemm_nt_rs<EPI>, hipFuncAttributeMaxDynamicSharedMemorySize, LDS) != hipSuccess) return OP_ELAUNCH;
+    configured = true;
+  }
+  a.tiles_m = a.M / 256; a.tiles_n = a.N / 256;
+  a.sup_m = g_sup_m; a.sup_n = g_sup_n;
+  const int pm_total = (a.tiles_m + 7) / 8;
+  const int grid = ((pm_total + a.sup_m - 1) / a.sup_m) * (a.sup_m * a.sup_n * ((a.tiles_n + a.sup_n - 1) / a.sup_n)) * 8;
+  hipLaunchKernelGGL((k_gemm_nt_rs<EPI>), dim3(grid), dim3(512), LDS, s, a);
+  return launch_status();
+}
+template <int EPI>
+static bool rs_eligible(const GemmArgs& a) {
+  if (a.M % 256 || a.N % 256 || a.K % 64 || a.lda % 64) return false;
+  if ((size_t)256 * a.lda * 2 >= (1ull << 31) || (size_t)256 * a.ldb * 2 >= (1ull << 31)) return false;
+  if (EPI == ONEPROT_EPI_QKV_ROPE && a.hd != 32 && a.hd != 64) return false;
+  return true;
+}
+
+// =====================================================================================================================================
 // Ping-pong form: ONE 512-thread work-group per CU, persistent over tiles, made of two 4-wave groups (one wave of each per SIMD) that run in
 // ANTI-PHASE on different 256 x 128 output tiles: while group g issues the MFMAs of its tile's K loop, group g^1 runs the epilogue of the tile
 // it has just finished (GELU / RoPE arithmetic, the fp32 residual read-modify-write, the stores) and then stages the first K-slices of its next
@@ -991,6 +1164,10 @@ static int launch_gemm(const GemmArgs& a, hipStream_t s) {
   if (shape >= 32 && (shape & 63) == 32) {            // ping-pong form; 32 + 64 * ring selects the ring depth (4..6) for A/B runs
     if (shape >> 6) g_pp_ring = shape >> 6;
     shape = 32;
+  }
+  if (shape == 8) {             // register-staged 256 x 256 form (falls back to the direct-store LDS-DMA form)
+    if (rs_eligible<EPI>(a)) return launch_rs<EPI>(a, s);
+    shape = 20;
   }
   if (shape == 32) {            // ping-pong form (falls back to the direct-store 256 x 128 form when the problem is not made of whole tiles)
     if (pp_eligible<EPI>(a)) return launch_pp<EPI>(a, s);

@@ -144,8 +144,8 @@ def _gemm_inputs(M, N, K, seed):
     return A, W, bias
 
 
-@pytest.fixture(params=[-1, 0, 1, 2, 3, 4, 5, 6, 7, 17, 19, 20, 32], ids=["auto", "128x128", "256x128", "256x256", "128x128bk64", "256x256bk64", "256x256nopipe", "4w128x128bk64",
-                                                                          "4w128x128bk32", "direct256x128", "direct128x128bk64", "direct256x256bk64", "pingpong"])
+@pytest.fixture(params=[-1, 0, 1, 2, 3, 4, 5, 6, 7, 8, 17, 19, 20, 32], ids=["auto", "128x128", "256x128", "256x256", "128x128bk64", "256x256bk64", "256x256nopipe", "4w128x128bk64",
+                                                                             "4w128x128bk32", "regstaged256x256", "direct256x128", "direct128x128bk64", "direct256x256bk64", "pingpong"])
 def gemm_shape(request):
     hip.query("oneprot_gemm_force_shape", request.param)
     yield request.param
