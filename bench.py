@@ -348,15 +348,20 @@ def main():
         flops = step_flops(module, subs, None)
         # HBM/fabric bytes per launch of the dominant kernel: PMC passes cannot run inside this process, so the figure measured with
         # rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE (separate passes, gfx950 x2 correction on FETCH_SIZE) is read from profiles/.
-        traffic, traffic_src = None, None
+        # The timed launches are of two kinds -- with the GELU' output (trainable tower: 5 tensor arguments) and without (frozen tower: 4) --
+        # measured separately; `traffic` is their launch-weighted mean.
+        traffic, traffic_src, traffic_alg = None, None, None
         if args.pair == "struct_token" and shapes == [(B * args.seq_len, 2560, 640)]:
-            for name in ("r02_pmc_traffic.json", "r01_pmc_traffic.json"):
-                try:
-                    with open(os.path.join(ROOT, "profiles", name)) as f:
-                        traffic, traffic_src = json.load(f)["traffic_bytes_per_launch"] / 1e9, name
-                    break
-                except Exception:
-                    pass
+            try:
+                with open(os.path.join(ROOT, "profiles", "r02_pmc_traffic.json")) as f:
+                    tj = json.load(f)
+                n2 = sum(1 for _, sc in launches if sc[-1] >= 5)
+                n1 = len(launches) - n2
+                traffic = (n2 * tj["ffn1"]["traffic_bytes_per_launch"] + n1 * tj["ffn1fwd"]["traffic_bytes_per_launch"]) / max(len(launches), 1) / 1e9
+                traffic_alg = (n2 * tj["ffn1"]["algorithmic_bytes_per_launch"] + n1 * tj["ffn1fwd"]["algorithmic_bytes_per_launch"]) / max(len(launches), 1) / 1e9
+                traffic_src = f"r02_pmc_traffic.json; {n2} launches with two bf16 outputs at {tj['ffn1']['traffic_bytes_per_launch'] / 1e9:.2f} GB, {n1} with one at {tj['ffn1fwd']['traffic_bytes_per_launch'] / 1e9:.2f} GB"
+            except Exception:
+                pass
         cfg_tag = {"struct_token": "cfg-2" if world == 1 else "cfg-3-shaped", "text": "cfg-4-shaped", "roundrobin": "cfg-5-shaped"}[args.pair]
         out = {
             "metric": work["metric"], "value": round(value, 2), "unit": "protein-pairs/sec/node",
@@ -369,7 +374,8 @@ def main():
             "step_tflops_per_gpu": round(flops / (ms_step * 1e-3) / 1e12, 1),
             "roofline": {"bound": "mfma", "kernel": "k_gemm_nt<BIAS_GELU> FFN-1 launches " + ", ".join(f"[{m}x{k}]x[{n}x{k}]^T" for m, n, k in shapes),
                          "achieved": round(achieved, 1), "peak": PEAK_BF16_TFLOPS, "unit": "TFLOP/s", "frac": round(achieved / PEAK_BF16_TFLOPS, 4),
-                         "traffic": traffic, "traffic_unit": f"GB/launch (rocprofv3 PMC, profiles/{traffic_src}; algorithmic 1.51 with two bf16 outputs, 0.84 with one)" if traffic else None,
+                         "traffic": round(traffic, 3) if traffic else None,
+                         "traffic_unit": f"GB/launch (rocprofv3 PMC FETCH_SIZE x2 + WRITE_SIZE, profiles/{traffic_src}; algorithmic {traffic_alg:.2f} GB/launch)" if traffic else None,
                          "launches_timed": len(launches), "avg_launch_ms": round(gemm_s / max(len(launches), 1) * 1e3, 4),
                          "flops_per_launch": gemm_flops / max(len(launches), 1)},
         }

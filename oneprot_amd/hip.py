@@ -147,7 +147,8 @@ def call(name, *args):
         e0.record()
         rc = fn(*cargs, stream())
         e1.record()
-        watch[1].append((e0, e1, tuple(a for a in args if isinstance(a, (int, float)))))
+        # scalar arguments + the number of tensor arguments (tells e.g. a GEMM launch with the optional second output from one without)
+        watch[1].append((e0, e1, tuple(a for a in args if isinstance(a, (int, float))) + (sum(isinstance(a, torch.Tensor) for a in args),)))
     else:
         rc = fn(*cargs, stream())
     if rc != 0:

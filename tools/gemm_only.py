@@ -7,7 +7,8 @@ from oneprot_amd import hip
 shape = int(sys.argv[1]); name = sys.argv[2]; iters = int(sys.argv[3]) if len(sys.argv) > 3 else 5
 B, L, H, hd = 256, 512, 20, 32
 d, f, T = 640, 2560, 256 * 512
-cfgs = {"qkv": (3 * d, d, hip.EPI_QKV_ROPE), "out": (d, d, hip.EPI_BIAS_RESID), "ffn1": (f, d, hip.EPI_BIAS_GELU), "ffn2": (d, f, hip.EPI_BIAS_RESID), "plain": (f, d, hip.EPI_BF16),
+cfgs = {"qkv": (3 * d, d, hip.EPI_QKV_ROPE), "out": (d, d, hip.EPI_BIAS_RESID), "ffn1": (f, d, hip.EPI_BIAS_GELU), "ffn1fwd": (f, d, hip.EPI_BIAS_GELU), "ffn2": (d, f, hip.EPI_BIAS_RESID),
+        "plain": (f, d, hip.EPI_BF16),
         "plain640": (d, d, hip.EPI_BF16)}
 N, K, epi = cfgs[name]
 g = torch.Generator(device="cuda").manual_seed(0)
@@ -23,7 +24,7 @@ elif epi == hip.EPI_BIAS_RESID:
     o0 = torch.randn(T, N, device="cuda")
     fn = lambda: hip.call("oneprot_gemm_bf16_nt", A, W, T, N, K, K, K, epi, bias, o0, None, None, o0, None, None, 1.0, 0, 0, 0)
 elif epi == hip.EPI_BIAS_GELU:
-    o0 = torch.empty(T, N, dtype=torch.bfloat16, device="cuda"); o1 = torch.empty_like(o0)
+    o0 = torch.empty(T, N, dtype=torch.bfloat16, device="cuda"); o1 = torch.empty_like(o0) if name == "ffn1" else None      # ffn1fwd: frozen tower, no derivative output
     fn = lambda: hip.call("oneprot_gemm_bf16_nt", A, W, T, N, K, K, K, epi, bias, o0, o1, None, None, None, None, 1.0, 0, 0, 0)
 else:
     o0 = torch.empty(T, N, dtype=torch.bfloat16, device="cuda")
