@@ -174,7 +174,8 @@ def step_flops(module, subs, L_of):
 
 
 def summarise_kernels(prof):
-    """per-kernel-family rates from hip.profile_end() of one step: [(ms, scalar args)] per entry point"""
+    """per-kernel-family rates from hip.profile_end() of one step: [(ms, scalar args + (number of tensor args,))] per entry point"""
+    prof = {k: [(ms, sc[:-1]) for ms, sc in v] for k, v in prof.items()}          # the trailing tensor count is not a scalar argument
     out = []
 
     def add(kernel, items, work, unit, peak):
