@@ -16,3 +16,8 @@ done
 for p in $PIDS; do wait $p || { echo "compile failed"; exit 1; }; done
 hipcc --offload-arch=gfx950 -shared -fPIC -o ../liboneprot_hip.so $OBJS
 echo "built $(cd .. && pwd)/liboneprot_hip.so"
+# RCCL wrappers (include/oneprot_comm.h) in their own library, so that the kernel library carries no RCCL dependency
+if [ ! -f ../liboneprot_comm.so ] || [ comm.cpp -nt ../liboneprot_comm.so ] || [ ../../include/oneprot_comm.h -nt ../liboneprot_comm.so ]; then
+  hipcc -O2 -fPIC -shared -std=c++17 comm.cpp -o ../liboneprot_comm.so -L/opt/rocm/lib -lrccl
+  echo "built $(cd .. && pwd)/liboneprot_comm.so"
+fi

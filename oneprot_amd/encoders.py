@@ -165,6 +165,14 @@ class _AttnPoolFn(torch.autograd.Function):
         return dx, None, dw.view_as(w), db
 
 
+class _IdentityPooling(nn.Identity):
+    """nn.Identity that tolerates the (x, input_mask) call of BaseEncoder.forward"""
+    mode = 3
+
+    def forward(self, x, input_mask=None):
+        return x
+
+
 def _ws(nbytes, dev):
     return torch.empty(max(int(nbytes), 16), dtype=torch.uint8, device=dev)
 
@@ -412,6 +420,41 @@ class _EncodeFn(torch.autograd.Function):
         return (None, None, gflat, None) + tuple(eg) + tuple(hg)
 
 
+class _ProjNormFn(torch.autograd.Function):
+    """proj -> L2-normalise [-> logit scale] of already pooled rows [B, d] on the HIP kernels, differentiable w.r.t. the rows, the head parameters
+    and a learnable logit scale: what BaseEncoder.forward (ref base_encoder.py:190-194) and StructEncoder.forward (ref struct_graph_encoder.py:36-42)
+    apply after pooling / after an opaque encoder."""
+
+    @staticmethod
+    def forward(ctx, enc, pooled, n_extra, *params):
+        if not pooled.is_cuda:
+            raise hip.HipKernelError("OneProt HIP path needs CUDA(ROCm) tensors; there is no CPU fallback")
+        pooled = pooled.contiguous().float()
+        learn = len(enc.norm) > 1 and enc.norm[1].learnable
+        scale_t, dscale_t = enc.norm[1].scale_device() if learn else (None, None)
+        scale = 1.0 if learn else enc.logit_scale_value()
+        need = any(ctx.needs_input_grad)
+        feat, hst = _Head.forward(pooled, enc.proj, scale, need, scale_t)
+        ctx.enc, ctx.hst, ctx.scale, ctx.scale_t, ctx.dscale_t = enc, hst, scale, scale_t, dscale_t
+        ctx.n_extra, ctx.n_params = n_extra, len(params)
+        return feat
+
+    @staticmethod
+    def backward(ctx, dfeat):
+        enc = ctx.enc
+        dfeat = dfeat.contiguous()
+        dpooled, hgrads = _Head.backward(dfeat, enc.proj, ctx.scale, ctx.hst, ctx.scale_t)
+        extra = []
+        if ctx.n_extra:           # learnable logit scale (the only extra parameter of a head-only application)
+            g = torch.zeros(1, device=dfeat.device)
+            hip.call("oneprot_sgemm", dfeat.view(1, -1), ctx.hst["feat"].view(1, -1), g, 1, 1, dfeat.numel(), 0, 0, 1.0, 0)
+            hip.call("oneprot_scale_by_device_scalar", g, 1, ctx.dscale_t)
+            extra.append(g.reshape(()))
+        n_head = ctx.n_params - ctx.n_extra
+        hg = list(hgrads) + [None] * (n_head - len(hgrads))
+        return (None, dpooled, None) + tuple(extra) + tuple(hg)
+
+
 # ------------------------------------------------------------------------------------------------- BaseEncoder
 class BaseEncoder(nn.Module):
     """ref base_encoder.py:129-194 (same members; forward(x, input_mask) applies pool -> proj -> norm to features)."""
@@ -448,7 +491,17 @@ class BaseEncoder(nn.Module):
             return CLSTokenPooling()
         if pooling_type == 'attention1d':
             return Attention1dPooling(hidden_size)
-        raise NotImplementedError(f"pooling_type={pooling_type!r}: the fused encoder supports 'mean' and 'cls'")
+        return _IdentityPooling()               # ref base_encoder.py:187-188: anything else is nn.Identity (StructEncoder passes None)
+
+    def apply_head(self, pooled):
+        """proj -> norm of pooled rows [B, d] on the HIP kernels (autograd-aware)"""
+        extra = [self.norm[1].log_logit_scale] if (len(self.norm) > 1 and self.norm[1].learnable) else []
+        return _ProjNormFn.apply(self, pooled, len(extra), *extra, *list(self.proj.parameters()))
+
+    def forward(self, x, input_mask=None):
+        """ref base_encoder.py:190-194: pooling -> proj -> norm of a hidden state x [B, L, d] (the token encoders override this with the fused
+        ids -> features path)."""
+        return self.apply_head(self.pooling(x, input_mask))
 
     def logit_scale_value(self) -> float:
         return self.norm[1].scale_value() if len(self.norm) > 1 else 1.0
@@ -505,6 +558,29 @@ class StructTokenEncoder(BaseEncoder):
 
     def forward(self, input_ids):
         return self.encode(input_ids)
+
+
+class StructEncoder(BaseEncoder):
+    """ref struct_graph_encoder.py:5-42 -- the pocket / struct_graph modality of cfg-5 (configs/model/components/{pocket,struct_graph}.yaml).
+    `encoder` is an OPAQUE torch module (the reference plugs in `dig.threedgraph.method.ProNet`, an un-vendored third-party GNN that is not on
+    the contrastive hot path built here): it runs as it is, under torch autograd; what this class owns -- dropout, the projection head, L2
+    normalisation and the logit scale -- runs on the HIP kernels and hands the gradient of the encoder output back to torch."""
+
+    def __init__(self, encoder: torch.nn.Module, output_dim: int, proj_type: str = None, use_logit_scale: bool = False,
+                 learnable_logit_scale: bool = False, pooling_type: str = None, level: str = "backbone", euler_noise: bool = True,
+                 data_augment_eachlayer: bool = True, dropout: float = 0.25):
+        super().__init__(d_model=output_dim, output_dim=output_dim, proj_type=proj_type, use_logit_scale=use_logit_scale,
+                         learnable_logit_scale=learnable_logit_scale, pooling_type=pooling_type)
+        self.encoder = encoder
+        self.level = level
+        self.euler_noise = euler_noise
+        self.data_augment_eachlayer = data_augment_eachlayer
+        self.dropout = nn.Dropout(dropout)
+
+    def forward(self, batch):
+        encoded = self.encoder(batch)
+        encoded = self.dropout(encoded)
+        return self.apply_head(encoded)
 
 
 class TextEncoder(BaseEncoder):

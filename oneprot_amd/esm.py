@@ -162,6 +162,11 @@ class ArenaModule(nn.Module):
         self.lora_A = nn.Parameter(A)
         self.lora_B = nn.Parameter(torch.zeros(n, len(targets), d, r))
         self._lora = dict(r=r, alpha=alpha, scaling=alpha / r, targets=targets, dropout=dropout)
+        if dropout and dropout > 0:
+            # peft applies dropout to the adapter branch's input in train mode (the reference default is lora_dropout 0.1); the merged-weight
+            # form W + (alpha/r) B A used here equals peft's two-branch form only at p = 0.  Say so instead of silently training another model.
+            warnings.warn(f"lora_dropout={dropout} is not applied: the HIP path merges the adapters into the GEMM operand, which is peft's forward at dropout 0 "
+                          "(deviation from the reference's train-mode behaviour; INTEGRATION.md, 'Deviations')", stacklevel=2)
         for p in self.parameters():
             p.requires_grad = False
         self.lora_A.requires_grad = True

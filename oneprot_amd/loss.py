@@ -22,6 +22,28 @@ from . import hip
 
 
 # ------------------------------------------------------------------------------------------------- collectives
+_feature_comm = None        # optional oneprot_amd.comm.RcclComm: the feature exchange then runs through the C-ABI RCCL wrappers instead of torch.distributed
+
+
+def set_feature_comm(comm):
+    """Install (or, with None, remove) a C-ABI RCCL communicator (include/oneprot_comm.h) for gather_features."""
+    global _feature_comm
+    _feature_comm = comm
+
+
+class _PackedAllGatherComm(torch.autograd.Function):
+    """_PackedAllGather on an oneprot_amd.comm.RcclComm (same semantics, no torch.distributed)"""
+
+    @staticmethod
+    def forward(ctx, packed, comm):
+        ctx.comm = comm
+        return comm.all_gather(packed.detach())
+
+    @staticmethod
+    def backward(ctx, grad_out):
+        return ctx.comm.reduce_scatter(grad_out.contiguous()), None
+
+
 class _PackedAllGather(torch.autograd.Function):
     """all_gather of a packed [2, B, D] buffer with gradient (backward = reduce_scatter SUM), i.e. the fused form of
     the reference's two torch.distributed.nn.all_gather calls (ref loss.py:31-33)."""
@@ -58,12 +80,14 @@ def gather_features(modality_features, sequence_features, local_loss=False, gath
     assert has_distributed, 'torch.distributed did not import correctly, please use a PyTorch version with support.'
     assert not use_horovod, "horovod is not supported"
     packed = torch.stack((modality_features, sequence_features))            # [2, B, D]
+    if _feature_comm is not None:
+        assert _feature_comm.nranks == world_size, "communicator size differs from world_size"
     if gather_with_grad:
-        allp = _PackedAllGather.apply(packed, world_size, None)           # [W, 2, B, D]
+        allp = _PackedAllGatherComm.apply(packed, _feature_comm) if _feature_comm is not None else _PackedAllGather.apply(packed, world_size, None)      # [W, 2, B, D]
         all_m = allp[:, 0].reshape(-1, packed.shape[-1])
         all_s = allp[:, 1].reshape(-1, packed.shape[-1])
     else:
-        allp = _all_gather_nograd(packed, world_size)
+        allp = _feature_comm.all_gather(packed.detach()) if _feature_comm is not None else _all_gather_nograd(packed, world_size)
         ms = list(allp[:, 0].unbind(0))
         ss = list(allp[:, 1].unbind(0))
         if not local_loss:

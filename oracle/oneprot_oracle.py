@@ -269,6 +269,13 @@ def encoder_features(kind: str, ids: Tensor, sd: Dict[str, Tensor], cfg: dict, p
     return y
 
 
+def struct_encoder_features(encoded: Tensor, sd: Dict[str, Tensor], proj_type: Optional[str], use_logit_scale: bool) -> Tensor:
+    """StructEncoder.forward after the opaque encoder (ref: struct_graph_encoder.py:36-42; dropout is the identity in eval mode / at p = 0):
+    proj -> L2 normalise -> logit scale.  `encoded` [B, output_dim] is what the opaque module (ProNet in the reference) returned."""
+    y = l2_normalize(projection(encoded, sd, proj_type))
+    return logit_scale(y, sd["norm.1.log_logit_scale"]) if use_logit_scale else y
+
+
 # --------------------------------------------------------------------------------------
 # losses (ref: src/models/components/loss.py)
 # --------------------------------------------------------------------------------------

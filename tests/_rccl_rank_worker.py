@@ -80,6 +80,29 @@ def main():
         a = feats[rank][0].clone().to(dev)
         fr, fl = neighbour_exchange_bidir_with_grad(left, right, a, a)
         assert torch.equal(fr.cpu(), feats[right][0]) and torch.equal(fl.cpu(), feats[left][0])
+    # ---- the same exchange through the C-ABI RCCL wrappers (include/oneprot_comm.h, oneprot_amd/comm.py): own communicator, no torch.distributed
+    from oneprot_amd import comm as C
+    from oneprot_amd import loss as LM
+    box = [C.unique_id() if rank == 0 else None]
+    dist.broadcast_object_list(box, src=0)
+    cm = C.RcclComm(world, rank, box[0])
+    LM.set_feature_comm(cm)
+    m2 = feats[rank][0].clone().to(dev).requires_grad_(True)
+    s2 = feats[rank][1].clone().to(dev).requires_grad_(True)
+    am, as_ = gather_features(m2, s2, local_loss=True, gather_with_grad=True, rank=rank, world_size=world)
+    assert torch.equal(am.detach().cpu(), exp_m) and torch.equal(as_.detach().cpu(), exp_s)
+    ((am * wm.to(dev)).sum() * (rank + 1) + (as_ * ws_.to(dev)).sum() * (rank + 1)).backward()
+    assert torch.allclose(m2.grad.cpu(), tot * wm[rank * B:(rank + 1) * B], rtol=1e-6, atol=1e-6)
+    assert torch.allclose(s2.grad.cpu(), tot * ws_[rank * B:(rank + 1) * B], rtol=1e-6, atol=1e-6)
+    gbuf = grads[rank].clone().to(dev)
+    cm.all_reduce_(gbuf, average=True)
+    hb = torch.arange(16, dtype=torch.float32).to(torch.bfloat16).to(dev) * (rank + 1)
+    cm.all_reduce_(hb)
+    torch.cuda.synchronize()
+    assert torch.allclose(gbuf.cpu(), mean, rtol=1e-6, atol=1e-6)
+    assert torch.equal(hb.float().cpu(), torch.arange(16, dtype=torch.float32) * tot)
+    LM.set_feature_comm(None)
+    cm.destroy()
     dist.barrier()
     dist.destroy_process_group()
     print(f"rccl worker rank {rank}/{world} ok", flush=True)

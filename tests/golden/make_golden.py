@@ -15,6 +15,7 @@ Reference pieces exercised (file:line in /root/reference):
   src/models/components/loss.py:19-311             gather_features/ClipLoss/SigLipLoss
   src/distributed.py:8-38                          _get_first_node
   src/models/components/retrieval_metric.py:76-102 RetrievalMetric.compute (torchmetrics base class: import-time placeholder)
+  src/models/components/struct_graph_encoder.py:5-42 StructEncoder around a stand-in opaque encoder (ProNet is not installed)
 The training-step composition follows src/models/oneprot_module.py:92-107
 (that file itself cannot be imported: pytorch_lightning/torchmetrics absent).
 
@@ -22,7 +23,7 @@ Third-party arithmetic under the reference (HF transformers EsmModel /
 BertModel) is whatever is installed here: transformers 5.15.0, torch 2.10 CPU,
 fp32, attention implementation "eager".
 
-Usage:  python tests/golden/make_golden.py [tag ...]   (writes *.pt / *.json; tags: pooling hd16 hd32 hd24 text text_train multirank distributed retrieval)
+Usage:  python tests/golden/make_golden.py [tag ...]   (writes *.pt / *.json; tags: pooling hd16 hd32 hd24 text text_train multirank distributed retrieval struct_graph)
 """
 import json
 import os
@@ -362,6 +363,34 @@ def gen_distributed(refdist):
         json.dump({"first_node": cases, "env": env_cases}, f, indent=1)
 
 
+def gen_struct_graph():
+    """StructEncoder (ref struct_graph_encoder.py:5-42) around a stand-in opaque encoder (the reference plugs in ProNet, which is not installed):
+    what the class itself contributes -- dropout (eval mode and p = 0 here), projection head, L2 normalisation, logit scale -- and the gradients
+    that flow back into the opaque module."""
+    sys.path.insert(0, REF)
+    from src.models.components.struct_graph_encoder import StructEncoder
+    cases = {}
+    for name, D, proj, scale, learn in (("linear_scaled", 48, "linear", True, False), ("mlp_learnable_scale", 64, "mlp", True, True), ("identity", 32, None, False, False)):
+        torch.manual_seed(71)
+        opaque = torch.nn.Sequential(torch.nn.Linear(12, 40), torch.nn.Tanh(), torch.nn.Linear(40, D))
+        enc = StructEncoder(opaque, output_dim=D, proj_type=proj, use_logit_scale=scale, learnable_logit_scale=learn, dropout=0.25)
+        with torch.no_grad():
+            for n, p in enc.proj.named_parameters():
+                if p.dim() == 1:
+                    p.add_(torch.randn_like(p) * 0.1)
+        enc.eval()                                   # dropout is the identity: deterministic fixture
+        gen = torch.Generator().manual_seed(72)
+        batch = torch.randn(7, 12, generator=gen)
+        tgt = torch.randn(7, D, generator=gen)
+        sd0 = {k: v.detach().clone() for k, v in enc.state_dict().items()}
+        feat = enc(batch)
+        (feat * tgt).sum().backward()
+        cases[name] = dict(D=D, proj_type=proj, use_logit_scale=scale, learnable=learn, batch=batch, tgt=tgt, sd=sd0, features=feat.detach().clone(),
+                           grads={n: p.grad.detach().clone() for n, p in enc.named_parameters() if p.grad is not None})
+        print("struct_graph", name, float(feat.norm(dim=-1).mean()), sorted(cases[name]["grads"])[:3])
+    torch.save(cases, os.path.join(OUT, "struct_graph.pt"))
+
+
 def gen_retrieval():
     """RetrievalMetric.compute (ref src/models/components/retrieval_metric.py:76-102) run on seeded features.  torchmetrics is absent here, so
     the file is imported with an import-time placeholder for the `torchmetrics` names it mentions (a `Metric` base that only implements
@@ -449,6 +478,8 @@ def main():
         gen_distributed(refdist)
     if want("retrieval"):
         gen_retrieval()
+    if want("struct_graph"):
+        gen_struct_graph()
 
 
 if __name__ == "__main__":

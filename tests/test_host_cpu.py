@@ -259,3 +259,15 @@ def test_bench_launches_its_own_ranks(monkeypatch):
     assert cmd[1:3] == ["-m", "torch.distributed.run"] and "--nproc-per-node=4" in cmd and "--nnodes=1" in cmd
     assert cmd[cmd.index("--master-addr") + 1] == "127.0.0.1" and cmd[-6:] == ["--gpus", "4", "--steps", "3", "--warmup", "1"]
     assert seen["env"]["HSA_ENABLE_IPC_MODE_LEGACY"] == "0"
+
+
+def test_comm_library_exports_every_declared_symbol():
+    """include/oneprot_comm.h <-> liboneprot_comm.so <-> oneprot_amd/comm.py (the RCCL wrappers of SURVEY 8b); no collective is run without a GPU."""
+    from oneprot_amd import comm
+    header = open(os.path.join(ROOT, "include", "oneprot_comm.h")).read()
+    declared = sorted(set(re.findall(r"\b(oneprot_comm_\w+)\s*\(", header)))
+    assert declared == comm.exported_symbols()
+    out = subprocess.run(["nm", "-D", "--defined-only", comm.LIB_PATH], capture_output=True, text=True, check=True).stdout
+    exported = sorted(l.split()[-1] for l in out.splitlines() if " T " in l and "oneprot_comm_" in l)
+    assert exported == declared
+    comm.lib()          # loads and binds every symbol

@@ -219,3 +219,13 @@ def test_retrieval_metrics_vs_reference(golden_dir):
         assert set(got) == set(c["expected"]), name
         for k, v in c["expected"].items():
             assert got[k] == v, (name, k, got[k], v)
+
+
+def test_struct_encoder_head_vs_reference(golden_dir):
+    """O.struct_encoder_features vs the reference's StructEncoder (struct_graph_encoder.py:5-42) around a stand-in opaque encoder."""
+    cases = _load(golden_dir, "struct_graph.pt")
+    for name, c in cases.items():
+        lin0_w, lin0_b, lin2_w, lin2_b = (c["sd"][k] for k in ("encoder.0.weight", "encoder.0.bias", "encoder.2.weight", "encoder.2.bias"))
+        encoded = torch.tanh(c["batch"] @ lin0_w.t() + lin0_b) @ lin2_w.t() + lin2_b
+        got = O.struct_encoder_features(encoded, c["sd"], c["proj_type"], c["use_logit_scale"])
+        _close(got, c["features"])

@@ -691,3 +691,40 @@ def test_attention1d_pooling_and_learnable_logit_scale(tmp_path, frozen):
         assert _cos(gq, leaf["transformer.encoder.layer.0.attention.self.value.weight"].grad) > 0.99
         ge = enc.transformer.view("encoder.emb_layer_norm_after.weight", enc.transformer.flat.grad).cpu()
         assert _cos(ge, leaf["transformer.encoder.emb_layer_norm_after.weight"].grad) > 0.99
+
+
+def test_struct_encoder_adapter_vs_reference(golden_dir):
+    """StructEncoder (pocket / struct_graph modality, ref struct_graph_encoder.py:5-42): the opaque encoder runs under torch autograd, the head /
+    normalisation / logit scale on the HIP kernels; features and EVERY gradient (opaque module, head, learnable logit scale) vs the reference's
+    own run (tests/golden/struct_graph.pt), and a CLIP sub-step through OneProtLitModule with the modality named `pocket`."""
+    os.environ.update(RANK="0", WORLD_SIZE="1", ONEPROT_ALLOW_RANDOM_INIT="1")
+    from src.models.components.struct_graph_encoder import StructEncoder
+    cases = torch.load(os.path.join(golden_dir, "struct_graph.pt"), weights_only=False)
+    for name, c in cases.items():
+        D = c["D"]
+        opaque = torch.nn.Sequential(torch.nn.Linear(12, 40), torch.nn.Tanh(), torch.nn.Linear(40, D))
+        enc = StructEncoder(opaque, output_dim=D, proj_type=c["proj_type"], use_logit_scale=c["use_logit_scale"], learnable_logit_scale=c["learnable"], dropout=0.25)
+        enc.load_state_dict(c["sd"], strict=True)
+        enc = enc.to(DEV).eval()
+        feat = enc(c["batch"].to(DEV))
+        (feat * c["tgt"].to(DEV)).sum().backward()
+        assert (feat.detach().cpu() - c["features"]).abs().max() < 1e-4 * max(1.0, float(c["features"].abs().max())), name
+        got = {n: p.grad.detach().cpu() for n, p in enc.named_parameters() if p.grad is not None}
+        assert set(got) == set(c["grads"]), (name, set(got) ^ set(c["grads"]))
+        for k, r in c["grads"].items():
+            assert (got[k] - r).abs().max() < 2e-4 * max(1.0, float(r.abs().max())) + 1e-6, (name, k, float((got[k] - r).abs().max()), float(r.abs().max()))
+    # through the module: sequence <-> pocket sub-step (the 4th modality of cfg-5), head + opaque encoder train, loss finite and decreasing
+    from src.models.components.sequence_encoder import SequenceEncoder
+    from src.models.oneprot_module import OneProtLitModule
+    from oneprot_amd.optim import FusedAdam
+    torch.manual_seed(9)
+    seq = SequenceEncoder("facebook/esm2_t6_8M_UR50D", output_dim=64, pooling_type="mean", proj_type="linear", use_lora=False, frozen=True)
+    pocket = StructEncoder(torch.nn.Sequential(torch.nn.Linear(12, 40), torch.nn.Tanh(), torch.nn.Linear(40, 64)), output_dim=64, proj_type="linear", use_logit_scale=True, dropout=0.0)
+    module = OneProtLitModule(components={"sequence": seq, "pocket": pocket}, optimizer=functools.partial(torch.optim.Adam, lr=1e-2), loss_fn="CLIP",
+                              use_l1_regularization=True).to(DEV)
+    gen = torch.Generator().manual_seed(4)
+    ids = torch.randint(4, 24, (8, 32), generator=gen); ids[:, 0] = 0; ids[:, -1] = 2
+    graph = torch.randn(8, 12, generator=gen)
+    batch = {"pocket": (ids.to(DEV), graph.to(DEV), "pocket", None)}
+    losses = [float(module.training_step(batch, i).detach()) for i in range(6)]
+    assert all(torch.isfinite(torch.tensor(losses))) and losses[-1] < losses[0], losses
