@@ -256,6 +256,47 @@ __device__ __forceinline__ void rope_store_direct(const GemmArgs& p, f32x4 (&acc
   }
 }
 
+// Starting values of the direct-form accumulators: the bias of the lane's four consecutive columns per tile and, for the residual epilogue, the
+// fp32 residual tile itself (acc = resid + bias + sum of products: one rounding order among equals; `out0` may alias the residual because every
+// lane reads exactly the elements it later writes).
+template <int EPI, int MT, int NTW>
+__device__ __forceinline__ void direct_init_acc(const GemmArgs& p, f32x4 (&acc)[MT][NTW], int m0, int n0, int wr, int wc, int lane) {
+  constexpr bool PAIR = DirectMap<EPI>::PAIR;
+  const int c = lane & 15, q = lane >> 4;
+#pragma unroll
+  for (int j = 0; j < NTW; ++j) {
+    const int gc = n0 + wc * (NTW * 16) + direct_nmap<PAIR>(j, q * 4);
+    f32x4 bj = {0.f, 0.f, 0.f, 0.f};
+    if (p.bias) { const float4 t = *reinterpret_cast<const float4*>(p.bias + gc); bj = (f32x4){t.x, t.y, t.z, t.w}; }
+#pragma unroll
+    for (int i = 0; i < MT; ++i) acc[i][j] = bj;
+  }
+}
+// the residual tile of the lane: requested BEFORE the first K-slices are staged, added AFTER their requests have been issued, so that both are in
+// flight together (the compiler waits for ordinary loads where their results are first used)
+template <int EPI, int MT, int NTW>
+__device__ __forceinline__ void direct_resid_load(const GemmArgs& p, float4 (&rs)[MT][NTW], int m0, int n0, int wr, int wc, int lane) {
+  if constexpr (EPI == ONEPROT_EPI_BIAS_RESID) {
+    const int c = lane & 15, q = lane >> 4;
+    const int mrow0 = m0 + wr * (MT * 16) + c, ncol0 = n0 + wc * (NTW * 16);
+#pragma unroll
+    for (int i = 0; i < MT; ++i) {
+      const float* rrow = (const float*)p.aux + (size_t)(mrow0 + i * 16) * p.N + ncol0 + q * 4;
+#pragma unroll
+      for (int j = 0; j < NTW; ++j) rs[i][j] = *reinterpret_cast<const float4*>(rrow + j * 16);
+    }
+  }
+}
+template <int EPI, int MT, int NTW>
+__device__ __forceinline__ void direct_resid_add(f32x4 (&acc)[MT][NTW], const float4 (&rs)[MT][NTW]) {
+  if constexpr (EPI == ONEPROT_EPI_BIAS_RESID) {
+#pragma unroll
+    for (int i = 0; i < MT; ++i)
+#pragma unroll
+      for (int j = 0; j < NTW; ++j) { acc[i][j][0] += rs[i][j].x; acc[i][j][1] += rs[i][j].y; acc[i][j][2] += rs[i][j].z; acc[i][j][3] += rs[i][j].w; }
+  }
+}
+
 template <int EPI, int MT, int NTW>
 __device__ __forceinline__ void gemm_epilogue_direct(const GemmArgs& p, f32x4 (&acc)[MT][NTW], int m0, int n0, int wr, int wc, int lane) {
   const int c = lane & 15, q = lane >> 4;
@@ -298,15 +339,11 @@ __device__ __forceinline__ void gemm_epilogue_direct(const GemmArgs& p, f32x4 (&
 #pragma unroll
     for (int i = 0; i < MT; ++i) {
       const size_t rowoff = (size_t)(mrow0 + i * 16) * p.N + ncol0 + q * 4;
-      float4 rs[NTW];
-      if (EPI == ONEPROT_EPI_BIAS_RESID) {
-#pragma unroll
-        for (int j = 0; j < NTW; ++j) rs[j] = *reinterpret_cast<const float4*>((const float*)p.aux + rowoff + j * 16);
-      }
+      // (BIAS_RESID: the residual tile was added to the accumulators' starting values by direct_init_acc -- its read overlaps the first K-slices'
+      // flight instead of sitting, latency exposed, in front of the stores)
 #pragma unroll
       for (int j = 0; j < NTW; ++j) {
         float4 v = make_float4(acc[i][j][0], acc[i][j][1], acc[i][j][2], acc[i][j][3]);
-        if (EPI == ONEPROT_EPI_BIAS_RESID) { v.x += rs[j].x; v.y += rs[j].y; v.z += rs[j].z; v.w += rs[j].w; }
         *reinterpret_cast<float4*>((float*)p.out0 + rowoff + j * 16) = v;
         if (EPI == ONEPROT_EPI_BIAS_RESID && p.out1) {
           u32x2 w; w.x = pack2bf(v.x, v.y); w.y = pack2bf(v.z, v.w);
@@ -420,15 +457,24 @@ __global__ void __launch_bounds__(WM * WN * 64, MINW) k_gemm_nt(const GemmArgs p
 
   // accumulators start at the bias of their column (C layout: column = lane & 15 within each 16-wide tile): the epilogues then have no bias
   // add and, for QKV/RoPE, the rotation partner read back from the staging tile already carries its own bias
+  // residual tile of the lane: held in registers across the prologue when the accumulator leaves room for it (<= 16 tiles), else added up front
+  constexpr bool RESID_ACC = DIRECT && EPI == ONEPROT_EPI_BIAS_RESID, RESID_DEFER = RESID_ACC && MT * NTW <= 16;
+  float4 resid[RESID_DEFER ? MT : 1][RESID_DEFER ? NTW : 1];
+  if constexpr (RESID_DEFER) direct_resid_load<EPI, MT, NTW>(p, resid, m0, n0, wr, wc, lane);
   f32x4 acc[MT][NTW];
-  if constexpr (DIRECT) {          // lane (c, q) holds 4 consecutive columns of its token row in every tile: the bias is a float4 per tile
+  if constexpr (DIRECT) {          // lane (c, q) holds 4 consecutive columns of its token row in every tile: bias (and residual) are float4 per tile
+    direct_init_acc<EPI, MT, NTW>(p, acc, m0, n0, wr, wc, lane);
+    if constexpr (RESID_ACC && !RESID_DEFER) {   // one tile row at a time
+      const int c = lane & 15, q = lane >> 4;
 #pragma unroll
-    for (int j = 0; j < NTW; ++j) {
-      const int gc = n0 + wc * (NTW * 16) + direct_nmap<DirectMap<EPI>::PAIR>(j, (lane >> 4) * 4);
-      f32x4 bj = {0.f, 0.f, 0.f, 0.f};
-      if (p.bias) { const float4 t = *reinterpret_cast<const float4*>(p.bias + gc); bj = (f32x4){t.x, t.y, t.z, t.w}; }
+      for (int i = 0; i < MT; ++i) {
+        const float* rrow = (const float*)p.aux + (size_t)(m0 + wr * (MT * 16) + i * 16 + c) * p.N + n0 + wc * (NTW * 16) + q * 4;
 #pragma unroll
-      for (int i = 0; i < MT; ++i) acc[i][j] = bj;
+        for (int j = 0; j < NTW; ++j) {
+          const float4 t = *reinterpret_cast<const float4*>(rrow + j * 16);
+          acc[i][j][0] += t.x; acc[i][j][1] += t.y; acc[i][j][2] += t.z; acc[i][j][3] += t.w;
+        }
+      }
     }
   } else {
 #pragma unroll
@@ -470,6 +516,7 @@ __global__ void __launch_bounds__(WM * WN * 64, MINW) k_gemm_nt(const GemmArgs p
   #pragma unroll
     for (int s = 0; s < NSTAGE; ++s)
       if (s < nk) stage(s, s);
+    if constexpr (RESID_DEFER) direct_resid_add<EPI, MT, NTW>(acc, resid);
     if (nk >= NSTAGE) wait_vmcnt<(NSTAGE - 1) * S::LPS>(); else wait_vmcnt<0>();
     asm volatile("s_barrier" ::: "memory");
     load_frags(0, smem, smem + S::BM_ * S::ROWB, 0);
@@ -512,6 +559,7 @@ __global__ void __launch_bounds__(WM * WN * 64, MINW) k_gemm_nt(const GemmArgs p
   #pragma unroll
     for (int s = 0; s < NSTAGE - 1; ++s)
       if (s < nk) stage(s, s);
+    if constexpr (RESID_DEFER) direct_resid_add<EPI, MT, NTW>(acc, resid);
     int buf = 0, nbuf = NSTAGE - 1;
     for (int t = 0; t < nk; ++t) {
       if (t + NSTAGE - 2 < nk) wait_vmcnt<(NSTAGE - 2) * S::LPS>(); else wait_vmcnt<0>();
@@ -663,15 +711,13 @@ __global__ void __launch_bounds__(512, 2) k_gemm_nt_rs(const GemmArgs p) {
     for (int i = 0; i < S::B_IPW; ++i) *reinterpret_cast<u32x4*>(sB + (wave * S::B_IPW + i) * 1024) = st[set][S::A_IPW + i];
   };
 
-  // accumulators start at the bias of their columns
+  // accumulators start at the bias of their columns (+ the residual tile)
   f32x4 acc[MT][NTW];
-#pragma unroll
-  for (int j = 0; j < NTW; ++j) {
-    const int gc = n0 + wc * (NTW * 16) + direct_nmap<PAIR>(j, (lane >> 4) * 4);
-    f32x4 bj = {0.f, 0.f, 0.f, 0.f};
-    if (p.bias) { const float4 t = *reinterpret_cast<const float4*>(p.bias + gc); bj = (f32x4){t.x, t.y, t.z, t.w}; }
-#pragma unroll
-    for (int i = 0; i < MT; ++i) acc[i][j] = bj;
+  direct_init_acc<EPI, MT, NTW>(p, acc, m0, n0, wr, wc, lane);
+  if constexpr (EPI == ONEPROT_EPI_BIAS_RESID) {      // (no spare registers for a deferred add next to two staging sets: the residual is added up front)
+    float4 resid[MT][NTW];
+    direct_resid_load<EPI, MT, NTW>(p, resid, m0, n0, wr, wc, lane);
+    direct_resid_add<EPI, MT, NTW>(acc, resid);
   }
   const int frow = lane & 15, fq = lane >> 4;
   const int a_off0 = (wr * (MT * 16) + frow) * S::ROWB + (swz<BKT>(frow, fq) << 4);
@@ -1160,6 +1206,7 @@ static int launch_gemm(const GemmArgs& a, hipStream_t s) {
   int shape;
   if (g_force_shape >= 0) shape = g_force_shape;
   else if (a.M < 2048) shape = 0;
+  else if (EPI == ONEPROT_EPI_BIAS_RESID) shape = 19;   // residual folded into the accumulator's initial value, direct fp32 stores: -6 % (out-proj), -2.5 % (FFN-2)
   else if (a.K >= 1024) shape = 3;
   else if (a.N >= 2048) shape = (EPI == ONEPROT_EPI_BIAS_GELU && a.out1 == nullptr) ? 20 : 4;      // forward-only GELU (frozen tower): direct-store form, -6 %
   else shape = 1;
