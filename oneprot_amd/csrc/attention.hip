@@ -491,9 +491,284 @@ __global__ void __launch_bounds__(256, 2) k_attn_bwd_dkv(const bf16_t* __restric
   }
 }
 
+// ---- fused backward for short sequences (L <= 512, hd <= 32): one 1024-thread work-group per (b, h) ---------------------------------
+// Wave w owns keys [32 w, 32 w + 32): K_j / V_j fragments and the dK_j / dV_j accumulators stay in its registers for the whole launch, so S, P,
+// dP and dS of every (query block, key block) tile are formed ONCE (the split kernels above form them twice: 2 x 16 exponentials, 8 extra
+// MFMAs per tile).  All Q and dO rows of the (b, h) slab, and the [-lse | -delta] row constants, are put in LDS once, behind the only barrier
+// of the kernel.  dQ needs the contraction over keys, which sit on the lanes here: the wave transposes its dS tile through a private 2 KB LDS
+// slab (4 ds_write_b64, 4 ds_read_b64_tr_b16), forms dQ_i^T += K_j^T dS^T with two MFMAs and adds the 32 x 32 fp32 result into block i's
+// accumulator in LDS (8 block buffers, rows of 36 floats: conflict-free 16-byte accesses).  The waves walk the query blocks from different
+// starting blocks (blocks 0-7, then 8-15 in the same buffers) and never meet at a barrier, so their MFMA and exponential phases stay
+// interleaved; the read-add-write on a block is serialised by a per-buffer ticket counter in LDS: wave w's visit to block i at its step t has
+// ticket (visits to i by earlier steps) + w / nblk, so every block receives its contributions in one fixed order -- deterministic like the
+// split kernels, no float atomics (ds_add_f32 measured ~6 x slower for the whole launch than this read-add-write).  The first visitor writes
+// instead of adding; the last one keeps the sums in registers, applies the inverse rotary + q-scale and stores the block's dQ rows.
+#define FQB 8                                          // dQ block buffers (query blocks of 32 in flight)
+template <int HD> struct FusedLds {
+  static constexpr int ROWS = 512;
+  static constexpr int TILE = ROWS * 64;                // all Q (or dO) rows, 64-byte swizzled rows (hd = 16 zero-padded)
+  static constexpr int QE = (ROWS + 1) * 16 + 48;       // row constants + FQB ticket counters
+  static constexpr int DQP = 36;                        // dQ row pitch in floats: 16-byte aligned rows, conflict-free 16-byte accesses
+  static constexpr int DQ = FQB * 32 * DQP * 4;
+  static constexpr int SLAB = 32 * 64;
+  static constexpr int TOTAL = 2 * TILE + QE + DQ + 16 * SLAB;
+};
+__device__ __forceinline__ float dot8_bf16(const u32x4 x, const u32x4 y) {
+  return (bflo(x.x) * bflo(y.x) + bfhi(x.x) * bfhi(y.x)) + (bflo(x.y) * bflo(y.y) + bfhi(x.y) * bfhi(y.y)) + (bflo(x.z) * bflo(y.z) + bfhi(x.z) * bfhi(y.z)) +
+         (bflo(x.w) * bflo(y.w) + bfhi(x.w) * bfhi(y.w));
+}
+
+template <int HD>
+__global__ void __launch_bounds__(1024, 1) k_attn_bwd_fused(const bf16_t* __restrict__ q, const bf16_t* __restrict__ k, const bf16_t* __restrict__ v,
+                                                         const float* __restrict__ key_bias, const bf16_t* __restrict__ ctx, const bf16_t* __restrict__ dctx,
+                                                         const float* __restrict__ lse, const float* __restrict__ cosT, const float* __restrict__ sinT,
+                                                         float q_scale, bf16_t* __restrict__ dqkv, int B, int H, int L, int abl) {
+  typedef Cfg<HD> C;
+  typedef FusedLds<HD> F;
+  extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+  unsigned char* sQ = smem;
+  unsigned char* sdO = sQ + F::TILE;
+  u32x4* sQE = reinterpret_cast<u32x4*>(sdO + F::TILE);       // per query: bf16 [-lse split in 3, 1, -delta split in 3, 0]; slot ROWS = zeros
+  volatile int* sTicket = reinterpret_cast<volatile int*>(sdO + F::TILE + (F::ROWS + 1) * 16);
+  float* sdQ = reinterpret_cast<float*>(sdO + F::TILE + F::QE);   // [buffer][32 queries][36] fp32
+  const int lane = threadIdx.x & 63, wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6), h = lane >> 5, r = lane & 31;
+  unsigned char* sT = reinterpret_cast<unsigned char*>(sdQ) + F::DQ + wave * F::SLAB;      // this wave's transpose slab
+  const int dm = H * HD;
+  const int bh = blockIdx.x;
+  const int b = bh / H, head = bh - b * H;
+  const int key0 = wave * 32;
+  const bool active = key0 < L;
+  const int kidx = key0 + r;
+  if (abl >> 8) {                      // experiment: start every other work-group late so that neighbouring CUs are in different phases
+    if (blockIdx.x & 1)
+      for (int z = 0; z < (abl >> 8); ++z) __builtin_amdgcn_s_sleep(127);
+  }
+
+  // the wave's own K_j / V_j rows and key bias are requested first, the (b, h) slab's rows right behind them: one exposed round trip
+  u32x4 kr[2], vr[2];
+#pragma unroll
+  for (int it = 0; it < 2; ++it) {
+    const int idx = lane + 64 * it, row = idx >> 2, ch = idx & 3;
+    const u32x4 z = {0u, 0u, 0u, 0u};
+    kr[it] = z; vr[it] = z;
+    if (key0 + row < L && ch < HD / 8) {
+      kr[it] = *reinterpret_cast<const u32x4*>(k + ((size_t)bh * L + key0 + row) * HD + ch * 8);
+      vr[it] = *reinterpret_cast<const u32x4*>(v + ((size_t)bh * L + key0 + row) * HD + ch * 8);
+    }
+  }
+  const float bias_k = kidx < L ? (key_bias ? key_bias[(size_t)b * L + kidx] : 0.f) : -INFINITY;
+  // ---- the slab's rows: Q, dO images and the row constants (delta = rowsum(dO * O)), two (row, 16-byte chunk) items per thread
+  {
+    const bf16_t* qrow0 = q + (size_t)bh * L * HD;
+    const bf16_t* dorow0 = dctx + (size_t)b * L * dm + head * HD;
+    const bf16_t* orow0 = ctx + (size_t)b * L * dm + head * HD;
+    u32x4 rq[2], rdo[2], ro[2];
+    float rl[2];
+#pragma unroll
+    for (int it = 0; it < 2; ++it) {
+      const int idx = threadIdx.x + 1024 * it, row = idx >> 2, ch = idx & 3;
+      const u32x4 z = {0u, 0u, 0u, 0u};
+      rq[it] = z; rdo[it] = z; ro[it] = z; rl[it] = 0.f;
+      if (row < L) {
+        if (ch < HD / 8) {
+          rq[it] = *reinterpret_cast<const u32x4*>(qrow0 + (size_t)row * HD + ch * 8);
+          rdo[it] = *reinterpret_cast<const u32x4*>(dorow0 + (size_t)row * dm + ch * 8);
+          ro[it] = *reinterpret_cast<const u32x4*>(orow0 + (size_t)row * dm + ch * 8);
+        }
+        if (ch == 0) rl[it] = lse[(size_t)bh * L + row];
+      }
+    }
+    const int nrows = (L + 31) & ~31;
+#pragma unroll
+    for (int it = 0; it < 2; ++it) {
+      const int idx = threadIdx.x + 1024 * it, row = idx >> 2, ch = idx & 3;
+      float part = dot8_bf16(rdo[it], ro[it]);
+      part += __shfl_xor(part, 1, 64);
+      part += __shfl_xor(part, 2, 64);
+      if (row < nrows) {
+        const int off = row * 64 + (swz<32>(row, ch) << 4);
+        *reinterpret_cast<u32x4*>(sQ + off) = rq[it];
+        *reinterpret_cast<u32x4*>(sdO + off) = rdo[it];
+        if (ch == 0) {
+          u32x4 e;
+          unsigned w01, w2;
+          split3_bf16(row < L ? -rl[it] * LOG2E : -1.0e30f, w01, w2);      // log2 units; finite for padding rows (-inf x 0 in the dP pick would be NaN)
+          e.x = w01; e.y = w2 | 0x3F800000u;
+          split3_bf16(row < L ? -part : 0.f, w01, w2);
+          e.z = w01; e.w = w2;
+          sQE[row] = e;
+        }
+      }
+    }
+    const u32x4 z = {0u, 0u, 0u, 0u};
+    if (threadIdx.x == 0) sQE[F::ROWS] = z;
+    if (threadIdx.x < FQB) sTicket[threadIdx.x] = 0;
+  }
+
+  // ---- the wave's own K_j / V_j through its slab: row fragments, and K_j^T fragments for dQ
+  bf8_t kf[C::KSTEPS], vf[C::KSTEPS], ktf[2];
+  {
+#pragma unroll
+    for (int it = 0; it < 2; ++it) {
+      const int idx = lane + 64 * it, row = idx >> 2, ch = idx & 3;
+      *reinterpret_cast<u32x4*>(sT + row * 64 + (swz<32>(row, ch) << 4)) = kr[it];
+    }
+#pragma unroll
+    for (int st = 0; st < C::KSTEPS; ++st) kf[st] = rd_row<HD>(sT, r, st, h);
+    ktf[0] = rd_tr<HD>(sT, 0, 0, 0, lane);
+    ktf[1] = rd_tr<HD>(sT, 0, 1, 0, lane);
+    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+#pragma unroll
+    for (int it = 0; it < 2; ++it) {
+      const int idx = lane + 64 * it, row = idx >> 2, ch = idx & 3;
+      *reinterpret_cast<u32x4*>(sT + row * 64 + (swz<32>(row, ch) << 4)) = vr[it];
+    }
+#pragma unroll
+    for (int st = 0; st < C::KSTEPS; ++st) vf[st] = rd_row<HD>(sT, r, st, h);
+    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+  }
+  u32x4 kS = {0u, 0u, 0u, 0u}, kD = {0u, 0u, 0u, 0u};
+  if (h == 0) { kS.x = 0x3F803F80u; kS.y = 0x3F80u | (pack2bf(bias_k, 0.f) << 16); kD.z = 0x3F803F80u; kD.w = 0x00003F80u; }
+  f32x16 adk = zero16(), adv = zero16();
+
+  // per-lane byte offsets inside a 32-row block of a swizzled 64-byte-row image
+  const int sw = (r >> 2) & 3;
+  int row_off[C::KSTEPS];
+#pragma unroll
+  for (int st = 0; st < C::KSTEPS; ++st) row_off[st] = r * 64 + (((2 * st + h) ^ sw) << 4);
+  int tr_off[2][2];
+  {
+    const int g = lane >> 4, i = lane & 15;
+    const int col = 16 * (g & 1) + 4 * (i & 3);
+#pragma unroll
+    for (int sb = 0; sb < 2; ++sb) {
+      const int r0 = 16 * sb + 4 * h + (i >> 2), r1 = r0 + 8;
+      tr_off[sb][0] = r0 * 64 + (swz<32>(r0, col >> 3) << 4) + (col & 7) * 2;
+      tr_off[sb][1] = r1 * 64 + (swz<32>(r1, col >> 3) << 4) + (col & 7) * 2;
+    }
+  }
+  const int wr_off = r * 64 + 8 * h;        // + ((g ^ sw) << 4) for query group g: row = key, 4 consecutive queries (8 g + 4 h ...)
+  auto tr_frag = [&](const unsigned char* base, int sb) -> bf8_t {
+    const s16x4 a = __builtin_amdgcn_ds_read_tr16_b64_v4i16((__attribute__((address_space(3))) s16x4*)(base + tr_off[sb][0]));
+    const s16x4 c = __builtin_amdgcn_ds_read_tr16_b64_v4i16((__attribute__((address_space(3))) s16x4*)(base + tr_off[sb][1]));
+    s16x8 o;
+    o[0] = a[0]; o[1] = a[1]; o[2] = a[2]; o[3] = a[3]; o[4] = c[0]; o[5] = c[1]; o[6] = c[2]; o[7] = c[3];
+    return __builtin_bit_cast(bf8_t, o);
+  };
+  __syncthreads();
+
+  if (active) {
+    const int nwaves = (L + 31) >> 5;                       // waves that own keys = query blocks = visits per block
+    int tbase = 0;                                          // tickets already used on a buffer by the earlier group of blocks
+    for (int blk0 = 0; blk0 < nwaves; blk0 += FQB) {
+      const int nblk = min(FQB, nwaves - blk0);
+      auto visits = [&](int blk) { return blk < nwaves ? (nwaves - blk + nblk - 1) / nblk : 0; };      // waves that start their walk at block blk
+      int i = wave % nblk;
+      int ticket = wave / nblk;
+      for (int t = 0; t < ((abl & 4) ? 0 : nblk); ++t) {
+        const int qblk = blk0 + i;
+        const unsigned char* tQ = sQ + qblk * 2048;
+        const unsigned char* tdO = sdO + qblk * 2048;
+        const bf8_t qe_row = __builtin_bit_cast(bf8_t, sQE[h ? F::ROWS : qblk * 32 + r]);
+        f32x16 s = MFMA32(qe_row, __builtin_bit_cast(bf8_t, kS), zero16());            // bias[key] - lse[query]
+        f32x16 dp = MFMA32(qe_row, __builtin_bit_cast(bf8_t, kD), zero16());           // -delta[query]
+#pragma unroll
+        for (int st = 0; st < C::KSTEPS; ++st) {
+          s = MFMA32(*reinterpret_cast<const bf8_t*>(tQ + row_off[st]), kf[st], s);          // S[query][key] + bias - lse
+          dp = MFMA32(*reinterpret_cast<const bf8_t*>(tdO + row_off[st]), vf[st], dp);       // dP[query][key] - delta
+        }
+        f32x16 p;
+#pragma unroll
+        for (int e = 0; e < 16; ++e) { p[e] = __builtin_amdgcn_exp2f(s[e]); s[e] = p[e] * dp[e]; }      // P, dS
+        bf8_t dsf[2];
+#pragma unroll
+        for (int sb = 0; sb < 2; ++sb) {
+          const bf8_t pf = pack8(p, sb);
+          dsf[sb] = pack8(s, sb);
+          adv = MFMA32(tr_frag(tdO, sb), pf, adv);           // dV^T += dO^T P
+          adk = MFMA32(tr_frag(tQ, sb), dsf[sb], adk);       // dK^T += Q^T dS
+        }
+        // dS^T through the wave's slab: lane (key, h) holds queries 8 g + 4 h .. + 3 of group g as one 8-byte piece
+        {
+          const u32x4 w0 = __builtin_bit_cast(u32x4, dsf[0]), w1 = __builtin_bit_cast(u32x4, dsf[1]);
+          u32x2 g0 = {w0.x, w0.y}, g1 = {w0.z, w0.w}, g2 = {w1.x, w1.y}, g3 = {w1.z, w1.w};
+          *reinterpret_cast<u32x2*>(sT + wr_off + ((0 ^ sw) << 4)) = g0;
+          *reinterpret_cast<u32x2*>(sT + wr_off + ((1 ^ sw) << 4)) = g1;
+          *reinterpret_cast<u32x2*>(sT + wr_off + ((2 ^ sw) << 4)) = g2;
+          *reinterpret_cast<u32x2*>(sT + wr_off + ((3 ^ sw) << 4)) = g3;
+        }
+        asm volatile("" ::: "memory");
+        f32x16 dq = MFMA32(ktf[0], tr_frag(sT, 0), zero16());       // dQ^T[d][query] = K^T dS^T
+        dq = MFMA32(ktf[1], tr_frag(sT, 1), dq);
+        // this wave's turn on the block's buffer (every wave reaches every ticket it waits for: a visit only waits for visits of earlier or
+        // equal steps, and for the earlier group of blocks to have left the buffer)
+        const int turn = tbase + ticket;
+        if (lane == 0 && !(abl & 1))
+          while (sTicket[i] != turn) __builtin_amdgcn_s_sleep(1);
+        asm volatile("" ::: "memory");
+        float4* drow = reinterpret_cast<float4*>(sdQ + (i * 32 + r) * F::DQP + 4 * h);
+        if (ticket != 0) {
+#pragma unroll
+          for (int g = 0; g < 4; ++g) {
+            const float4 o = drow[2 * g];
+            dq[4 * g] += o.x; dq[4 * g + 1] += o.y; dq[4 * g + 2] += o.z; dq[4 * g + 3] += o.w;
+          }
+        }
+        if (ticket != nwaves - 1) {
+#pragma unroll
+          for (int g = 0; g < 4; ++g) drow[2 * g] = make_float4(dq[4 * g], dq[4 * g + 1], dq[4 * g + 2], dq[4 * g + 3]);
+        }
+        asm volatile("" ::: "memory");
+        if (lane == 0) sTicket[i] = turn + 1;          // LDS operations of a wave complete in order: the sums land before the counter moves
+        if (ticket == nwaves - 1) {                    // last visitor: the block's dQ rows leave from registers
+          const int qidx = qblk * 32 + r;
+          f32x16 a0[1] = {dq};
+          if (qidx < L && !(abl & 16)) unrope_store<HD>(a0, cosT, sinT, qidx, h, q_scale, cosT != nullptr, dqkv + ((size_t)b * L + qidx) * (3 * dm) + head * HD);
+        }
+        i = i + 1 == nblk ? 0 : i + 1;
+        ticket += visits(i);                             // visits to the next block by all earlier steps (+ this wave's rank among the waves of its own step)
+      }
+      tbase += nwaves;
+    }
+  }
+  // dK, dV: inverse rotary in registers, then through the wave's slab ([key][64 B dK | 64 B dV]... two 2 KB images one after the other) so
+  // that every key's row leaves as whole 16-byte chunks, 64 contiguous bytes per 4 lanes
+  if (active && !(abl & 32)) {
+    f32x16 a1[1] = {adk}, a2[1] = {adv};
+#pragma unroll
+    for (int which = 0; which < 2; ++which) {
+      // unrope_store writes 8-byte pieces at dst + dd (dd = 8 g + 4 h): aimed at the lane's slab row it builds the row-major bf16 image
+      bf16_t* img = reinterpret_cast<bf16_t*>(sT + r * 64);
+      if (which == 0) unrope_store<HD>(a1, cosT, sinT, kidx < L ? kidx : 0, h, 0.6931471805599453f, cosT != nullptr, img);      // q is stored x log2(e): dK = ln2 * dS^T q
+      else unrope_store<HD>(a2, cosT, sinT, 0, h, 1.0f, false, img);
+      asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+#pragma unroll
+      for (int it = 0; it < 2; ++it) {
+        const int idx = lane + 64 * it, row = idx >> 2, ch = idx & 3;
+        const u32x4 w = *reinterpret_cast<const u32x4*>(sT + row * 64 + ch * 16);
+        if (key0 + row < L && ch < HD / 8)
+          *reinterpret_cast<u32x4*>(dqkv + ((size_t)b * L + key0 + row) * (3 * dm) + (which + 1) * dm + head * HD + ch * 8) = w;
+      }
+      asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+    }
+  }
+}
+
+static int g_attn_bwd_path = -1;      // -1 automatic, 0 split kernels, 1 fused where eligible (A/B runs and tests)
+extern "C" void oneprot_attn_force_bwd_path(int path) { g_attn_bwd_path = path; }
+
 template <int HD>
 static int launch_bwd(const void* q, const void* k, const void* v, const float* key_bias, const void* ctx, const void* dctx, const float* lse, float* delta,
                       const float* cosT, const float* sinT, float q_scale, void* dqkv, int B, int H, int L, hipStream_t s) {
+  if constexpr (HD <= 32) {
+    if (L <= 512 && g_attn_bwd_path != 0) {
+      static bool attr_set = false;
+      if (!attr_set) { hipFuncSetAttribute((const void*)k_attn_bwd_fused<HD>, hipFuncAttributeMaxDynamicSharedMemorySize, FusedLds<HD>::TOTAL); attr_set = true; }
+      hipLaunchKernelGGL(k_attn_bwd_fused<HD>, dim3(B * H), dim3(1024), FusedLds<HD>::TOTAL, s, (const bf16_t*)q, (const bf16_t*)k, (const bf16_t*)v, key_bias,
+                         (const bf16_t*)ctx, (const bf16_t*)dctx, lse, cosT, sinT, q_scale, (bf16_t*)dqkv, B, H, L, g_attn_bwd_path > 0 ? g_attn_bwd_path >> 4 : 0);      // (bits 4+ of the forced path: ablation mask, A/B runs)
+      return launch_status();
+    }
+  }
   const int nb = (L + 127) / 128;
   const int nbh8 = ((B * H + 7) / 8) * 8;
   const size_t lds_q = (size_t)2 * KC * Cfg<HD>::ROWB + (KC + 1) * 16;

@@ -55,6 +55,7 @@ _SIGS = {
     "oneprot_attn_fwd": (I, [P, P, P, P, P, P, I, I, I, I, P]),
     "oneprot_attn_bwd_workspace": (SZ, [I, I, I]),
     "oneprot_attn_bwd": (I, [P, P, P, P, P, P, P, P, P, F, P, P, I, I, I, I, P]),
+    "oneprot_attn_force_bwd_path": (None, [I]),
     "oneprot_gelu_f32": (I, [P, P, L64, P]),
     "oneprot_gelu_bwd_f32": (I, [P, P, P, L64, P]),
     "oneprot_l2norm_fwd": (I, [P, P, P, I, I, F, P]),

@@ -283,8 +283,16 @@ def _attn_ref(q, k, v, bias):
     return p @ v.float(), torch.logsumexp(s, -1)
 
 
-@pytest.mark.parametrize("B,H,L,hd", [(2, 3, 37, 32), (1, 2, 128, 16), (2, 2, 300, 32), (1, 2, 70, 64), (1, 1, 513, 32)])
-def test_attention_fwd_bwd(B, H, L, hd):
+@pytest.fixture(params=[0, 1], ids=["bwd_split", "bwd_fused"])
+def attn_bwd_path(request):
+    hip.query("oneprot_attn_force_bwd_path", request.param)
+    yield request.param
+    hip.query("oneprot_attn_force_bwd_path", -1)
+
+
+@pytest.mark.parametrize("B,H,L,hd", [(2, 3, 37, 32), (1, 2, 128, 16), (2, 2, 300, 32), (1, 2, 70, 64), (1, 1, 513, 32), (2, 2, 512, 32), (1, 3, 256, 32),
+                                      (2, 1, 257, 16), (1, 2, 31, 16), (3, 2, 480, 32)])
+def test_attention_fwd_bwd(B, H, L, hd, attn_bwd_path):
     g = torch.Generator().manual_seed(8)
     q = bf(torch.randn(B, H, L, hd, generator=g) * 0.7 * hip.LOG2E).to(DEV)          # the kernels take q x log2(e) (scores in log2 units)
     k = bf(torch.randn(B, H, L, hd, generator=g)).to(DEV)
@@ -314,9 +322,10 @@ def test_attention_fwd_bwd(B, H, L, hd):
         assert_close(gt, rf, 5e-2, 5e-2 * rf.abs().max().item(), name)
 
 
-def test_attention_bwd_rope_chain():
+@pytest.mark.parametrize("L,hd", [(45, 32), (300, 32), (77, 16)])
+def test_attention_bwd_rope_chain(L, hd, attn_bwd_path):
     """dqkv must be the gradient w.r.t. the un-rotated, un-scaled projections (transpose of q-scale + RoPE)."""
-    B, H, L, hd = 2, 2, 45, 32
+    B, H = 2, 2
     g = torch.Generator().manual_seed(9)
     ylin = (torch.randn(3, B, H, L, hd, generator=g)).requires_grad_(True)
     cos, sin = O.rope_tables(L, hd)

@@ -1,0 +1,37 @@
+#!/usr/bin/env python3
+"""Runs a handful of attention forward + backward launches at the cfg-2 shape (for rocprofv3 passes) and prints their event-timed durations.
+usage: attn_only.py [iters] [B]"""
+import os, sys
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+import torch
+from oneprot_amd import hip
+iters = int(sys.argv[1]) if len(sys.argv) > 1 else 3
+B = int(sys.argv[2]) if len(sys.argv) > 2 else 256
+L, H, hd = 512, 20, 32
+g = torch.Generator(device="cuda").manual_seed(0)
+mk = lambda: (torch.randn(B, H, L, hd, device="cuda", generator=g) * 0.7).to(torch.bfloat16)
+q, k, v = mk(), mk(), mk()
+lens = torch.randint(L // 2, L + 1, (B,), device="cuda", generator=g)
+key_bias = torch.where(torch.arange(L, device="cuda")[None, :] < lens[:, None], 0.0, float("-inf")).float().contiguous()
+ctx = torch.empty(B * L, H * hd, dtype=torch.bfloat16, device="cuda"); lse = torch.empty(B, H, L, device="cuda")
+dctx = (torch.randn(B * L, H * hd, device="cuda", generator=g) * 0.1).to(torch.bfloat16)
+dqkv = torch.empty(B * L, 3 * H * hd, dtype=torch.bfloat16, device="cuda")
+ws = torch.empty(hip.query("oneprot_attn_bwd_workspace", B, H, L), dtype=torch.uint8, device="cuda")
+cos = torch.rand(L, hd // 2, device="cuda"); sin = torch.rand(L, hd // 2, device="cuda")
+fwd = lambda: hip.call("oneprot_attn_fwd", q, k, v, key_bias, ctx, lse, B, H, L, hd)
+bwd = lambda: hip.call("oneprot_attn_bwd", q, k, v, key_bias, ctx, dctx, lse, cos, sin, hd ** -0.5, dqkv, ws, B, H, L, hd)
+def timeit(fn):
+    fn(); torch.cuda.synchronize()
+    e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    e0.record()
+    for _ in range(iters): fn()
+    e1.record(); torch.cuda.synchronize()
+    return e0.elapsed_time(e1) / iters
+tf, tb = timeit(fwd), timeit(bwd)
+fl = 4.0 * B * H * L * L * hd
+print(f"attn fwd {tf * 1e3:.1f} us ({fl / tf / 1e9:.0f} TFLOP/s)   bwd {tb * 1e3:.1f} us ({2.5 * fl / tb / 1e9:.0f} TFLOP/s)")
+for abl in [int(x) for x in os.environ.get("ATTN_ABL", "").split(",") if x]:
+    hip.query("oneprot_attn_force_bwd_path", 1 + 16 * abl)
+    print(f"fused bwd, ablation mask {abl}: {timeit(bwd) * 1e3:.1f} us")
+hip.query("oneprot_attn_force_bwd_path", 0)
+print(f"split bwd: {timeit(bwd) * 1e3:.1f} us")
