@@ -513,6 +513,7 @@ template <int HD> struct FusedLds {
   static constexpr int SLAB = 32 * 64;
   static constexpr int TOTAL = 2 * TILE + QE + DQ + 16 * SLAB;
 };
+typedef __attribute__((address_space(3))) volatile int lds_vint;      // (a generic volatile pointer polls with flat loads, which also wait for the wave's global stores)
 __device__ __forceinline__ float dot8_bf16(const u32x4 x, const u32x4 y) {
   return (bflo(x.x) * bflo(y.x) + bfhi(x.x) * bfhi(y.x)) + (bflo(x.y) * bflo(y.y) + bfhi(x.y) * bfhi(y.y)) + (bflo(x.z) * bflo(y.z) + bfhi(x.z) * bfhi(y.z)) +
          (bflo(x.w) * bflo(y.w) + bfhi(x.w) * bfhi(y.w));
@@ -529,20 +530,20 @@ __global__ void __launch_bounds__(1024, 1) k_attn_bwd_fused(const bf16_t* __rest
   unsigned char* sQ = smem;
   unsigned char* sdO = sQ + F::TILE;
   u32x4* sQE = reinterpret_cast<u32x4*>(sdO + F::TILE);       // per query: bf16 [-lse split in 3, 1, -delta split in 3, 0]; slot ROWS = zeros
-  volatile int* sTicket = reinterpret_cast<volatile int*>(sdO + F::TILE + (F::ROWS + 1) * 16);
+  lds_vint* sTicket = (lds_vint*)LDS_PTR(sdO + F::TILE + (F::ROWS + 1) * 16);
   float* sdQ = reinterpret_cast<float*>(sdO + F::TILE + F::QE);   // [buffer][32 queries][36] fp32
   const int lane = threadIdx.x & 63, wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6), h = lane >> 5, r = lane & 31;
   unsigned char* sT = reinterpret_cast<unsigned char*>(sdQ) + F::DQ + wave * F::SLAB;      // this wave's transpose slab
   const int dm = H * HD;
-  const int bh = blockIdx.x;
+  // consecutive work-groups go to consecutive XCDs: XCD x takes the x-th eighth of the (b, h) slabs, so the heads of one batch element --
+  // which share the 128-byte lines of dctx / ctx rows and of the dqkv rows they write 64 bytes of -- meet in one L2
+  const int nbh = B * H, per_xcd = (nbh + 7) >> 3;
+  const int bh = (int)(blockIdx.x & 7) * per_xcd + (int)(blockIdx.x >> 3);
+  if (bh >= nbh) return;
   const int b = bh / H, head = bh - b * H;
   const int key0 = wave * 32;
   const bool active = key0 < L;
   const int kidx = key0 + r;
-  if (abl >> 8) {                      // experiment: start every other work-group late so that neighbouring CUs are in different phases
-    if (blockIdx.x & 1)
-      for (int z = 0; z < (abl >> 8); ++z) __builtin_amdgcn_s_sleep(127);
-  }
 
   // the wave's own K_j / V_j rows and key bias are requested first, the (b, h) slab's rows right behind them: one exposed round trip
   u32x4 kr[2], vr[2];
@@ -764,7 +765,7 @@ static int launch_bwd(const void* q, const void* k, const void* v, const float* 
     if (L <= 512 && g_attn_bwd_path != 0) {
       static bool attr_set = false;
       if (!attr_set) { hipFuncSetAttribute((const void*)k_attn_bwd_fused<HD>, hipFuncAttributeMaxDynamicSharedMemorySize, FusedLds<HD>::TOTAL); attr_set = true; }
-      hipLaunchKernelGGL(k_attn_bwd_fused<HD>, dim3(B * H), dim3(1024), FusedLds<HD>::TOTAL, s, (const bf16_t*)q, (const bf16_t*)k, (const bf16_t*)v, key_bias,
+      hipLaunchKernelGGL(k_attn_bwd_fused<HD>, dim3(((B * H + 7) / 8) * 8), dim3(1024), FusedLds<HD>::TOTAL, s, (const bf16_t*)q, (const bf16_t*)k, (const bf16_t*)v, key_bias,
                          (const bf16_t*)ctx, (const bf16_t*)dctx, lse, cosT, sinT, q_scale, (bf16_t*)dqkv, B, H, L, g_attn_bwd_path > 0 ? g_attn_bwd_path >> 4 : 0);      // (bits 4+ of the forced path: ablation mask, A/B runs)
       return launch_status();
     }
