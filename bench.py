@@ -345,6 +345,7 @@ def main():
         gemm_flops = sum(2.0 * sc[0] * sc[1] * sc[2] for _, sc in launches)
         gemm_s = sum(ms for ms, _ in launches) * 1e-3
         achieved = gemm_flops / gemm_s / 1e12 if gemm_s > 0 else 0.0
+        alg_bytes = sum(2.0 * (sc[0] * sc[2] + sc[1] * sc[2] + sc[0] * sc[1] * (2 if sc[-1] >= 5 else 1)) for _, sc in launches)
         shapes = sorted({(sc[0], sc[1], sc[2]) for _, sc in launches})
         flops = step_flops(module, subs, None)
         # HBM/fabric bytes per launch of the dominant kernel: PMC passes cannot run inside this process, so the figure measured with
@@ -378,7 +379,12 @@ def main():
                          "traffic": round(traffic, 3) if traffic else None,
                          "traffic_unit": f"GB/launch (rocprofv3 PMC FETCH_SIZE x2 + WRITE_SIZE, profiles/{traffic_src}; algorithmic {traffic_alg:.2f} GB/launch)" if traffic else None,
                          "launches_timed": len(launches), "avg_launch_ms": round(gemm_s / max(len(launches), 1) * 1e3, 4),
-                         "flops_per_launch": gemm_flops / max(len(launches), 1)},
+                         "flops_per_launch": gemm_flops / max(len(launches), 1),
+                         # the same launches against the HBM roof: A + W read once, one bf16 output (two with the GELU' output) written once.  With two
+                         # outputs the HBM bound (1.51 GB / 8 TB/s = 0.189 ms) is above the MFMA bound (429.5 GFLOP / 2.5 PF = 0.172 ms) of this launch.
+                         "hbm_view": {"achieved": round(alg_bytes / gemm_s / 1e9, 1) if gemm_s > 0 else 0.0, "peak": PEAK_HBM_GBS, "unit": "GB/s",
+                                      "frac": round(alg_bytes / gemm_s / 1e9 / PEAK_HBM_GBS, 4) if gemm_s > 0 else 0.0,
+                                      "algorithmic_GB_per_launch": round(alg_bytes / max(len(launches), 1) / 1e9, 3)}},
         }
         out.update(extras)
         if world == 1 and not args.no_cpu_baseline:

@@ -39,7 +39,15 @@ struct GemmArgs {
   int L, H, hd;
   int tiles_m, tiles_n;
   int sup_m, sup_n;             // L2 super-tile of the per-tile kernels: sup_m row panels x sup_n column tiles per XCD at a time
+  int nt_store;                 // output stores non-temporal (streamed past the L2 instead of displacing the operand panels and W)
 };
+// 16- / 8-byte output stores with the launch's cache policy (wave-uniform branch)
+__device__ __forceinline__ void gst(u32x4* p, u32x4 v, int nt) { if (nt) __builtin_nontemporal_store(v, p); else *p = v; }
+__device__ __forceinline__ void gst(u32x2* p, u32x2 v, int nt) { if (nt) __builtin_nontemporal_store(v, p); else *p = v; }
+__device__ __forceinline__ void gst(float* p, float a, float b, float c, float d, int nt) {
+  const f32x4 v = {a, b, c, d};
+  if (nt) __builtin_nontemporal_store(v, reinterpret_cast<f32x4*>(p)); else *reinterpret_cast<f32x4*>(p) = v;
+}
 
 // WM x WN waves, MT x NTW 16x16 accumulator tiles per wave (wave tile = MT*16 x NTW*16), BKT = K-slice per LDS stage (32 or 64), NSTAGE ring depth,
 // EPH = rows per epilogue staging pass (wave-private LDS tile EPH x 64 fp32)
@@ -66,7 +74,12 @@ template <int BKT> __device__ __forceinline__ int swz(int row, int chunk) {
 template <int N> __device__ __forceinline__ void wait_vmcnt() { asm volatile("s_waitcnt vmcnt(%0)" ::"n"(N) : "memory"); }
 
 static int g_sup_m = 4, g_sup_n = 10;      // L2 super-tile (tuning hook oneprot_gemm_tune)
-extern "C" void oneprot_gemm_tune(int sup_m, int sup_n) { if (sup_m > 0) g_sup_m = sup_m; if (sup_n > 0) g_sup_n = sup_n; }
+static int g_nt_store = 0;                 // output store policy (A/B hook: sup_m = 256 * (1 + policy) + sup_m)
+extern "C" void oneprot_gemm_tune(int sup_m, int sup_n) {
+  if (sup_m >= 256) { g_nt_store = (sup_m >> 8) - 1; sup_m &= 255; }
+  if (sup_m > 0) g_sup_m = sup_m;
+  if (sup_n > 0) g_sup_n = sup_n;
+}
 
 // ---- epilogue: the wave parks EPH rows x 64 columns of its fp32 accumulators in its own padded LDS tile `et` and re-reads them row-wise,
 // 8 columns per lane -> 16-byte coalesced stores in whatever layout the consumer wants.  FULL = the tile lies entirely inside [M, N] (no masks).
@@ -136,38 +149,38 @@ __device__ __forceinline__ void gemm_epilogue(const GemmArgs& p, f32x4 (&acc)[MT
     const size_t o = (size_t)gm * p.N + gn;
     if (EPI == ONEPROT_EPI_BF16) {
       u32x4 w; w.x = pack2bf(v[0], v[1]); w.y = pack2bf(v[2], v[3]); w.z = pack2bf(v[4], v[5]); w.w = pack2bf(v[6], v[7]);
-      *reinterpret_cast<u32x4*>((bf16_t*)p.out0 + o) = w;
+      gst(reinterpret_cast<u32x4*>((bf16_t*)p.out0 + o), w, p.nt_store);
     } else if (EPI == ONEPROT_EPI_F32) {
       float* c = (float*)p.out0 + o;
-      *reinterpret_cast<float4*>(c) = make_float4(v[0], v[1], v[2], v[3]);
-      *reinterpret_cast<float4*>(c + 4) = make_float4(v[4], v[5], v[6], v[7]);
+      gst(c, v[0], v[1], v[2], v[3], p.nt_store);
+      gst(c + 4, v[4], v[5], v[6], v[7], p.nt_store);
     } else if (EPI == ONEPROT_EPI_BIAS_GELU) {
       float dg[8];
 #pragma unroll
       for (int e = 0; e < 8; ++e) gelu_fwd_and_grad(v[e], v[e], dg[e]);
       if (p.out1) {          // gelu'(z), consumed by the GELU_BWD epilogue of the dgrad GEMM
         u32x4 z; z.x = pack2bf(dg[0], dg[1]); z.y = pack2bf(dg[2], dg[3]); z.z = pack2bf(dg[4], dg[5]); z.w = pack2bf(dg[6], dg[7]);
-        *reinterpret_cast<u32x4*>((bf16_t*)p.out1 + o) = z;
+        gst(reinterpret_cast<u32x4*>((bf16_t*)p.out1 + o), z, p.nt_store);
       }
       u32x4 w; w.x = pack2bf(v[0], v[1]); w.y = pack2bf(v[2], v[3]); w.z = pack2bf(v[4], v[5]); w.w = pack2bf(v[6], v[7]);
-      *reinterpret_cast<u32x4*>((bf16_t*)p.out0 + o) = w;
+      gst(reinterpret_cast<u32x4*>((bf16_t*)p.out0 + o), w, p.nt_store);
     } else if (EPI == ONEPROT_EPI_BIAS_RESID) {
       const float* rs = (const float*)p.aux + o;
       const float4 r0 = *reinterpret_cast<const float4*>(rs), r1 = *reinterpret_cast<const float4*>(rs + 4);
       v[0] += r0.x; v[1] += r0.y; v[2] += r0.z; v[3] += r0.w; v[4] += r1.x; v[5] += r1.y; v[6] += r1.z; v[7] += r1.w;
       float* c = (float*)p.out0 + o;
-      *reinterpret_cast<float4*>(c) = make_float4(v[0], v[1], v[2], v[3]);
-      *reinterpret_cast<float4*>(c + 4) = make_float4(v[4], v[5], v[6], v[7]);
+      gst(c, v[0], v[1], v[2], v[3], p.nt_store);
+      gst(c + 4, v[4], v[5], v[6], v[7], p.nt_store);
       if (p.out1) {
         u32x4 w; w.x = pack2bf(v[0], v[1]); w.y = pack2bf(v[2], v[3]); w.z = pack2bf(v[4], v[5]); w.w = pack2bf(v[6], v[7]);
-        *reinterpret_cast<u32x4*>((bf16_t*)p.out1 + o) = w;
+        gst(reinterpret_cast<u32x4*>((bf16_t*)p.out1 + o), w, p.nt_store);
       }
     } else if (EPI == ONEPROT_EPI_GELU_BWD) {
       const u32x4 z = *reinterpret_cast<const u32x4*>((const bf16_t*)p.aux + o);     // aux = gelu'(z) saved by the forward epilogue
       v[0] *= bflo(z.x); v[1] *= bfhi(z.x); v[2] *= bflo(z.y); v[3] *= bfhi(z.y);
       v[4] *= bflo(z.z); v[5] *= bfhi(z.z); v[6] *= bflo(z.w); v[7] *= bfhi(z.w);
       u32x4 w; w.x = pack2bf(v[0], v[1]); w.y = pack2bf(v[2], v[3]); w.z = pack2bf(v[4], v[5]); w.w = pack2bf(v[6], v[7]);
-      *reinterpret_cast<u32x4*>((bf16_t*)p.out0 + o) = w;
+      gst(reinterpret_cast<u32x4*>((bf16_t*)p.out0 + o), w, p.nt_store);
     } else if (EPI == ONEPROT_EPI_QKV_ROPE) {
       if (sec < 2) {
         float pv[8];
@@ -183,7 +196,7 @@ __device__ __forceinline__ void gemm_epilogue(const GemmArgs& p, f32x4 (&acc)[MT
       }
       bf16_t* dst = (bf16_t*)(sec == 0 ? p.out0 : (sec == 1 ? p.out1 : p.out2));
       u32x4 w; w.x = pack2bf(v[0], v[1]); w.y = pack2bf(v[2], v[3]); w.z = pack2bf(v[4], v[5]); w.w = pack2bf(v[6], v[7]);
-      *reinterpret_cast<u32x4*>(dst + rp_off) = w;
+      gst(reinterpret_cast<u32x4*>(dst + rp_off), w, p.nt_store);
     }
   }
     }
@@ -319,7 +332,7 @@ __device__ __forceinline__ void gemm_epilogue_direct(const GemmArgs& p, f32x4 (&
 #pragma unroll
             for (int e = 0; e < 8; ++e) gelu_fwd_and_grad(v[e], v[e], dg[e]);
             u32x4 z; z.x = pack2bf(dg[0], dg[1]); z.y = pack2bf(dg[2], dg[3]); z.z = pack2bf(dg[4], dg[5]); z.w = pack2bf(dg[6], dg[7]);
-            *reinterpret_cast<u32x4*>((bf16_t*)p.out1 + o) = z;
+            gst(reinterpret_cast<u32x4*>((bf16_t*)p.out1 + o), z, p.nt_store);
           } else {
 #pragma unroll
             for (int e = 0; e < 8; ++e) v[e] = gelu_fwd_only(v[e]);
@@ -330,7 +343,7 @@ __device__ __forceinline__ void gemm_epilogue_direct(const GemmArgs& p, f32x4 (&
           v[4] *= bflo(z.z); v[5] *= bfhi(z.z); v[6] *= bflo(z.w); v[7] *= bfhi(z.w);
         }
         u32x4 w; w.x = pack2bf(v[0], v[1]); w.y = pack2bf(v[2], v[3]); w.z = pack2bf(v[4], v[5]); w.w = pack2bf(v[6], v[7]);
-        *reinterpret_cast<u32x4*>((bf16_t*)p.out0 + o) = w;
+        gst(reinterpret_cast<u32x4*>((bf16_t*)p.out0 + o), w, p.nt_store);
       }
     }
   } else if constexpr (EPI == ONEPROT_EPI_QKV_ROPE) {
@@ -344,10 +357,10 @@ __device__ __forceinline__ void gemm_epilogue_direct(const GemmArgs& p, f32x4 (&
 #pragma unroll
       for (int j = 0; j < NTW; ++j) {
         float4 v = make_float4(acc[i][j][0], acc[i][j][1], acc[i][j][2], acc[i][j][3]);
-        *reinterpret_cast<float4*>((float*)p.out0 + rowoff + j * 16) = v;
+        gst((float*)p.out0 + rowoff + j * 16, v.x, v.y, v.z, v.w, p.nt_store);
         if (EPI == ONEPROT_EPI_BIAS_RESID && p.out1) {
           u32x2 w; w.x = pack2bf(v.x, v.y); w.y = pack2bf(v.z, v.w);
-          *reinterpret_cast<u32x2*>((bf16_t*)p.out1 + rowoff + j * 16) = w;
+          gst(reinterpret_cast<u32x2*>((bf16_t*)p.out1 + rowoff + j * 16), w, p.nt_store);
         }
       }
     }
@@ -1247,7 +1260,7 @@ extern "C" int oneprot_gemm_bf16_nt(const void* A, const void* Bw, int64_t M, in
   GemmArgs a;
   a.A = (const bf16_t*)A; a.B = (const bf16_t*)Bw; a.M = (int)M; a.N = N; a.K = K; a.lda = lda; a.ldb = ldb; a.bias = bias;
   a.out0 = out0; a.out1 = out1; a.out2 = out2; a.aux = aux; a.cos = rope_cos; a.sin = rope_sin; a.q_scale = q_scale; a.L = L; a.H = H; a.hd = hd;
-  a.tiles_m = 0; a.tiles_n = 0; a.sup_m = g_sup_m; a.sup_n = g_sup_n;
+  a.tiles_m = 0; a.tiles_n = 0; a.sup_m = g_sup_m; a.sup_n = g_sup_n; a.nt_store = g_nt_store;
   hipStream_t s = (hipStream_t)stream;
   switch (epilogue) {
     case ONEPROT_EPI_BF16: return launch_gemm<ONEPROT_EPI_BF16>(a, s);

@@ -47,11 +47,14 @@ def timeit(fn, iters=5):
     e1.record(); torch.cuda.synchronize()
     return e0.elapsed_time(e1) / iters
 res = {(c, s): [] for c in cases for s in shapes}
+# AB_NT=1: shapes >= 1000 mean "shape - 1000 with non-temporal output stores"
 for r in range(rounds):
     for c, (fn, fl) in cases.items():
         for s in shapes:
-            hip.query("oneprot_gemm_force_shape", s)
+            hip.query("oneprot_gemm_tune", 256 * (2 if s >= 1000 else 1), 0)
+            hip.query("oneprot_gemm_force_shape", s - 1000 if s >= 1000 else s)
             res[(c, s)].append(timeit(fn))
+hip.query("oneprot_gemm_tune", 256, 0)
 hip.query("oneprot_gemm_force_shape", -1)
 print("median ms per launch (TFLOP/s); shapes: 0=128x128 1=256x128 2=256x256bk32x4 3=128x128bk64 4=256x256bk64x2 5=256x256 nopipe")
 for c, (fn, fl) in cases.items():
