@@ -112,7 +112,9 @@ int oneprot_attn_bwd(const void* q, const void* k, const void* v, const float* k
                      const float* rope_cos, const float* rope_sin, float q_scale, void* dqkv, void* workspace, int B, int H, int L, int hd,
                      void* stream);
 /* Test / A-B hook: -1 automatic (default), 0 the two split kernels (dQ, then dK/dV), 1 the fused short-sequence kernel where eligible
-   (L <= 512, hd <= 32: S, P, dP, dS formed once per tile; dQ summed in LDS with ds_add_f32, so its last fp32 bit is not run-to-run stable). */
+   (L <= 512, hd <= 32: S, P, dP, dS formed once per tile; dQ summed in LDS in a fixed ticket order: deterministic like the split kernels).
+   Bits 4 and up of a positive value are an ablation mask for timing runs only (tools/attn_only.py: 1 no ticket wait, 4 no tiles, 16 no dQ
+   stores, 32 no dK/dV stores) -- results are then wrong by construction. */
 void oneprot_attn_force_bwd_path(int path);
 
 /* ---------------- small fp32 feature ops (ref base_encoder.py:6-38, loss.py:103-114, oneprot_module.py:99-101) --- */
