@@ -197,7 +197,7 @@ def summarise_kernels(prof):
     af = [(ms, 4.0 * sc[-4] * sc[-3] * sc[-2] * sc[-2] * sc[-1]) for ms, sc in prof.get("oneprot_attn_fwd", [])]
     add("k_attn_fwd", af, sum(w for _, w in af), "TFLOP/s", PEAK_BF16_TFLOPS)
     ab = [(ms, 8.0 * sc[-4] * sc[-3] * sc[-2] * sc[-2] * sc[-1]) for ms, sc in prof.get("oneprot_attn_bwd", [])]
-    add("k_attn_bwd (dq + dkv kernels; algorithmic 2x forward)", ab, sum(w for _, w in ab), "TFLOP/s", PEAK_BF16_TFLOPS)
+    add("k_attn_bwd (fused short-sequence kernel, or dq + dkv; algorithmic 2x forward)", ab, sum(w for _, w in ab), "TFLOP/s", PEAK_BF16_TFLOPS)
     big = lambda items, idx: [(ms, sc) for ms, sc in items if sc[idx] >= 4096]          # the [T, d] launches, not the [B, d] head ones
     lf = [(ms, 6.0 * sc[-3] * sc[-2]) for ms, sc in big(prof.get("oneprot_layernorm_fwd", []), -3)]
     add("k_layernorm_fwd (fp32 in, bf16 out: 6 B/elem)", lf, sum(w for _, w in lf), "GB/s", PEAK_HBM_GBS)
