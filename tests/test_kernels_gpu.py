@@ -322,6 +322,44 @@ def test_attention_fwd_bwd(B, H, L, hd, attn_bwd_path):
         assert_close(gt, rf, 5e-2, 5e-2 * rf.abs().max().item(), name)
 
 
+@pytest.mark.parametrize("L", [1, 2, 31, 32, 33, 63, 64, 65, 255, 256, 257, 288, 479, 511, 512])
+@pytest.mark.parametrize("hd", [16, 32])
+def test_attention_bwd_fused_equals_split_at_block_edges(L, hd):
+    """The fused short-sequence backward against the split kernels at every block / group boundary of its walk (32-query blocks, 8-block
+    groups, 16 key waves): same inputs, both paths.  The sums run in different orders (dK / dV: each wave starts its walk over the query blocks at a
+    different block; dQ: ticket order over key blocks vs one wave's key loop), so the results agree up to the bf16 rounding of the stored gradient."""
+    B, H = 2, 3
+    g = torch.Generator().manual_seed(1000 + L + hd)
+    q = bf(torch.randn(B, H, L, hd, generator=g) * 0.7 * hip.LOG2E).to(DEV)
+    k = bf(torch.randn(B, H, L, hd, generator=g)).to(DEV)
+    v = bf(torch.randn(B, H, L, hd, generator=g)).to(DEV)
+    bias = torch.zeros(B, L)
+    if L > 2:
+        bias[1, L - L // 4:] = torch.finfo(torch.float32).min
+    bias = bias.to(DEV)
+    ctx = torch.empty(B * L, H * hd, dtype=torch.bfloat16, device=DEV)
+    lse = torch.empty(B, H, L, device=DEV)
+    hip.call("oneprot_attn_fwd", q, k, v, bias, ctx, lse, B, H, L, hd)
+    dctx = bf(torch.randn(B * L, H * hd, generator=g)).to(DEV)
+    cos, sin = O.rope_tables(L, hd)
+    cosd, sind = cos[:, : hd // 2].contiguous().to(DEV), sin[:, : hd // 2].contiguous().to(DEV)
+    outs = []
+    for path in (0, 1):
+        hip.query("oneprot_attn_force_bwd_path", path)
+        try:
+            dqkv = torch.zeros(B * L, 3 * H * hd, dtype=torch.bfloat16, device=DEV)
+            w = ws(hip.query("oneprot_attn_bwd_workspace", B, H, L))
+            hip.call("oneprot_attn_bwd", q, k, v, bias, ctx, dctx, lse, cosd, sind, hd ** -0.5, dqkv, w, B, H, L, hd)
+            outs.append(dqkv.float().view(B * L, 3, H * hd))
+        finally:
+            hip.query("oneprot_attn_force_bwd_path", -1)
+    split, fused = outs
+    assert torch.isfinite(fused).all()
+    for part, name in enumerate(("dQ", "dK", "dV")):
+        assert_close(fused[:, part], split[:, part], 2 ** -7, 2 ** -7 * float(split[:, part].abs().max()), name)
+        assert rel_err(fused[:, part], split[:, part]) < 3e-3, name
+
+
 @pytest.mark.parametrize("L,hd", [(45, 32), (300, 32), (77, 16)])
 def test_attention_bwd_rope_chain(L, hd, attn_bwd_path):
     """dqkv must be the gradient w.r.t. the un-rotated, un-scaled projections (transpose of q-scale + RoPE)."""
