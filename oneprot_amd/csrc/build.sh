@@ -2,12 +2,12 @@
 # Builds liboneprot_hip.so (gfx950) in-tree.  hipcc cross-compiles without a GPU.
 set -e
 cd "$(dirname "$0")"
-SRCS="rowops.hip gemm_nt.hip gemm_tn.hip sgemm.hip attention.hip featops.hip"
+SRCS="rowops.hip gemm_nt.hip gemm_nt8.hip gemm_tn.hip sgemm.hip attention.hip featops.hip"
 OBJS=""
 PIDS=""
 for s in $SRCS; do
   o="${s%.hip}.o"
-  if [ ! -f "$o" ] || [ "$s" -nt "$o" ] || [ common.h -nt "$o" ] || [ ../../include/oneprot_hip.h -nt "$o" ]; then
+  if [ ! -f "$o" ] || [ "$s" -nt "$o" ] || [ common.h -nt "$o" ] || [ gemm_epi.h -nt "$o" ] || [ ../../include/oneprot_hip.h -nt "$o" ]; then
     ( hipcc --offload-arch=gfx950 -O3 -fPIC -std=c++17 -Wno-unused-value -c "$s" -o "$o.tmp" && mv "$o.tmp" "$o" ) &
     PIDS="$PIDS $!"
   fi

@@ -23,31 +23,12 @@
 #include <type_traits>
 #include <utility>
 #include <stdlib.h>
+#include "gemm_epi.h"
 
 #define EPI_LD 68                                   // fp32 row pitch of a wave's epilogue tile (64 columns + pad)
 
 static __device__ __attribute__((aligned(16))) unsigned int g_zero_page[4] = {0, 0, 0, 0};
 
-struct GemmArgs {
-  const bf16_t* A; const bf16_t* B;
-  int M, N, K, lda, ldb;
-  const float* bias;
-  void* out0; void* out1; void* out2;
-  const void* aux;
-  const float* cos; const float* sin;
-  float q_scale;
-  int L, H, hd;
-  int tiles_m, tiles_n;
-  int sup_m, sup_n;             // L2 super-tile of the per-tile kernels: sup_m row panels x sup_n column tiles per XCD at a time
-  int nt_store;                 // output stores non-temporal (streamed past the L2 instead of displacing the operand panels and W)
-};
-// 16- / 8-byte output stores with the launch's cache policy (wave-uniform branch)
-__device__ __forceinline__ void gst(u32x4* p, u32x4 v, int nt) { if (nt) __builtin_nontemporal_store(v, p); else *p = v; }
-__device__ __forceinline__ void gst(u32x2* p, u32x2 v, int nt) { if (nt) __builtin_nontemporal_store(v, p); else *p = v; }
-__device__ __forceinline__ void gst(float* p, float a, float b, float c, float d, int nt) {
-  const f32x4 v = {a, b, c, d};
-  if (nt) __builtin_nontemporal_store(v, reinterpret_cast<f32x4*>(p)); else *reinterpret_cast<f32x4*>(p) = v;
-}
 
 // WM x WN waves, MT x NTW 16x16 accumulator tiles per wave (wave tile = MT*16 x NTW*16), BKT = K-slice per LDS stage (32 or 64), NSTAGE ring depth,
 // EPH = rows per epilogue staging pass (wave-private LDS tile EPH x 64 fp32)
@@ -71,7 +52,6 @@ template <int BKT> __device__ __forceinline__ int swz(int row, int chunk) {
   return BKT == 64 ? (chunk ^ ((row >> 1) & 7)) : (chunk ^ ((0x1320 >> (((row >> 2) & 3) << 2)) & 3));
 }
 
-template <int N> __device__ __forceinline__ void wait_vmcnt() { asm volatile("s_waitcnt vmcnt(%0)" ::"n"(N) : "memory"); }
 
 static int g_sup_m = 4, g_sup_n = 10;      // L2 super-tile (tuning hook oneprot_gemm_tune)
 static int g_nt_store = 0;                 // output store policy (A/B hook: sup_m = 256 * (1 + policy) + sup_m)
@@ -205,167 +185,6 @@ __device__ __forceinline__ void gemm_epilogue(const GemmArgs& p, f32x4 (&acc)[MT
   }
 }
 
-// ---- DIRECT form (full tiles only).  The MFMA is issued with the operand roles swapped -- a = weight fragment, b = activation fragment -- so
-// the accumulator of lane (c = lane & 15, q = lane >> 4) is C[token c][feature slot q*4 + r]: four consecutive slots of ONE token row per
-// register quad.  Which logical column a slot is, is decided when the weight tile is staged: LDS row slot s of the tile receives global weight
-// row nmap(s) (the LDS-DMA source address is per lane, so the permutation costs nothing in the loop and leaves the bank pattern of the fragment
-// reads untouched).  bf16 outputs use the PAIR map (slots of tiles 2p / 2p+1 interleaved in runs of four: a lane owns 8 consecutive columns
-// = one 16-byte store, four lanes cover 64 contiguous bytes of a row); fp32 outputs and QKV/RoPE use the NATURAL map (4 consecutive fp32 = 16 bytes
-// per lane; the RoPE partner column +-hd/2 is the same register of tile j^1 (hd 32) / j^2 (hd 64) of the SAME lane).  No LDS staging of the
-// accumulators, no waits on the LDS queue, no reuse of the operand ring: 1 ds_write_b32 + 1/4 ds_read_b128 per element less than the staged form.
-template <int EPI> struct DirectMap { static constexpr bool PAIR = (EPI == ONEPROT_EPI_BF16 || EPI == ONEPROT_EPI_BIAS_GELU || EPI == ONEPROT_EPI_GELU_BWD); };
-// logical column (within the wave's NTW*16-column block) of slot rho of 16-slot tile j
-template <bool PAIR> __device__ __forceinline__ constexpr int direct_nmap(int j, int rho) {
-  return PAIR ? ((j >> 1) * 32 + (rho >> 2) * 8 + (j & 1) * 4 + (rho & 3)) : (j * 16 + rho);
-}
-
-__device__ __forceinline__ float gelu_fwd_only(float x) {
-  const float t = __builtin_amdgcn_rcpf(fmaf(0.23164189f, fabsf(x), 1.0f));
-  const float e = __builtin_amdgcn_exp2f(x * x * -0.72134752f);
-  float poly = fmaf(0.5307027145f, t, -0.7265760135f);
-  poly = fmaf(poly, t, 0.7107068705f);
-  poly = fmaf(poly, t, -0.142248368f);
-  poly = fmaf(poly, t, 0.127414796f);
-  const float h = poly * t * e;
-  return x * (0.5f + copysignf(0.5f - h, x));
-}
-
-// QKV/RoPE tail of the direct epilogue (natural map: lane owns columns [j*16 + q*4, +4) of tile j).  H*hd is a multiple of 64 = the wave's
-// column block, so the whole wave sits in one section (q / k / v); with HD in {32, 64} a head is 2 or 4 tiles of the block, the position of
-// tile j inside its head and its rotation partner (tile j ^ (HD/32)) are compile-time constants -- the partner value is a register of the SAME lane.
-template <int HD, int MT, int NTW>
-__device__ __forceinline__ void rope_store_direct(const GemmArgs& p, f32x4 (&acc)[MT][NTW], int mrow0, int ncol0, int q) {
-  static_assert((NTW * 16) % HD == 0, "a head must not straddle the wave's column block");
-  constexpr int HALF = HD / 2, JP = HALF / 16;
-  const int dm = p.H * HD;
-  const int sec = __builtin_amdgcn_readfirstlane(ncol0 / dm);
-  const int head0 = (ncol0 - sec * dm) / HD;
-  bf16_t* dst = (bf16_t*)(sec == 0 ? p.out0 : (sec == 1 ? p.out1 : p.out2));
-  const float sc = sec == 0 ? p.q_scale : 1.0f;
-#pragma unroll
-  for (int i = 0; i < MT; ++i) {
-    const int gm = mrow0 + i * 16;
-    const int b = gm / p.L, l = gm - b * p.L;
-    const float* cs_row = p.cos + (size_t)l * HALF + q * 4;
-    const float* sn_row = p.sin + (size_t)l * HALF + q * 4;
-#pragma unroll
-    for (int j = 0; j < NTW; ++j) {
-      const int jt = (j * 16) % HD;                    // column of the tile inside its head (compile-time after unrolling)
-      const bool lo = jt < HALF;
-      const int head = head0 + (j * 16) / HD;
-      float v[4] = {acc[i][j][0], acc[i][j][1], acc[i][j][2], acc[i][j][3]};
-      if (sec < 2) {
-        const f32x4 pv = acc[i][lo ? j + JP : j - JP];
-        const int jj = lo ? jt : jt - HALF;
-        const float4 cs = *reinterpret_cast<const float4*>(cs_row + jj);
-        const float4 sn = *reinterpret_cast<const float4*>(sn_row + jj);
-        const float sp = lo ? -sc : sc;
-        v[0] = (v[0] * sc) * cs.x + (pv[0] * sp) * sn.x; v[1] = (v[1] * sc) * cs.y + (pv[1] * sp) * sn.y;
-        v[2] = (v[2] * sc) * cs.z + (pv[2] * sp) * sn.z; v[3] = (v[3] * sc) * cs.w + (pv[3] * sp) * sn.w;
-      }
-      u32x2 w; w.x = pack2bf(v[0], v[1]); w.y = pack2bf(v[2], v[3]);
-      *reinterpret_cast<u32x2*>(dst + (((size_t)b * p.H + head) * p.L + l) * HD + jt + q * 4) = w;
-    }
-  }
-}
-
-// Starting values of the direct-form accumulators: the bias of the lane's four consecutive columns per tile and, for the residual epilogue, the
-// fp32 residual tile itself (acc = resid + bias + sum of products: one rounding order among equals; `out0` may alias the residual because every
-// lane reads exactly the elements it later writes).
-template <int EPI, int MT, int NTW>
-__device__ __forceinline__ void direct_init_acc(const GemmArgs& p, f32x4 (&acc)[MT][NTW], int m0, int n0, int wr, int wc, int lane) {
-  constexpr bool PAIR = DirectMap<EPI>::PAIR;
-  const int c = lane & 15, q = lane >> 4;
-#pragma unroll
-  for (int j = 0; j < NTW; ++j) {
-    const int gc = n0 + wc * (NTW * 16) + direct_nmap<PAIR>(j, q * 4);
-    f32x4 bj = {0.f, 0.f, 0.f, 0.f};
-    if (p.bias) { const float4 t = *reinterpret_cast<const float4*>(p.bias + gc); bj = (f32x4){t.x, t.y, t.z, t.w}; }
-#pragma unroll
-    for (int i = 0; i < MT; ++i) acc[i][j] = bj;
-  }
-}
-// the residual tile of the lane: requested BEFORE the first K-slices are staged, added AFTER their requests have been issued, so that both are in
-// flight together (the compiler waits for ordinary loads where their results are first used)
-template <int EPI, int MT, int NTW>
-__device__ __forceinline__ void direct_resid_load(const GemmArgs& p, float4 (&rs)[MT][NTW], int m0, int n0, int wr, int wc, int lane) {
-  if constexpr (EPI == ONEPROT_EPI_BIAS_RESID) {
-    const int c = lane & 15, q = lane >> 4;
-    const int mrow0 = m0 + wr * (MT * 16) + c, ncol0 = n0 + wc * (NTW * 16);
-#pragma unroll
-    for (int i = 0; i < MT; ++i) {
-      const float* rrow = (const float*)p.aux + (size_t)(mrow0 + i * 16) * p.N + ncol0 + q * 4;
-#pragma unroll
-      for (int j = 0; j < NTW; ++j) rs[i][j] = *reinterpret_cast<const float4*>(rrow + j * 16);
-    }
-  }
-}
-template <int EPI, int MT, int NTW>
-__device__ __forceinline__ void direct_resid_add(f32x4 (&acc)[MT][NTW], const float4 (&rs)[MT][NTW]) {
-  if constexpr (EPI == ONEPROT_EPI_BIAS_RESID) {
-#pragma unroll
-    for (int i = 0; i < MT; ++i)
-#pragma unroll
-      for (int j = 0; j < NTW; ++j) { acc[i][j][0] += rs[i][j].x; acc[i][j][1] += rs[i][j].y; acc[i][j][2] += rs[i][j].z; acc[i][j][3] += rs[i][j].w; }
-  }
-}
-
-template <int EPI, int MT, int NTW>
-__device__ __forceinline__ void gemm_epilogue_direct(const GemmArgs& p, f32x4 (&acc)[MT][NTW], int m0, int n0, int wr, int wc, int lane) {
-  const int c = lane & 15, q = lane >> 4;
-  const int mrow0 = m0 + wr * (MT * 16) + c;                 // + i*16
-  const int ncol0 = n0 + wc * (NTW * 16);
-  if constexpr (DirectMap<EPI>::PAIR) {
-    const bool with_grad = (EPI == ONEPROT_EPI_BIAS_GELU) && p.out1 != nullptr;      // wave-uniform
-#pragma unroll
-    for (int i = 0; i < MT; ++i) {
-      const size_t rowoff = (size_t)(mrow0 + i * 16) * p.N + ncol0 + q * 8;
-#pragma unroll
-      for (int pp = 0; pp < NTW / 2; ++pp) {
-        const size_t o = rowoff + pp * 32;
-        float v[8];
-#pragma unroll
-        for (int r = 0; r < 4; ++r) { v[r] = acc[i][2 * pp][r]; v[4 + r] = acc[i][2 * pp + 1][r]; }
-        if (EPI == ONEPROT_EPI_BIAS_GELU) {
-          if (with_grad) {
-            float dg[8];
-#pragma unroll
-            for (int e = 0; e < 8; ++e) gelu_fwd_and_grad(v[e], v[e], dg[e]);
-            u32x4 z; z.x = pack2bf(dg[0], dg[1]); z.y = pack2bf(dg[2], dg[3]); z.z = pack2bf(dg[4], dg[5]); z.w = pack2bf(dg[6], dg[7]);
-            gst(reinterpret_cast<u32x4*>((bf16_t*)p.out1 + o), z, p.nt_store);
-          } else {
-#pragma unroll
-            for (int e = 0; e < 8; ++e) v[e] = gelu_fwd_only(v[e]);
-          }
-        } else if (EPI == ONEPROT_EPI_GELU_BWD) {
-          const u32x4 z = *reinterpret_cast<const u32x4*>((const bf16_t*)p.aux + o);
-          v[0] *= bflo(z.x); v[1] *= bfhi(z.x); v[2] *= bflo(z.y); v[3] *= bfhi(z.y);
-          v[4] *= bflo(z.z); v[5] *= bfhi(z.z); v[6] *= bflo(z.w); v[7] *= bfhi(z.w);
-        }
-        u32x4 w; w.x = pack2bf(v[0], v[1]); w.y = pack2bf(v[2], v[3]); w.z = pack2bf(v[4], v[5]); w.w = pack2bf(v[6], v[7]);
-        gst(reinterpret_cast<u32x4*>((bf16_t*)p.out0 + o), w, p.nt_store);
-      }
-    }
-  } else if constexpr (EPI == ONEPROT_EPI_QKV_ROPE) {
-    if (p.hd == 32) rope_store_direct<32, MT, NTW>(p, acc, mrow0, ncol0, q); else rope_store_direct<64, MT, NTW>(p, acc, mrow0, ncol0, q);
-  } else {      // fp32 outputs: ONEPROT_EPI_F32, ONEPROT_EPI_BIAS_RESID (natural map, 16 bytes per lane per tile)
-#pragma unroll
-    for (int i = 0; i < MT; ++i) {
-      const size_t rowoff = (size_t)(mrow0 + i * 16) * p.N + ncol0 + q * 4;
-      // (BIAS_RESID: the residual tile was added to the accumulators' starting values by direct_init_acc -- its read overlaps the first K-slices'
-      // flight instead of sitting, latency exposed, in front of the stores)
-#pragma unroll
-      for (int j = 0; j < NTW; ++j) {
-        float4 v = make_float4(acc[i][j][0], acc[i][j][1], acc[i][j][2], acc[i][j][3]);
-        gst((float*)p.out0 + rowoff + j * 16, v.x, v.y, v.z, v.w, p.nt_store);
-        if (EPI == ONEPROT_EPI_BIAS_RESID && p.out1) {
-          u32x2 w; w.x = pack2bf(v.x, v.y); w.y = pack2bf(v.z, v.w);
-          gst(reinterpret_cast<u32x2*>((bf16_t*)p.out1 + rowoff + j * 16), w, p.nt_store);
-        }
-      }
-    }
-  }
-}
 
 template <int EPI, int WM, int WN, int MT, int NTW, int BKT, int NSTAGE, int EPH, int MINW, bool PIPE, bool FULLT, bool DIRECT = false>
 __global__ void __launch_bounds__(WM * WN * 64, MINW) k_gemm_nt(const GemmArgs p) {
@@ -1217,6 +1036,15 @@ extern "C" void oneprot_gemm_force_shape(int shape) { g_force_shape = shape; }
 template <int EPI>
 static int launch_gemm(const GemmArgs& a, hipStream_t s) {
   int shape;
+  if (g_force_shape < 0) {
+    // Large whole-tile problems (every GEMM of the BASELINE configurations): the persistent 8-phase forms, 256 x 320 tiles where N allows
+    // (d = 320 / 640 / 1280 encoders: N = d, 3d, 4d), else 256 x 256 (BERT-base d = 768; head_dim-64 QKV whose heads straddle 160-column wave
+    // blocks).  Round-3 A/B on the cfg-2 shapes (tools/ab/g8_ab.py): 10-34 % less time than the per-tile kernels on every launch.
+    for (int cfg = 1; cfg >= 0; --cfg) {
+      const int rc = launch_gemm8(EPI, a, cfg, 192, s);
+      if (rc != G8_NOT_ELIGIBLE) return rc;
+    }
+  }
   if (g_force_shape >= 0) shape = g_force_shape;
   else if (a.M < 2048) shape = 0;
   else if (EPI == ONEPROT_EPI_BIAS_RESID) shape = 19;   // residual folded into the accumulator's initial value, direct fp32 stores: -6 % (out-proj), -2.5 % (FFN-2)
@@ -1226,6 +1054,11 @@ static int launch_gemm(const GemmArgs& a, hipStream_t s) {
   if (shape >= 32 && (shape & 63) == 32) {            // ping-pong form; 32 + 64 * ring selects the ring depth (4..6) for A/B runs
     if (shape >> 6) g_pp_ring = shape >> 6;
     shape = 32;
+  }
+  if (shape == 40 || shape == 41) {      // 8-phase form (gemm_nt8.hip): 256 x 256 / 256 x 320 tiles; anything it is not built for takes the per-tile forms
+    const int rc = launch_gemm8(EPI, a, shape - 40, 0, s);
+    if (rc != G8_NOT_ELIGIBLE) return rc;
+    shape = (EPI == ONEPROT_EPI_BIAS_RESID) ? 19 : (a.K >= 1024 ? 3 : (a.N >= 2048 ? 4 : 1));
   }
   if (shape == 8) {             // register-staged 256 x 256 form (falls back to the direct-store LDS-DMA form)
     if (rs_eligible<EPI>(a)) return launch_rs<EPI>(a, s);

@@ -1,0 +1,403 @@
+// bf16 MFMA GEMM, C[M,N] = A[M,K] * B[N,K]^T (+ fused epilogue) -- the 8-PHASE form.  gfx950 only.
+//
+// One persistent 512-thread work-group per CU.  Its eight waves are two groups of four (one wave of each group per SIMD) that run the SAME
+// instruction stream half a phase apart: while group 0 issues the MFMAs of phase p, group 1 reads the LDS fragments of phase p and issues its
+// share of the LDS-DMA prefetch, and the other way round one barrier later.  The matrix pipe of a SIMD therefore always has exactly one wave
+// feeding it, and that wave's LDS reads and DMA issue were done while its partner computed (cdna_hip_programming.md section 5, "The 256^2
+// 8-phase template"; MI355X_MICROARCH.md "Two waves per SIMD").
+//
+//   * a K-tile is 64 deep (128-byte LDS rows, every LDS-DMA piece covers whole 128-byte lines); the wave tile is split in 2 x 2 quadrants and
+//     a PHASE is one quadrant x K = 64 (16 or 20 MFMAs): { ds_read the quadrant's fragments | issue one unit of LDS-DMA -> s_barrier ->
+//     lgkmcnt(0) -> MFMAs -> s_barrier }.  Four phases per K-tile, the loop body is two K-tiles = 8 phases (LDS buffers are compile-time);
+//   * the operand slice of a K-tile is staged as four UNITS (two row halves of the A tile, two column halves of the W tile), laid out so that
+//     a unit holds exactly the rows ONE phase reads: the "major" operand X (the one with the larger fragment set per quadrant) is read once per
+//     unit and held in registers for two phases, the "minor" operand Y keeps both its fragment sets.  Quadrant order (X0,Y0) (X0,Y1) (X1,Y1)
+//     (X1,Y0): reads are X0+Y0 | Y1 | X1 | none, so a unit's LDS is dead one phase after it was needed and can be refilled for the K-tile after
+//     next: the DMA stream runs 7 units (1.75 K-tiles, up to 126 KB) ahead of the reads behind ONE counted vmcnt per K-tile;
+//   * the unit stream is continuous across the output tiles of the work-group: the first K-tiles of the next tile arrive while the epilogue
+//     of the current one runs, and the epilogue works straight from the accumulators (gemm_epi.h, DIRECT form), never touching LDS;
+//   * hazards (slot = the interval between two consecutive barriers; group 0 reads phase p in slot 2p and computes in 2p+1, group 1 one slot
+//     later): a DMA may overwrite what phase p read from phase p+2 on -- or from p+1 on when the reads were retired (counted lgkmcnt) before
+//     the first barrier of phase p, which is how X0 is recycled; data waited for (counted vmcnt, before a phase's first barrier) in phase p is
+//     read from phase p+1 on.
+//
+// Configurations:  256 x 256 (waves 2 x 4, wave tile 128 x 64, X = A)  -- N % 256 == 0
+//                  256 x 320 (waves 4 x 2, wave tile  64 x 160, X = W) -- every GEMM of a d = 640 / 1280 / 320 encoder (N = d, 3d, 4d)
+// Whole tiles only, K % 128 == 0; everything else takes the per-tile kernels of gemm_nt.hip.
+#include "gemm_epi.h"
+
+namespace g8 {
+
+template <int WM_, int WN_, int MTW_, int NTW_, bool XA_, bool Y3_> struct Cfg {
+  static constexpr int WM = WM_, WN = WN_, MTW = MTW_, NTW = NTW_;
+  static constexpr bool XA = XA_;                           // major operand: A (activations) or W
+  static constexpr bool Y3 = Y3_;                           // ONE register set for the minor operand: Y0 is read again in phase 4 and therefore lives in a 3-slot ring
+  static constexpr int MH = MTW / 2, NH = NTW / 2;          // 16-row tiles per quadrant side
+  static constexpr int BM = WM * MTW * 16, BN = WN * NTW * 16;
+  static constexpr int A_ROWS = BM / 2, B_ROWS = BN / 2;    // rows per unit
+  static constexpr int A_UNIT = A_ROWS * 128, B_UNIT = B_ROWS * 128;
+  static constexpr int A_PIECES = A_ROWS / 8, B_PIECES = B_ROWS / 8;       // 1 KiB LDS-DMA pieces (8 rows x 128 B) per unit
+  static constexpr int A_IPW = (A_PIECES + 7) / 8, B_IPW = (B_PIECES + 7) / 8;      // instructions per wave (the last one only in waves < *_REM)
+  static constexpr int A_REM = A_PIECES % 8, B_REM = B_PIECES % 8;                // 0: every wave issues *_IPW
+  static constexpr int Y_UNIT = XA ? B_UNIT : A_UNIT, X_UNIT = XA ? A_UNIT : B_UNIT;
+  // LDS: two buffers of [X0 | X1 | Y1 (| Y0)], and with Y3 the three Y0 slots behind them
+  static constexpr int BUF = 2 * X_UNIT + Y_UNIT + (Y3 ? 0 : Y_UNIT);
+  static constexpr int OFF_X0 = 0, OFF_X1 = X_UNIT, OFF_Y1 = 2 * X_UNIT, OFF_Y0 = 2 * X_UNIT + Y_UNIT;      // OFF_Y0: inside the buffer (!Y3)
+  static constexpr int RING_Y0 = 2 * BUF;                                                                   // Y3: slot k at RING_Y0 + k * Y_UNIT
+  static constexpr int LDS = 2 * BUF + (Y3 ? 3 * Y_UNIT : 0);
+  static_assert(MTW % 2 == 0 && NTW % 2 == 0, "quadrants");
+  static_assert(A_REM == 0 || A_REM == 4, "uneven units: group 0 carries the extra piece");
+  static_assert(B_REM == 0 || B_REM == 4, "uneven units: group 0 carries the extra piece");
+  static_assert(LDS <= 160 * 1024, "LDS");
+  // LDS-DMA instructions of wave group g per unit
+  static constexpr int a_cnt(int g) { return A_IPW - ((A_REM != 0 && g != 0) ? 1 : 0); }
+  static constexpr int b_cnt(int g) { return B_IPW - ((B_REM != 0 && g != 0) ? 1 : 0); }
+  static constexpr int x_cnt(int g) { return XA ? a_cnt(g) : b_cnt(g); }
+  static constexpr int y_cnt(int g) { return XA ? b_cnt(g) : a_cnt(g); }
+};
+
+__device__ __forceinline__ void bar() { asm volatile("s_barrier" ::: "memory"); }
+// Diagnostic build (-DG8_STAMP, tools/ab/g8_stamps.py): the first wave of each group of work-group 0 records s_memtime after every barrier of its
+// first 32 K-tiles into the buffer passed as `out2` -- never compiled into the product library.
+#ifdef G8_STAMP
+#define STAMP(i) do { if (blockIdx.x == 0 && (wave & 3) == 0 && s < 32) { unsigned long long t_; asm volatile("s_memtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(t_) :: "memory"); \
+    if (lane == 0) reinterpret_cast<unsigned long long*>(p.out2)[(grp * 32 + s) * 8 + (i)] = t_; } } while (0)
+#else
+#define STAMP(i) do { } while (0)
+#endif
+// One LDS-DMA piece: 64 lanes x 16 bytes from `sbase + voff` (wave-uniform base in SGPRs + 32-bit per-lane offset) to LDS bytes [lds_dst, +1024).
+// Inline asm for two reasons: (i) the saddr + 32-bit-voffset form -- through the builtin hipcc keeps a zero-extended 64-bit offset PAIR per piece
+// alive (16 VGPRs that the 160-accumulator configuration does not have: it spilled them and reloaded behind a vmcnt(0), draining the prefetch);
+// (ii) none of these loads enters hipcc's own s_waitcnt bookkeeping, which is what the hand-counted vmcnt waits below assume.  M0 (the LDS
+// destination) is written in the statement that uses it and restored afterwards (cdna_hip_programming.md section 5.7).
+__device__ __forceinline__ void glds16(unsigned voff, const unsigned char* sbase, unsigned lds_dst) {
+  unsigned keep;
+  asm volatile("s_mov_b32 %0, m0\n\ts_mov_b32 m0, %3\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %1, %2\n\ts_mov_b32 m0, %0"
+               : "=&s"(keep) : "v"(voff), "s"(sbase), "s"(lds_dst) : "memory");
+}
+template <int N> __device__ __forceinline__ void wait_lgkm() { asm volatile("s_waitcnt lgkmcnt(%0)" ::"n"(N) : "memory"); }
+
+// logical column (inside the wave's NTW*16-column block) held by LDS row slot `rho` of the wave's tile jt -- see gemm_epi.h
+template <bool PAIR> __device__ __forceinline__ int slot_col(int jt, int rho) { return direct_nmap<PAIR>(jt, rho); }
+
+template <class C, int EPI>
+__global__ void __launch_bounds__(512, 2) k_gemm8(const GemmArgs p, const int g8n) {
+  constexpr int MT = C::MTW, NT = C::NTW, MH = C::MH, NH = C::NH;
+  constexpr bool XA = C::XA;
+  constexpr bool PAIR = DirectMap<EPI>::PAIR;
+  extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+  const int tid = threadIdx.x, lane = tid & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int grp = wave >> 2;                               // waves w and w + 4 share a SIMD: one of each group
+  const int wr = wave / C::WN, wc = wave % C::WN;
+  const int nk = p.K >> 6;
+
+  // ---- this work-group's tiles: XCD x (= blockIdx & 7 under round-robin dispatch; speed only) walks row panels x, x+8, ... with n fastest
+  const int x = blockIdx.x & 7, w = blockIdx.x >> 3;
+  const int panels_x = p.tiles_m > x ? (p.tiles_m - x + 7) >> 3 : 0;
+  const int Tx = panels_x * p.tiles_n;
+  const int Q = Tx > w ? (Tx - w + g8n - 1) / g8n : 0;
+  if (Q == 0) return;
+  auto tile_origin = [&](int qi, int& m0, int& n0) {
+    const int u = qi * g8n + w;
+    const int pl = u / p.tiles_n, tn = u - pl * p.tiles_n;
+    m0 = (pl * 8 + x) * C::BM; n0 = tn * C::BN;
+  };
+  const int S = Q * nk;                                    // K-tiles in this work-group's stream
+
+  // ---- per-lane LDS-DMA source offsets.  Piece P (8 rows x 128 B) of a unit is issued by wave P & 7 as its instruction P >> 3; the lane
+  // (sr = lane >> 3, sc = lane & 7) fills LDS row P*8 + sr, chunk slot sc, with source chunk sc ^ ((row >> 1) & 7) (bank swizzle on the source
+  // address, undone by the same XOR on the fragment read address).
+  const int sr = lane >> 3, sc = lane & 7;
+  unsigned a_voff[C::A_IPW], b_voff[2][C::B_IPW];
+#pragma unroll
+  for (int i = 0; i < C::A_IPW; ++i) {
+    const int hr = (i * 8 + wave) * 8 + sr;                         // LDS row inside the unit
+    const int trow = (hr / (MH * 16)) * (MT * 16) + (hr % (MH * 16));   // tile row of half 0 (half 1: + MH*16)
+    a_voff[i] = (unsigned)trow * (unsigned)p.lda * 2u + (unsigned)(sc ^ ((hr >> 1) & 7)) * 16u;
+  }
+#pragma unroll
+  for (int h = 0; h < 2; ++h)
+#pragma unroll
+    for (int i = 0; i < C::B_IPW; ++i) {
+      const int hr = (i * 8 + wave) * 8 + sr;
+      const int wcs = hr / (NH * 16), in = hr % (NH * 16);            // wave column block, slot inside the block's half
+      const int jt = h * NH + (in >> 4);
+      const int col = wcs * (NT * 16) + slot_col<PAIR>(jt, in & 15);
+      b_voff[h][i] = (unsigned)col * (unsigned)p.ldb * 2u + (unsigned)(sc ^ ((hr >> 1) & 7)) * 16u;
+    }
+
+  // unit U of a K-tile: 0 = X0, 1 = Y0, 2 = Y1, 3 = X1 (the order in which the phases need them)
+  const unsigned lds0 = (unsigned)(uintptr_t)LDS_PTR(smem);
+  auto issue_a = [&](const unsigned char* abase, int half, unsigned dst) {
+    const unsigned char* src = abase + (size_t)half * (MH * 16) * p.lda * 2;
+#pragma unroll
+    for (int i = 0; i < C::A_IPW; ++i)
+      if (C::A_REM == 0 || i + 1 < C::A_IPW || wave < C::A_REM) glds16(a_voff[i], src, lds0 + dst + (i * 8 + wave) * 1024);
+  };
+  auto issue_b = [&](const unsigned char* bbase, int half, unsigned dst) {
+#pragma unroll
+    for (int i = 0; i < C::B_IPW; ++i)
+      if (C::B_REM == 0 || i + 1 < C::B_IPW || wave < C::B_REM) glds16(half ? b_voff[1][i] : b_voff[0][i], bbase, lds0 + dst + (i * 8 + wave) * 1024);
+  };
+  // unit U of K-tile n goes to buffer n & 1 (Y0 under Y3: ring slot n % 3, passed as `y0slot`)
+  auto issue_unit = [&](auto uc, int buf, int y0slot, const unsigned char* abase, const unsigned char* bbase) {
+    constexpr int U = decltype(uc)::value;
+    constexpr bool isx = (U == 0 || U == 3);
+    constexpr int half = (U == 0 || U == 1) ? 0 : 1;
+    constexpr bool isa = (isx == XA);
+    unsigned dst;
+    if constexpr (U == 1 && C::Y3) dst = C::RING_Y0 + y0slot * C::Y_UNIT;
+    else dst = buf * C::BUF + (U == 0 ? C::OFF_X0 : (U == 3 ? C::OFF_X1 : (U == 2 ? C::OFF_Y1 : C::OFF_Y0)));
+    if constexpr (isa) issue_a(abase, half, dst); else issue_b(bbase, half, dst);
+  };
+
+  // ---- stream cursors (all on the scalar unit): operand bases of K-tiles s+1 and s+2 of the stream, where s is the K-tile being computed
+  struct Cur { const unsigned char* a; const unsigned char* b; int t; int q; };
+  auto cur_origin = [&](Cur& c) {
+    int m0, n0; tile_origin(c.q < Q ? c.q : Q - 1, m0, n0);
+    c.a = reinterpret_cast<const unsigned char*>(p.A + (size_t)m0 * p.lda);
+    c.b = reinterpret_cast<const unsigned char*>(p.B + (size_t)n0 * p.ldb);
+  };
+  auto cur_next = [&](Cur& c) {
+    c.a += 128; c.b += 128;
+    if (++c.t == nk) { c.t = 0; ++c.q; cur_origin(c); }
+  };
+  Cur c1, c2;                                              // K-tiles s+1, s+2
+  c1.t = 0; c1.q = 0; cur_origin(c1);
+
+  // ---- fragment read addresses: lane (fr = lane & 15, fq = lane >> 4) reads row fr of a 16-row tile, chunk (kk*4 + fq) ^ ((row >> 1) & 7);
+  // rows of different tiles differ by multiples of 16, so the XOR term is (fr >> 1) and kk flips byte-offset bit 6
+  const int fr = lane & 15, fq = lane >> 4;
+  const unsigned rd_lane = (unsigned)fr * 128u + (unsigned)((fq ^ (fr >> 1)) << 4);
+  const unsigned a_rd = (unsigned)(wr * (MH * 16)) * 128u + rd_lane;                        // + unit offset + mt * 2048, ^ 64 for kk = 1
+  const unsigned b_rd = (unsigned)(wc * (NH * 16)) * 128u + rd_lane;                        // + unit offset + nt * 2048
+
+  f32x4 acc[MT][NT];
+  constexpr int YSETS = C::Y3 ? 1 : 2;
+  bf8_t fa[XA ? 1 : YSETS][MH][2], fb[XA ? YSETS : 1][NH][2];       // [set][tile][kk]; the major operand has one set
+  auto read_a = [&](auto setc, const unsigned char* unit) {
+    constexpr int set = decltype(setc)::value;
+#pragma unroll
+    for (int mt = 0; mt < MH; ++mt)
+#pragma unroll
+      for (int kk = 0; kk < 2; ++kk) fa[set][mt][kk] = *reinterpret_cast<const bf8_t*>(unit + ((a_rd + mt * 2048) ^ (kk << 6)));
+  };
+  auto read_b = [&](auto setc, const unsigned char* unit) {
+    constexpr int set = decltype(setc)::value;
+#pragma unroll
+    for (int nt = 0; nt < NH; ++nt)
+#pragma unroll
+      for (int kk = 0; kk < 2; ++kk) fb[set][nt][kk] = *reinterpret_cast<const bf8_t*>(unit + ((b_rd + nt * 2048) ^ (kk << 6)));
+  };
+  // X unit h -> set 0; Y unit h -> set h (set 0 under Y3)
+  auto read_x = [&](const unsigned char* unit) { if constexpr (XA) read_a(std::integral_constant<int, 0>{}, unit); else read_b(std::integral_constant<int, 0>{}, unit); };
+  auto read_y = [&](auto hc, const unsigned char* unit) {
+    constexpr int set = C::Y3 ? 0 : decltype(hc)::value;
+    if constexpr (XA) read_b(std::integral_constant<int, set>{}, unit); else read_a(std::integral_constant<int, set>{}, unit);
+  };
+  // MFMAs of quadrant (X half xh, Y half yh), operand roles swapped (a = weight fragment, b = activation fragment): lane (c, q) owns
+  // C[token c][slots q*4 .. q*4+3] of every tile (gemm_epi.h)
+  auto quadrant = [&](auto xhc, auto yhc) {
+    constexpr int xh = decltype(xhc)::value, yh = decltype(yhc)::value;
+    constexpr int mh = XA ? xh : yh, nh = XA ? yh : xh;
+    constexpr int yset = C::Y3 ? 0 : yh, aset = XA ? 0 : yset, bset = XA ? yset : 0;
+    __builtin_amdgcn_s_setprio(1);
+#pragma unroll
+    for (int kk = 0; kk < 2; ++kk)
+#pragma unroll
+      for (int mt = 0; mt < MH; ++mt)
+#pragma unroll
+        for (int nt = 0; nt < NH; ++nt)
+          acc[mh * MH + mt][nh * NH + nt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(fb[bset][nt][kk], fa[aset][mt][kk], acc[mh * MH + mt][nh * NH + nt], 0, 0, 0);
+    __builtin_amdgcn_s_setprio(0);
+  };
+  constexpr int NY = XA ? NH * 2 : MH * 2;                // ds_reads of one Y fragment set
+
+  // ---- one K-tile = four phases.  s = stream index of the K-tile (buffer BUFI = s & 1, compile-time through the two-fold unrolling);
+  // r3 = s % 3 (Y0 ring slot under Y3).
+  int r3 = 0;
+  auto ktile = [&](auto bufc, int s) {
+    constexpr int BUFI = decltype(bufc)::value;
+    const unsigned char* bufp = smem + BUFI * C::BUF;
+    const unsigned char* y0p = C::Y3 ? smem + C::RING_Y0 + r3 * C::Y_UNIT : bufp + C::OFF_Y0;
+    const int r3n2 = r3 == 0 ? 2 : r3 - 1;                 // (s + 2) % 3
+    const bool more1 = s + 1 < S, more2 = s + 2 < S;
+    // P1 (X0, Y0): X0 reads first and retired before the barrier -- its LDS is refilled in the NEXT phase
+    read_x(bufp + C::OFF_X0);
+    __builtin_amdgcn_sched_barrier(0);
+    read_y(std::integral_constant<int, 0>{}, y0p);
+    __builtin_amdgcn_sched_barrier(0);
+    if (more1) issue_unit(std::integral_constant<int, 3>{}, BUFI ^ 1, 0, c1.a, c1.b);          // X1 of K-tile s+1
+    wait_lgkm<NY>();
+    bar();
+    STAMP(0);
+    wait_lgkm<0>();
+    __builtin_amdgcn_sched_barrier(0);
+    quadrant(std::integral_constant<int, 0>{}, std::integral_constant<int, 0>{});
+    __builtin_amdgcn_sched_barrier(0);
+    bar();
+    STAMP(1);
+    // P2 (X0, Y1)
+    c2 = c1; cur_next(c2);
+    read_y(std::integral_constant<int, 1>{}, bufp + C::OFF_Y1);
+    __builtin_amdgcn_sched_barrier(0);
+    if (more2) issue_unit(std::integral_constant<int, 0>{}, BUFI, 0, c2.a, c2.b);              // X0 of K-tile s+2
+    bar();
+    STAMP(2);
+    wait_lgkm<0>();
+    __builtin_amdgcn_sched_barrier(0);
+    quadrant(std::integral_constant<int, 0>{}, std::integral_constant<int, 1>{});
+    __builtin_amdgcn_sched_barrier(0);
+    bar();
+    STAMP(3);
+    // P3 (X1, Y1)
+    read_x(bufp + C::OFF_X1);
+    __builtin_amdgcn_sched_barrier(0);
+    if (more2) issue_unit(std::integral_constant<int, 1>{}, BUFI, r3n2, c2.a, c2.b);           // Y0 of K-tile s+2
+    bar();
+    STAMP(4);
+    wait_lgkm<0>();
+    __builtin_amdgcn_sched_barrier(0);
+    quadrant(std::integral_constant<int, 1>{}, std::integral_constant<int, 1>{});
+    __builtin_amdgcn_sched_barrier(0);
+    bar();
+    STAMP(5);
+    // P4 (X1, Y0): Y0 again from LDS under Y3, else still in registers; K-tile s+1 must have landed when this phase's first barrier opens
+    // (it is read from the next phase on)
+    if constexpr (C::Y3) { read_y(std::integral_constant<int, 0>{}, y0p); __builtin_amdgcn_sched_barrier(0); }
+    if (more2) {
+      issue_unit(std::integral_constant<int, 2>{}, BUFI, 0, c2.a, c2.b);                       // Y1 of K-tile s+2
+      if (grp == 0) wait_vmcnt<C::x_cnt(0) + 2 * C::y_cnt(0)>(); else wait_vmcnt<C::x_cnt(1) + 2 * C::y_cnt(1)>();
+    } else {
+      wait_vmcnt<0>();
+    }
+    bar();
+    STAMP(6);
+    if constexpr (C::Y3) wait_lgkm<0>();
+    __builtin_amdgcn_sched_barrier(0);
+    quadrant(std::integral_constant<int, 1>{}, std::integral_constant<int, 0>{});
+    __builtin_amdgcn_sched_barrier(0);
+    bar();
+    STAMP(7);
+    c1 = c2;
+    r3 = r3 == 2 ? 0 : r3 + 1;
+  };
+
+  // ---- prologue: units 0..6 of the stream (K-tile 0 whole, X0 Y0 Y1 of K-tile 1); K-tile 0 landed before the first phase reads it
+  {
+    int m0, n0; tile_origin(0, m0, n0);
+    direct_init_acc<EPI, MT, NT>(p, acc, m0, n0, wr, wc, lane);
+    if constexpr (EPI == ONEPROT_EPI_BIAS_RESID) {
+      const int c = lane & 15, q = lane >> 4;
+#pragma unroll
+      for (int i = 0; i < MT; ++i) {
+        const float* rrow = (const float*)p.aux + (size_t)(m0 + wr * (MT * 16) + i * 16 + c) * p.N + n0 + wc * (NT * 16) + q * 4;
+#pragma unroll
+        for (int j = 0; j < NT; ++j) { const float4 t = *reinterpret_cast<const float4*>(rrow + j * 16); acc[i][j][0] += t.x; acc[i][j][1] += t.y; acc[i][j][2] += t.z; acc[i][j][3] += t.w; }
+      }
+    }
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+  }
+  issue_unit(std::integral_constant<int, 0>{}, 0, 0, c1.a, c1.b);
+  issue_unit(std::integral_constant<int, 1>{}, 0, 0, c1.a, c1.b);
+  issue_unit(std::integral_constant<int, 2>{}, 0, 0, c1.a, c1.b);
+  issue_unit(std::integral_constant<int, 3>{}, 0, 0, c1.a, c1.b);
+  cur_next(c1);                                            // c1 = K-tile 1 (S >= 2: K % 128 == 0)
+  issue_unit(std::integral_constant<int, 0>{}, 1, 1, c1.a, c1.b);
+  issue_unit(std::integral_constant<int, 1>{}, 1, 1, c1.a, c1.b);
+  issue_unit(std::integral_constant<int, 2>{}, 1, 1, c1.a, c1.b);
+  if (grp == 0) wait_vmcnt<C::x_cnt(0) + 2 * C::y_cnt(0)>(); else wait_vmcnt<C::x_cnt(1) + 2 * C::y_cnt(1)>();
+  bar();
+  auto next_tile_acc = [&](int qn) {
+    int m0, n0; tile_origin(qn, m0, n0);
+    direct_init_acc<EPI, MT, NT>(p, acc, m0, n0, wr, wc, lane);
+    if constexpr (EPI == ONEPROT_EPI_BIAS_RESID) {
+      const int c = lane & 15, qq = lane >> 4;
+#pragma unroll
+      for (int i = 0; i < MT; ++i) {
+        const float* rrow = (const float*)p.aux + (size_t)(m0 + wr * (MT * 16) + i * 16 + c) * p.N + n0 + wc * (NT * 16) + qq * 4;
+#pragma unroll
+        for (int j = 0; j < NT; ++j) { const float4 t = *reinterpret_cast<const float4*>(rrow + j * 16); acc[i][j][0] += t.x; acc[i][j][1] += t.y; acc[i][j][2] += t.z; acc[i][j][3] += t.w; }
+      }
+    }
+  };
+  // Per output tile: group 1 drops one barrier behind (stagger), the K loop runs, group 0 waits one barrier (both groups aligned again) and
+  // the two groups run the epilogue TOGETHER -- two waves per SIMD issue vector instructions at twice the rate of one, so epilogues run one
+  // group after the other would take twice as long -- while the first K-tiles of the next tile keep arriving.
+  int s = 0;
+  for (int q = 0; q < Q; ++q) {
+    if (grp == 1) bar();
+    for (int t = 0; t < nk; t += 2, s += 2) {
+      ktile(std::integral_constant<int, 0>{}, s);
+      ktile(std::integral_constant<int, 1>{}, s + 1);
+    }
+    if (grp == 0) bar();
+    int m0, n0; tile_origin(q, m0, n0);
+    if (p.nt_store != 77) gemm_epilogue_direct<EPI, MT, NT>(p, acc, m0, n0, wr, wc, lane);       // (77: timing-only runs of the main loop, tools/ab)
+    if (q + 1 < Q) next_tile_acc(q + 1);
+  }
+}
+
+template <class C, int EPI>
+static int launch_cfg(GemmArgs a, hipStream_t s) {
+  static bool configured = false;
+  static int n_cu = 0;
+  if (!configured) {
+    if (hipFuncSetAttribute((const void*)k_gemm8<C, EPI>, hipFuncAttributeMaxDynamicSharedMemorySize, C::LDS) != hipSuccess) return OP_ELAUNCH;
+    int dev = 0; hipDeviceProp_t prop;
+    if (hipGetDevice(&dev) != hipSuccess || hipGetDeviceProperties(&prop, dev) != hipSuccess) return OP_ELAUNCH;
+    n_cu = prop.multiProcessorCount;
+    configured = true;
+  }
+  a.tiles_m = a.M / C::BM; a.tiles_n = a.N / C::BN;
+  const long tiles = (long)a.tiles_m * a.tiles_n;
+  int g8n = n_cu / 8;
+  const long per_xcd = (tiles + 7) / 8;
+  if (g8n > per_xcd) g8n = (int)per_xcd;
+  if (g8n < 1) g8n = 1;
+  hipLaunchKernelGGL((k_gemm8<C, EPI>), dim3(g8n * 8), dim3(512), C::LDS, s, a, g8n);
+  return launch_status();
+}
+
+typedef Cfg<2, 4, 8, 4, true, false> C256;       // 256 x 256, wave tile 128 x 64, X = A (32 registers per quadrant), both W sets held
+typedef Cfg<4, 2, 4, 10, false, true> C320;      // 256 x 320, wave tile 64 x 160, X = W (40 registers), ONE activation set, A0 in a 3-slot ring (160 KB of LDS)
+
+template <class C>
+static bool eligible(const GemmArgs& a, int epi) {
+  if (a.M % C::BM || a.N % C::BN || a.K % 128 || a.lda % 8 || a.ldb % 8) return false;
+  if ((size_t)C::BM * a.lda * 2 >= (1ull << 31) || (size_t)C::BN * a.ldb * 2 >= (1ull << 31)) return false;      // 32-bit per-lane source offsets
+  if (epi == ONEPROT_EPI_QKV_ROPE) {
+    if (a.hd != 32 && a.hd != 64) return false;
+    if ((C::NTW * 16) % a.hd) return false;                // a head must not straddle the wave's column block
+    if ((a.H * a.hd) % (C::NTW * 16)) return false;        // nor a wave block the q / k / v sections
+    if (a.L % 16) return false;
+  }
+  return true;
+}
+
+template <class C>
+static int launch_epi(int epi, const GemmArgs& a, hipStream_t s) {
+  switch (epi) {
+    case ONEPROT_EPI_BF16: return launch_cfg<C, ONEPROT_EPI_BF16>(a, s);
+    case ONEPROT_EPI_F32: return launch_cfg<C, ONEPROT_EPI_F32>(a, s);
+    case ONEPROT_EPI_BIAS_GELU: return launch_cfg<C, ONEPROT_EPI_BIAS_GELU>(a, s);
+    case ONEPROT_EPI_BIAS_RESID: return launch_cfg<C, ONEPROT_EPI_BIAS_RESID>(a, s);
+    case ONEPROT_EPI_GELU_BWD: return launch_cfg<C, ONEPROT_EPI_GELU_BWD>(a, s);
+    case ONEPROT_EPI_QKV_ROPE: return launch_cfg<C, ONEPROT_EPI_QKV_ROPE>(a, s);
+    default: return OP_EINVAL;
+  }
+}
+
+}  // namespace g8
+
+// cfg 0: 256 x 256, cfg 1: 256 x 320.  Returns G8_NOT_ELIGIBLE when the problem is not made of whole tiles of that configuration or has fewer
+// than `min_tiles` of them (a persistent work-group per CU only pays when most CUs get a tile).
+int launch_gemm8(int epi, const GemmArgs& a, int cfg, long min_tiles, hipStream_t s) {
+  if (cfg == 0) {
+    if (!g8::eligible<g8::C256>(a, epi) || (long)(a.M / g8::C256::BM) * (a.N / g8::C256::BN) < min_tiles) return G8_NOT_ELIGIBLE;
+    return g8::launch_epi<g8::C256>(epi, a, s);
+  }
+  if (!g8::eligible<g8::C320>(a, epi) || (long)(a.M / g8::C320::BM) * (a.N / g8::C320::BN) < min_tiles) return G8_NOT_ELIGIBLE;
+  return g8::launch_epi<g8::C320>(epi, a, s);
+}

@@ -144,8 +144,9 @@ def _gemm_inputs(M, N, K, seed):
     return A, W, bias
 
 
-@pytest.fixture(params=[-1, 0, 1, 2, 3, 4, 5, 6, 7, 8, 17, 19, 20, 32], ids=["auto", "128x128", "256x128", "256x256", "128x128bk64", "256x256bk64", "256x256nopipe", "4w128x128bk64",
-                                                                             "4w128x128bk32", "regstaged256x256", "direct256x128", "direct128x128bk64", "direct256x256bk64", "pingpong"])
+@pytest.fixture(params=[-1, 0, 1, 2, 3, 4, 5, 6, 7, 8, 17, 19, 20, 32, 40, 41], ids=["auto", "128x128", "256x128", "256x256", "128x128bk64", "256x256bk64", "256x256nopipe", "4w128x128bk64",
+                                                                                     "4w128x128bk32", "regstaged256x256", "direct256x128", "direct128x128bk64", "direct256x256bk64", "pingpong",
+                                                                                     "8phase256x256", "8phase256x320"])
 def gemm_shape(request):
     hip.query("oneprot_gemm_force_shape", request.param)
     yield request.param
@@ -154,9 +155,12 @@ def gemm_shape(request):
 
 @pytest.mark.parametrize("M,N,K", [(300, 136, 72), (128, 128, 64), (1024, 640, 640), (257, 2560, 640), (515, 640, 2560), (144, 64, 160), (2304, 1920, 640), (8192, 512, 160),
                                    (1024, 1280, 640), (512, 768, 2560), (8192, 640, 640), (4096, 2560, 128), (16384, 128, 192),
-                                   (4096, 256, 512), (2048, 384, 576), (256, 128, 1024), (768, 256, 640)])
+                                   (4096, 256, 512), (2048, 384, 576), (256, 128, 1024), (768, 256, 640), (16384, 2560, 640), (2048, 1920, 640), (66304, 640, 256), (256, 320, 128)])
 # (1024, 1280, 640) onwards are whole tiles in every block shape (direct-store and ping-pong forms).  For the persistent ping-pong kernel (K >= 512):
 # several tiles per work-group, K = 512 (16 K-steps: every slot carries an epilogue chunk) and 576, a single tile, and XCDs without any tile.
+# For the persistent 8-phase kernels (whole 256 x 256 / 256 x 320 tiles, K % 128 == 0): (16384, 2560, 640) gives every work-group two or three tiles
+# (the operand stream crosses tile boundaries), (66304, 640, 256) = 259 row panels x 2 leaves some work-groups with three tiles and others with two,
+# (256, 320, 128) is a single tile of two K-tiles (the shortest stream); shapes that are not whole tiles fall through to the per-tile kernels.
 def test_gemm_nt_epilogues(M, N, K, gemm_shape):
     A, W, bias = _gemm_inputs(M, N, K, 3)
     ref = A.float() @ W.float().t()
