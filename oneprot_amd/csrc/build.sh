@@ -7,7 +7,7 @@ OBJS=""
 PIDS=""
 for s in $SRCS; do
   o="${s%.hip}.o"
-  if [ ! -f "$o" ] || [ "$s" -nt "$o" ] || [ common.h -nt "$o" ] || [ gemm_epi.h -nt "$o" ] || [ ../../include/oneprot_hip.h -nt "$o" ]; then
+  if [ ! -f "$o" ] || [ "$s" -nt "$o" ] || [ common.h -nt "$o" ] || [ gemm_epi.h -nt "$o" ] || [ gemm_epi8.h -nt "$o" ] || [ ../../include/oneprot_hip.h -nt "$o" ]; then
     ( hipcc --offload-arch=gfx950 -O3 -fPIC -std=c++17 -Wno-unused-value -c "$s" -o "$o.tmp" && mv "$o.tmp" "$o" ) &
     PIDS="$PIDS $!"
   fi

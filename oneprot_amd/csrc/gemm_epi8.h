@@ -1,0 +1,239 @@
+// Epilogues of the persistent 8-phase NT GEMM (gemm_nt8.hip), DIRECT accumulator layout of gemm_epi.h (lane (c = lane & 15, q = lane >> 4) owns
+// C[token c][slots q*4 .. q*4+3] of every 16 x 16 tile; pair map for bf16 outputs, natural map for fp32 outputs and QKV / RoPE).
+//
+// What is different from gemm_epilogue_direct: the kernel is persistent, and the stores of one tile must be able to drain while the next tile's K
+// loop runs.  vmcnt retires in issue order, so a wait for ANY load issued after a store also waits for that store (thousands of cycles until the
+// write is acknowledged).  Therefore
+//   * the accumulators start at zero and the bias is added here, so that no operand load follows the stores of the previous tile;
+//   * every operand of the epilogue (bias, GELU', residual, RoPE tables) is fetched in GROUPS that run two groups ahead of the stores: the
+//     loads of group g+2 are issued before the stores of group g, by inline asm (hipcc would put its own wait at the first use, behind the
+//     stores), and each group is waited for with a hand-counted vmcnt that leaves exactly the younger stores and loads in flight;
+//   * groups are column blocks (8 columns x all rows of the wave tile for the pair map, one 16-column tile x all rows for the natural map),
+//     so a group's bias is 2 (1) float4 per lane and the register cost of running ahead stays at 16-80 registers.
+//   * LANE TRANSPOSE before every store / after every operand load.  In the accumulator layout the 16 lanes of a lane group hold 16 DIFFERENT rows
+//     (16 bytes each) and the four 16-byte pieces of one row's 64 bytes sit 16 lanes apart: the memory pipeline coalesces neighbouring lanes
+//     only, so such a store leaves the CU as 64 requests of 16 bytes -- measured 13 B/clk per CU however few CUs are active, against 48-57 B/clk for
+//     the same bytes with the pieces of a row in neighbouring lanes (tools/ab/store_probe.hip).  ds_bpermute_b32 (LDS crossbar, no LDS memory)
+//     moves lane (q*16 + c) to lane (c*4 + q): four per 16-byte store, and the store becomes 16 requests of 64 bytes.
+#pragma once
+#include "gemm_epi.h"
+
+namespace g8 {
+
+#ifdef G8_STAMP      // diagnostic build only (tools/ab/g8_stamps.py): s_memtime after every group of the pair-map epilogue, first wave of each wave group of work-group 0
+#define G8_ESTAMP(k) do { if (blockIdx.x == 0 && (threadIdx.x & 255) == 0) { unsigned long long t_; asm volatile("s_memtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(t_) :: "memory"); \
+    reinterpret_cast<unsigned long long*>(p.out2)[768 + (threadIdx.x >> 8) * 16 + (k)] = t_; } } while (0)
+#else
+#define G8_ESTAMP(k) do { } while (0)
+#endif
+
+__device__ __forceinline__ void gload16(u32x4& d, const void* ptr) { asm volatile("global_load_dwordx4 %0, %1, off" : "=v"(d) : "v"(ptr) : "memory"); }
+// wait until at most N vector-memory operations are in flight; the loaded registers are defined from here on
+template <int N, int G> __device__ __forceinline__ void wait_vm_pin(u32x4 (&r)[G]) {
+  asm volatile("s_waitcnt vmcnt(%1)" : "+v"(r[0]) : "n"(N) : "memory");
+#pragma unroll
+  for (int k = 1; k < G; ++k) asm volatile("" : "+v"(r[k]));
+}
+__device__ __forceinline__ float as_f(unsigned u) { return __builtin_bit_cast(float, u); }
+// accumulator layout -> row layout: lane l receives the value of lane (l & 3) * 16 + (l >> 2); and back: lane l receives that of lane (l & 15) * 4 + (l >> 4)
+__device__ __forceinline__ int to_rows_addr(int lane) { return ((((lane & 3) << 4) | (lane >> 2)) << 2); }
+__device__ __forceinline__ int to_acc_addr(int lane) { return ((((lane & 15) << 2) | (lane >> 4)) << 2); }
+__device__ __forceinline__ u32x4 lane_perm(int addr, u32x4 v) {
+  u32x4 r;
+  r.x = (unsigned)__builtin_amdgcn_ds_bpermute(addr, (int)v.x); r.y = (unsigned)__builtin_amdgcn_ds_bpermute(addr, (int)v.y);
+  r.z = (unsigned)__builtin_amdgcn_ds_bpermute(addr, (int)v.z); r.w = (unsigned)__builtin_amdgcn_ds_bpermute(addr, (int)v.w);
+  return r;
+}
+
+template <class F, int... Is> __device__ __forceinline__ void static_for(F&& f, std::integer_sequence<int, Is...>) { (f(std::integral_constant<int, Is>{}), ...); }
+
+// Runs NG groups: load(g, regs) issues GL loads, finish(g, regs) consumes them and issues GS stores.  Two groups of loads in flight.
+template <int NG, int GL, int GS, class LoadF, class FinF>
+__device__ __forceinline__ void run_groups(LoadF&& load, FinF&& finish) {
+  if constexpr (GL == 0) {
+    static_for([&](auto gc) { u32x4 none[1]; finish(gc, none); }, std::make_integer_sequence<int, NG>{});
+  } else {
+    u32x4 r[2][GL];
+    load(std::integral_constant<int, 0>{}, r[0]);
+    if constexpr (NG > 1) load(std::integral_constant<int, 1>{}, r[1]);
+    static_for([&](auto gc) {
+      constexpr int g = decltype(gc)::value;
+      // younger than the loads of group g: the stores of group g-1 and the loads of group g+1
+      constexpr int younger = (g >= 1 ? GS : 0) + (g + 1 < NG ? GL : 0);
+      wait_vm_pin<(younger > 63 ? 63 : younger)>(r[g & 1]);
+      finish(gc, r[g & 1]);
+      if constexpr (g + 2 < NG) load(std::integral_constant<int, g + 2>{}, r[g & 1]);
+    }, std::make_integer_sequence<int, NG>{});
+  }
+}
+
+// EPI in {BF16, BIAS_GELU, GELU_BWD}: pair map.  HB: bias present.  DUAL: BIAS_GELU writes gelu'(z) to out1 as well.
+template <int EPI, bool HB, bool DUAL, int MT, int NT>
+__device__ __forceinline__ void epilogue_pair(const GemmArgs& p, f32x4 (&acc)[MT][NT], int m0, int n0, int wr, int wc, int lane) {
+  constexpr bool AUX = EPI == ONEPROT_EPI_GELU_BWD;
+  constexpr int NG = NT / 2, GL = (HB ? 2 : 0) + (AUX ? MT : 0), GS = MT * (DUAL ? 2 : 1);
+  const int q = lane >> 4;                                  // accumulator layout: lane (c, q) owns columns q*8 .. q*8+7 of the pair, row c
+  const int sr = lane >> 2, sq = lane & 3;                  // row layout (stores, GELU' loads): lane owns row sr, columns sq*8 .. sq*8+7
+  const int pa = to_rows_addr(lane), pb = to_acc_addr(lane);
+  const size_t o0 = (size_t)(m0 + wr * (MT * 16) + sr) * p.N + n0 + wc * (NT * 16) + sq * 8;     // + i * 16 * N + pp * 32
+  const size_t rstep = (size_t)16 * p.N;
+  const float* bcol = HB ? p.bias + n0 + wc * (NT * 16) + q * 8 : nullptr;
+  const bf16_t* aux = AUX ? (const bf16_t*)p.aux + o0 : nullptr;
+  bf16_t* out0 = (bf16_t*)p.out0 + o0;
+  bf16_t* out1 = DUAL ? (bf16_t*)p.out1 + o0 : nullptr;
+  auto load = [&](auto gc, u32x4 (&r)[GL > 0 ? GL : 1]) {
+    constexpr int pp = decltype(gc)::value;
+    if constexpr (HB) { gload16(r[0], bcol + pp * 32); gload16(r[1], bcol + pp * 32 + 4); }
+    if constexpr (AUX) {
+#pragma unroll
+      for (int i = 0; i < MT; ++i) gload16(r[(HB ? 2 : 0) + i], aux + i * rstep + pp * 32);
+    }
+  };
+  auto finish = [&](auto gc, const u32x4 (&r)[GL > 0 ? GL : 1]) {
+    constexpr int pp = decltype(gc)::value;
+#pragma unroll
+    for (int i = 0; i < MT; ++i) {
+      float v[8];
+#pragma unroll
+      for (int e = 0; e < 4; ++e) { v[e] = acc[i][2 * pp][e]; v[4 + e] = acc[i][2 * pp + 1][e]; }
+      if constexpr (HB) {
+        v[0] += as_f(r[0].x); v[1] += as_f(r[0].y); v[2] += as_f(r[0].z); v[3] += as_f(r[0].w);
+        v[4] += as_f(r[1].x); v[5] += as_f(r[1].y); v[6] += as_f(r[1].z); v[7] += as_f(r[1].w);
+      }
+      if constexpr (EPI == ONEPROT_EPI_BIAS_GELU) {
+        if constexpr (DUAL) {
+          float dg[8];
+#pragma unroll
+          for (int e = 0; e < 8; ++e) gelu_fwd_and_grad(v[e], v[e], dg[e]);
+          u32x4 z; z.x = pack2bf(dg[0], dg[1]); z.y = pack2bf(dg[2], dg[3]); z.z = pack2bf(dg[4], dg[5]); z.w = pack2bf(dg[6], dg[7]);
+          gst(reinterpret_cast<u32x4*>(out1 + i * rstep + pp * 32), lane_perm(pa, z), p.nt_store);
+        } else {
+#pragma unroll
+          for (int e = 0; e < 8; ++e) v[e] = gelu_fwd_only(v[e]);
+        }
+      } else if constexpr (AUX) {
+        const u32x4 z = lane_perm(pb, r[(HB ? 2 : 0) + i]);
+        v[0] *= bflo(z.x); v[1] *= bfhi(z.x); v[2] *= bflo(z.y); v[3] *= bfhi(z.y);
+        v[4] *= bflo(z.z); v[5] *= bfhi(z.z); v[6] *= bflo(z.w); v[7] *= bfhi(z.w);
+      }
+      u32x4 w; w.x = pack2bf(v[0], v[1]); w.y = pack2bf(v[2], v[3]); w.z = pack2bf(v[4], v[5]); w.w = pack2bf(v[6], v[7]);
+      gst(reinterpret_cast<u32x4*>(out0 + i * rstep + pp * 32), lane_perm(pa, w), p.nt_store);
+    }
+    G8_ESTAMP(pp + 1);
+  };
+  G8_ESTAMP(0);
+  run_groups<NG, GL, GS>(load, finish);
+}
+
+// EPI in {F32, BIAS_RESID}: natural map, fp32 output.  DUAL: BIAS_RESID writes a bf16 copy to out1.  out0 may alias the residual: a lane reads
+// exactly the elements it writes, and reads them first.
+template <int EPI, bool HB, bool DUAL, int MT, int NT>
+__device__ __forceinline__ void epilogue_f32(const GemmArgs& p, f32x4 (&acc)[MT][NT], int m0, int n0, int wr, int wc, int lane) {
+  constexpr bool RES = EPI == ONEPROT_EPI_BIAS_RESID;
+  constexpr int NG = NT, GL = (HB ? 1 : 0) + (RES ? MT : 0), GS = MT * (DUAL ? 2 : 1);
+  const int q = lane >> 4;                                  // accumulator layout: columns q*4 .. q*4+3 of tile j, row c
+  const int sr = lane >> 2, sq = lane & 3;                  // row layout (stores, residual loads)
+  const int pa = to_rows_addr(lane), pb = to_acc_addr(lane);
+  const size_t o0 = (size_t)(m0 + wr * (MT * 16) + sr) * p.N + n0 + wc * (NT * 16) + sq * 4;     // + i * 16 * N + j * 16
+  const size_t rstep = (size_t)16 * p.N;
+  const float* bcol = HB ? p.bias + n0 + wc * (NT * 16) + q * 4 : nullptr;
+  const float* res = RES ? (const float*)p.aux + o0 : nullptr;
+  float* out0 = (float*)p.out0 + o0;
+  bf16_t* out1 = DUAL ? (bf16_t*)p.out1 + o0 : nullptr;
+  auto load = [&](auto gc, u32x4 (&r)[GL > 0 ? GL : 1]) {
+    constexpr int j = decltype(gc)::value;
+    if constexpr (HB) gload16(r[0], bcol + j * 16);
+    if constexpr (RES) {
+#pragma unroll
+      for (int i = 0; i < MT; ++i) gload16(r[(HB ? 1 : 0) + i], res + i * rstep + j * 16);
+    }
+  };
+  auto finish = [&](auto gc, const u32x4 (&r)[GL > 0 ? GL : 1]) {
+    constexpr int j = decltype(gc)::value;
+#pragma unroll
+    for (int i = 0; i < MT; ++i) {
+      float x0 = acc[i][j][0], x1 = acc[i][j][1], x2 = acc[i][j][2], x3 = acc[i][j][3];
+      if constexpr (HB) { x0 += as_f(r[0].x); x1 += as_f(r[0].y); x2 += as_f(r[0].z); x3 += as_f(r[0].w); }
+      // the residual stays in the row layout (as loaded, coalesced); the accumulator quad goes there too, and the sum is formed and stored there
+      u32x4 a; a.x = __builtin_bit_cast(unsigned, x0); a.y = __builtin_bit_cast(unsigned, x1); a.z = __builtin_bit_cast(unsigned, x2); a.w = __builtin_bit_cast(unsigned, x3);
+      a = lane_perm(pa, a);
+      x0 = as_f(a.x); x1 = as_f(a.y); x2 = as_f(a.z); x3 = as_f(a.w);
+      if constexpr (RES) { const u32x4 t = r[(HB ? 1 : 0) + i]; x0 += as_f(t.x); x1 += as_f(t.y); x2 += as_f(t.z); x3 += as_f(t.w); }
+      gst(out0 + i * rstep + j * 16, x0, x1, x2, x3, p.nt_store);
+      if constexpr (DUAL) { u32x2 w; w.x = pack2bf(x0, x1); w.y = pack2bf(x2, x3); gst(reinterpret_cast<u32x2*>(out1 + i * rstep + j * 16), w, p.nt_store); }
+    }
+  };
+  run_groups<NG, GL, GS>(load, finish);
+}
+
+// QKV / RoPE, head_dim 32 (natural map; a head = tiles 2h, 2h+1 of the wave's column block, the rotation partner of a column is the same
+// register of the other tile).  Group = one head.  The RoPE table rows of the wave's MT row groups are fetched once, before any store.
+template <bool HB, int MT, int NT>
+__device__ __forceinline__ void epilogue_rope32(const GemmArgs& p, f32x4 (&acc)[MT][NT], int m0, int n0, int wr, int wc, int lane) {
+  constexpr int HD = 32, HALF = 16, NG = NT / 2, GL = HB ? 2 : 0, GS = MT * 2;
+  const int c = lane & 15, q = lane >> 4;
+  const int mrow0 = m0 + wr * (MT * 16) + c, ncol0 = n0 + wc * (NT * 16);
+  const int dm = p.H * HD;
+  const int sec = __builtin_amdgcn_readfirstlane(ncol0 / dm);
+  const int head0 = (ncol0 - sec * dm) / HD;
+  bf16_t* dst = (bf16_t*)(sec == 0 ? p.out0 : (sec == 1 ? p.out1 : p.out2));
+  const float sc = sec == 0 ? p.q_scale : 1.0f;
+  const float* bcol = HB ? p.bias + ncol0 + q * 4 : nullptr;
+  float4 cs[MT], sn[MT];
+  size_t roff[MT];                                          // row layout (stores): element offset of (b, head0, l, sq*4) in the head-major output
+  const int sr = lane >> 2, sq = lane & 3, pa = to_rows_addr(lane);
+#pragma unroll
+  for (int i = 0; i < MT; ++i) {
+    const int gs = m0 + wr * (MT * 16) + i * 16 + sr;
+    const int bs = gs / p.L, ls = gs - bs * p.L;
+    roff[i] = (((size_t)bs * p.H + head0) * p.L + ls) * HD + sq * 4;
+    const int gm = mrow0 + i * 16;                          // accumulator layout (rotation arithmetic): row c
+    const int l = gm % p.L;
+    if (sec < 2) {
+      cs[i] = *reinterpret_cast<const float4*>(p.cos + (size_t)l * HALF + q * 4);
+      sn[i] = *reinterpret_cast<const float4*>(p.sin + (size_t)l * HALF + q * 4);
+    } else { cs[i] = make_float4(1.f, 1.f, 1.f, 1.f); sn[i] = make_float4(0.f, 0.f, 0.f, 0.f); }
+  }
+#pragma unroll
+  for (int i = 0; i < MT; ++i) asm volatile("" : "+v"(cs[i].x), "+v"(cs[i].y), "+v"(cs[i].z), "+v"(cs[i].w), "+v"(sn[i].x), "+v"(sn[i].y), "+v"(sn[i].z), "+v"(sn[i].w));
+  const size_t hstep = (size_t)p.L * HD;                    // next head of the same token
+  auto load = [&](auto gc, u32x4 (&r)[GL > 0 ? GL : 1]) {
+    constexpr int h = decltype(gc)::value;
+    if constexpr (HB) { gload16(r[0], bcol + h * 32); gload16(r[1], bcol + h * 32 + 16); }
+  };
+  auto finish = [&](auto gc, const u32x4 (&r)[GL > 0 ? GL : 1]) {
+    constexpr int h = decltype(gc)::value;
+#pragma unroll
+    for (int i = 0; i < MT; ++i) {
+      float lo[4] = {acc[i][2 * h][0], acc[i][2 * h][1], acc[i][2 * h][2], acc[i][2 * h][3]};
+      float hi[4] = {acc[i][2 * h + 1][0], acc[i][2 * h + 1][1], acc[i][2 * h + 1][2], acc[i][2 * h + 1][3]};
+      if constexpr (HB) {
+        lo[0] += as_f(r[0].x); lo[1] += as_f(r[0].y); lo[2] += as_f(r[0].z); lo[3] += as_f(r[0].w);
+        hi[0] += as_f(r[1].x); hi[1] += as_f(r[1].y); hi[2] += as_f(r[1].z); hi[3] += as_f(r[1].w);
+      }
+      const float cv[4] = {cs[i].x, cs[i].y, cs[i].z, cs[i].w}, sv[4] = {sn[i].x, sn[i].y, sn[i].z, sn[i].w};
+      float ol[4], oh[4];
+#pragma unroll
+      for (int e = 0; e < 4; ++e) {                         // v: sec 2 -> cos = 1, sin = 0, scale = 1: the value itself
+        ol[e] = (lo[e] * sc) * cv[e] - (hi[e] * sc) * sv[e];
+        oh[e] = (hi[e] * sc) * cv[e] + (lo[e] * sc) * sv[e];
+      }
+      bf16_t* d = dst + roff[i] + h * hstep;
+      u32x4 w; w.x = pack2bf(ol[0], ol[1]); w.y = pack2bf(ol[2], ol[3]); w.z = pack2bf(oh[0], oh[1]); w.w = pack2bf(oh[2], oh[3]);
+      w = lane_perm(pa, w);                                 // row layout: four neighbouring lanes hold the 32 + 32 bytes of one (token, head) row
+      u32x2 w0; w0.x = w.x; w0.y = w.y;
+      u32x2 w1; w1.x = w.z; w1.y = w.w;
+      gst(reinterpret_cast<u32x2*>(d), w0, p.nt_store);
+      gst(reinterpret_cast<u32x2*>(d + HALF), w1, p.nt_store);
+    }
+  };
+  run_groups<NG, GL, GS>(load, finish);
+}
+
+// vector-memory stores one wave issues per tile (for the store-tolerant wait that follows the epilogue)
+template <int EPI, bool DUAL, int MT, int NT> constexpr int epilogue_stores() {
+  if (EPI == ONEPROT_EPI_BF16 || EPI == ONEPROT_EPI_GELU_BWD || EPI == ONEPROT_EPI_BIAS_GELU) return MT * NT / 2 * (DUAL ? 2 : 1);
+  return MT * NT * (DUAL ? 2 : 1);      // F32, BIAS_RESID (fp32 + optional bf16 copy), QKV_ROPE (8-byte stores, one per tile)
+}
+
+}  // namespace g8

@@ -24,7 +24,7 @@
 // Configurations:  256 x 256 (waves 2 x 4, wave tile 128 x 64, X = A)  -- N % 256 == 0
 //                  256 x 320 (waves 4 x 2, wave tile  64 x 160, X = W) -- every GEMM of a d = 640 / 1280 / 320 encoder (N = d, 3d, 4d)
 // Whole tiles only, K % 128 == 0; everything else takes the per-tile kernels of gemm_nt.hip.
-#include "gemm_epi.h"
+#include "gemm_epi8.h"
 
 namespace g8 {
 
@@ -62,8 +62,11 @@ __device__ __forceinline__ void bar() { asm volatile("s_barrier" ::: "memory"); 
 #ifdef G8_STAMP
 #define STAMP(i) do { if (blockIdx.x == 0 && (wave & 3) == 0 && s < 32) { unsigned long long t_; asm volatile("s_memtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(t_) :: "memory"); \
     if (lane == 0) reinterpret_cast<unsigned long long*>(p.out2)[(grp * 32 + s) * 8 + (i)] = t_; } } while (0)
+#define STAMP_E(i) do { if (blockIdx.x == 0 && (wave & 3) == 0 && q < 8) { unsigned long long t_; asm volatile("s_memtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(t_) :: "memory"); \
+    if (lane == 0) reinterpret_cast<unsigned long long*>(p.out2)[512 + (grp * 8 + q) * 8 + (i)] = t_; } } while (0)
 #else
 #define STAMP(i) do { } while (0)
+#define STAMP_E(i) do { } while (0)
 #endif
 // One LDS-DMA piece: 64 lanes x 16 bytes from `sbase + voff` (wave-uniform base in SGPRs + 32-bit per-lane offset) to LDS bytes [lds_dst, +1024).
 // Inline asm for two reasons: (i) the saddr + 32-bit-voffset form -- through the builtin hipcc keeps a zero-extended 64-bit offset PAIR per piece
@@ -80,8 +83,8 @@ template <int N> __device__ __forceinline__ void wait_lgkm() { asm volatile("s_w
 // logical column (inside the wave's NTW*16-column block) held by LDS row slot `rho` of the wave's tile jt -- see gemm_epi.h
 template <bool PAIR> __device__ __forceinline__ int slot_col(int jt, int rho) { return direct_nmap<PAIR>(jt, rho); }
 
-template <class C, int EPI>
-__global__ void __launch_bounds__(512, 2) k_gemm8(const GemmArgs p, const int g8n) {
+template <class C, int EPI, bool HB, bool DUAL>
+__global__ void __launch_bounds__(512, 2) k_gemm8(const GemmArgs p, const int g8n, const int dph_groups, const int dph_sleeps) {
   constexpr int MT = C::MTW, NT = C::NTW, MH = C::MH, NH = C::NH;
   constexpr bool XA = C::XA;
   constexpr bool PAIR = DirectMap<EPI>::PAIR;
@@ -104,6 +107,13 @@ __global__ void __launch_bounds__(512, 2) k_gemm8(const GemmArgs p, const int g8
     m0 = (pl * 8 + x) * C::BM; n0 = tn * C::BN;
   };
   const int S = Q * nk;                                    // K-tiles in this work-group's stream
+  // ---- de-phasing.  Every work-group runs the same number of equally long tiles, so without it all 256 CUs reach their epilogues together and
+  // the output bursts (160-320 KB per CU) queue on the HBM write path while nothing computes.  Phase group (w mod G) starts (w mod G) * dph_sleeps
+  // sleeps of 8128 cycles late; the offsets persist, and the stores of one group drain under the K loops of the others.
+  if (dph_groups > 1) {
+    const int late = (w % dph_groups) * dph_sleeps;
+    for (int i = 0; i < late; ++i) __builtin_amdgcn_s_sleep(127);
+  }
 
   // ---- per-lane LDS-DMA source offsets.  Piece P (8 rows x 128 B) of a unit is issued by wave P & 7 as its instruction P >> 3; the lane
   // (sr = lane >> 3, sc = lane & 7) fills LDS row P*8 + sr, chunk slot sc, with source chunk sc ^ ((row >> 1) & 7) (bank swizzle on the source
@@ -217,7 +227,8 @@ __global__ void __launch_bounds__(512, 2) k_gemm8(const GemmArgs p, const int g8
   // ---- one K-tile = four phases.  s = stream index of the K-tile (buffer BUFI = s & 1, compile-time through the two-fold unrolling);
   // r3 = s % 3 (Y0 ring slot under Y3).
   int r3 = 0;
-  auto ktile = [&](auto bufc, int s) {
+  constexpr int ST = epilogue_stores<EPI, DUAL, MT, NT>();
+  auto ktile = [&](auto bufc, int s, const bool after_epi) {
     constexpr int BUFI = decltype(bufc)::value;
     const unsigned char* bufp = smem + BUFI * C::BUF;
     const unsigned char* y0p = C::Y3 ? smem + C::RING_Y0 + r3 * C::Y_UNIT : bufp + C::OFF_Y0;
@@ -228,7 +239,7 @@ __global__ void __launch_bounds__(512, 2) k_gemm8(const GemmArgs p, const int g8
     __builtin_amdgcn_sched_barrier(0);
     read_y(std::integral_constant<int, 0>{}, y0p);
     __builtin_amdgcn_sched_barrier(0);
-    if (more1) issue_unit(std::integral_constant<int, 3>{}, BUFI ^ 1, 0, c1.a, c1.b);          // X1 of K-tile s+1
+    if (more1 && !after_epi) issue_unit(std::integral_constant<int, 3>{}, BUFI ^ 1, 0, c1.a, c1.b);          // X1 of K-tile s+1 (issued ahead of the epilogue at a tile start)
     wait_lgkm<NY>();
     bar();
     STAMP(0);
@@ -268,7 +279,11 @@ __global__ void __launch_bounds__(512, 2) k_gemm8(const GemmArgs p, const int g8
     if constexpr (C::Y3) { read_y(std::integral_constant<int, 0>{}, y0p); __builtin_amdgcn_sched_barrier(0); }
     if (more2) {
       issue_unit(std::integral_constant<int, 2>{}, BUFI, 0, c2.a, c2.b);                       // Y1 of K-tile s+2
-      if (grp == 0) wait_vmcnt<C::x_cnt(0) + 2 * C::y_cnt(0)>(); else wait_vmcnt<C::x_cnt(1) + 2 * C::y_cnt(1)>();
+      // after_epi (first K-tile after an epilogue): K-tile s+1 was requested BEFORE the epilogue's ST stores, so that many more operations may
+      // stay in flight -- the stores drain under the first two K-tiles of the new tile instead of being waited for here
+      constexpr int N0 = C::x_cnt(0) + 2 * C::y_cnt(0), N1 = C::x_cnt(1) + 2 * C::y_cnt(1);
+      if (!after_epi) { if (grp == 0) wait_vmcnt<N0>(); else wait_vmcnt<N1>(); }
+      else { if (grp == 0) wait_vmcnt<(N0 + ST > 63 ? 63 : N0 + ST)>(); else wait_vmcnt<(N1 + ST > 63 ? 63 : N1 + ST)>(); }
     } else {
       wait_vmcnt<0>();
     }
@@ -284,21 +299,19 @@ __global__ void __launch_bounds__(512, 2) k_gemm8(const GemmArgs p, const int g8
     r3 = r3 == 2 ? 0 : r3 + 1;
   };
 
-  // ---- prologue: units 0..6 of the stream (K-tile 0 whole, X0 Y0 Y1 of K-tile 1); K-tile 0 landed before the first phase reads it
-  {
-    int m0, n0; tile_origin(0, m0, n0);
-    direct_init_acc<EPI, MT, NT>(p, acc, m0, n0, wr, wc, lane);
-    if constexpr (EPI == ONEPROT_EPI_BIAS_RESID) {
-      const int c = lane & 15, q = lane >> 4;
+  // ---- prologue: units 0..6 of the stream (K-tile 0 whole, X0 Y0 Y1 of K-tile 1); K-tile 0 landed before the first phase reads it.
+  // Accumulators start at zero: the bias is added by the epilogue (gemm_epi8.h).
+  // (an opaque zero: with a literal 0 hipcc peels the first K-tiles of every tile off the loop to fold the constant into the first MFMAs, and
+  // the peeled copy -- 256 registers, like the loop -- spills accumulators and reloads them behind vmcnt(0))
+  auto zero_acc = [&]() {
+    float z = 0.f;
+    asm volatile("" : "+v"(z));
 #pragma unroll
-      for (int i = 0; i < MT; ++i) {
-        const float* rrow = (const float*)p.aux + (size_t)(m0 + wr * (MT * 16) + i * 16 + c) * p.N + n0 + wc * (NT * 16) + q * 4;
+    for (int i = 0; i < MT; ++i)
 #pragma unroll
-        for (int j = 0; j < NT; ++j) { const float4 t = *reinterpret_cast<const float4*>(rrow + j * 16); acc[i][j][0] += t.x; acc[i][j][1] += t.y; acc[i][j][2] += t.z; acc[i][j][3] += t.w; }
-      }
-    }
-    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-  }
+      for (int j = 0; j < NT; ++j) acc[i][j] = (f32x4){z, z, z, z};
+  };
+  zero_acc();
   issue_unit(std::integral_constant<int, 0>{}, 0, 0, c1.a, c1.b);
   issue_unit(std::integral_constant<int, 1>{}, 0, 0, c1.a, c1.b);
   issue_unit(std::integral_constant<int, 2>{}, 0, 0, c1.a, c1.b);
@@ -309,42 +322,61 @@ __global__ void __launch_bounds__(512, 2) k_gemm8(const GemmArgs p, const int g8
   issue_unit(std::integral_constant<int, 2>{}, 1, 1, c1.a, c1.b);
   if (grp == 0) wait_vmcnt<C::x_cnt(0) + 2 * C::y_cnt(0)>(); else wait_vmcnt<C::x_cnt(1) + 2 * C::y_cnt(1)>();
   bar();
-  auto next_tile_acc = [&](int qn) {
-    int m0, n0; tile_origin(qn, m0, n0);
-    direct_init_acc<EPI, MT, NT>(p, acc, m0, n0, wr, wc, lane);
-    if constexpr (EPI == ONEPROT_EPI_BIAS_RESID) {
-      const int c = lane & 15, qq = lane >> 4;
-#pragma unroll
-      for (int i = 0; i < MT; ++i) {
-        const float* rrow = (const float*)p.aux + (size_t)(m0 + wr * (MT * 16) + i * 16 + c) * p.N + n0 + wc * (NT * 16) + qq * 4;
-#pragma unroll
-        for (int j = 0; j < NT; ++j) { const float4 t = *reinterpret_cast<const float4*>(rrow + j * 16); acc[i][j][0] += t.x; acc[i][j][1] += t.y; acc[i][j][2] += t.z; acc[i][j][3] += t.w; }
-      }
-    }
-  };
   // Per output tile: group 1 drops one barrier behind (stagger), the K loop runs, group 0 waits one barrier (both groups aligned again) and
   // the two groups run the epilogue TOGETHER -- two waves per SIMD issue vector instructions at twice the rate of one, so epilogues run one
   // group after the other would take twice as long -- while the first K-tiles of the next tile keep arriving.
+  // Order at a tile boundary: next tile's bias -> X1 of the next tile's K-tile 1 (now BOTH of its first K-tiles are requested) -> epilogue stores
+  // -> accumulators = bias.  Nothing after the stores waits for them until the K-tile-2 wait, two K-tiles later.
   int s = 0;
+  bool after_epi = false;
+#pragma clang loop unroll(disable)
   for (int q = 0; q < Q; ++q) {
     if (grp == 1) bar();
+#pragma clang loop unroll(disable)
     for (int t = 0; t < nk; t += 2, s += 2) {
-      ktile(std::integral_constant<int, 0>{}, s);
-      ktile(std::integral_constant<int, 1>{}, s + 1);
+      ktile(std::integral_constant<int, 0>{}, s, after_epi);
+      ktile(std::integral_constant<int, 1>{}, s + 1, false);
+      after_epi = false;
     }
+    STAMP_E(0);
     if (grp == 0) bar();
+    STAMP_E(1);
     int m0, n0; tile_origin(q, m0, n0);
-    if (p.nt_store != 77) gemm_epilogue_direct<EPI, MT, NT>(p, acc, m0, n0, wr, wc, lane);       // (77: timing-only runs of the main loop, tools/ab)
-    if (q + 1 < Q) next_tile_acc(q + 1);
+    if (q + 1 < Q) {
+      issue_unit(std::integral_constant<int, 3>{}, 1, 0, c1.a, c1.b);        // X1 of the next tile's K-tile 1 (c1; s is even: buffer 1)
+      after_epi = true;
+    }
+    STAMP_E(2);
+    if (p.nt_store != 77) {                                                  // (77: timing-only runs of the main loop, tools/ab)
+      if constexpr (DirectMap<EPI>::PAIR) epilogue_pair<EPI, HB, DUAL, MT, NT>(p, acc, m0, n0, wr, wc, lane);
+      else if constexpr (EPI == ONEPROT_EPI_QKV_ROPE) {
+        if (p.hd == 32) epilogue_rope32<HB, MT, NT>(p, acc, m0, n0, wr, wc, lane);
+        else if constexpr ((NT * 16) % 64 == 0) {                            // head_dim 64: bias into the accumulators, then the generic tail
+          if constexpr (HB) {
+#pragma unroll
+            for (int j = 0; j < NT; ++j) {
+              const float4 t = *reinterpret_cast<const float4*>(p.bias + n0 + wc * (NT * 16) + j * 16 + (lane >> 4) * 4);
+#pragma unroll
+              for (int i = 0; i < MT; ++i) { acc[i][j][0] += t.x; acc[i][j][1] += t.y; acc[i][j][2] += t.z; acc[i][j][3] += t.w; }
+            }
+          }
+          gemm_epilogue_direct<EPI, MT, NT>(p, acc, m0, n0, wr, wc, lane);
+        }
+      } else epilogue_f32<EPI, HB, DUAL, MT, NT>(p, acc, m0, n0, wr, wc, lane);
+    }
+    STAMP_E(3);
+    zero_acc();
+    STAMP_E(4);
   }
 }
 
-template <class C, int EPI>
+static int g_dph_groups = 1, g_dph_sleeps = 0, g_g8n_cap = 0;
+template <class C, int EPI, bool HB, bool DUAL>
 static int launch_cfg(GemmArgs a, hipStream_t s) {
   static bool configured = false;
   static int n_cu = 0;
   if (!configured) {
-    if (hipFuncSetAttribute((const void*)k_gemm8<C, EPI>, hipFuncAttributeMaxDynamicSharedMemorySize, C::LDS) != hipSuccess) return OP_ELAUNCH;
+    if (hipFuncSetAttribute((const void*)k_gemm8<C, EPI, HB, DUAL>, hipFuncAttributeMaxDynamicSharedMemorySize, C::LDS) != hipSuccess) return OP_ELAUNCH;
     int dev = 0; hipDeviceProp_t prop;
     if (hipGetDevice(&dev) != hipSuccess || hipGetDeviceProperties(&prop, dev) != hipSuccess) return OP_ELAUNCH;
     n_cu = prop.multiProcessorCount;
@@ -356,7 +388,8 @@ static int launch_cfg(GemmArgs a, hipStream_t s) {
   const long per_xcd = (tiles + 7) / 8;
   if (g8n > per_xcd) g8n = (int)per_xcd;
   if (g8n < 1) g8n = 1;
-  hipLaunchKernelGGL((k_gemm8<C, EPI>), dim3(g8n * 8), dim3(512), C::LDS, s, a, g8n);
+  if (g_g8n_cap > 0 && g8n > g_g8n_cap) g8n = g_g8n_cap;      // experiment hook: fewer work-groups per XCD
+  hipLaunchKernelGGL((k_gemm8<C, EPI, HB, DUAL>), dim3(g8n * 8), dim3(512), C::LDS, s, a, g8n, g_dph_groups, g_dph_sleeps);
   return launch_status();
 }
 
@@ -367,6 +400,7 @@ template <class C>
 static bool eligible(const GemmArgs& a, int epi) {
   if (a.M % C::BM || a.N % C::BN || a.K % 128 || a.lda % 8 || a.ldb % 8) return false;
   if ((size_t)C::BM * a.lda * 2 >= (1ull << 31) || (size_t)C::BN * a.ldb * 2 >= (1ull << 31)) return false;      // 32-bit per-lane source offsets
+  if (epi == ONEPROT_EPI_GELU_BWD && a.bias) return false;
   if (epi == ONEPROT_EPI_QKV_ROPE) {
     if (a.hd != 32 && a.hd != 64) return false;
     if ((C::NTW * 16) % a.hd) return false;                // a head must not straddle the wave's column block
@@ -378,18 +412,24 @@ static bool eligible(const GemmArgs& a, int epi) {
 
 template <class C>
 static int launch_epi(int epi, const GemmArgs& a, hipStream_t s) {
+  const bool hb = a.bias != nullptr, dual = a.out1 != nullptr;
   switch (epi) {
-    case ONEPROT_EPI_BF16: return launch_cfg<C, ONEPROT_EPI_BF16>(a, s);
-    case ONEPROT_EPI_F32: return launch_cfg<C, ONEPROT_EPI_F32>(a, s);
-    case ONEPROT_EPI_BIAS_GELU: return launch_cfg<C, ONEPROT_EPI_BIAS_GELU>(a, s);
-    case ONEPROT_EPI_BIAS_RESID: return launch_cfg<C, ONEPROT_EPI_BIAS_RESID>(a, s);
-    case ONEPROT_EPI_GELU_BWD: return launch_cfg<C, ONEPROT_EPI_GELU_BWD>(a, s);
-    case ONEPROT_EPI_QKV_ROPE: return launch_cfg<C, ONEPROT_EPI_QKV_ROPE>(a, s);
+    case ONEPROT_EPI_BF16: return hb ? launch_cfg<C, ONEPROT_EPI_BF16, true, false>(a, s) : launch_cfg<C, ONEPROT_EPI_BF16, false, false>(a, s);
+    case ONEPROT_EPI_F32: return hb ? launch_cfg<C, ONEPROT_EPI_F32, true, false>(a, s) : launch_cfg<C, ONEPROT_EPI_F32, false, false>(a, s);
+    case ONEPROT_EPI_BIAS_GELU: return dual ? launch_cfg<C, ONEPROT_EPI_BIAS_GELU, true, true>(a, s) : launch_cfg<C, ONEPROT_EPI_BIAS_GELU, true, false>(a, s);
+    case ONEPROT_EPI_BIAS_RESID:
+      if (hb) return dual ? launch_cfg<C, ONEPROT_EPI_BIAS_RESID, true, true>(a, s) : launch_cfg<C, ONEPROT_EPI_BIAS_RESID, true, false>(a, s);
+      return dual ? launch_cfg<C, ONEPROT_EPI_BIAS_RESID, false, true>(a, s) : launch_cfg<C, ONEPROT_EPI_BIAS_RESID, false, false>(a, s);
+    case ONEPROT_EPI_GELU_BWD: return launch_cfg<C, ONEPROT_EPI_GELU_BWD, false, false>(a, s);
+    case ONEPROT_EPI_QKV_ROPE: return hb ? launch_cfg<C, ONEPROT_EPI_QKV_ROPE, true, false>(a, s) : launch_cfg<C, ONEPROT_EPI_QKV_ROPE, false, false>(a, s);
     default: return OP_EINVAL;
   }
 }
 
 }  // namespace g8
+
+// experiment hook (tools/ab/g8_ab.py): de-phasing of the persistent work-groups
+extern "C" void oneprot_gemm8_dephase(int groups, int sleeps) { g8::g_dph_groups = groups & 0xffff; g8::g_dph_sleeps = sleeps; g8::g_g8n_cap = groups >> 16; }
 
 // cfg 0: 256 x 256, cfg 1: 256 x 320.  Returns G8_NOT_ELIGIBLE when the problem is not made of whole tiles of that configuration or has fewer
 // than `min_tiles` of them (a persistent work-group per CU only pays when most CUs get a tile).

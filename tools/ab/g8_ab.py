@@ -10,6 +10,9 @@ B, L, H, hd = 256, 512, 20, 32
 d, f, T = 640, 2560, 256 * 512
 rounds = int(sys.argv[1]) if len(sys.argv) > 1 else 3
 shapes = [int(x) for x in os.environ.get("G8_SHAPES", "-1,40,41").split(",")]
+import ctypes
+_dph = hip.lib().oneprot_gemm8_dephase; _dph.argtypes = [ctypes.c_int, ctypes.c_int]; _dph.restype = None
+DPH = [tuple(int(v) for v in x.split(":")) for x in os.environ.get("G8_DPH", "1:0").split(",")]      # groups:sleeps variants of the 8-phase columns
 g = torch.Generator(device="cuda").manual_seed(0)
 rnd = lambda *s: torch.randn(*s, device="cuda", generator=g)
 cos = torch.rand(L, hd // 2, device="cuda"); sin = torch.rand(L, hd // 2, device="cuda")
@@ -49,20 +52,22 @@ def timeit(fn, iters=5):
     for _ in range(iters): fn()
     e1.record(); torch.cuda.synchronize()
     return e0.elapsed_time(e1) / iters
-cols = [(s, False) for s in shapes] + [(s, True) for s in shapes if s >= 40]
+cols = [(s, False, DPH[0]) for s in shapes] + [(s, False, dp) for s in shapes if s >= 40 for dp in DPH[1:]] + [(s, True, DPH[0]) for s in shapes if s >= 40]
 res = {(c, k): [] for c in cases for k in cols}
 for r in range(rounds):
     for c, (fn, fl) in cases.items():
-        for (s, noepi) in cols:
-            hip.query("oneprot_gemm_tune", 256 * (78 if noepi else 1), 0)
+        for (s, noepi, dp) in cols:
+            hip.query("oneprot_gemm_tune", 256 * (78 if noepi else (2 if os.environ.get("G8_NT") == "1" and s >= 40 else 1)), 0)
             hip.query("oneprot_gemm_force_shape", s)
-            res[(c, (s, noepi))].append(timeit(fn))
+            _dph(*dp)
+            res[(c, (s, noepi, dp))].append(timeit(fn))
 hip.query("oneprot_gemm_tune", 256, 0)
 hip.query("oneprot_gemm_force_shape", -1)
+_dph(1, 0)
 print("median ms per launch (TFLOP/s)")
 for c, (fn, fl) in cases.items():
     row = []
     for k in cols:
         m = statistics.median(res[(c, k)])
-        row.append(f"s{k[0]}{'noepi' if k[1] else ''}:{m:.3f}({fl / m / 1e9:.0f})")
+        row.append(f"s{k[0]}{'noepi' if k[1] else ''}{'' if k[2] == DPH[0] else '/d%d:%d' % k[2]}:{m:.3f}({fl / m / 1e9:.0f})")
     print(f"{c:36s} " + " ".join(row), flush=True)
