@@ -14,9 +14,10 @@ RCCL) before anything touches the GPU, or runs as one of them when a launcher ha
 Workloads (all weak-scaling: `--batch` pairs per GPU per modality, default 256; reference default model flags):
   struct_token (default)  cfg-2 (N=1) / cfg-3 (N=8): ESM-2-150M x2, L=512; sequence encoder frozen, struct-token encoder trainable
   text                    cfg-4: ESM-2-150M (L=512, frozen) <-> BERT-base text tower (T=256, frozen: text.yaml), heads train
-  roundrobin              cfg-5 without the pocket/ProNet modality: ESM-2-650M anchor (attention1d pooling, linear head, frozen,
-                          train_ddp_1.yaml:45-49) against struct_token (ESM-2-35M, trainable) and text (BERT-base, frozen) in one
-                          mixed batch -> two optimiser sub-steps per step
+  roundrobin              cfg-5: ESM-2-650M anchor (attention1d pooling, linear head, frozen, train_ddp_1.yaml:45-49) against struct_token
+                          (ESM-2-35M, trainable), text (BERT-base, frozen) and pocket in one mixed batch -> three optimiser sub-steps per step.
+                          The pocket modality runs through StructEncoder (head / normalisation / logit scale on the HIP kernels) around a
+                          STAND-IN opaque torch encoder: the reference's ProNet GNN is un-vendored third-party code and is not reproduced
 
 Extra objects on the JSON line:
   roofline     dominant kernel = the bf16 MFMA NT GEMM with the bias+erf-GELU epilogue (FFN-1 launches): algorithmic FLOPs (2*M*N*K of every
@@ -42,6 +43,7 @@ import time
 ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, ROOT)
 
+PROFILE_ROUND = "r03"         # committed rocprofv3 summaries this file quotes (profiles/<round>_*.json, tools/profile_round.sh)
 PEAK_BF16_TFLOPS = 2500.0
 PEAK_HBM_GBS = 8000.0
 ESM = {"8M": "facebook/esm2_t6_8M_UR50D", "35M": "facebook/esm2_t12_35M_UR50D", "150M": "facebook/esm2_t30_150M_UR50D", "650M": "facebook/esm2_t33_650M_UR50D"}
@@ -131,6 +133,11 @@ def build_workload(args, dev, rank):
         comps["text"] = TextEncoder("microsoft/BiomedNLP-BiomedBERT-base-uncased-abstract-fulltext", output_dim=1024, pooling_type="cls", proj_type="mlp",
                                     use_logit_scale=True, learnable_logit_scale=False, frozen=True, use_lora=False)
         specs["text"] = dict(kind="bert", pooling="cls", proj_type="mlp", use_logit_scale=True)
+    if rr:       # pocket.yaml: StructEncoder(encoder=<opaque GNN>, proj_type linear, logit scale on); the GNN itself is a labelled stand-in
+        from src.models.components.struct_graph_encoder import StructEncoder
+        from oneprot_amd.data import StandInGraphEncoder
+        comps["pocket"] = StructEncoder(StandInGraphEncoder(16, 256, 1024), output_dim=1024, proj_type="linear", use_logit_scale=True, learnable_logit_scale=False, dropout=0.25)
+        specs["pocket"] = dict(kind="opaque_graph", proj_type="linear", use_logit_scale=True)
     module = OneProtLitModule(components=comps, optimizer=functools.partial(FusedAdam, lr=1e-3, weight_decay=0.0), loss_fn="CLIP",
                               use_l1_regularization=True, local_loss=True, gather_with_grad=True).to(dev)
     module.train()
@@ -140,7 +147,9 @@ def build_workload(args, dev, rank):
         if m == "sequence":
             continue
         seq_ids = synth_ids(B, L, 4, 23, gen, dev)
-        if m == "text":
+        if m == "pocket":
+            mod_ids = torch.randn(B, 64, 16, generator=gen).to(dev)          # 64 nodes x 16 descriptors per pocket: input of the stand-in encoder
+        elif m == "text":
             mod_ids = synth_ids(B, T, 5, 30521, gen, dev, cls=2, eos=3)
         else:
             mod_ids = synth_ids(B, L, 33, 52, gen, dev)
@@ -156,9 +165,9 @@ def build_workload(args, dev, rank):
         desc = f"seq<->text sub-step, {name_seq} (L={L}) / BERT-base text tower (T={T}), both transformers frozen (sequence.yaml:12, text.yaml:12)"
         metric = f"protein-pairs/sec/node (seq+text, L={L}/T={T}, {short(name_seq)} + BERT-base)"
     else:
-        desc = (f"mixed-batch round-robin step = 2 sub-steps (struct_token, text), anchor {name_seq} attention1d+linear frozen, struct_token {name_mod}, "
-                f"text BERT-base frozen, L={L}/T={T}; pocket (ProNet) modality not built")
-        metric = f"protein-pairs/sec/node (round-robin seq+struct-token / seq+text, anchor {short(name_seq)})"
+        desc = (f"mixed-batch round-robin step = 3 sub-steps (struct_token, text, pocket), anchor {name_seq} attention1d+linear frozen, struct_token {name_mod}, "
+                f"text BERT-base frozen, pocket = StructEncoder around a STAND-IN opaque torch encoder (ProNet is un-vendored, not reproduced), L={L}/T={T}")
+        metric = f"protein-pairs/sec/node (round-robin seq+struct-token / seq+text / seq+pocket[stand-in], anchor {short(name_seq)})"
     return dict(module=module, batch=batch, subs=subs, specs=specs, names=dict(seq=name_seq, mod=name_mod), desc=desc, metric=metric)
 
 
@@ -167,6 +176,8 @@ def step_flops(module, subs, L_of):
     total = 0
     for m, seq_ids, mod_ids in subs:
         for name, ids in (("sequence", seq_ids), (m, mod_ids)):
+            if not hasattr(module.network[name], "transformer"):      # opaque stand-in encoder: no transformer FLOPs to count
+                continue
             tr = module.network[name].transformer
             mult = 3 if tr.flat.requires_grad else 1
             total += ids.shape[0] * tower_fwd_flops(tr, ids.shape[1]) * mult
@@ -215,8 +226,8 @@ def cpu_baseline(work, sample_pairs, threads):
     torch.set_num_threads(threads)
     module, subs, specs = work["module"], work["subs"], work["specs"]
     sds = {k: {n: v.detach().cpu() for n, v in enc.state_dict().items()} for k, enc in module.network.items()}
-    cfgs = {k: tower_cfg(enc.transformer) for k, enc in module.network.items()}
-    frozen = tuple(k for k, enc in module.network.items() if not enc.transformer.flat.requires_grad)
+    cfgs = {k: (tower_cfg(enc.transformer) if hasattr(enc, "transformer") else None) for k, enc in module.network.items()}
+    frozen = tuple(k for k, enc in module.network.items() if hasattr(enc, "transformer") and not enc.transformer.flat.requires_grad)
     n = sample_pairs
     batches = [{m: (s[:n].cpu(), x[:n].cpu()) for m, s, x in subs}]
     run = lambda: O.train_round_robin(batches, sds, cfgs, specs, use_l1=True, frozen=frozen)      # one sub-step per modality, clip 1.0, Adam
@@ -289,6 +300,7 @@ def main():
     for _ in range(args.warmup):
         module.training_step(batch, 0)
     barrier()
+    xt = D.ExchangeTimer.enable() if world > 1 else None
     # live per-launch timing of the dominant kernel (FFN-1 GEMM, bias+GELU epilogue) with events on the launch stream
     hip.profile_begin({"oneprot_gemm_bf16_nt": hip.EPI_BIAS_GELU})
     t0 = time.perf_counter()
@@ -297,6 +309,14 @@ def main():
     barrier()
     elapsed = time.perf_counter() - t0
     launches = hip.profile_end()["oneprot_gemm_bf16_nt"]
+    exchange = None
+    if xt is not None:        # per-rank exchange time per step: feature all-gather + its reduce-scatter + the un-hidden part of the gradient all-reduce
+        parts = {k: round(v / args.steps, 3) for k, v in xt.totals_ms().items()}
+        D.ExchangeTimer.disable()
+        mine = {"rank": rank, "exchange_ms": round(sum(parts.values()), 3), "parts": parts}
+        box = [None] * world
+        torch.distributed.all_gather_object(box, mine)
+        exchange = box
     el = torch.tensor([elapsed], device=dev, dtype=torch.float64)
     if world > 1:
         torch.distributed.all_reduce(el, op=torch.distributed.ReduceOp.MAX)
@@ -319,15 +339,21 @@ def main():
             torch.cuda.synchronize()
         fwd_ms = e0.elapsed_time(e1) / reps
         fwd_tf = seq_ids.shape[0] * tower_fwd_flops(seq_tr, seq_ids.shape[1]) / (fwd_ms * 1e-3) / 1e12
-        mfma_busy = None
+        # MFMA-busy % comes from a committed rocprofv3 PMC pass (counters cannot be read from inside this process): quoted only when this run IS the
+        # profiled workload (model, batch, L), and labelled with its source
+        mfma_busy, mfma_src = None, None
         try:
-            with open(os.path.join(ROOT, "profiles", "r02_encoder_fwd_mfma_busy.json")) as f:
-                mfma_busy = json.load(f)["mfma_busy_pct"]
+            with open(os.path.join(ROOT, "profiles", f"{PROFILE_ROUND}_encoder_fwd_mfma_busy.json")) as f:
+                mj = json.load(f)
+            wl = mj.get("workload", {"model": ESM["150M"], "batch": 256, "seq_len": 512})
+            if (wl["model"], wl["batch"], wl["seq_len"]) == (work["names"]["seq"], seq_ids.shape[0], seq_ids.shape[1]):
+                mfma_busy = mj["mfma_busy_pct"]
+                mfma_src = f"profiles/{PROFILE_ROUND}_encoder_fwd_mfma_busy.json (rocprofv3 --pmc SQ_VALU_MFMA_BUSY_CYCLES GRBM_GUI_ACTIVE of tools/encoder_fwd_only.py; not measured by this run)"
         except Exception:
             pass
         extras["encoder_fwd"] = {"what": f"{work['names']['seq']} forward, {seq_ids.shape[0]} x L={seq_ids.shape[1]} (embedding + {seq_tr.n_layers} layers, no pooling head)",
                                  "ms": round(fwd_ms, 3), "achieved": round(fwd_tf, 1), "unit": "TFLOP/s", "peak": PEAK_BF16_TFLOPS,
-                                 "frac": round(fwd_tf / PEAK_BF16_TFLOPS, 4), "mfma_busy_pct": mfma_busy, "target_frac": 0.40}
+                                 "frac": round(fwd_tf / PEAK_BF16_TFLOPS, 4), "mfma_busy_pct": mfma_busy, "mfma_busy_source": mfma_src, "target_frac": 0.40}
     if not args.no_extras:
         # ---- one extra step with every kernel family bracketed by events (outside the timed region: the brackets cost launch time)
         hip.profile_begin({k: None for k in ("oneprot_gemm_bf16_nt", "oneprot_gemm_bf16_tn", "oneprot_attn_fwd", "oneprot_attn_bwd", "oneprot_layernorm_fwd",
@@ -355,13 +381,13 @@ def main():
         traffic, traffic_src, traffic_alg = None, None, None
         if args.pair == "struct_token" and shapes == [(B * args.seq_len, 2560, 640)]:
             try:
-                with open(os.path.join(ROOT, "profiles", "r02_pmc_traffic.json")) as f:
+                with open(os.path.join(ROOT, "profiles", f"{PROFILE_ROUND}_pmc_traffic.json")) as f:
                     tj = json.load(f)
                 n2 = sum(1 for _, sc in launches if sc[-1] >= 5)
                 n1 = len(launches) - n2
                 traffic = (n2 * tj["ffn1"]["traffic_bytes_per_launch"] + n1 * tj["ffn1fwd"]["traffic_bytes_per_launch"]) / max(len(launches), 1) / 1e9
                 traffic_alg = (n2 * tj["ffn1"]["algorithmic_bytes_per_launch"] + n1 * tj["ffn1fwd"]["algorithmic_bytes_per_launch"]) / max(len(launches), 1) / 1e9
-                traffic_src = f"r02_pmc_traffic.json; {n2} launches with two bf16 outputs at {tj['ffn1']['traffic_bytes_per_launch'] / 1e9:.2f} GB, {n1} with one at {tj['ffn1fwd']['traffic_bytes_per_launch'] / 1e9:.2f} GB"
+                traffic_src = f"{PROFILE_ROUND}_pmc_traffic.json; {n2} launches with two bf16 outputs at {tj['ffn1']['traffic_bytes_per_launch'] / 1e9:.2f} GB, {n1} with one at {tj['ffn1fwd']['traffic_bytes_per_launch'] / 1e9:.2f} GB"
             except Exception:
                 pass
         cfg_tag = {"struct_token": "cfg-2" if world == 1 else "cfg-3-shaped", "text": "cfg-4-shaped", "roundrobin": "cfg-5-shaped"}[args.pair]
@@ -377,7 +403,7 @@ def main():
             "roofline": {"bound": "mfma", "kernel": "k_gemm_nt<BIAS_GELU> FFN-1 launches " + ", ".join(f"[{m}x{k}]x[{n}x{k}]^T" for m, n, k in shapes),
                          "achieved": round(achieved, 1), "peak": PEAK_BF16_TFLOPS, "unit": "TFLOP/s", "frac": round(achieved / PEAK_BF16_TFLOPS, 4),
                          "traffic": round(traffic, 3) if traffic else None,
-                         "traffic_unit": f"GB/launch (rocprofv3 PMC FETCH_SIZE x2 + WRITE_SIZE, profiles/{traffic_src}; algorithmic {traffic_alg:.2f} GB/launch)" if traffic else None,
+                         "traffic_unit": f"GB/launch, from a committed profile, not this run (rocprofv3 PMC FETCH_SIZE x2 + WRITE_SIZE, profiles/{traffic_src}; algorithmic {traffic_alg:.2f} GB/launch)" if traffic else None,
                          "launches_timed": len(launches), "avg_launch_ms": round(gemm_s / max(len(launches), 1) * 1e3, 4),
                          "flops_per_launch": gemm_flops / max(len(launches), 1),
                          # the same launches against the HBM roof: A + W read once, one bf16 output (two with the GELU' output) written once.  With two
@@ -387,6 +413,9 @@ def main():
                                       "algorithmic_GB_per_launch": round(alg_bytes / max(len(launches), 1) / 1e9, 3)}},
         }
         out.update(extras)
+        if exchange is not None:
+            out["exchange"] = {"what": "per rank, ms per step on the launch stream: packed feature all-gather + reduce-scatter backward + the part of the gradient all-reduce not hidden under the backward",
+                               "per_rank": exchange}
         if world == 1 and not args.no_cpu_baseline:
             threads = min(len(os.sched_getaffinity(0)), 16)
             out["cpu_baseline"] = cpu_baseline(work, args.cpu_sample_pairs, threads)

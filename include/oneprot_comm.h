@@ -6,6 +6,7 @@
  *   oneprot_comm_all_gather      torch.distributed.nn.all_gather / dist.all_gather of the features   ref src/models/components/loss.py:31-44
  *   oneprot_comm_reduce_scatter  the autograd backward of that gather (sum of the slice gradients)    ref loss.py:31-33 (torch.distributed.nn)
  *   oneprot_comm_all_reduce      Lightning DDP's gradient all-reduce (mean)                           ref configs/trainer/ddp.yaml:12
+ *   oneprot_comm_send_recv       the SigLIP neighbour exchange (isend + irecv pairs)                 ref loss.py:116-154 (batch_isend_irecv)
  *   oneprot_comm_init / _destroy process-group bootstrap                                             ref src/distributed.py:41-60 + Lightning
  *
  * One communicator per process (one process per GPU); the 128-byte unique id is created on rank 0 (oneprot_comm_unique_id) and handed to the
@@ -35,6 +36,13 @@ int oneprot_comm_all_gather(void* comm, const void* send, void* recv, size_t cou
 int oneprot_comm_reduce_scatter(void* comm, const void* send, void* recv, size_t recv_count, int dtype, void* stream);
 /* in place */
 int oneprot_comm_all_reduce(void* comm, void* buf, size_t count, int dtype, int op, void* stream);
+/* Point-to-point exchange over one xGMI link pair: `count` elements of `send` go to rank `to_rank` while `count` elements from rank `from_rank`
+   land in `recv`, as ONE grouped RCCL operation (ncclGroupStart / ncclSend / ncclRecv / ncclGroupEnd), so that every rank may call it with its own
+   (to, from) pair without deadlock.  send == NULL or recv == NULL skips that half; to_rank / from_rank may be the caller itself.  Several calls
+   bracketed by oneprot_comm_group_begin / _end form one group (the bidirectional SigLIP step: two sends and two receives in flight together). */
+int oneprot_comm_send_recv(void* comm, const void* send, int to_rank, void* recv, int from_rank, size_t count, int dtype, void* stream);
+int oneprot_comm_group_begin(void);
+int oneprot_comm_group_end(void);
 
 #ifdef __cplusplus
 }

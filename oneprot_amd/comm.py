@@ -22,6 +22,9 @@ _SIGS = {
     "oneprot_comm_all_gather": (c_int, [c_void_p, c_void_p, c_void_p, c_size_t, c_int, c_void_p]),
     "oneprot_comm_reduce_scatter": (c_int, [c_void_p, c_void_p, c_void_p, c_size_t, c_int, c_void_p]),
     "oneprot_comm_all_reduce": (c_int, [c_void_p, c_void_p, c_size_t, c_int, c_int, c_void_p]),
+    "oneprot_comm_send_recv": (c_int, [c_void_p, c_void_p, c_int, c_void_p, c_int, c_size_t, c_int, c_void_p]),
+    "oneprot_comm_group_begin": (c_int, []),
+    "oneprot_comm_group_end": (c_int, []),
 }
 _lib = None
 
@@ -75,6 +78,8 @@ class RcclComm:
 
     def __init__(self, nranks: int, rank: int, uid: bytes):
         self.nranks, self.rank = nranks, rank
+        if not isinstance(uid, (bytes, bytearray)) or len(uid) != ID_BYTES:      # the C side copies ID_BYTES: a short id would be read past its end
+            raise CommError(f"unique id must be {ID_BYTES} bytes (oneprot_comm.unique_id() on rank 0), got {len(uid) if hasattr(uid, '__len__') else type(uid)}")
         h = c_void_p()
         _check(lib().oneprot_comm_init(ctypes.byref(h), nranks, rank, ctypes.c_char_p(uid)), "oneprot_comm_init")
         self._h = h
@@ -99,6 +104,23 @@ class RcclComm:
         assert buf.is_contiguous()
         _check(lib().oneprot_comm_all_reduce(self._h, buf.data_ptr(), buf.numel(), _dtype(buf), AVG if average else SUM, self._stream()), "oneprot_comm_all_reduce")
         return buf
+
+    def exchange(self, pairs, stream=None):
+        """pairs: [(send or None, to_rank, recv or None, from_rank), ...] -- all of them in flight together as one RCCL group on `stream`
+        (default: the current stream).  Every tensor of a pair has the same element count and dtype."""
+        st = self._stream() if stream is None else stream
+        _check(lib().oneprot_comm_group_begin(), "oneprot_comm_group_begin")
+        try:
+            for send, to, recv, frm in pairs:
+                ref = send if send is not None else recv
+                assert (send is None or send.is_contiguous()) and (recv is None or recv.is_contiguous())
+                _check(lib().oneprot_comm_send_recv(self._h, None if send is None else send.data_ptr(), int(to), None if recv is None else recv.data_ptr(), int(frm),
+                                                    ref.numel(), _dtype(ref), st), "oneprot_comm_send_recv")
+        finally:
+            _check(lib().oneprot_comm_group_end(), "oneprot_comm_group_end")
+
+    def send_recv(self, send, to_rank, recv, from_rank, stream=None):
+        self.exchange([(send, to_rank, recv, from_rank)], stream)
 
     def destroy(self):
         if self._h:

@@ -18,6 +18,11 @@ hipcc --offload-arch=gfx950 -shared -fPIC -o ../liboneprot_hip.so $OBJS
 echo "built $(cd .. && pwd)/liboneprot_hip.so"
 # RCCL wrappers (include/oneprot_comm.h) in their own library, so that the kernel library carries no RCCL dependency
 if [ ! -f ../liboneprot_comm.so ] || [ comm.cpp -nt ../liboneprot_comm.so ] || [ ../../include/oneprot_comm.h -nt ../liboneprot_comm.so ]; then
-  hipcc -O2 -fPIC -shared -std=c++17 comm.cpp -o ../liboneprot_comm.so -L/opt/rocm/lib -lrccl
-  echo "built $(cd .. && pwd)/liboneprot_comm.so"
+  ROCM_LIB="${ROCM_PATH:-/opt/rocm}/lib"
+  if [ ! -e "$ROCM_LIB/librccl.so" ]; then
+    echo "liboneprot_comm.so NOT built: $ROCM_LIB/librccl.so not found (set ROCM_PATH); the kernel library above is complete, only oneprot_amd.comm.RcclComm is unavailable" >&2
+  else
+    hipcc -O2 -fPIC -shared -std=c++17 comm.cpp -o ../liboneprot_comm.so -L"$ROCM_LIB" -lrccl
+    echo "built $(cd .. && pwd)/liboneprot_comm.so"
+  fi
 fi

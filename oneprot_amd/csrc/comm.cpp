@@ -62,3 +62,20 @@ extern "C" int oneprot_comm_all_reduce(void* comm, void* buf, size_t count, int 
   if (!comm || !buf || count == 0 || !to_nccl_type(dtype, &t) || (op != ONEPROT_COMM_SUM && op != ONEPROT_COMM_AVG)) return COMM_EINVAL;
   return ncclAllReduce(buf, buf, count, t, op == ONEPROT_COMM_AVG ? ncclAvg : ncclSum, (ncclComm_t)comm, (hipStream_t)stream) == ncclSuccess ? COMM_OK : COMM_ERCCL;
 }
+
+extern "C" int oneprot_comm_group_begin(void) { return ncclGroupStart() == ncclSuccess ? COMM_OK : COMM_ERCCL; }
+extern "C" int oneprot_comm_group_end(void) { return ncclGroupEnd() == ncclSuccess ? COMM_OK : COMM_ERCCL; }
+
+extern "C" int oneprot_comm_send_recv(void* comm, const void* send, int to_rank, void* recv, int from_rank, size_t count, int dtype, void* stream) {
+  ncclDataType_t t;
+  if (!comm || (!send && !recv) || count == 0 || !to_nccl_type(dtype, &t)) return COMM_EINVAL;
+  int n = 0;
+  if (ncclCommCount((ncclComm_t)comm, &n) != ncclSuccess) return COMM_ERCCL;
+  if ((send && (to_rank < 0 || to_rank >= n)) || (recv && (from_rank < 0 || from_rank >= n))) return COMM_EINVAL;
+  if (ncclGroupStart() != ncclSuccess) return COMM_ERCCL;
+  bool ok = true;
+  if (send) ok = ok && ncclSend(send, count, t, to_rank, (ncclComm_t)comm, (hipStream_t)stream) == ncclSuccess;
+  if (recv) ok = ok && ncclRecv(recv, count, t, from_rank, (ncclComm_t)comm, (hipStream_t)stream) == ncclSuccess;
+  ok = (ncclGroupEnd() == ncclSuccess) && ok;
+  return ok ? COMM_OK : COMM_ERCCL;
+}

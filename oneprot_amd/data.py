@@ -74,6 +74,21 @@ class SyntheticPairs:
             yield seq.to(self.device), mod.to(self.device), self.modality, None
 
 
+class StandInGraphEncoder(torch.nn.Module):
+    """NOT ProNet.  A stand-in for the opaque `encoder` argument of StructEncoder (pocket / struct_graph modality, ref struct_graph_encoder.py:5-42;
+    the reference plugs in dig.threedgraph.method.ProNet, un-vendored third-party code that is not part of the hot path built here) so that the
+    mixed-batch scheduler can be exercised with a 4th modality of cfg-5's shape: per-node MLP on [B, nodes, in_dim] descriptors, mean over the
+    nodes, linear to `out_channels` -- plain torch modules under torch autograd, exactly how a user-supplied GNN would run."""
+
+    def __init__(self, in_dim=16, hidden=256, out_channels=1024):
+        super().__init__()
+        self.node = torch.nn.Linear(in_dim, hidden)
+        self.out = torch.nn.Linear(hidden, out_channels)
+
+    def forward(self, batch):
+        return self.out(torch.nn.functional.silu(self.node(batch)).mean(dim=1))
+
+
 def save_checkpoint(module, path):
     torch.save({"state_dict": {k: v.detach().cpu() for k, v in module.state_dict().items()}, "global_step": getattr(module, "global_step", 0)}, path)
 

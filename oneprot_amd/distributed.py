@@ -87,6 +87,49 @@ def mkdir(path):
             raise
 
 
+class ExchangeTimer:
+    """Per-rank time spent in the exchange steps of the data path, measured with events on the launch stream: the packed feature all-gather,
+    its reduce-scatter backward, and the part of the gradient all-reduce that is NOT hidden under the backward (from entering
+    allreduce_gradients until every handle has been waited for).  bench.py --gpus N prints it per rank so that a scaling curve explains itself.
+    Off by default (enable(): a handful of event records per step)."""
+    active = None
+
+    def __init__(self):
+        self.spans = {}
+
+    @classmethod
+    def enable(cls):
+        cls.active = cls()
+        return cls.active
+
+    @classmethod
+    def disable(cls):
+        cls.active = None
+
+    class _Span:
+        def __init__(self, timer, key):
+            self.timer, self.key = timer, key
+
+        def __enter__(self):
+            if self.timer is not None and torch.cuda.is_available():
+                self.e0, self.e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+                self.e0.record()
+            return self
+
+        def __exit__(self, *exc):
+            if self.timer is not None and torch.cuda.is_available():
+                self.e1.record()
+                self.timer.spans.setdefault(self.key, []).append((self.e0, self.e1))
+
+    @classmethod
+    def span(cls, key):
+        return cls._Span(cls.active, key)
+
+    def totals_ms(self):
+        torch.cuda.synchronize()
+        return {k: sum(a.elapsed_time(b) for a, b in v) for k, v in self.spans.items()}
+
+
 class GradOverlap:
     """Asynchronous mean-all-reduce of arena-gradient ranges issued from inside an encoder's backward (one RCCL call per ~6 layers), so
     the reduction of the upper layers runs under the backward of the lower ones.  `allreduce_gradients` waits for the handles of a
@@ -122,6 +165,11 @@ def allreduce_gradients(parameters, bucket_bytes=256 << 20, average=True):
     handful of RCCL calls sized for the per-link xGMI bandwidth (bucket_bytes), issued asynchronously and waited once."""
     if not is_dist_avail_and_initialized() or get_world_size() == 1:
         return
+    with ExchangeTimer.span("grad_allreduce_exposed"):
+        _allreduce_gradients(parameters, bucket_bytes, average)
+
+
+def _allreduce_gradients(parameters, bucket_bytes, average):
     world = get_world_size()
     use_avg = average and dist.get_backend() == "nccl"           # RCCL: ncclAvg inside the collective; gloo: divide, then SUM
     op = dist.ReduceOp.AVG if use_avg else dist.ReduceOp.SUM

@@ -374,7 +374,7 @@ class _EncodeFn(torch.autograd.Function):
         if ctx.need_tr_grad:
             saved = ctx.saved
             B, L, d = saved["B"], saved["L"], tr.d
-            gflat = torch.zeros(tr._total, device=dev)
+            gflat = _arena_grad_buffer(tr, dev)
             mean, rstd, wrow = ctx.fin
             g = torch.empty(B * L, d, device=dev)
             g16 = torch.empty(B * L, d, dtype=torch.bfloat16, device=dev)
@@ -418,6 +418,25 @@ class _EncodeFn(torch.autograd.Function):
         hg = list(hgrads) + [None] * (n_head - len(hgrads))
         eg = list(extra_grads) + [None] * (ctx.n_extra - len(extra_grads))
         return (None, None, gflat, None) + tuple(eg) + tuple(hg)
+
+
+def _arena_grad_buffer(tr, dev):
+    """The fp32 arena-gradient tensor of a backward pass.  ONE persistent buffer per encoder (592 MB at ESM-2-150M), zero-filled per use: the
+    gradient ranges handed to RCCL (distributed.GradOverlap) then sit at the same addresses in every step instead of wherever the caching allocator
+    put a fresh tensor.  Autograd receives a fresh VIEW of it (a view object nobody else holds is adopted as .grad without a copy); while an earlier
+    gradient still lives in the buffer -- a second application of the encoder in the same step (seqsim), or accumulation without zero_grad -- a
+    separate tensor is returned and autograd adds the two."""
+    buf = getattr(tr, "_gflat_buf", None)
+    if buf is not None and (buf.device != dev or buf.numel() != tr._total):
+        buf = None
+    g = tr.flat.grad
+    if buf is not None and g is not None and g.data_ptr() == buf.data_ptr():
+        return torch.zeros(tr._total, device=dev)
+    if buf is None:
+        buf = tr._gflat_buf = torch.zeros(tr._total, device=dev)
+    else:
+        buf.zero_()
+    return buf.view(-1)
 
 
 class _ProjNormFn(torch.autograd.Function):

@@ -77,6 +77,21 @@ _SIGS = {
     "oneprot_colsum_bf16": (I, [P, P, P, L64, I, I, P]),
 }
 
+# Expected element type of every pointer argument, in order (f = float32, h = bfloat16, l = int64, i = int32, b = uint8 workspace, * = stated by a
+# flag argument / epilogue id).  The C side validates shapes and alignment but cannot see a tensor's dtype, device or strides: a strided view or an
+# fp16 tensor would compute garbage silently, so the binding refuses them (HipKernelError) before the launch.
+_PTR_DTYPES = {
+    "oneprot_esm_embed_fwd": "lfff", "oneprot_esm_embed_bwd": "lfffb", "oneprot_bert_embed_fwd": "lffffffh", "oneprot_pool_fwd": "flf",
+    "oneprot_pool_bwd": "flfh", "oneprot_embed_scatter_sorted": "flllf", "oneprot_rowsum_f32": "ff", "oneprot_attnpool_fwd": "flffff",
+    "oneprot_attnpool_bwd": "fffffffb", "oneprot_layernorm_fwd": "*ffhfff", "oneprot_layernorm_bwd": "*f*fffffhffb", "oneprot_lnpool_fwd": "flffffffhf",
+    "oneprot_gemm_bf16_nt": "hhf**h*ff", "oneprot_gemm_bf16_tn": "hhffb", "oneprot_sgemm": "fff", "oneprot_attn_fwd": "hhhfhf",
+    "oneprot_attn_bwd": "hhhfhhfffhb", "oneprot_gelu_f32": "ff", "oneprot_gelu_bwd_f32": "fff", "oneprot_l2norm_fwd": "fff", "oneprot_l2norm_bwd": "ffff",
+    "oneprot_ce_fwd_bwd": "fff", "oneprot_siglip_fwd_bwd": "fff", "oneprot_diag_rank": "fii", "oneprot_abs_sum": "ffb", "oneprot_l1_bwd": "fff",
+    "oneprot_scale_by_device_scalar": "ff", "oneprot_key_padding_bias": "lf", "oneprot_sumsq": "ffb", "oneprot_clip_coef": "fff", "oneprot_adam_step": "fffff",
+    "oneprot_cast_f32_to_bf16": "fh", "oneprot_transpose_cast_f32_to_bf16": "fh", "oneprot_colsum_bf16": "hfb",
+}
+_DT = {"f": torch.float32, "h": torch.bfloat16, "l": torch.int64, "i": torch.int32, "b": torch.uint8}
+
 _lib = None
 
 
@@ -110,6 +125,23 @@ def ptr(t):
     return t.data_ptr()
 
 
+def _check_tensors(name, args):
+    """device / layout / dtype of every tensor handed to `name` (see _PTR_DTYPES)"""
+    kinds = _PTR_DTYPES.get(name)
+    slot = 0
+    for a in args:
+        if not (a is None or isinstance(a, torch.Tensor)):
+            continue
+        if a is not None:
+            if not a.is_cuda:
+                raise HipKernelError(f"{name}: pointer argument {slot} is a {a.device} tensor; the HIP path has no CPU fallback")
+            if not a.is_contiguous():
+                raise HipKernelError(f"{name}: pointer argument {slot} is not contiguous (shape {tuple(a.shape)}, strides {a.stride()}); the kernels take dense row-major memory")
+            if kinds is not None and slot < len(kinds) and kinds[slot] != "*" and a.dtype != _DT[kinds[slot]]:
+                raise HipKernelError(f"{name}: pointer argument {slot} has dtype {a.dtype}, the entry point takes {_DT[kinds[slot]]}")
+        slot += 1
+
+
 def stream():
     return torch.cuda.current_stream().cuda_stream
 
@@ -141,6 +173,7 @@ def profile_end():
 def call(name, *args):
     """Invoke an int-returning entry point on the current torch stream; raise on a non-zero status."""
     fn = getattr(lib(), name)
+    _check_tensors(name, args)
     cargs = [ptr(a) if isinstance(a, torch.Tensor) or a is None else a for a in args]
     watch = _prof.get(name) if _prof is not None else None
     if watch is not None and (watch[0] is None or args[7] == watch[0]):

@@ -21,6 +21,11 @@ except ImportError:      # pragma: no cover
 from . import hip
 
 
+def _timer_span(key):
+    from .distributed import ExchangeTimer
+    return ExchangeTimer.span(key)
+
+
 # ------------------------------------------------------------------------------------------------- collectives
 _feature_comm = None        # optional oneprot_amd.comm.RcclComm: the feature exchange then runs through the C-ABI RCCL wrappers instead of torch.distributed
 
@@ -51,7 +56,8 @@ class _PackedAllGather(torch.autograd.Function):
     @staticmethod
     def forward(ctx, packed, world_size, group):
         ctx.world_size, ctx.group, ctx.rank = world_size, group, dist.get_rank(group)
-        return _all_gather_nograd(packed, world_size, group)
+        with _timer_span("feature_all_gather"):
+            return _all_gather_nograd(packed, world_size, group)
 
     @staticmethod
     def backward(ctx, grad_out):
@@ -63,7 +69,8 @@ class _PackedAllGather(torch.autograd.Function):
             dist.all_reduce(buf, op=dist.ReduceOp.SUM, group=ctx.group)
             return buf[ctx.rank].clone(), None, None
         grad_in = torch.empty(grad_out.shape[1:], dtype=grad_out.dtype, device=grad_out.device)
-        dist.reduce_scatter_tensor(grad_in, flat, op=dist.ReduceOp.SUM, group=ctx.group)      # RCCL: errors propagate, no silent 2x-larger fallback
+        with _timer_span("feature_reduce_scatter"):
+            dist.reduce_scatter_tensor(grad_in, flat, op=dist.ReduceOp.SUM, group=ctx.group)      # RCCL: errors propagate, no silent 2x-larger fallback
         return grad_in, None, None
 
 
@@ -192,55 +199,192 @@ class ClipLoss(nn.Module):
         return {"contrastive_loss": total_loss} if output_dict else total_loss
 
 
-# ------------------------------------------------------------------------------------------------- SigLIP (ring)
+# ------------------------------------------------------------------------------------------------- SigLIP (peer exchange)
+# The reference circulates the sequence-feature chunks around a ring of W-1 hops, each hop an isend/irecv pair between NEIGHBOURS, and its
+# autograd sends every chunk gradient back the same W-1 hops (ref loss.py:116-201,257-309) -- a pattern for switch-less ethernet rings.  xGMI
+# is point-to-point between every pair of GPUs of a node, so here
+#   * step k of the forward is ONE direct exchange with the chunk's owner (receive s of rank r+k resp. r-k, send the own s the other way): no
+#     relaying, every transfer crosses exactly one link;
+#   * the transfer of step k+1 is posted before the block of step k is computed (RCCL group on a side stream / asynchronous P2P requests), so
+#     it runs under the block's GEMMs and pointwise kernel;
+#   * a block's kernel produces its loss AND dloss/dlogits in one pass, so the chunk gradients exist at the end of the forward: the backward is
+#     ONE reduce-scatter (SUM) of the [W, B, D] buffer "gradient w.r.t. the chunk of rank j", instead of W-1 more hops.
+# The blocks are visited, and the loss is summed, in the reference's order (bidirectional: r+1, r-1, r+2, r-2, ...; else r-1, r-2, ...).
+class _PeerExchange:
+    """Point-to-point transport of the exchange: the C-ABI communicator (include/oneprot_comm.h: oneprot_comm_send_recv groups) when one is
+    installed with set_feature_comm, else torch.distributed P2P requests."""
+
+    def __init__(self):
+        self.comm = _feature_comm
+        self._side = None
+
+    def post(self, pairs):
+        """pairs: [(send, to_rank, recv, from_rank), ...]; returns a handle for wait().  Asynchronous with respect to the current stream."""
+        if self.comm is not None:
+            cur = torch.cuda.current_stream()
+            if self._side is None:
+                self._side = torch.cuda.Stream()
+            self._side.wait_stream(cur)                       # send data written, receive buffers no longer read
+            sends = [s_.detach().contiguous() for s_, _, _, _ in pairs]
+            self.comm.exchange([(snd, to, r, frm) for snd, (_, to, r, frm) in zip(sends, pairs)], stream=self._side.cuda_stream)
+            ev = torch.cuda.Event()
+            ev.record(self._side)
+            for snd, (_, _, r, _) in zip(sends, pairs):
+                snd.record_stream(self._side)
+                r.record_stream(self._side)
+            return ("event", ev)
+        staged = dist.get_backend() == "gloo" and pairs[0][0].is_cuda        # gloo moves host memory only (rehearsals with ranks sharing a GPU)
+        ops, back = [], []
+        for s_, to, r, frm in pairs:
+            snd = s_.detach().contiguous()
+            rcv = r
+            if staged:
+                snd, rcv = snd.cpu(), torch.empty(r.shape, dtype=r.dtype)
+                back.append((r, rcv))
+            ops.append(dist.P2POp(dist.isend, snd, to))
+            ops.append(dist.P2POp(dist.irecv, rcv, frm))
+        return ("reqs", dist.batch_isend_irecv(ops), back)
+
+    def wait(self, handle):
+        if handle[0] == "event":
+            torch.cuda.current_stream().wait_event(handle[1])
+            return
+        for req in handle[1]:
+            req.wait()
+        for dst, host in handle[2]:
+            dst.copy_(host)
+
+    def reduce_scatter(self, buf, rank):
+        """buf [W, B, D] -> sum over ranks of buf[rank]"""
+        if self.comm is not None:
+            return self.comm.reduce_scatter(buf)
+        if dist.get_backend() == "gloo":
+            tmp = buf.cpu() if buf.is_cuda else buf.clone()
+            dist.all_reduce(tmp, op=dist.ReduceOp.SUM)
+            return tmp[rank].to(buf.device)
+        out = torch.empty(buf.shape[1:], dtype=buf.dtype, device=buf.device)
+        dist.reduce_scatter_tensor(out, buf.view((-1,) + tuple(buf.shape[2:])), op=dist.ReduceOp.SUM)
+        return out
+
+
 def neighbour_exchange(from_rank, to_rank, tensor, group=None):
-    tensor_recv = torch.zeros_like(tensor)
-    ops = [dist.P2POp(dist.isend, tensor.contiguous(), to_rank, group=group), dist.P2POp(dist.irecv, tensor_recv, from_rank, group=group)]
-    for req in dist.batch_isend_irecv(ops):
-        req.wait()
-    return tensor_recv
+    """ref loss.py:116-132: send `tensor` to `to_rank`, return what `from_rank` sent (one grouped exchange)."""
+    x = _PeerExchange()
+    recv = torch.empty_like(tensor)
+    x.wait(x.post([(tensor, to_rank, recv, from_rank)]))
+    return recv
 
 
 def neighbour_exchange_bidir(left_rank, right_rank, tensor_to_left, tensor_to_right, group=None):
-    tensor_from_left = torch.zeros_like(tensor_to_right)
-    tensor_from_right = torch.zeros_like(tensor_to_left)
-    ops = [dist.P2POp(dist.isend, tensor_to_right.contiguous(), right_rank, group=group),
-           dist.P2POp(dist.isend, tensor_to_left.contiguous(), left_rank, group=group),
-           dist.P2POp(dist.irecv, tensor_from_right, right_rank, group=group),
-           dist.P2POp(dist.irecv, tensor_from_left, left_rank, group=group)]
-    for req in dist.batch_isend_irecv(ops):
-        req.wait()
-    return tensor_from_right, tensor_from_left
+    """ref loss.py:135-154: returns (tensor_from_right, tensor_from_left); both directions in flight together."""
+    x = _PeerExchange()
+    from_right, from_left = torch.empty_like(tensor_to_left), torch.empty_like(tensor_to_right)
+    x.wait(x.post([(tensor_to_right, right_rank, from_left, left_rank), (tensor_to_left, left_rank, from_right, right_rank)]))
+    return from_right, from_left
 
 
-class NeighbourExchange(torch.autograd.Function):
-    @staticmethod
-    def forward(ctx, from_rank, to_rank, group, tensor):
-        ctx.group, ctx.from_rank, ctx.to_rank = group, from_rank, to_rank
-        return neighbour_exchange(from_rank, to_rank, tensor, group=group)
+class _ExchangeFn(torch.autograd.Function):
+    """Differentiable peer exchange: the gradient of what arrived from src[i] travels back to it, i.e. the backward is the same exchange with
+    the roles of the peers swapped (the reference has two classes for this, NeighbourExchange and NeighbourExchangeBidir)."""
 
     @staticmethod
-    def backward(ctx, grad_output):
-        return (None, None, None) + (NeighbourExchange.apply(ctx.to_rank, ctx.from_rank, ctx.group, grad_output),)
+    def forward(ctx, dst, src, *tensors):
+        ctx.dst, ctx.src = dst, src
+        x = _PeerExchange()
+        recv = [torch.empty_like(t) for t in tensors]
+        x.wait(x.post([(t, d, r, s_) for t, d, r, s_ in zip(tensors, dst, recv, src)]))
+        return tuple(recv)
+
+    @staticmethod
+    def backward(ctx, *grads):
+        return (None, None) + _ExchangeFn.apply(ctx.src, ctx.dst, *[g.contiguous() for g in grads])
 
 
 def neighbour_exchange_with_grad(from_rank, to_rank, tensor, group=None):
-    return NeighbourExchange.apply(from_rank, to_rank, group, tensor)
-
-
-class NeighbourExchangeBidir(torch.autograd.Function):
-    @staticmethod
-    def forward(ctx, left_rank, right_rank, group, tensor_to_left, tensor_to_right):
-        ctx.group, ctx.left_rank, ctx.right_rank = group, left_rank, right_rank
-        return neighbour_exchange_bidir(left_rank, right_rank, tensor_to_left, tensor_to_right, group=group)
-
-    @staticmethod
-    def backward(ctx, *grad_outputs):
-        return (None, None, None) + NeighbourExchangeBidir.apply(ctx.right_rank, ctx.left_rank, ctx.group, *grad_outputs)
+    return _ExchangeFn.apply((to_rank,), (from_rank,), tensor)[0]
 
 
 def neighbour_exchange_bidir_with_grad(left_rank, right_rank, tensor_to_left, tensor_to_right, group=None):
-    return NeighbourExchangeBidir.apply(left_rank, right_rank, group, tensor_to_left, tensor_to_right)
+    from_left, from_right = _ExchangeFn.apply((right_rank, left_rank), (left_rank, right_rank), tensor_to_right, tensor_to_left)
+    return from_right, from_left
+
+
+class NeighbourExchange:
+    """ref loss.py:157-179 (callers use `.apply(from_rank, to_rank, group, tensor)`)"""
+    apply = staticmethod(lambda from_rank, to_rank, group, tensor: neighbour_exchange_with_grad(from_rank, to_rank, tensor, group))
+
+
+class NeighbourExchangeBidir:
+    """ref loss.py:182-197 (`.apply(left_rank, right_rank, group, tensor_to_left, tensor_to_right)`)"""
+    apply = staticmethod(lambda left_rank, right_rank, group, to_left, to_right: neighbour_exchange_bidir_with_grad(left_rank, right_rank, to_left, to_right, group))
+
+
+def _siglip_block_hip(m, c, logit_scale, logit_bias, negative_only, need_grad):
+    """One [B, B] block on the HIP kernels: (loss, dloss/dm, dloss/dc); the pointwise kernel leaves dloss/dlogits in the logits buffer."""
+    B, D = m.shape
+    logits = torch.empty(B, B, device=m.device)
+    hip.call("oneprot_sgemm", m, c, logits, B, B, D, 0, 0, float(logit_scale), 0)
+    loss = torch.zeros(1, device=m.device)
+    rw = torch.empty(B, device=m.device)
+    hip.call("oneprot_siglip_fwd_bwd", logits, loss, rw, B, 0.0 if logit_bias is None else float(logit_bias), 1 if negative_only else 0)
+    if not need_grad:
+        return loss.reshape(()), None, None
+    dm, dc = torch.empty_like(m), torch.empty_like(c)
+    hip.call("oneprot_sgemm", logits, c, dm, B, D, B, 0, 1, float(logit_scale), 0)
+    hip.call("oneprot_sgemm", logits, m, dc, B, D, B, 1, 1, float(logit_scale), 0)
+    return loss.reshape(()), dm, dc
+
+
+class _SigLipExchangeFn(torch.autograd.Function):
+    """Whole multi-rank SigLIP loss of one rank as ONE autograd node (see the section comment)."""
+
+    @staticmethod
+    def forward(ctx, m, s, logit_scale, logit_bias, rank, world, bidir, block):
+        m, s = m.detach().contiguous().float(), s.detach().contiguous().float()
+        need_grad = ctx.needs_input_grad[0] or ctx.needs_input_grad[1]
+        # peers in the reference's order of visits
+        if bidir:
+            nb, rem = divmod(world - 1, 2)
+            steps = [[(rank + k) % world, (rank - k) % world] for k in range(1, nb + 1)]
+            if rem:
+                steps.append([(rank - nb - 1) % world])
+        else:
+            steps = [[(rank - k) % world] for k in range(1, world)]
+        x = _PeerExchange()
+
+        def post(step):
+            # receive the chunk of every peer of the step; the own chunk goes to the rank that visits us at the same step (the mirror image)
+            bufs = [torch.empty_like(s) for _ in step]
+            return bufs, x.post([(s, (2 * rank - peer) % world, buf, peer) for peer, buf in zip(step, bufs)])
+
+        pending = post(steps[0])
+        loss, dm, ds_local = block(m, s, logit_scale, logit_bias, False, need_grad)
+        gbuf = None
+        if need_grad:
+            gbuf = torch.zeros((world,) + tuple(s.shape), device=s.device)
+            gbuf[rank] = ds_local
+        for i, step in enumerate(steps):
+            bufs, handle = pending
+            if i + 1 < len(steps):
+                pending = post(steps[i + 1])              # next transfer runs under this step's blocks
+            x.wait(handle)
+            for peer, chunk in zip(step, bufs):
+                l, dmi, dci = block(m, chunk, logit_scale, logit_bias, True, need_grad)
+                loss = loss + l
+                if need_grad:
+                    dm = dm + dmi
+                    gbuf[peer] = dci
+        ctx.rank, ctx.x = rank, x
+        if need_grad:
+            ctx.save_for_backward(dm, gbuf)
+        return loss
+
+    @staticmethod
+    def backward(ctx, gout):
+        dm, gbuf = ctx.saved_tensors
+        g = gout.reshape(()).to(dm)
+        ds = ctx.x.reduce_scatter(gbuf * g, ctx.rank)        # every rank scales ITS contributions by ITS upstream gradient
+        return dm * g, ds, None, None, None, None, None, None
 
 
 class _SigLipBlockFn(torch.autograd.Function):
@@ -274,7 +418,8 @@ class _SigLipBlockFn(torch.autograd.Function):
 
 
 class SigLipLoss(nn.Module):
-    """Sigmoid loss (https://arxiv.org/abs/2303.15343) with the reference's neighbour-exchange ring (ref loss.py:203-311)."""
+    """Sigmoid loss (https://arxiv.org/abs/2303.15343), ref loss.py:203-311.  Same constructor and call convention; across ranks the chunks are
+    exchanged directly with their owners and the chunk gradients return in one reduce-scatter (_SigLipExchangeFn)."""
 
     def __init__(self, cache_labels=False, rank=0, world_size=1, bidir=True, use_horovod=False):
         super().__init__()
@@ -286,32 +431,16 @@ class SigLipLoss(nn.Module):
         self.bidir = bidir
         self.prev_num_logits = 0
         self.labels = {}
+        self._block = _siglip_block_hip          # (m, chunk, scale, bias, negative_only, need_grad) -> (loss, dm, dchunk); CPU tests install the oracle's
 
     def _loss(self, modality_features, sequence_features, logit_scale, logit_bias=None, negative_only=False):
         return _SigLipBlockFn.apply(modality_features, sequence_features, logit_scale, logit_bias, negative_only)
 
     def forward(self, modality_features, sequence_features, logit_scale=1.0, logit_bias=None, output_dict=False):
-        loss = self._loss(modality_features, sequence_features, logit_scale, logit_bias)
         if self.world_size > 1:
-            right_rank = (self.rank + 1) % self.world_size
-            left_rank = (self.rank - 1 + self.world_size) % self.world_size
-            if self.bidir:
-                to_right = to_left = sequence_features
-                num_bidir, remainder = divmod(self.world_size - 1, 2)
-                for _ in range(num_bidir):
-                    recv = neighbour_exchange_bidir_with_grad(left_rank, right_rank, to_left, to_right)
-                    for f in recv:
-                        loss = loss + self._loss(modality_features, f, logit_scale, logit_bias, negative_only=True)
-                    to_left, to_right = recv
-                if remainder:
-                    recv = neighbour_exchange_with_grad(left_rank, right_rank, to_right)
-                    loss = loss + self._loss(modality_features, recv, logit_scale, logit_bias, negative_only=True)
-            else:
-                to_right = sequence_features
-                for _ in range(self.world_size - 1):
-                    from_left = neighbour_exchange_with_grad(left_rank, right_rank, to_right)
-                    loss = loss + self._loss(modality_features, from_left, logit_scale, logit_bias, negative_only=True)
-                    to_right = from_left
+            loss = _SigLipExchangeFn.apply(modality_features, sequence_features, float(logit_scale), logit_bias, self.rank, self.world_size, self.bidir, self._block)
+        else:
+            loss = self._loss(modality_features, sequence_features, logit_scale, logit_bias)
         return {"contrastive_loss": loss} if output_dict else loss
 
 

@@ -268,7 +268,7 @@ class OneProtLitModule(_Base):
 
     def on_validation_epoch_end(self):
         """ref oneprot_module.py:123-135"""
-        loss = self.val_loss.compute()
+        loss = self._epoch_val_loss()
         self.val_loss_best(loss)
         self.log("val/loss_best", self.val_loss_best.compute(), sync_dist=True, prog_bar=True)
         for name, metric in self.metrics.items():
@@ -280,9 +280,25 @@ class OneProtLitModule(_Base):
         if sched and self._owns_gradient_sync():        # what Lightning does for {"interval": "epoch", "monitor": "val/loss_best"} (ref oneprot_module.py:161-169)
             s = sched["scheduler"]
             if "metrics" in s.step.__code__.co_varnames:
-                s.step(self.val_loss_best.compute())
+                s.step(self.val_loss_best.compute())      # identical on every rank (_epoch_val_loss): the replicas take the same plateau decisions
             else:
                 s.step()
+        if self._owns_gradient_sync():
+            self.val_loss.reset()                          # per-epoch mean, as torchmetrics resets a logged metric at epoch end under Lightning
+
+    def _epoch_val_loss(self):
+        """Mean validation loss of the epoch over ALL ranks.  Under a Trainer `self.log(..., sync_dist=True)` / torchmetrics reduce it; without one
+        the running sum and count are all-reduced here -- each rank's local_loss value differs, and a rank-local value fed to ReduceLROnPlateau
+        would let the data-parallel replicas drift apart through different learning rates."""
+        m = self.val_loss
+        if not (self._owns_gradient_sync() and D.is_dist_avail_and_initialized() and D.get_world_size() > 1):
+            return m.compute()
+        import torch.distributed as dist
+        total = m.total if m.total is not None else torch.zeros(())
+        dev = total.device if dist.get_backend() != "nccl" or total.is_cuda else torch.device("cuda", torch.cuda.current_device())
+        buf = torch.stack([total.to(dev).double(), torch.tensor(float(m.count), dtype=torch.float64, device=dev)])
+        dist.all_reduce(buf, op=dist.ReduceOp.SUM)
+        return (buf[0] / buf[1].clamp(min=1.0)).float()
 
     def on_test_epoch_end(self):
         """ref oneprot_module.py:148-154"""

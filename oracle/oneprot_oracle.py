@@ -383,6 +383,27 @@ def train_substep(seq_ids: Tensor, mod_ids: Tensor, sd_seq: Dict[str, Tensor], s
                 grads=grads, grad_total_norm=total, new_params=new)
 
 
+def train_substep_seqsim(ids_a: Tensor, ids_b: Tensor, sd_seq: Dict[str, Tensor], cfg_seq: dict, seq_spec: dict, use_l1: bool = True, lr: float = 1e-3):
+    """The `seqsim` sub-step of ref oneprot_module.py:84-107 with `use_seqsim=True`: BOTH inputs go through the sequence encoder
+    (`forward(x, "seqsim")` maps to `network["sequence"]`, oneprot_module.py:67-71), i.e. ONE parameter set is applied twice before one backward;
+    its gradient is the sum over the two applications.  Then clip 1.0 and Adam step 1 on that one set."""
+    ps = {}
+    for k, v in sd_seq.items():
+        t = v.detach().clone()
+        if t.is_floating_point() and k != "norm.1.log_logit_scale" and "inv_freq" not in k:
+            t.requires_grad_(True)
+        ps[k] = t
+    feats = [encoder_features(seq_spec["kind"], ids, ps, cfg_seq, seq_spec["pooling"], seq_spec["proj_type"], seq_spec["use_logit_scale"]) for ids in (ids_a, ids_b)]
+    loss_c = clip_loss(feats[0], feats[1])
+    loss = loss_c + 0.01 * (feats[0].abs().mean() + feats[1].abs().mean()) if use_l1 else loss_c
+    loss.backward()
+    grads = {"seq." + k: t.grad for k, t in ps.items() if t.requires_grad and t.grad is not None}
+    total, clipped = clip_grad_norm(grads, 1.0)
+    new = {k: adam_first_step(ps[k[4:]].detach(), g, lr=lr) for k, g in clipped.items()}
+    return dict(features_a=feats[0].detach(), features_b=feats[1].detach(), loss_clip=loss_c.detach(), loss=loss.detach(), grads=grads,
+                grad_total_norm=total, new_params=new)
+
+
 def train_multi_substeps(seq_ids, mod_ids, sd_seq, sd_mod, cfg_seq, cfg_mod, seq_spec, mod_spec, n_steps, use_l1=True, frozen_seq=False, lr=1e-3):
     """n consecutive iterations of the loop body at ref oneprot_module.py:92-107 with ONE persistent torch.optim.Adam over all
     trainable tensors (ref configure_optimizers :157-170 + configs/model/default.yaml:2-6) and clip-norm 1.0 before every step.
@@ -415,7 +436,16 @@ def train_multi_substeps(seq_ids, mod_ids, sd_seq, sd_mod, cfg_seq, cfg_mod, seq
     return losses, {k: v.detach() for k, v in ps.items()}, {k: v.detach() for k, v in pm.items()}
 
 
+def standin_graph_encoder(x: Tensor, sd: Dict[str, Tensor], pre: str = "encoder.") -> Tensor:
+    """Functional twin of the bench's stand-in for the opaque pocket encoder (oneprot_amd.data.StandInGraphEncoder -- NOT ProNet, which is
+    un-vendored): silu(x W1^T + b1) averaged over the nodes, then W2."""
+    h = torch.nn.functional.silu(linear(x, sd[pre + "node.weight"], sd[pre + "node.bias"])).mean(dim=1)
+    return linear(h, sd[pre + "out.weight"], sd[pre + "out.bias"])
+
+
 def _features(spec: dict, ids: Tensor, sd: Dict[str, Tensor], cfg: dict) -> Tensor:
+    if spec["kind"] == "opaque_graph":      # StructEncoder (ref struct_graph_encoder.py:36-42) around the stand-in encoder, dropout off
+        return struct_encoder_features(standin_graph_encoder(ids, sd), sd, spec["proj_type"], spec["use_logit_scale"])
     return encoder_features(spec["kind"], ids, sd, cfg, spec["pooling"], spec["proj_type"], spec["use_logit_scale"])
 
 

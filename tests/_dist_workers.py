@@ -40,7 +40,8 @@ def clip_gather_worker(rank, world, port, golden_path, out_dir):
 
 
 def siglip_ring_worker(rank, world, port, golden_path, out_dir):
-    """SigLipLoss' neighbour-exchange ring (uni- and bi-directional, with autograd) with the block arithmetic swapped for the oracle's."""
+    """SigLipLoss across ranks (direct peer exchanges in the reference's visiting order, uni- and bi-directional; one reduce-scatter backward) with the
+    block arithmetic swapped for the oracle's; also the reference-named differentiable exchange helpers on their own."""
     D = _init(rank, world, port)
     from oneprot_amd import loss as L
     from oracle import oneprot_oracle as O
@@ -48,12 +49,32 @@ def siglip_ring_worker(rank, world, port, golden_path, out_dir):
     res = {}
     for bidir in (False, True):
         fn = L.SigLipLoss(cache_labels=True, rank=rank, world_size=world, bidir=bidir)
-        fn._loss = lambda m, s, scale, bias=None, negative_only=False: O.siglip_block(m, s, scale, bias, negative_only)
+
+        def oracle_block(m_, c_, scale, bias, negative_only, need_grad):      # the HIP block arithmetic swapped for the oracle's (no GPU here)
+            with torch.enable_grad():                                          # (called from inside an autograd node's forward)
+                mm, cc = m_.detach().requires_grad_(need_grad), c_.detach().requires_grad_(need_grad)
+                l = O.siglip_block(mm, cc, scale, bias, negative_only)
+                if not need_grad:
+                    return l.detach(), None, None
+                dm, dc = torch.autograd.grad(l, (mm, cc))
+            return l.detach(), dm, dc
+        fn._block = oracle_block
         m = g["m"][rank].clone().requires_grad_(True)
         s = g["s"][rank].clone().requires_grad_(True)
         loss = fn(m, s, logit_scale=1.0)
         loss.backward()
         res[f"siglip_bidir{int(bidir)}"] = (loss.detach(), m.grad.clone(), s.grad.clone())
+    # the helpers other code may import by the reference's names: values and the reverse path of the gradient
+    left, right = (rank - 1) % world, (rank + 1) % world
+    base = torch.arange(6, dtype=torch.float32).reshape(2, 3)
+    t = (base + 10 * rank).requires_grad_(True)
+    got = L.neighbour_exchange_with_grad(left, right, t)
+    assert torch.equal(got.detach(), base + 10 * left)
+    (got * (rank + 1)).sum().backward()
+    assert torch.equal(t.grad, torch.full((2, 3), float(right + 1)))
+    fr, fl = L.neighbour_exchange_bidir_with_grad(left, right, t.detach(), t.detach() + 1)
+    assert torch.equal(fr, base + 10 * right) and torch.equal(fl, base + 10 * left + 1)
+    assert torch.equal(L.NeighbourExchange.apply(left, right, None, t.detach()), base + 10 * left)
     torch.save(res, os.path.join(out_dir, f"siglip_rank{rank}.pt"))
     dist.barrier()
     dist.destroy_process_group()
@@ -72,5 +93,31 @@ def allreduce_worker(rank, world, port, out_dir):
     assert unused.grad is None
     torch.save({"mine": mine, "reduced": [p.grad.clone() for p in [big] + small]}, os.path.join(out_dir, f"ar_rank{rank}.pt"))
     assert D.get_rank() == rank and D.get_world_size() == world and D.is_main_process() == (rank == 0)
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+def val_plateau_worker(rank, world, port, out_dir):
+    """Standalone (no Trainer) validation epochs on two ranks whose LOCAL losses differ: the monitored value must be the global mean, the
+    ReduceLROnPlateau decisions -- hence the learning rates -- identical on every rank, and the running mean must restart every epoch."""
+    D = _init(rank, world, port)
+    import functools
+    from oneprot_amd.module import OneProtLitModule
+    comps = {"sequence": torch.nn.Linear(4, 4), "struct_token": torch.nn.Linear(4, 4)}
+    mod = OneProtLitModule(components=comps, optimizer=functools.partial(torch.optim.SGD, lr=1.0), loss_fn="CLIP",
+                           scheduler=functools.partial(torch.optim.lr_scheduler.ReduceLROnPlateau, mode="min", factor=0.5, patience=0, threshold=0.0))
+    opt = mod.optimizers()
+    mod.on_train_start()
+    # local epoch means: rank 0 sees an improvement in epoch 1 (3.0 -> 1.0), rank 1 a deterioration (3.0 -> 5.0); globally 3.0 -> 3.0 -> 2.0
+    local = [[3.0, 3.0], [1.0, 5.0], [2.0, 2.0]]
+    seen, lrs = [], []
+    for epoch in local:
+        for v in (epoch[rank], epoch[rank]):                      # two validation batches per epoch
+            mod.val_loss(torch.tensor(v))
+        mod.on_validation_epoch_end()
+        seen.append(float(mod.val_loss_best.compute()))
+        lrs.append(opt.param_groups[0]["lr"])
+        assert mod.val_loss.count == 0, "the epoch mean must restart"
+    torch.save({"seen": seen, "lrs": lrs}, os.path.join(out_dir, f"val_rank{rank}.pt"))
     dist.barrier()
     dist.destroy_process_group()

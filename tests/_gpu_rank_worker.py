@@ -13,6 +13,7 @@ import torch
 
 def main():
     rank, world, port, out_dir, golden = int(sys.argv[1]), int(sys.argv[2]), sys.argv[3], sys.argv[4], sys.argv[5]
+    loss_name = sys.argv[6] if len(sys.argv) > 6 else "CLIP"
     os.environ.update(RANK=str(rank), WORLD_SIZE=str(world), LOCAL_RANK="0", MASTER_ADDR="127.0.0.1", MASTER_PORT=port, ONEPROT_ALLOW_RANDOM_INIT="1")
     warnings.filterwarnings("ignore")
     from oneprot_amd import distributed as D
@@ -34,7 +35,7 @@ def main():
     seq = SequenceEncoder(p, output_dim=cfg["output_dim"], pooling_type="mean", proj_type="mlp", use_lora=False, frozen=False)
     st = StructTokenEncoder(p, output_dim=cfg["output_dim"], pooling_type="mean", proj_type="linear", use_logit_scale=True)
     seq.load_state_dict(g["sd_seq"]); st.load_state_dict(g["sd_st"])
-    module = OneProtLitModule(components={"sequence": seq, "struct_token": st}, optimizer=functools.partial(FusedAdam, lr=1e-3), loss_fn="CLIP",
+    module = OneProtLitModule(components={"sequence": seq, "struct_token": st}, optimizer=functools.partial(FusedAdam, lr=1e-3), loss_fn=loss_name,
                               use_l1_regularization=False, local_loss=True, gather_with_grad=True).to("cuda:0")
     B = g["seq_ids"].shape[0]
     per = B // world
@@ -46,7 +47,7 @@ def main():
     out = {"loss": float(loss.detach()), "gnorm": float(module.last_grad_norm), "overlap_calls": (ov.calls if ov is not None else 0),
            "w": module.network["struct_token"].state_dict()["transformer.encoder.layer.0.output.dense.weight"].cpu(),
            "emb": module.network["sequence"].state_dict()["transformer.embeddings.word_embeddings.weight"].cpu()}
-    torch.save(out, os.path.join(out_dir, f"w{world}_rank{rank}.pt"))
+    torch.save(out, os.path.join(out_dir, f"{loss_name}_w{world}_rank{rank}.pt"))
     if world > 1:
         torch.distributed.barrier()
         torch.distributed.destroy_process_group()

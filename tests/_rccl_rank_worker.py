@@ -94,6 +94,37 @@ def main():
     ((am * wm.to(dev)).sum() * (rank + 1) + (as_ * ws_.to(dev)).sum() * (rank + 1)).backward()
     assert torch.allclose(m2.grad.cpu(), tot * wm[rank * B:(rank + 1) * B], rtol=1e-6, atol=1e-6)
     assert torch.allclose(s2.grad.cpu(), tot * ws_[rank * B:(rank + 1) * B], rtol=1e-6, atol=1e-6)
+    # ---- point-to-point exchange of the C ABI (oneprot_comm_send_recv): to the right neighbour, from the left one (world 1: a self-exchange)
+    a = (torch.arange(8, dtype=torch.float32) + 100 * rank).to(dev)
+    b = torch.empty_like(a)
+    cm.send_recv(a, (rank + 1) % world, b, (rank - 1) % world)
+    torch.cuda.synchronize()
+    assert torch.equal(b.cpu(), torch.arange(8, dtype=torch.float32) + 100 * ((rank - 1) % world)), "send_recv"
+    c2, d2 = torch.empty_like(a), torch.empty_like(a)
+    cm.exchange([(a, (rank + 1) % world, c2, (rank - 1) % world), (a * 2, (rank - 1) % world, d2, (rank + 1) % world)])      # both directions in one group
+    torch.cuda.synchronize()
+    assert torch.equal(c2.cpu(), b.cpu()) and torch.equal(d2.cpu(), 2 * (torch.arange(8, dtype=torch.float32) + 100 * ((rank + 1) % world))), "grouped exchange"
+    if world > 1:
+        # ---- the whole multi-rank SigLIP loss (direct peer exchanges + reduce-scatter backward) with the HIP block kernels, on both transports,
+        # against the oracle's blocks evaluated for ALL ranks on the host; rank r back-propagates (r + 1) * loss_r (per-rank upstream scaling)
+        from oracle import oneprot_oracle as O
+        ms = [f[0].clone().requires_grad_(True) for f in feats]
+        ss = [f[1].clone().requires_grad_(True) for f in feats]
+        per = [O.siglip_block(ms[r], ss[r], 1.0, None, False) + sum(O.siglip_block(ms[r], ss[j], 1.0, None, True) for j in range(world) if j != r) for r in range(world)]
+        sum((r + 1) * per[r] for r in range(world)).backward()
+        for transport in ("rccl_c_abi", "torch_distributed"):
+            LM.set_feature_comm(cm if transport == "rccl_c_abi" else None)
+            for bidir in (True, False):
+                fn = LM.SigLipLoss(cache_labels=True, rank=rank, world_size=world, bidir=bidir)
+                m3 = feats[rank][0].clone().to(dev).requires_grad_(True)
+                s3 = feats[rank][1].clone().to(dev).requires_grad_(True)
+                l3 = fn(m3, s3)
+                (l3 * (rank + 1)).backward()
+                torch.cuda.synchronize()
+                assert abs(float(l3) - float(per[rank])) < 1e-4 * abs(float(per[rank])), (transport, bidir, float(l3), float(per[rank]))
+                assert torch.allclose(m3.grad.cpu(), ms[rank].grad, rtol=1e-4, atol=1e-5), (transport, bidir, "dm")
+                assert torch.allclose(s3.grad.cpu(), ss[rank].grad, rtol=1e-4, atol=1e-5), (transport, bidir, "ds")
+        LM.set_feature_comm(cm)
     gbuf = grads[rank].clone().to(dev)
     cm.all_reduce_(gbuf, average=True)
     hb = torch.arange(16, dtype=torch.float32).to(torch.bfloat16).to(dev) * (rank + 1)

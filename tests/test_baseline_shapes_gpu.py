@@ -303,3 +303,54 @@ def test_cfg2_full_size_substep_properties():
     l3, g3, f3 = one(0)                                                                          # split attention backward
     assert l3 == l1, (l1, l3)
     assert abs(g3 - g1) / g1 < 1e-3 and _cos(f1, f3) > 0.99999, (g1, g3, _cos(f1, f3))
+
+
+def test_cfg5_full_depth_650m_anchor_properties():
+    """BASELINE cfg-5 at the anchor's REAL depth: ESM-2-650M (33 layers, d=1280, 20 heads of 64; attention1d pooling + linear head, frozen:
+    train_ddp_1.yaml:45-49) against the trainable ESM-2-35M struct-token encoder, 32 pairs (train_ddp_1.yaml:18-37) at L=512 -- too large for the
+    oracle, so the size-independent properties of test_cfg2_full_size_substep_properties (the 4-layer variant above carries the oracle parity):
+    bit-reproducible sub-step, fused == split attention backward on the padded-head (24 -> 32) tower, unit / 1/0.07 feature norms, loss near ln 32."""
+    _env()
+    from src.models.components.sequence_encoder import SequenceEncoder
+    from src.models.components.struct_token_encoder import StructTokenEncoder
+    from src.models.oneprot_module import OneProtLitModule
+    from oneprot_amd.optim import FusedAdam
+    from oneprot_amd import hip
+    import math
+    torch.manual_seed(5)
+    seq = SequenceEncoder("facebook/esm2_t33_650M_UR50D", output_dim=1024, pooling_type="attention1d", proj_type="linear", use_lora=False, frozen=True)
+    st = StructTokenEncoder("facebook/esm2_t12_35M_UR50D", output_dim=1024, pooling_type="mean", proj_type="linear", use_logit_scale=True)
+    assert (seq.transformer.n_layers, seq.transformer.d, seq.transformer.hd) == (33, 1280, 64) and (st.transformer.hd, st.transformer.hdp) == (24, 32)
+    _randomise_biases(seq, st)
+    with torch.no_grad():
+        seq.pooling.layer.weight.normal_(0, 0.05)
+    module = OneProtLitModule(components={"sequence": seq, "struct_token": st}, optimizer=functools.partial(FusedAdam, lr=1e-3), loss_fn="CLIP",
+                              use_l1_regularization=True, local_loss=True, gather_with_grad=True).to(DEV)
+    gen = torch.Generator().manual_seed(1881)
+    B, L = 32, 512
+    lens = [L if i % 3 else int(torch.randint(L // 4, L + 1, (1,), generator=gen)) for i in range(B)]
+    seq_ids = _ragged_ids(B, L, 4, 23, lens, gen)
+    st_ids = _ragged_ids(B, L, 33, 52, lens, gen)
+    with torch.no_grad():
+        sf = module(seq_ids.to(DEV), "sequence")
+        mf = module(st_ids.to(DEV), "struct_token")
+    assert torch.isfinite(sf).all() and torch.allclose(sf.norm(dim=-1), torch.ones(B, device=DEV), atol=1e-4)
+    assert torch.allclose(mf.norm(dim=-1), torch.full((B,), 1 / 0.07, device=DEV), rtol=1e-4)
+    state0 = {k: v.detach().clone() for k, v in module.state_dict().items()}
+
+    def one(path):
+        hip.query("oneprot_attn_force_bwd_path", path)
+        try:
+            module.load_state_dict(state0)
+            loss, gn, grads = _run_substep(module, "struct_token", seq_ids, st_ids, ["struct_token"])
+        finally:
+            hip.query("oneprot_attn_force_bwd_path", -1)
+        return loss, gn, torch.cat([g.flatten() for g in grads["struct_token"].values()])
+
+    l1, g1, f1 = one(-1)
+    l2, g2, f2 = one(-1)
+    assert math.isfinite(l1) and abs(l1 - math.log(B)) < 1.0, l1
+    assert l1 == l2 and g1 == g2 and torch.equal(f1, f2), (l1, l2, g1, g2)
+    l3, g3, f3 = one(0)
+    assert l3 == l1 and abs(g3 - g1) / g1 < 1e-3 and _cos(f1, f3) > 0.99999, (l1, l3, g1, g3, _cos(f1, f3))
+    assert seq.pooling.layer.weight.grad is not None and seq.transformer.flat.grad is None      # only the pooling conv + head of the frozen anchor train

@@ -60,6 +60,15 @@ def test_bucketed_gradient_allreduce(tmp_path):
         _close(a["reduced"][i], mean); _close(b["reduced"][i], mean)
 
 
+def test_validation_loss_is_global_before_the_plateau_scheduler(tmp_path):
+    """without a Trainer the monitored validation loss was rank-local, so ReduceLROnPlateau could decide differently per rank."""
+    _run(W.val_plateau_worker, 2, 29726, str(tmp_path))
+    a = torch.load(os.path.join(str(tmp_path), "val_rank0.pt"), weights_only=False)
+    b = torch.load(os.path.join(str(tmp_path), "val_rank1.pt"), weights_only=False)
+    assert a["seen"] == b["seen"] == [3.0, 3.0, 2.0]            # best-so-far of the GLOBAL epoch means (3, 3, 2), not of 3, 1, 2 / 3, 5, 2
+    assert a["lrs"] == b["lrs"] == [1.0, 0.5, 0.5]              # epoch 1 is a plateau for everyone (patience 0), epoch 2 an improvement
+
+
 def test_first_node_and_env_mapping(golden_dir, monkeypatch):
     from oneprot_amd import distributed as D
     with open(os.path.join(golden_dir, "distributed_cases.json")) as f:

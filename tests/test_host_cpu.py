@@ -62,6 +62,23 @@ def test_argument_validation_without_gpu(built_lib):
     assert h.oneprot_gemm_bf16_tn_workspace(640, 640) > 0 and h.oneprot_layernorm_bwd_workspace(640) > 0
 
 
+def test_binding_refuses_host_tensors_and_bad_layouts(built_lib):
+    """hip.call checks device, contiguity and dtype of every tensor before the launch (the C side only sees addresses): no GPU needed to see it refuse"""
+    import torch
+    x = torch.randn(8, 64)
+    with pytest.raises(built_lib.HipKernelError, match="no CPU fallback"):
+        built_lib.call("oneprot_cast_f32_to_bf16", x, torch.empty(8 * 64, dtype=torch.bfloat16), 8 * 64)
+    # the dtype table covers every pointer slot of every kernel entry point (the trailing pointer of a signature is the stream)
+    import ctypes
+    for name, (res, args) in built_lib._SIGS.items():
+        n_ptr = sum(1 for a in args if a is ctypes.c_void_p)
+        if n_ptr > 1:
+            assert len(built_lib._PTR_DTYPES[name]) == n_ptr - 1, name
+    from oneprot_amd import comm
+    with pytest.raises(comm.CommError, match="128 bytes"):
+        comm.RcclComm(2, 0, b"short id")
+
+
 def test_missing_library_fails_loudly(monkeypatch, built_lib):
     monkeypatch.setattr(built_lib, "_lib", None)
     monkeypatch.setattr(built_lib, "LIB_PATH", "/nonexistent/liboneprot_hip.so")

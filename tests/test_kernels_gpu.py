@@ -265,6 +265,24 @@ def test_gemm_tn_large_m_every_width(M, N, K):
         hip.call("oneprot_gemm_bf16_tn", dY, X, M, N, K, N, K, dW, db, w, need // 2, 0)
 
 
+def test_binding_refuses_what_the_c_side_cannot_see():
+    """a strided view, a wrong dtype or a host tensor used to reach the kernels as a bare data_ptr() and compute garbage."""
+    x = torch.randn(64, 128, device=DEV)
+    y = torch.empty(64, 64, dtype=torch.bfloat16, device=DEV)
+    g, b = torch.ones(64, device=DEV), torch.zeros(64, device=DEV)
+    with pytest.raises(hip.HipKernelError, match="not contiguous"):
+        hip.call("oneprot_layernorm_fwd", x[:, ::2], 0, g, b, y, None, None, None, 64, 64, 1e-5)
+    with pytest.raises(hip.HipKernelError, match="dtype"):
+        hip.call("oneprot_layernorm_fwd", x[:, :64].contiguous(), 0, g.half(), b, y, None, None, None, 64, 64, 1e-5)
+    with pytest.raises(hip.HipKernelError, match="dtype"):
+        hip.call("oneprot_cast_f32_to_bf16", x.contiguous(), torch.empty(64 * 128, dtype=torch.float16, device=DEV), 64 * 128)
+    with pytest.raises(hip.HipKernelError, match="no CPU fallback"):
+        hip.call("oneprot_cast_f32_to_bf16", x.cpu(), torch.empty(64 * 128, dtype=torch.bfloat16, device=DEV), 64 * 128)
+    ok = torch.empty(64, 64, dtype=torch.bfloat16, device=DEV)
+    hip.call("oneprot_layernorm_fwd", x[:, :64].contiguous(), 0, g, b, ok, None, None, None, 64, 64, 1e-5)      # the dense form still runs
+    assert torch.isfinite(ok.float()).all()
+
+
 @pytest.mark.parametrize("tA,bkn", [(0, 0), (0, 1), (1, 1), (1, 0)])
 def test_sgemm(tA, bkn):
     M, N, K = 70, 130, 45

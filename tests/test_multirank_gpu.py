@@ -13,8 +13,8 @@ pytestmark = pytest.mark.gpu
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 
 
-def _run(world, out_dir, golden, port):
-    procs = [subprocess.Popen([sys.executable, os.path.join(ROOT, "tests", "_gpu_rank_worker.py"), str(r), str(world), str(port), out_dir, golden])
+def _run(world, out_dir, golden, port, loss_name="CLIP"):
+    procs = [subprocess.Popen([sys.executable, os.path.join(ROOT, "tests", "_gpu_rank_worker.py"), str(r), str(world), str(port), out_dir, golden, loss_name])
              for r in range(world)]
     for p in procs:
         assert p.wait(timeout=300) == 0
@@ -39,14 +39,18 @@ def test_rccl_collectives_two_gpus():
     _run_rccl(2, 29752)
 
 
-def test_two_ranks_equal_single_process(golden_dir, tmp_path):
+@pytest.mark.parametrize("loss_name,port", [("CLIP", 29741), ("SIGLIP", 29745)])
+def test_two_ranks_equal_single_process(golden_dir, tmp_path, loss_name, port):
+    """CLIP: packed all-gather + reduce-scatter.  SIGLIP: the direct peer exchange of the sequence chunks (here one step, staged through the host
+    because gloo moves host memory only) with the HIP block kernels, and the one-collective backward -- both losses are means over the LOCAL rows,
+    so the mean over ranks equals the single-process loss on the whole batch and the mean-reduced gradient equals its gradient."""
     golden = os.path.join(golden_dir, "esm_pair_hd16.pt")       # batch 6 -> 3 pairs per rank
     out = str(tmp_path)
-    _run(1, out, golden, 29741)
-    _run(2, out, golden, 29742)
-    one = torch.load(os.path.join(out, "w1_rank0.pt"), weights_only=False)
-    r0 = torch.load(os.path.join(out, "w2_rank0.pt"), weights_only=False)
-    r1 = torch.load(os.path.join(out, "w2_rank1.pt"), weights_only=False)
+    _run(1, out, golden, port, loss_name)
+    _run(2, out, golden, port + 1, loss_name)
+    one = torch.load(os.path.join(out, f"{loss_name}_w1_rank0.pt"), weights_only=False)
+    r0 = torch.load(os.path.join(out, f"{loss_name}_w2_rank0.pt"), weights_only=False)
+    r1 = torch.load(os.path.join(out, f"{loss_name}_w2_rank1.pt"), weights_only=False)
     assert r0["overlap_calls"] >= 2 and one["overlap_calls"] == 0          # arena gradient reduced in ranges from inside the backward
     mean_loss = 0.5 * (r0["loss"] + r1["loss"])
     assert abs(mean_loss - one["loss"]) / one["loss"] < 1e-3, (r0["loss"], r1["loss"], one["loss"])

@@ -134,6 +134,59 @@ def test_training_substep_vs_reference(golden_dir, tag, tmp_path):
             assert (sd[k] - v).abs().max() < 2.1e-3, k
 
 
+def test_seqsim_substep_applies_the_sequence_encoder_twice(golden_dir, tmp_path):
+    """`use_seqsim=True` with a TRAINABLE sequence encoder (ref oneprot_module.py:16,84-97): the batch entry "seqsim" sends both inputs through
+    network["sequence"], so one encoder is applied twice before one backward -- the multi-application branch of the encoder's autograd node (the
+    arena gradient of the second application is accumulated onto the first by autograd; no overlapped reduction).  Checked against the oracle
+    applying ONE parameter set twice: loss 1e-3, whole-gradient cosine, gradient norm, the Adam step."""
+    g, module = _build(golden_dir, "hd32", tmp_path)
+    module.use_seqsim = True
+    ids_a = g["seq_ids"]
+    gen = torch.Generator().manual_seed(77)
+    ids_b = ids_a.clone()
+    body = (ids_b >= 4) & (ids_b <= 23)
+    ids_b[body] = torch.randint(4, 24, (int(body.sum()),), generator=gen)          # another sequence of the same lengths / padding
+    cfg = g["cfg"]
+    cfg_o = dict(layers=cfg["layers"], hidden=cfg["hidden"], heads=cfg["heads"], ffn=cfg["ffn"], pad=cfg["pad"], mask=cfg["mask"], eps=cfg["eps"])
+    spec = dict(kind="esm", pooling="mean", proj_type="mlp", use_logit_scale=False)
+    ref = O.train_substep_seqsim(ids_a, ids_b, g["sd_seq"], cfg_o, spec, use_l1=True)
+    grads = {}
+    orig_clip = module.clip_gradients
+
+    def spy(opt, **kw):
+        enc = module.network["sequence"]
+        tr = enc.transformer
+        for k in tr._spec:
+            grads["seq.transformer." + k] = tr.view(k, tr.flat.grad).detach().cpu().clone()
+        for k, p_ in enc.proj.named_parameters():
+            grads["seq.proj." + k] = p_.grad.detach().cpu().clone()
+        assert module.network["struct_token"].transformer.flat.grad is None      # the inactive modality receives nothing
+        return orig_clip(opt, **kw)
+
+    module.clip_gradients = spy
+    # "struct_token" also in the batch would be a second sub-step; here only the seqsim pair
+    loss = float(module.training_step({"seqsim": (ids_a.to(DEV), ids_b.to(DEV), "seqsim", None)}, 0))
+    assert abs(loss - float(ref["loss"])) / abs(float(ref["loss"])) < 1e-3, (loss, float(ref["loss"]))
+    gn = float(module.last_grad_norm)
+    assert abs(gn - float(ref["grad_total_norm"])) / float(ref["grad_total_norm"]) < 2e-2, (gn, float(ref["grad_total_norm"]))
+    keys = [k for k, v in ref["grads"].items() if k in grads and v.abs().max() >= 1e-7]
+    assert len(keys) > 30
+    allg = torch.cat([grads[k].flatten() for k in keys]); allr = torch.cat([ref["grads"][k].flatten() for k in keys])
+    assert _cos(allg, allr) > 0.9999, _cos(allg, allr)
+    big = max(float(ref["grads"][k].norm()) for k in keys)
+    for k in keys:
+        if float(ref["grads"][k].norm()) >= 0.01 * big:
+            assert _cos(grads[k], ref["grads"][k]) > 0.999, (k, _cos(grads[k], ref["grads"][k]))
+    sd = {k: v.cpu() for k, v in module.network["sequence"].state_dict().items()}
+    for k, v in ref["new_params"].items():
+        assert (sd[k[4:]] - v).abs().max() < 2.1e-3, k
+    tr = module.network["sequence"].transformer
+    assert getattr(tr, "_live_apps", 0) == 0 and not getattr(tr, "_multi_app_step", False)      # bookkeeping of the two applications is back to idle
+    # without use_seqsim the entry is skipped, as in the reference (oneprot_module.py:88-90)
+    module.use_seqsim = False
+    assert module.training_step({"seqsim": (ids_a.to(DEV), ids_b.to(DEV), "seqsim", None)}, 1) is None
+
+
 def test_frozen_sequence_encoder_gets_no_grad(golden_dir, tmp_path):
     g, module = _build(golden_dir, "hd32", tmp_path, frozen_seq=True)
     before = module.network["sequence"].transformer.flat.detach().clone()
