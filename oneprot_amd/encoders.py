@@ -374,7 +374,10 @@ class _EncodeFn(torch.autograd.Function):
         if ctx.need_tr_grad:
             saved = ctx.saved
             B, L, d = saved["B"], saved["L"], tr.d
-            gflat = _arena_grad_buffer(tr, dev)
+            # the persistent buffer only for the encoder's single application of a step: with several (seqsim) the first gradient waits inside the
+            # autograd engine, invisible as .grad, until the last one has been produced -- each application then gets a tensor of its own
+            lone = getattr(tr, "_live_apps", 1) == 1 and not getattr(tr, "_multi_app_step", False)
+            gflat = _arena_grad_buffer(tr, dev) if lone else torch.zeros(tr._total, device=dev)
             mean, rstd, wrow = ctx.fin
             g = torch.empty(B * L, d, device=dev)
             g16 = torch.empty(B * L, d, dtype=torch.bfloat16, device=dev)
