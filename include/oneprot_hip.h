@@ -90,7 +90,8 @@ void oneprot_gemm_tune(int sup_m, int sup_n);
    dbias[N] (+)= column sums of dY (optional, fused: an all-ones MFMA operand in the k-tile-0 workgroups). */
 /* workspace bytes for an (N, K) weight gradient, for any M (the split count is capped by M inside the call, never raised). */
 size_t oneprot_gemm_bf16_tn_workspace(int N, int K);
-/* test / tuning hook: -1 = auto (default, = 2), 0 = 64-token stages x2 (LDS-DMA ring), 1 = 32-token stages x3, 2 = 64-token stages x2 with register-staged fill. */
+/* test / tuning hook: -1 = auto (default: the 8-phase 320 x 128 form where the problem is made of whole tiles, else 2), 0 = 64-token stages x2 (LDS-DMA ring),
+   1 = 32-token stages x3, 2 = 64-token stages x2 with register-staged fill, 3 = 8-phase form where eligible (else 2). */
 void oneprot_gemm_tn_variant(int v);
 /* workspace_bytes = size of `workspace`; -1 (invalid argument) when it is smaller than oneprot_gemm_bf16_tn_workspace(N, K). */
 int oneprot_gemm_bf16_tn(const void* dY, const void* X, int64_t M, int N, int K, int ldy, int ldx, float* dW, float* dbias, void* workspace,

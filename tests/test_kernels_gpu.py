@@ -215,14 +215,16 @@ def test_gemm_qkv_rope_epilogue(B, L, H, hd, gemm_shape):
     assert_close(v.cpu(), y[2], 2 ** -7, 2e-2, "v")
 
 
-@pytest.fixture(params=[-1, 0, 1, 2], ids=["auto", "dma64x2", "dma32x3", "regstaged"])
+@pytest.fixture(params=[-1, 0, 1, 2, 3], ids=["auto", "dma64x2", "dma32x3", "regstaged", "8phase"])
 def tn_variant(request):
     hip.query("oneprot_gemm_tn_variant", request.param)
     yield request.param
     hip.query("oneprot_gemm_tn_variant", -1)
 
 
-@pytest.mark.parametrize("M,N,K", [(300, 136, 72), (4096, 640, 640), (5000, 1920, 640), (777, 160, 64), (1500, 2560, 640)])
+# (16384, 1920, 640), (8192, 640, 2560), (32768, 320, 128) and (4096, 640, 640) are whole 320 x 128 tiles with M a multiple of 64 x splits: they take the
+# 8-phase form (auto and forced); the others fall through to the 128 x 128 kernels
+@pytest.mark.parametrize("M,N,K", [(300, 136, 72), (4096, 640, 640), (5000, 1920, 640), (777, 160, 64), (1500, 2560, 640), (16384, 1920, 640), (8192, 640, 2560), (32768, 320, 128)])
 def test_gemm_tn(M, N, K, tn_variant):
     g = torch.Generator().manual_seed(6)
     dY = bf(torch.randn(M, N, generator=g)).to(DEV)
