@@ -82,6 +82,13 @@ enum {
 int oneprot_gemm_bf16_nt(const void* A, const void* Bw, int64_t M, int N, int K, int lda, int ldb, int epilogue, const float* bias,
                          void* out0, void* out1, void* out2, const void* aux, const float* rope_cos, const float* rope_sin, float q_scale,
                          int L, int H, int hd, void* stream);
+/* Full-row form for N = 640 with the FOLLOWING LayerNorm fused into the epilogue (hf modeling_esm.py:399-409 + :429 / :455-463 + :518 of the next
+   layer): x_out fp32 [M,640] = A * W^T + bias + resid (x_out may alias resid); h_out bf16 [M,640] = LayerNorm(x_out; gamma, beta, eps); mean / rstd [M]
+   (optional) as oneprot_layernorm_fwd would return them.  Wp = the weight packed by oneprot_gemm_ln_pack_weight (same byte count as W).
+   Needs N == 640, M % 128 == 0, K % 64 == 0; -1 otherwise (callers then use oneprot_gemm_bf16_nt + oneprot_layernorm_fwd). */
+int oneprot_gemm_ln_pack_weight(const void* W_bf16 /* [N,K] row-major */, void* Wp, int N, int K, void* stream);
+int oneprot_gemm_bf16_nt_resid_ln(const void* A, const void* Wp, int64_t M, int N, int K, int lda, const float* bias, const float* resid, float* x_out,
+                                  const float* gamma, const float* beta, float eps, void* h_out, float* mean, float* rstd, void* stream);
 /* test / tuning hook: force the block shape of oneprot_gemm_bf16_nt (0..5, see csrc/gemm_nt.hip; -1 = heuristic). */
 void oneprot_gemm_force_shape(int shape);
 /* test / tuning hook: L2 super-tile of the per-tile kernels (sup_m row panels x sup_n column tiles per XCD at a time; <= 0 keeps a value). */

@@ -2,7 +2,7 @@
 # Builds liboneprot_hip.so (gfx950) in-tree.  hipcc cross-compiles without a GPU.
 set -e
 cd "$(dirname "$0")"
-SRCS="rowops.hip gemm_nt.hip gemm_nt8.hip gemm_tn.hip sgemm.hip attention.hip featops.hip"
+SRCS="rowops.hip gemm_nt.hip gemm_nt8.hip gemm_nt_ln.hip gemm_tn.hip sgemm.hip attention.hip featops.hip"
 OBJS=""
 PIDS=""
 for s in $SRCS; do

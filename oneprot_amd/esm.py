@@ -354,6 +354,7 @@ class EsmTransformer(ArenaModule):
         self.register_buffer("inv_freq", inv_freq, persistent=False)
         self._rope_cache = {}
         self._pad_ops = {}
+        self._wo_packed = {}
         self.reset_parameters()
 
     @torch.no_grad()
@@ -413,6 +414,13 @@ class EsmTransformer(ArenaModule):
         dev = self.flat.device
         if self._padded:
             self._refresh_padded_heads()
+        # out-projection weights packed for the full-row GEMM that also applies the following LayerNorm (csrc/gemm_nt_ln.hip; d = 640 only)
+        if self._fused_ln_ok():
+            for i in range(self.n_layers):
+                t = self._wo_packed.get(i)
+                if t is None or t.device != dev:
+                    t = self._wo_packed[i] = torch.empty(self.d * self.dp, dtype=torch.bfloat16, device=dev)
+                hip.call("oneprot_gemm_ln_pack_weight", self._w16(f"encoder.layer.{i}.attention.output.dense.weight"), t, self.d, self.dp)
         if self.flat.requires_grad:
             d, f = self.d, self.f
             for i in range(self.n_layers):
@@ -428,6 +436,10 @@ class EsmTransformer(ArenaModule):
                         t = torch.empty(C, R, dtype=torch.bfloat16, device=dev)
                         self._bf16_T[(i, key)] = t
                     hip.call("oneprot_transpose_cast_f32_to_bf16", src, t, R, C)
+
+    def _fused_ln_ok(self):
+        """the full-row GEMM + LayerNorm kernel is built for 640-wide rows with un-padded heads (ESM-2-150M); ONEPROT_FUSED_LN=0 keeps the pair (A/B runs)"""
+        return self.d == 640 and not self._padded and os.environ.get("ONEPROT_FUSED_LN", "1") != "0"
 
     def _head_pad_maps(self):
         """(rowmap [3d], colmap [d]): position of HF row s*d + h*hd + j of the fused QKV weight inside the padded [3*dp] layout, and of
@@ -515,6 +527,7 @@ class EsmTransformer(ArenaModule):
         ctx_ = b16(T, dp)
         u = b16(T, f)
         eps = cfg.layer_norm_eps
+        fused_ln = self._fused_ln_ok() and T % 128 == 0
         for i in range(self.n_layers):
             p = f"encoder.layer.{i}."
             if save:
@@ -531,9 +544,16 @@ class EsmTransformer(ArenaModule):
             hip.call("oneprot_gemm_bf16_nt", h1, w_qkv, T, 3 * dp, d, d, d, hip.EPI_QKV_ROPE, b_qkv, q, k, v, None, cos, sin, q_scale * hip.LOG2E, L, H, hd)
             hip.call("oneprot_attn_fwd", q, k, v, key_bias, ctx_, lse, B, H, L, hd)
             x_mid = f32(T, d) if save else x
-            hip.call("oneprot_gemm_bf16_nt", ctx_, w_o, T, d, dp, dp, dp, hip.EPI_BIAS_RESID,
-                     self.view(p + "attention.output.dense.bias"), x_mid, None, None, x, None, None, 1.0, 0, 0, 0)
-            hip.call("oneprot_layernorm_fwd", x_mid, 0, self.view(p + "LayerNorm.weight"), self.view(p + "LayerNorm.bias"), h2, None, m2, r2, T, d, eps)
+            if fused_ln:
+                # out-projection + bias + residual AND the FFN's pre-LayerNorm in one full-row kernel: x_mid is not read back by a LayerNorm launch
+                # (measured on cfg-2: 0.28-0.29 ms against 0.31-0.32 ms for the pair; the FFN-2 / next-layer pair stays split -- there the
+                # fused form is slower)
+                hip.call("oneprot_gemm_bf16_nt_resid_ln", ctx_, self._wo_packed[i], T, d, dp, dp, self.view(p + "attention.output.dense.bias"), x, x_mid,
+                         self.view(p + "LayerNorm.weight"), self.view(p + "LayerNorm.bias"), eps, h2, m2, r2)
+            else:
+                hip.call("oneprot_gemm_bf16_nt", ctx_, w_o, T, d, dp, dp, dp, hip.EPI_BIAS_RESID,
+                         self.view(p + "attention.output.dense.bias"), x_mid, None, None, x, None, None, 1.0, 0, 0, 0)
+                hip.call("oneprot_layernorm_fwd", x_mid, 0, self.view(p + "LayerNorm.weight"), self.view(p + "LayerNorm.bias"), h2, None, m2, r2, T, d, eps)
             hip.call("oneprot_gemm_bf16_nt", h2, self._w16(p + "intermediate.dense.weight"), T, f, d, d, d, hip.EPI_BIAS_GELU,
                      self.view(p + "intermediate.dense.bias"), u, z, None, None, None, None, 1.0, 0, 0, 0)
             x_out = f32(T, d) if save else x_mid

@@ -198,6 +198,38 @@ def test_gemm_nt_epilogues(M, N, K, gemm_shape):
     assert_close(dz, ref * z.float(), 2 ** -6, 3e-2, "gelu bwd")
 
 
+@pytest.mark.parametrize("M,K,inplace", [(128, 64, False), (256, 640, True), (1024, 2560, False), (33280, 640, True), (65536 + 128, 128, False)])
+def test_gemm_resid_layernorm_fused(M, K, inplace):
+    """Full-row N = 640 GEMM with bias + residual AND the following LayerNorm in the epilogue (oneprot_gemm_bf16_nt_resid_ln) against fp32 torch:
+    x (fp32), h = LN(x) (bf16), mean, rstd.  33280 rows = 260 tiles (work-groups with one and with two tiles: the operand stream crosses a tile
+    boundary behind an epilogue), 65664 rows = 513 tiles (two and three), K = 64 is a single K-tile, in-place residual as the frozen tower runs it."""
+    N = 640
+    g = torch.Generator().manual_seed(11)
+    A = bf(torch.randn(M, K, generator=g)).to(DEV)
+    W = bf(torch.randn(N, K, generator=g) * 0.1).to(DEV)
+    bias = (torch.randn(N, generator=g) * 0.5).to(DEV)
+    resid = (torch.randn(M, N, generator=g) * 2.0 + 0.3).to(DEV)
+    gamma = (1.0 + 0.2 * torch.randn(N, generator=g)).to(DEV)
+    beta = (0.1 * torch.randn(N, generator=g)).to(DEV)
+    Wp = torch.empty(N * K, dtype=torch.bfloat16, device=DEV)
+    hip.call("oneprot_gemm_ln_pack_weight", W, Wp, N, K)
+    xr = A.float() @ W.float().t() + bias + resid
+    mu = xr.mean(-1, keepdim=True)
+    var = ((xr - mu) ** 2).mean(-1, keepdim=True)
+    hr = (xr - mu) * torch.rsqrt(var + 1e-5) * gamma + beta
+    x = resid.clone() if inplace else torch.empty(M, N, device=DEV)
+    h = torch.empty(M, N, dtype=torch.bfloat16, device=DEV)
+    mean, rstd = torch.empty(M, device=DEV), torch.empty(M, device=DEV)
+    hip.call("oneprot_gemm_bf16_nt_resid_ln", A, Wp, M, N, K, K, bias, x if inplace else resid, x, gamma, beta, 1e-5, h, mean, rstd)
+    assert_close(x, xr, 1e-4, 1e-3 * math.sqrt(K / 64), "x = A W^T + bias + resid")
+    assert_close(mean, mu.squeeze(-1), 1e-4, 1e-4 * math.sqrt(K / 64), "mean")
+    assert_close(rstd, torch.rsqrt(var + 1e-5).squeeze(-1), 1e-3, 1e-5, "rstd")
+    assert_close(h, hr, 2 ** -7, 2e-2, "h = LayerNorm(x)")
+    # not built for this: the caller keeps the GEMM + LayerNorm pair
+    with pytest.raises(hip.HipKernelError):
+        hip.call("oneprot_gemm_bf16_nt_resid_ln", A[:100].contiguous(), Wp, 100, N, K, K, bias, resid, x, gamma, beta, 1e-5, h, mean, rstd)
+
+
 @pytest.mark.parametrize("B,L,H,hd", [(3, 24, 4, 16), (2, 37, 2, 32), (2, 130, 20, 32), (2, 50, 2, 64), (5, 512, 20, 32), (16, 512, 8, 32), (4, 128, 4, 64), (8, 96, 8, 32)])
 def test_gemm_qkv_rope_epilogue(B, L, H, hd, gemm_shape):
     d = H * hd
