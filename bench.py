@@ -400,7 +400,7 @@ def main():
                        "global_batch": B * world, "seq_len": args.seq_len, "parallelism": f"dp{world}", "frozen_sequence_encoder": not args.train_seq,
                        "sub_steps_per_step": len(subs), "loss": round(loss_val, 5)},
             "step_tflops_per_gpu": round(flops / (ms_step * 1e-3) / 1e12, 1),
-            "roofline": {"bound": "mfma", "kernel": "k_gemm_nt<BIAS_GELU> FFN-1 launches " + ", ".join(f"[{m}x{k}]x[{n}x{k}]^T" for m, n, k in shapes),
+            "roofline": {"bound": "mfma", "kernel": "g8::k_gemm8<256x320 tile, BIAS_GELU> FFN-1 launches " + ", ".join(f"[{m}x{k}]x[{n}x{k}]^T" for m, n, k in shapes),
                          "achieved": round(achieved, 1), "peak": PEAK_BF16_TFLOPS, "unit": "TFLOP/s", "frac": round(achieved / PEAK_BF16_TFLOPS, 4),
                          "traffic": round(traffic, 3) if traffic else None,
                          "traffic_unit": f"GB/launch, from a committed profile, not this run (rocprofv3 PMC FETCH_SIZE x2 + WRITE_SIZE, profiles/{traffic_src}; algorithmic {traffic_alg:.2f} GB/launch)" if traffic else None,

@@ -143,6 +143,9 @@ int oneprot_diag_rank(const float* logits, int* rank_row, int* rank_col, int N, 
 /* sum_abs += coef * sum |x|   (L1 feature regulariser, ref oneprot_module.py:101) */
 int oneprot_abs_sum(const float* x, float* out_sum, void* workspace /* oneprot_sumsq_workspace() bytes */, int64_t n, float coef, void* stream);
 
+/* out_sum += coef * sum x[i]*y[i]   (gradient of a tensor logit scale: sum(dlogits * logits) / scale, ref oneprot_module.py:142 feeds `log_logit_scale.exp()`) */
+int oneprot_dot_f32(const float* x, const float* y, float* out_sum, void* workspace /* oneprot_sumsq_workspace() bytes */, int64_t n, float coef, void* stream);
+
 /* dx (+)= coef * upstream[0] * sign(x); upstream is a device scalar (NULL = 1). */
 int oneprot_l1_bwd(const float* x, float* dx, int64_t n, float coef, const float* upstream, int accumulate, void* stream);
 int oneprot_scale_by_device_scalar(float* x, int64_t n, const float* s, void* stream);

@@ -756,18 +756,30 @@ __global__ void __launch_bounds__(1024, 1) k_attn_bwd_fused(const bf16_t* __rest
 }
 
 static int g_attn_bwd_path = -1;      // -1 automatic, 0 split kernels, 1 fused where eligible (A/B runs and tests)
-extern "C" void oneprot_attn_force_bwd_path(int path) { g_attn_bwd_path = path; }
+extern "C" void oneprot_attn_force_bwd_path(int path) { g_attn_bwd_path = path < 0 ? -1 : (path ? 1 : 0); }
+#ifdef ONEPROT_ATTN_ABLATE
+static int g_attn_bwd_ablate = 0;      // timing builds only (tools/attn_only.py with a library built -DONEPROT_ATTN_ABLATE): skips parts of the fused kernel, results are wrong by construction
+extern "C" void oneprot_attn_debug_ablate(int mask) { g_attn_bwd_ablate = mask; }
+#else
+static constexpr int g_attn_bwd_ablate = 0;
+#endif
 
 template <int HD>
 static int launch_bwd(const void* q, const void* k, const void* v, const float* key_bias, const void* ctx, const void* dctx, const float* lse, float* delta,
                       const float* cosT, const float* sinT, float q_scale, void* dqkv, int B, int H, int L, hipStream_t s) {
   if constexpr (HD <= 32) {
     if (L <= 512 && g_attn_bwd_path != 0) {
-      static bool attr_set = false;
-      if (!attr_set) { hipFuncSetAttribute((const void*)k_attn_bwd_fused<HD>, hipFuncAttributeMaxDynamicSharedMemorySize, FusedLds<HD>::TOTAL); attr_set = true; }
+      // the fused kernel needs the 143 KB dynamic-LDS opt-in; a device / driver that refuses it takes the split kernels from then on (forced
+      // fused path: the refusal is the caller's error)
+      static int fused_ok = -1;
+      if (fused_ok < 0)
+        fused_ok = hipFuncSetAttribute((const void*)k_attn_bwd_fused<HD>, hipFuncAttributeMaxDynamicSharedMemorySize, FusedLds<HD>::TOTAL) == hipSuccess ? 1 : 0;
+      if (!fused_ok) { (void)hipGetLastError(); if (g_attn_bwd_path > 0) return OP_EINVAL; }
+      else {
       hipLaunchKernelGGL(k_attn_bwd_fused<HD>, dim3(((B * H + 7) / 8) * 8), dim3(1024), FusedLds<HD>::TOTAL, s, (const bf16_t*)q, (const bf16_t*)k, (const bf16_t*)v, key_bias,
-                         (const bf16_t*)ctx, (const bf16_t*)dctx, lse, cosT, sinT, q_scale, (bf16_t*)dqkv, B, H, L, g_attn_bwd_path > 0 ? g_attn_bwd_path >> 4 : 0);      // (bits 4+ of the forced path: ablation mask, A/B runs)
+                         (const bf16_t*)ctx, (const bf16_t*)dctx, lse, cosT, sinT, q_scale, (bf16_t*)dqkv, B, H, L, g_attn_bwd_ablate);
       return launch_status();
+      }
     }
   }
   const int nb = (L + 127) / 128;

@@ -121,32 +121,39 @@ extern "C" int oneprot_ce_fwd_bwd(float* logits, float* loss_sum, float* row_los
 }
 
 // ---------------------------------------------------------------------------------------------------------
-// deterministic reductions: MODE 0 sum x^2, MODE 1 sum |x|
+// deterministic reductions: MODE 0 sum x^2, MODE 1 sum |x|, MODE 2 sum x*y
 template <int MODE>
-__global__ void __launch_bounds__(256) k_reduce_stage1(const float* __restrict__ x, size_t n, float* __restrict__ partial) {
+__global__ void __launch_bounds__(256) k_reduce_stage1(const float* __restrict__ x, size_t n, float* __restrict__ partial, const float* __restrict__ y = nullptr) {
   __shared__ float s4[4];
   float s = 0.f;
   const size_t n4 = n >> 2;
   for (size_t i = (size_t)blockIdx.x * 256 + threadIdx.x; i < n4; i += (size_t)gridDim.x * 256) {
     const float4 v = reinterpret_cast<const float4*>(x)[i];
     if (MODE == 0) s += (v.x * v.x + v.y * v.y) + (v.z * v.z + v.w * v.w);
-    else s += (fabsf(v.x) + fabsf(v.y)) + (fabsf(v.z) + fabsf(v.w));
+    else if (MODE == 1) s += (fabsf(v.x) + fabsf(v.y)) + (fabsf(v.z) + fabsf(v.w));
+    else { const float4 u = reinterpret_cast<const float4*>(y)[i]; s += (v.x * u.x + v.y * u.y) + (v.z * u.z + v.w * u.w); }
   }
-  if (blockIdx.x == 0 && threadIdx.x < (n & 3)) { const float t = x[(n4 << 2) + threadIdx.x]; s += MODE == 0 ? t * t : fabsf(t); }
+  if (blockIdx.x == 0 && threadIdx.x < (n & 3)) {
+    const float t = x[(n4 << 2) + threadIdx.x];
+    s += MODE == 0 ? t * t : MODE == 1 ? fabsf(t) : t * y[(n4 << 2) + threadIdx.x];
+  }
   s = block_sum_256(s, s4);
   if (threadIdx.x == 0) partial[blockIdx.x] = s;
 }
 extern "C" size_t oneprot_sumsq_workspace(void) { return RED_BLOCKS * sizeof(float); }
-static int reduce_launch(int mode, const float* x, int64_t n, float* out, void* ws, float coef, hipStream_t s) {
+static int reduce_launch(int mode, const float* x, int64_t n, float* out, void* ws, float coef, hipStream_t s, const float* y = nullptr) {
   if (!x || !out || !ws || n <= 0 || ((uintptr_t)x & 15)) return OP_EINVAL;
+  if (mode == 2 && (!y || ((uintptr_t)y & 15))) return OP_EINVAL;
   size_t blocks = ((size_t)n / 4 + 255) / 256; if (blocks > RED_BLOCKS) blocks = RED_BLOCKS; if (blocks == 0) blocks = 1;
   if (mode == 0) hipLaunchKernelGGL(k_reduce_stage1<0>, dim3((unsigned)blocks), dim3(256), 0, s, x, (size_t)n, (float*)ws);
-  else hipLaunchKernelGGL(k_reduce_stage1<1>, dim3((unsigned)blocks), dim3(256), 0, s, x, (size_t)n, (float*)ws);
+  else if (mode == 1) hipLaunchKernelGGL(k_reduce_stage1<1>, dim3((unsigned)blocks), dim3(256), 0, s, x, (size_t)n, (float*)ws);
+  else hipLaunchKernelGGL(k_reduce_stage1<2>, dim3((unsigned)blocks), dim3(256), 0, s, x, (size_t)n, (float*)ws, y);
   hipLaunchKernelGGL(k_final_sum, dim3(1), dim3(256), 0, s, (const float*)ws, (int)blocks, out, coef);
   return launch_status();
 }
 extern "C" int oneprot_sumsq(const float* x, int64_t n, float* sumsq, void* workspace, void* stream) { return reduce_launch(0, x, n, sumsq, workspace, 1.0f, (hipStream_t)stream); }
 extern "C" int oneprot_abs_sum(const float* x, float* out_sum, void* workspace, int64_t n, float coef, void* stream) { return reduce_launch(1, x, n, out_sum, workspace, coef, (hipStream_t)stream); }
+extern "C" int oneprot_dot_f32(const float* x, const float* y, float* out_sum, void* workspace, int64_t n, float coef, void* stream) { return reduce_launch(2, x, n, out_sum, workspace, coef, (hipStream_t)stream, y); }
 
 __global__ void k_clip_coef(const float* __restrict__ sumsq, float max_norm, float* __restrict__ coef, float* __restrict__ norm_out) {
   const float nrm = sqrtf(sumsq[0]);

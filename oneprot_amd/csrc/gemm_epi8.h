@@ -67,11 +67,35 @@ __device__ __forceinline__ void run_groups(LoadF&& load, FinF&& finish) {
   }
 }
 
+// ---- store order.  One store instruction of the row layout covers 16 rows x 64 bytes: half of a 128-byte line per row.  When the other half
+// follows a whole group later (thousands of cycles, while all CUs pour 40 MB of outputs through 32 MB of L2) the L2 has often evicted the
+// half-written line in between and WRITE_SIZE shows 12-23 % more bytes than the tensor has (measured, round 3; the launches are bound by that
+// write burst: FFN-1 with both outputs 0.57 -> 0.53 ms, plain bf16 0.40 -> 0.36 ms once fixed).  So a group is made of 4 units = {the two halves
+// of a line} x {two row blocks}, and the stores of the two halves leave back to back (the first unit's packed result waits in registers for the
+// second; not in the two-output GELU form, which has no registers left for that and keeps them one unit apart).  A wave block of 160 bf16
+// columns is 2.5 lines: the half line it shares with the neighbouring wave (its last column pair for an even wave column, its first for an odd
+// one) is a group of its own (4 row blocks) and goes FIRST, so both waves write their halves right after the barrier that precedes the epilogue.
+// (Groups of 2 units with half the registers in flight were measured too: the shallower store queue costs more than the registers gain.)
+template <int MT, int NP, bool ODD> struct LinePlan {      // NP column units of half a line each per wave block
+  static constexpr bool LONE = (NP & 1) != 0;
+  static constexpr int NSG = LONE ? MT / 4 : 0;             // groups of the lone half line
+  static constexpr int S = ODD ? 0 : NP - 1, F0 = LONE && ODD ? 1 : 0;
+  static constexpr int NG = NSG + (NP / 2) * (MT / 2);
+  static constexpr int col(int g, int u) { return g < NSG ? S : F0 + 2 * ((g - NSG) / (MT / 2)) + (u & 1); }
+  static constexpr int row(int g, int u) { return g < NSG ? g * 4 + u : 2 * ((g - NSG) % (MT / 2)) + (u >> 1); }
+  static_assert(MT % 2 == 0 && (!LONE || MT % 4 == 0), "row blocks per wave");
+};
+
 // EPI in {BF16, BIAS_GELU, GELU_BWD}: pair map.  HB: bias present.  DUAL: BIAS_GELU writes gelu'(z) to out1 as well.
-template <int EPI, bool HB, bool DUAL, int MT, int NT>
-__device__ __forceinline__ void epilogue_pair(const GemmArgs& p, f32x4 (&acc)[MT][NT], int m0, int n0, int wr, int wc, int lane) {
+template <int EPI, bool HB, bool DUAL, int MT, int NT, bool ODD>
+__device__ __forceinline__ void epilogue_pair_body(const GemmArgs& p, f32x4 (&acc)[MT][NT], int m0, int n0, int wr, int wc, int lane) {
   constexpr bool AUX = EPI == ONEPROT_EPI_GELU_BWD;
-  constexpr int NG = NT / 2, GL = (HB ? 2 : 0) + (AUX ? MT : 0), GS = MT * (DUAL ? 2 : 1);
+#ifndef G8_HOLD_DUAL
+#define G8_HOLD_DUAL 1
+#endif
+  constexpr bool HOLD = !DUAL || G8_HOLD_DUAL;
+  using Plan = LinePlan<MT, NT / 2, ODD>;
+  constexpr int NG = Plan::NG, GL = (HB ? 4 : 0) + (AUX ? 4 : 0), GS = 4 * (DUAL ? 2 : 1);
   const int q = lane >> 4;                                  // accumulator layout: lane (c, q) owns columns q*8 .. q*8+7 of the pair, row c
   const int sr = lane >> 2, sq = lane & 3;                  // row layout (stores, GELU' loads): lane owns row sr, columns sq*8 .. sq*8+7
   const int pa = to_rows_addr(lane), pb = to_acc_addr(lane);
@@ -82,23 +106,29 @@ __device__ __forceinline__ void epilogue_pair(const GemmArgs& p, f32x4 (&acc)[MT
   bf16_t* out0 = (bf16_t*)p.out0 + o0;
   bf16_t* out1 = DUAL ? (bf16_t*)p.out1 + o0 : nullptr;
   auto load = [&](auto gc, u32x4 (&r)[GL > 0 ? GL : 1]) {
-    constexpr int pp = decltype(gc)::value;
-    if constexpr (HB) { gload16(r[0], bcol + pp * 32); gload16(r[1], bcol + pp * 32 + 4); }
+    constexpr int g = decltype(gc)::value;
+    if constexpr (HB) {                                     // (a lone-half group fetches its bias twice: the count per group stays uniform)
+      gload16(r[0], bcol + Plan::col(g, 0) * 32); gload16(r[1], bcol + Plan::col(g, 0) * 32 + 4);
+      gload16(r[2], bcol + Plan::col(g, 1) * 32); gload16(r[3], bcol + Plan::col(g, 1) * 32 + 4);
+    }
     if constexpr (AUX) {
-#pragma unroll
-      for (int i = 0; i < MT; ++i) gload16(r[(HB ? 2 : 0) + i], aux + i * rstep + pp * 32);
+      static_for([&](auto uc) {
+        constexpr int u = decltype(uc)::value;
+        gload16(r[(HB ? 4 : 0) + u], aux + Plan::row(g, u) * rstep + Plan::col(g, u) * 32);
+      }, std::make_integer_sequence<int, 4>{});
     }
   };
   auto finish = [&](auto gc, const u32x4 (&r)[GL > 0 ? GL : 1]) {
-    constexpr int pp = decltype(gc)::value;
-#pragma unroll
-    for (int i = 0; i < MT; ++i) {
+    constexpr int g = decltype(gc)::value;
+    u32x4 hw, hz;                                           // HOLD: unit 2k waits, packed, for unit 2k+1
+    static_for([&](auto uc) {
+      constexpr int u = decltype(uc)::value, pp = Plan::col(g, u), i = Plan::row(g, u), bs = 2 * (u & 1);
       float v[8];
 #pragma unroll
       for (int e = 0; e < 4; ++e) { v[e] = acc[i][2 * pp][e]; v[4 + e] = acc[i][2 * pp + 1][e]; }
       if constexpr (HB) {
-        v[0] += as_f(r[0].x); v[1] += as_f(r[0].y); v[2] += as_f(r[0].z); v[3] += as_f(r[0].w);
-        v[4] += as_f(r[1].x); v[5] += as_f(r[1].y); v[6] += as_f(r[1].z); v[7] += as_f(r[1].w);
+        v[0] += as_f(r[bs].x); v[1] += as_f(r[bs].y); v[2] += as_f(r[bs].z); v[3] += as_f(r[bs].w);
+        v[4] += as_f(r[bs + 1].x); v[5] += as_f(r[bs + 1].y); v[6] += as_f(r[bs + 1].z); v[7] += as_f(r[bs + 1].w);
       }
       if constexpr (EPI == ONEPROT_EPI_BIAS_GELU) {
         if constexpr (DUAL) {
@@ -106,34 +136,61 @@ __device__ __forceinline__ void epilogue_pair(const GemmArgs& p, f32x4 (&acc)[MT
 #pragma unroll
           for (int e = 0; e < 8; ++e) gelu_fwd_and_grad(v[e], v[e], dg[e]);
           u32x4 z; z.x = pack2bf(dg[0], dg[1]); z.y = pack2bf(dg[2], dg[3]); z.z = pack2bf(dg[4], dg[5]); z.w = pack2bf(dg[6], dg[7]);
-          gst(reinterpret_cast<u32x4*>(out1 + i * rstep + pp * 32), lane_perm(pa, z), p.nt_store);
+          z = lane_perm(pa, z);
+          if constexpr (!HOLD) gst(reinterpret_cast<u32x4*>(out1 + i * rstep + pp * 32), z, p.nt_store);
+          else if constexpr ((u & 1) == 0) hz = z;
+          else {
+            __builtin_amdgcn_sched_barrier(0);
+            gst(reinterpret_cast<u32x4*>(out1 + Plan::row(g, u - 1) * rstep + Plan::col(g, u - 1) * 32), hz, p.nt_store);
+            gst(reinterpret_cast<u32x4*>(out1 + i * rstep + pp * 32), z, p.nt_store);
+            __builtin_amdgcn_sched_barrier(0);
+          }
         } else {
 #pragma unroll
           for (int e = 0; e < 8; ++e) v[e] = gelu_fwd_only(v[e]);
         }
       } else if constexpr (AUX) {
-        const u32x4 z = lane_perm(pb, r[(HB ? 2 : 0) + i]);
-        v[0] *= bflo(z.x); v[1] *= bfhi(z.x); v[2] *= bflo(z.y); v[3] *= bfhi(z.y);
-        v[4] *= bflo(z.z); v[5] *= bfhi(z.z); v[6] *= bflo(z.w); v[7] *= bfhi(z.w);
+        const u32x4 t = lane_perm(pb, r[(HB ? 4 : 0) + u]);
+        v[0] *= bflo(t.x); v[1] *= bfhi(t.x); v[2] *= bflo(t.y); v[3] *= bfhi(t.y);
+        v[4] *= bflo(t.z); v[5] *= bfhi(t.z); v[6] *= bflo(t.w); v[7] *= bfhi(t.w);
       }
       u32x4 w; w.x = pack2bf(v[0], v[1]); w.y = pack2bf(v[2], v[3]); w.z = pack2bf(v[4], v[5]); w.w = pack2bf(v[6], v[7]);
-      gst(reinterpret_cast<u32x4*>(out0 + i * rstep + pp * 32), lane_perm(pa, w), p.nt_store);
-    }
-    G8_ESTAMP(pp + 1);
+      w = lane_perm(pa, w);
+      if constexpr (!HOLD) gst(reinterpret_cast<u32x4*>(out0 + i * rstep + pp * 32), w, p.nt_store);
+      else if constexpr ((u & 1) == 0) hw = w;
+      else {
+        constexpr int pp0 = Plan::col(g, u - 1), i0 = Plan::row(g, u - 1);
+        __builtin_amdgcn_sched_barrier(0);
+        gst(reinterpret_cast<u32x4*>(out0 + i0 * rstep + pp0 * 32), hw, p.nt_store);
+        gst(reinterpret_cast<u32x4*>(out0 + i * rstep + pp * 32), w, p.nt_store);
+        __builtin_amdgcn_sched_barrier(0);
+      }
+    }, std::make_integer_sequence<int, 4>{});
+    G8_ESTAMP(g + 1);
   };
   G8_ESTAMP(0);
   run_groups<NG, GL, GS>(load, finish);
 }
+template <int EPI, bool HB, bool DUAL, int MT, int NT>
+__device__ __forceinline__ void epilogue_pair(const GemmArgs& p, f32x4 (&acc)[MT][NT], int m0, int n0, int wr, int wc, int lane) {
+  if constexpr (((NT / 2) & 1) != 0) {
+    if (wc & 1) epilogue_pair_body<EPI, HB, DUAL, MT, NT, true>(p, acc, m0, n0, wr, wc, lane);
+    else epilogue_pair_body<EPI, HB, DUAL, MT, NT, false>(p, acc, m0, n0, wr, wc, lane);
+  } else epilogue_pair_body<EPI, HB, DUAL, MT, NT, false>(p, acc, m0, n0, wr, wc, lane);
+}
 
-// EPI in {F32, BIAS_RESID}: natural map, fp32 output.  DUAL: BIAS_RESID writes a bf16 copy to out1.  out0 may alias the residual: a lane reads
-// exactly the elements it writes, and reads them first.
+// EPI in {F32, BIAS_RESID}: natural map, fp32 output (one 16-column tile = half a line).  DUAL: BIAS_RESID writes a bf16 copy to out1.  out0 may
+// alias the residual: a lane reads exactly the elements it writes, and reads them first.
 template <int EPI, bool HB, bool DUAL, int MT, int NT>
 __device__ __forceinline__ void epilogue_f32(const GemmArgs& p, f32x4 (&acc)[MT][NT], int m0, int n0, int wr, int wc, int lane) {
   constexpr bool RES = EPI == ONEPROT_EPI_BIAS_RESID;
-  constexpr int NG = NT, GL = (HB ? 1 : 0) + (RES ? MT : 0), GS = MT * (DUAL ? 2 : 1);
+  static_assert(NT % 2 == 0, "whole lines per wave block");
+  using Plan = LinePlan<MT, NT, false>;
+  static_assert(!Plan::LONE);
+  constexpr int NG = Plan::NG, GL = (HB ? 2 : 0) + (RES ? 4 : 0), GS = 4 * (DUAL ? 2 : 1);
   const int q = lane >> 4;                                  // accumulator layout: columns q*4 .. q*4+3 of tile j, row c
   const int sr = lane >> 2, sq = lane & 3;                  // row layout (stores, residual loads)
-  const int pa = to_rows_addr(lane), pb = to_acc_addr(lane);
+  const int pa = to_rows_addr(lane);
   const size_t o0 = (size_t)(m0 + wr * (MT * 16) + sr) * p.N + n0 + wc * (NT * 16) + sq * 4;     // + i * 16 * N + j * 16
   const size_t rstep = (size_t)16 * p.N;
   const float* bcol = HB ? p.bias + n0 + wc * (NT * 16) + q * 4 : nullptr;
@@ -141,27 +198,40 @@ __device__ __forceinline__ void epilogue_f32(const GemmArgs& p, f32x4 (&acc)[MT]
   float* out0 = (float*)p.out0 + o0;
   bf16_t* out1 = DUAL ? (bf16_t*)p.out1 + o0 : nullptr;
   auto load = [&](auto gc, u32x4 (&r)[GL > 0 ? GL : 1]) {
-    constexpr int j = decltype(gc)::value;
-    if constexpr (HB) gload16(r[0], bcol + j * 16);
+    constexpr int g = decltype(gc)::value;
+    if constexpr (HB) { gload16(r[0], bcol + Plan::col(g, 0) * 16); gload16(r[1], bcol + Plan::col(g, 1) * 16); }
     if constexpr (RES) {
-#pragma unroll
-      for (int i = 0; i < MT; ++i) gload16(r[(HB ? 1 : 0) + i], res + i * rstep + j * 16);
+      static_for([&](auto uc) {
+        constexpr int u = decltype(uc)::value;
+        gload16(r[(HB ? 2 : 0) + u], res + Plan::row(g, u) * rstep + Plan::col(g, u) * 16);
+      }, std::make_integer_sequence<int, 4>{});
     }
   };
   auto finish = [&](auto gc, const u32x4 (&r)[GL > 0 ? GL : 1]) {
-    constexpr int j = decltype(gc)::value;
-#pragma unroll
-    for (int i = 0; i < MT; ++i) {
+    constexpr int g = decltype(gc)::value;
+    float h0, h1, h2, h3;
+    static_for([&](auto uc) {
+      constexpr int u = decltype(uc)::value, j = Plan::col(g, u), i = Plan::row(g, u);
       float x0 = acc[i][j][0], x1 = acc[i][j][1], x2 = acc[i][j][2], x3 = acc[i][j][3];
-      if constexpr (HB) { x0 += as_f(r[0].x); x1 += as_f(r[0].y); x2 += as_f(r[0].z); x3 += as_f(r[0].w); }
+      if constexpr (HB) { const u32x4 t = r[u & 1]; x0 += as_f(t.x); x1 += as_f(t.y); x2 += as_f(t.z); x3 += as_f(t.w); }
       // the residual stays in the row layout (as loaded, coalesced); the accumulator quad goes there too, and the sum is formed and stored there
       u32x4 a; a.x = __builtin_bit_cast(unsigned, x0); a.y = __builtin_bit_cast(unsigned, x1); a.z = __builtin_bit_cast(unsigned, x2); a.w = __builtin_bit_cast(unsigned, x3);
       a = lane_perm(pa, a);
       x0 = as_f(a.x); x1 = as_f(a.y); x2 = as_f(a.z); x3 = as_f(a.w);
-      if constexpr (RES) { const u32x4 t = r[(HB ? 1 : 0) + i]; x0 += as_f(t.x); x1 += as_f(t.y); x2 += as_f(t.z); x3 += as_f(t.w); }
-      gst(out0 + i * rstep + j * 16, x0, x1, x2, x3, p.nt_store);
-      if constexpr (DUAL) { u32x2 w; w.x = pack2bf(x0, x1); w.y = pack2bf(x2, x3); gst(reinterpret_cast<u32x2*>(out1 + i * rstep + j * 16), w, p.nt_store); }
-    }
+      if constexpr (RES) { const u32x4 t = r[(HB ? 2 : 0) + u]; x0 += as_f(t.x); x1 += as_f(t.y); x2 += as_f(t.z); x3 += as_f(t.w); }
+      if constexpr ((u & 1) == 0) { h0 = x0; h1 = x1; h2 = x2; h3 = x3; }
+      else {                                                // the two halves of a line leave back to back
+        constexpr int j0 = Plan::col(g, u - 1), i0 = Plan::row(g, u - 1);
+        __builtin_amdgcn_sched_barrier(0);
+        gst(out0 + i0 * rstep + j0 * 16, h0, h1, h2, h3, p.nt_store);
+        gst(out0 + i * rstep + j * 16, x0, x1, x2, x3, p.nt_store);
+        if constexpr (DUAL) {
+          u32x2 w; w.x = pack2bf(h0, h1); w.y = pack2bf(h2, h3); gst(reinterpret_cast<u32x2*>(out1 + i0 * rstep + j0 * 16), w, p.nt_store);
+          w.x = pack2bf(x0, x1); w.y = pack2bf(x2, x3); gst(reinterpret_cast<u32x2*>(out1 + i * rstep + j * 16), w, p.nt_store);
+        }
+        __builtin_amdgcn_sched_barrier(0);
+      }
+    }, std::make_integer_sequence<int, 4>{});
   };
   run_groups<NG, GL, GS>(load, finish);
 }

@@ -995,7 +995,8 @@ static int launch_pp3(GemmArgs a, hipStream_t s) {
   a.tiles_m = a.M / 256; a.tiles_n = a.N / 128;
   const long tiles = (long)a.tiles_m * a.tiles_n;
   int g8 = n_cu / 8;                                   // work-groups per XCD
-  if (const char* e = getenv("ONEPROT_PP_G8")) { const int v = atoi(e); if (v > 0 && v < g8) g8 = v; }      // experiment hook (tools/ab/cu_scaling.py): fewer CUs at work
+  static const int g8_env = [] { const char* e = getenv("ONEPROT_PP_G8"); return e ? atoi(e) : 0; }();      // experiment hook (tools/ab/cu_scaling.py): fewer CUs at work; read once
+  if (g8_env > 0 && g8_env < g8) g8 = g8_env;
   const long per_xcd = (tiles + 7) / 8;
   if (g8 > per_xcd) g8 = (int)per_xcd;
   if (g8 < 1) g8 = 1;

@@ -109,33 +109,48 @@ __global__ void __launch_bounds__(512, 2) k_gemm8(const GemmArgs p, const int g8
   const int S = Q * nk;                                    // K-tiles in this work-group's stream
   // ---- de-phasing.  Every work-group runs the same number of equally long tiles, so without it all 256 CUs reach their epilogues together and
   // the output bursts (160-320 KB per CU) queue on the HBM write path while nothing computes.  Phase group (w mod G) starts (w mod G) * dph_sleeps
-  // sleeps of 8128 cycles late; the offsets persist, and the stores of one group drain under the K loops of the others.
+  // sleeps of 1024 cycles late; the offsets persist, and the stores of one group drain under the K loops of the others.
   if (dph_groups > 1) {
     const int late = (w % dph_groups) * dph_sleeps;
-    for (int i = 0; i < late; ++i) __builtin_amdgcn_s_sleep(127);
+    for (int i = 0; i < late; ++i) __builtin_amdgcn_s_sleep(16);
   }
 
   // ---- per-lane LDS-DMA source offsets.  Piece P (8 rows x 128 B) of a unit is issued by wave P & 7 as its instruction P >> 3; the lane
   // (sr = lane >> 3, sc = lane & 7) fills LDS row P*8 + sr, chunk slot sc, with source chunk sc ^ ((row >> 1) & 7) (bank swizzle on the source
   // address, undone by the same XOR on the fragment read address).
-  const int sr = lane >> 3, sc = lane & 7;
+  // These per-lane constants (and the fragment read addresses below) are RE-DERIVED from the lane id after every epilogue rather than kept: the
+  // epilogue of the 160-accumulator configuration has no registers for them, and a spilled value is reloaded behind the whole store burst
+  // (vector-memory operations retire in order), which would stall the next tile's first K-tiles.
   unsigned a_voff[C::A_IPW], b_voff[2][C::B_IPW];
+  unsigned a_rd, b_rd;
+  auto lane_consts = [&]() {
+    int ln = lane;
+    asm volatile("" : "+v"(ln));                            // opaque: not hoisted out of the tile loop
+    const int sr = ln >> 3, sc = ln & 7;
 #pragma unroll
-  for (int i = 0; i < C::A_IPW; ++i) {
-    const int hr = (i * 8 + wave) * 8 + sr;                         // LDS row inside the unit
-    const int trow = (hr / (MH * 16)) * (MT * 16) + (hr % (MH * 16));   // tile row of half 0 (half 1: + MH*16)
-    a_voff[i] = (unsigned)trow * (unsigned)p.lda * 2u + (unsigned)(sc ^ ((hr >> 1) & 7)) * 16u;
-  }
-#pragma unroll
-  for (int h = 0; h < 2; ++h)
-#pragma unroll
-    for (int i = 0; i < C::B_IPW; ++i) {
-      const int hr = (i * 8 + wave) * 8 + sr;
-      const int wcs = hr / (NH * 16), in = hr % (NH * 16);            // wave column block, slot inside the block's half
-      const int jt = h * NH + (in >> 4);
-      const int col = wcs * (NT * 16) + slot_col<PAIR>(jt, in & 15);
-      b_voff[h][i] = (unsigned)col * (unsigned)p.ldb * 2u + (unsigned)(sc ^ ((hr >> 1) & 7)) * 16u;
+    for (int i = 0; i < C::A_IPW; ++i) {
+      const int hr = (i * 8 + wave) * 8 + sr;                         // LDS row inside the unit
+      const int trow = (hr / (MH * 16)) * (MT * 16) + (hr % (MH * 16));   // tile row of half 0 (half 1: + MH*16)
+      a_voff[i] = (unsigned)trow * (unsigned)p.lda * 2u + (unsigned)(sc ^ ((hr >> 1) & 7)) * 16u;
     }
+#pragma unroll
+    for (int h = 0; h < 2; ++h)
+#pragma unroll
+      for (int i = 0; i < C::B_IPW; ++i) {
+        const int hr = (i * 8 + wave) * 8 + sr;
+        const int wcs = hr / (NH * 16), in = hr % (NH * 16);            // wave column block, slot inside the block's half
+        const int jt = h * NH + (in >> 4);
+        const int col = wcs * (NT * 16) + slot_col<PAIR>(jt, in & 15);
+        b_voff[h][i] = (unsigned)col * (unsigned)p.ldb * 2u + (unsigned)(sc ^ ((hr >> 1) & 7)) * 16u;
+      }
+    // fragment read addresses: lane (fr = lane & 15, fq = lane >> 4) reads row fr of a 16-row tile, chunk (kk*4 + fq) ^ ((row >> 1) & 7);
+    // rows of different tiles differ by multiples of 16, so the XOR term is (fr >> 1) and kk flips byte-offset bit 6
+    const int fr = ln & 15, fq = ln >> 4;
+    const unsigned rd_lane = (unsigned)fr * 128u + (unsigned)((fq ^ (fr >> 1)) << 4);
+    a_rd = (unsigned)(wr * (MH * 16)) * 128u + rd_lane;                        // + unit offset + mt * 2048, ^ 64 for kk = 1
+    b_rd = (unsigned)(wc * (NH * 16)) * 128u + rd_lane;                        // + unit offset + nt * 2048
+  };
+  lane_consts();
 
   // unit U of a K-tile: 0 = X0, 1 = Y0, 2 = Y1, 3 = X1 (the order in which the phases need them)
   const unsigned lds0 = (unsigned)(uintptr_t)LDS_PTR(smem);
@@ -175,13 +190,6 @@ __global__ void __launch_bounds__(512, 2) k_gemm8(const GemmArgs p, const int g8
   };
   Cur c1, c2;                                              // K-tiles s+1, s+2
   c1.t = 0; c1.q = 0; cur_origin(c1);
-
-  // ---- fragment read addresses: lane (fr = lane & 15, fq = lane >> 4) reads row fr of a 16-row tile, chunk (kk*4 + fq) ^ ((row >> 1) & 7);
-  // rows of different tiles differ by multiples of 16, so the XOR term is (fr >> 1) and kk flips byte-offset bit 6
-  const int fr = lane & 15, fq = lane >> 4;
-  const unsigned rd_lane = (unsigned)fr * 128u + (unsigned)((fq ^ (fr >> 1)) << 4);
-  const unsigned a_rd = (unsigned)(wr * (MH * 16)) * 128u + rd_lane;                        // + unit offset + mt * 2048, ^ 64 for kk = 1
-  const unsigned b_rd = (unsigned)(wc * (NH * 16)) * 128u + rd_lane;                        // + unit offset + nt * 2048
 
   f32x4 acc[MT][NT];
   constexpr int YSETS = C::Y3 ? 1 : 2;
@@ -348,23 +356,26 @@ __global__ void __launch_bounds__(512, 2) k_gemm8(const GemmArgs p, const int g8
     }
     STAMP_E(2);
     if (p.nt_store != 77) {                                                  // (77: timing-only runs of the main loop, tools/ab)
-      if constexpr (DirectMap<EPI>::PAIR) epilogue_pair<EPI, HB, DUAL, MT, NT>(p, acc, m0, n0, wr, wc, lane);
+      int lane_e = lane;
+      asm volatile("" : "+v"(lane_e));                                        // the epilogue's per-lane addresses are formed here, per tile: hoisted out of the tile loop they are spilled
+      if constexpr (DirectMap<EPI>::PAIR) epilogue_pair<EPI, HB, DUAL, MT, NT>(p, acc, m0, n0, wr, wc, lane_e);
       else if constexpr (EPI == ONEPROT_EPI_QKV_ROPE) {
-        if (p.hd == 32) epilogue_rope32<HB, MT, NT>(p, acc, m0, n0, wr, wc, lane);
+        if (p.hd == 32) epilogue_rope32<HB, MT, NT>(p, acc, m0, n0, wr, wc, lane_e);
         else if constexpr ((NT * 16) % 64 == 0) {                            // head_dim 64: bias into the accumulators, then the generic tail
           if constexpr (HB) {
 #pragma unroll
             for (int j = 0; j < NT; ++j) {
-              const float4 t = *reinterpret_cast<const float4*>(p.bias + n0 + wc * (NT * 16) + j * 16 + (lane >> 4) * 4);
+              const float4 t = *reinterpret_cast<const float4*>(p.bias + n0 + wc * (NT * 16) + j * 16 + (lane_e >> 4) * 4);
 #pragma unroll
               for (int i = 0; i < MT; ++i) { acc[i][j][0] += t.x; acc[i][j][1] += t.y; acc[i][j][2] += t.z; acc[i][j][3] += t.w; }
             }
           }
-          gemm_epilogue_direct<EPI, MT, NT>(p, acc, m0, n0, wr, wc, lane);
+          gemm_epilogue_direct<EPI, MT, NT>(p, acc, m0, n0, wr, wc, lane_e);
         }
-      } else epilogue_f32<EPI, HB, DUAL, MT, NT>(p, acc, m0, n0, wr, wc, lane);
+      } else epilogue_f32<EPI, HB, DUAL, MT, NT>(p, acc, m0, n0, wr, wc, lane_e);
     }
     STAMP_E(3);
+    lane_consts();
     zero_acc();
     STAMP_E(4);
   }

@@ -66,6 +66,7 @@ _SIGS = {
     "oneprot_siglip_fwd_bwd": (I, [P, P, P, I, F, I, P]),
     "oneprot_diag_rank": (I, [P, P, P, I, P]),
     "oneprot_abs_sum": (I, [P, P, P, L64, F, P]),
+    "oneprot_dot_f32": (I, [P, P, P, P, L64, F, P]),
     "oneprot_l1_bwd": (I, [P, P, L64, F, P, I, P]),
     "oneprot_scale_by_device_scalar": (I, [P, L64, P, P]),
     "oneprot_key_padding_bias": (I, [P, P, L64, I, P]),
@@ -88,7 +89,7 @@ _PTR_DTYPES = {
     "oneprot_attnpool_bwd": "fffffffb", "oneprot_layernorm_fwd": "*ffhfff", "oneprot_layernorm_bwd": "*f*fffffhffb", "oneprot_lnpool_fwd": "flffffffhf",
     "oneprot_gemm_bf16_nt": "hhf**h*ff", "oneprot_gemm_ln_pack_weight": "hh", "oneprot_gemm_bf16_nt_resid_ln": "hhfffffhff", "oneprot_gemm_bf16_tn": "hhffb", "oneprot_sgemm": "fff", "oneprot_attn_fwd": "hhhfhf",
     "oneprot_attn_bwd": "hhhfhhfffhb", "oneprot_gelu_f32": "ff", "oneprot_gelu_bwd_f32": "fff", "oneprot_l2norm_fwd": "fff", "oneprot_l2norm_bwd": "ffff",
-    "oneprot_ce_fwd_bwd": "fff", "oneprot_siglip_fwd_bwd": "fff", "oneprot_diag_rank": "fii", "oneprot_abs_sum": "ffb", "oneprot_l1_bwd": "fff",
+    "oneprot_ce_fwd_bwd": "fff", "oneprot_siglip_fwd_bwd": "fff", "oneprot_diag_rank": "fii", "oneprot_abs_sum": "ffb", "oneprot_dot_f32": "fffb", "oneprot_l1_bwd": "fff",
     "oneprot_scale_by_device_scalar": "ff", "oneprot_key_padding_bias": "lf", "oneprot_sumsq": "ffb", "oneprot_clip_coef": "fff", "oneprot_adam_step": "fffff",
     "oneprot_cast_f32_to_bf16": "fh", "oneprot_transpose_cast_f32_to_bf16": "fh", "oneprot_colsum_bf16": "hfb",
 }

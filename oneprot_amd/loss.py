@@ -137,6 +137,7 @@ class _ClipLossFn(torch.autograd.Function):
         ctx.save_for_backward(rows_m, cols_s, rows_s, cols_m, lm, ls)      # lm/ls now hold dlogits
         ctx.alpha, ctx.scale_t, ctx.keep = alpha, scale_t, keep
         ctx.scale_shape = logit_scale.shape if scale_t is not None else None
+        ctx.scale_device = logit_scale.device if scale_t is not None else None
         return loss.reshape(())
 
     @staticmethod
@@ -159,10 +160,11 @@ class _ClipLossFn(torch.autograd.Function):
         d_scale = None
         if ctx.keep is not None:
             acc = torch.zeros(1, device=rows_m.device)
-            hip.call("oneprot_sgemm", dlm.view(1, -1), ctx.keep[0].view(1, -1), acc, 1, 1, dlm.numel(), 0, 0, 1.0, 0)
-            hip.call("oneprot_sgemm", dls.view(1, -1), ctx.keep[1].view(1, -1), acc, 1, 1, dls.numel(), 0, 0, 1.0, 1)
+            ws = torch.empty(hip.query("oneprot_sumsq_workspace"), dtype=torch.uint8, device=rows_m.device)
+            hip.call("oneprot_dot_f32", dlm, ctx.keep[0], acc, ws, dlm.numel(), 1.0)       # chip-wide two-stage reduction, fixed order
+            hip.call("oneprot_dot_f32", dls, ctx.keep[1], acc, ws, dls.numel(), 1.0)
             hip.call("oneprot_scale_by_device_scalar", acc, 1, g)
-            d_scale = (acc / ctx.scale_t).reshape(ctx.scale_shape)
+            d_scale = (acc / ctx.scale_t).reshape(ctx.scale_shape).to(ctx.scale_device)     # the caller's scale may live on the host
         return d_rows_m, d_cols_s, d_rows_s, d_cols_m, d_scale, None
 
 

@@ -634,6 +634,24 @@ def test_clip_loss_tensor_logit_scale_stays_on_device_and_gets_a_gradient():
     assert abs(log_scale.grad.item() - log_scale_ref.grad.item()) < 1e-4 * abs(log_scale_ref.grad.item()) + 1e-6
     with torch.no_grad():
         assert abs(fn(md, sd, log_scale.exp()).item() - fn(md, sd, float(log_scale.exp())).item()) < 1e-6
+    # a scale parameter that lives on the host (a bare tensor the caller never moved): its gradient comes back on the host, same value
+    host_scale = torch.tensor(1.7, requires_grad=True)
+    md2, sd2 = m.to(DEV).requires_grad_(True), s.to(DEV).requires_grad_(True)
+    fn(md2, sd2, host_scale.exp()).backward()
+    assert host_scale.grad.device.type == "cpu"
+    assert abs(host_scale.grad.item() - log_scale_ref.grad.item()) < 1e-4 * abs(log_scale_ref.grad.item()) + 1e-6
+    # at a batch where the reduction spans many work-groups (R*C = 262144 products per logits matrix)
+    B2 = 512
+    m2 = torch.nn.functional.normalize(torch.randn(B2, D, generator=g), dim=-1)
+    s2 = torch.nn.functional.normalize(m2 + 0.5 * torch.randn(B2, D, generator=g), dim=-1)
+    lr = torch.tensor(2.3, requires_grad=True)
+    r2 = torch.nn.functional.cross_entropy(lr.exp() * m2 @ s2.t(), torch.arange(B2)) / 2 + torch.nn.functional.cross_entropy(lr.exp() * s2 @ m2.t(), torch.arange(B2)) / 2
+    r2.backward()
+    ld = torch.tensor(2.3, device=DEV, requires_grad=True)
+    l2 = fn(m2.to(DEV), s2.to(DEV), ld.exp())
+    l2.backward()
+    assert abs(l2.item() - r2.item()) < 1e-5 * abs(r2.item())
+    assert abs(ld.grad.item() - lr.grad.item()) < 1e-4 * abs(lr.grad.item()) + 1e-6
 
 
 def test_public_pooling_and_normalize_modules():

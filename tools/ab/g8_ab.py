@@ -1,11 +1,13 @@
 #!/usr/bin/env python3
 """Development tool (GPU): the 8-phase NT GEMM forms (oneprot_gemm_force_shape 40 = 256x256, 41 = 256x320) against the per-tile heuristic on the
 training shapes, interleaved rounds in one process, medians.  `noepi` = the same launch with the epilogue skipped (store policy 77: timing only).
-usage: g8_ab.py [rounds]   env G8_SHAPES=-1,40,41"""
+usage: g8_ab.py [rounds]   env G8_SHAPES=-1,40,41  G8_LIB=<other liboneprot_hip.so>"""
 import os, sys, statistics
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__)))))
 import torch
 from oneprot_amd import hip
+if os.environ.get("G8_LIB"):      # another build of the whole library (e.g. a -D variant made with build.sh into another file)
+    hip.LIB_PATH = os.path.abspath(os.environ["G8_LIB"])
 B, L, H, hd = 256, 512, 20, 32
 d, f, T = 640, 2560, 256 * 512
 rounds = int(sys.argv[1]) if len(sys.argv) > 1 else 3

@@ -29,7 +29,8 @@ ptr = lambda t: t.data_ptr() if t is not None else None
 lib.oneprot_gemm_force_shape(shape)
 cap = int(os.environ.get("G8_CAP", "0"))
 lib.oneprot_gemm8_dephase.argtypes = [I, I]
-lib.oneprot_gemm8_dephase((cap << 16) | 1, 0)
+dg, ds = int(os.environ.get("G8_DG", "1")), int(os.environ.get("G8_DS", "0"))
+lib.oneprot_gemm8_dephase((cap << 16) | dg, ds)
 for _ in range(3):
     rc = lib.oneprot_gemm_bf16_nt(ptr(A), ptr(W), T, N, K, K, K, epi, ptr(bias), ptr(o0), ptr(o1), ptr(stamps), ptr(aux), None, None, 1.0, 0, 0, 0, st)
     assert rc == 0, rc

@@ -31,7 +31,8 @@ tf, tb = timeit(fwd), timeit(bwd)
 fl = 4.0 * B * H * L * L * hd
 print(f"attn fwd {tf * 1e3:.1f} us ({fl / tf / 1e9:.0f} TFLOP/s)   bwd {tb * 1e3:.1f} us ({2.5 * fl / tb / 1e9:.0f} TFLOP/s)")
 for abl in [int(x) for x in os.environ.get("ATTN_ABL", "").split(",") if x]:
-    hip.query("oneprot_attn_force_bwd_path", 1 + 16 * abl)
+    # needs a library built with -DONEPROT_ATTN_ABLATE (the hook is not part of the shipped C-ABI: the ablated kernel computes wrong results)
+    hip.query("oneprot_attn_force_bwd_path", 1); hip.lib().oneprot_attn_debug_ablate(abl)
     print(f"fused bwd, ablation mask {abl}: {timeit(bwd) * 1e3:.1f} us")
 hip.query("oneprot_attn_force_bwd_path", 0)
 print(f"split bwd: {timeit(bwd) * 1e3:.1f} us")

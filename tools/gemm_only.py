@@ -17,6 +17,8 @@ W = (torch.randn(N, K, device="cuda", generator=g) * 0.05).to(torch.bfloat16)
 bias = torch.randn(N, device="cuda", generator=g)
 cos = torch.rand(L, hd // 2, device="cuda"); sin = torch.rand(L, hd // 2, device="cuda")
 hip.query("oneprot_gemm_force_shape", shape)
+if os.environ.get("GEMM_TUNE"):      # e.g. 512 = non-temporal output stores (sup_m field 256 * (1 + policy))
+    hip.query("oneprot_gemm_tune", int(os.environ["GEMM_TUNE"]), 0)
 if epi == hip.EPI_QKV_ROPE:
     o = [torch.empty(B, H, L, hd, dtype=torch.bfloat16, device="cuda") for _ in range(3)]
     fn = lambda: hip.call("oneprot_gemm_bf16_nt", A, W, T, N, K, K, K, epi, bias, o[0], o[1], o[2], None, cos, sin, hd ** -0.5, L, H, hd)

@@ -5,7 +5,7 @@
 #   pass 4  --pmc SQ_VALU_MFMA_BUSY_CYCLES GRBM_GUI_ACTIVE of the ESM-2-150M encoder forward (north_star: MFMA utilisation of the encoder forward)
 # PMC passes never combine with --sys-trace etc. (gpurun refuses that); the program itself follows `--` (no env / bash -c hop).
 set -e
-R=${1:-r02}
+R=${1:-r03}
 ROOT=$(cd "$(dirname "$0")/.." && pwd)
 OUT=$ROOT/gpurun_out/prof_$R
 mkdir -p $OUT

@@ -6,7 +6,7 @@
    <round>_encoder_fwd_mfma_busy.json / <round>_mfma_busy.csv   MFMA-pipe busy fractions (encoder forward; whole step per kernel)
 usage: profile_summarise.py r02"""
 import collections, csv, json, os, re, shutil, subprocess, sys
-R = sys.argv[1] if len(sys.argv) > 1 else "r02"
+R = sys.argv[1] if len(sys.argv) > 1 else "r03"
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 SRC = os.path.join(ROOT, "gpurun_out", f"prof_{R}")
 DST = os.path.join(ROOT, "profiles")
@@ -26,8 +26,8 @@ def counter_per_dispatch(d, counter, pattern):
 
 traffic = {}
 for what, label in (("ffn1", "two bf16 outputs (gelu and gelu': trainable tower)"), ("ffn1fwd", "one bf16 output (frozen tower)")):
-    f, kn = counter_per_dispatch(f"fetch_{what}", "FETCH_SIZE", "k_gemm_nt")
-    w, _ = counter_per_dispatch(f"write_{what}", "WRITE_SIZE", "k_gemm_nt")
+    f, kn = counter_per_dispatch(f"fetch_{what}", "FETCH_SIZE", "k_gemm")
+    w, _ = counter_per_dispatch(f"write_{what}", "WRITE_SIZE", "k_gemm")
     fmed, wmed = f[len(f) // 2], w[len(w) // 2]
     alg = 131072 * 640 * 2 + 2560 * 640 * 2 + 131072 * 2560 * 2 * (2 if what == "ffn1" else 1)
     traffic[what] = {"kernel": kn, "what": "FFN-1 [131072,640]x[2560,640]^T + bias + GELU, " + label, "FETCH_SIZE_KB_raw_median": fmed, "WRITE_SIZE_KB_raw_median": wmed,
@@ -56,7 +56,7 @@ def mfma_table(d):
 
 
 tab, tot, busy = mfma_table("mfma_fwd")
-json.dump({"mfma_busy_pct": round(100 * busy, 1), "what": "ESM-2-150M sequence-encoder forward (tools/encoder_fwd_only.py: embedding + 30 layers, 256 x L=512), "
+json.dump({"mfma_busy_pct": round(100 * busy, 1), "workload": {"model": "facebook/esm2_t30_150M_UR50D", "batch": 256, "seq_len": 512}, "what": "ESM-2-150M sequence-encoder forward (tools/encoder_fwd_only.py: embedding + 30 layers, 256 x L=512), "
            "SQ_VALU_MFMA_BUSY_CYCLES / (GRBM_GUI_ACTIVE/8 * 256 CUs * 4 SIMDs), GPU-active-cycle weighted over its kernels",
            "command": "rocprofv3 --kernel-trace --pmc SQ_VALU_MFMA_BUSY_CYCLES GRBM_GUI_ACTIVE -- python3 tools/encoder_fwd_only.py 2",
            "per_kernel": [{"kernel": k[:90], "launches": n, "share_pct": round(100 * g / tot, 1), "mfma_busy_pct": round(100 * u, 1)} for g, k, n, u in sorted(tab, reverse=True)[:10]]},
