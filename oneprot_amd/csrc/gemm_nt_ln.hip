@@ -200,29 +200,41 @@ __global__ void __launch_bounds__(512, 2) k_gemm_ln(const LnArgs p) {
     float* xo = p.x_out + o0;
     float s1[MT] = {0.f, 0.f, 0.f, 0.f};
     {
-      constexpr int GL = 1 + MT, GS = MT;
+      // group = one 128-byte line of x (tiles 2a, 2a+1) x two row blocks; the stores of the two halves leave back to back (gemm_epi8.h: half
+      // lines written a group apart are evicted half-written from the L2 during the burst and cost 17 % extra write traffic here)
+      constexpr int GL = 2 + 4, GS = 4, NG = (NT / 2) * (MT / 2);
       auto load = [&](auto gc, u32x4 (&r)[GL]) {
-        constexpr int j = decltype(gc)::value;
-        gload16s<j * 64>(r[0], bias_off, p.bias);
-#pragma unroll
-        for (int i = 0; i < MT; ++i) gload16s<j * 64>(r[1 + i], row_off, res_t + i * rstep);
+        constexpr int g = decltype(gc)::value, a2 = 2 * (g / (MT / 2)), i2 = 2 * (g % (MT / 2));
+        gload16s<a2 * 64>(r[0], bias_off, p.bias);
+        gload16s<(a2 + 1) * 64>(r[1], bias_off, p.bias);
+        gload16s<a2 * 64>(r[2], row_off, res_t + i2 * rstep);
+        gload16s<(a2 + 1) * 64>(r[3], row_off, res_t + i2 * rstep);
+        gload16s<a2 * 64>(r[4], row_off, res_t + (i2 + 1) * rstep);
+        gload16s<(a2 + 1) * 64>(r[5], row_off, res_t + (i2 + 1) * rstep);
       };
       auto finish = [&](auto gc, const u32x4 (&r)[GL]) {
-        constexpr int j = decltype(gc)::value;
-#pragma unroll
-        for (int i = 0; i < MT; ++i) {
+        constexpr int g = decltype(gc)::value, a2 = 2 * (g / (MT / 2)), i2 = 2 * (g % (MT / 2));
+        float h0, h1, h2, h3;
+        g8::static_for([&](auto uc) {
+          constexpr int u = decltype(uc)::value, j = a2 + (u & 1), i = i2 + (u >> 1);
           u32x4 a;
-          a.x = __builtin_bit_cast(unsigned, acc[i][j][0] + as_f(r[0].x)); a.y = __builtin_bit_cast(unsigned, acc[i][j][1] + as_f(r[0].y));
-          a.z = __builtin_bit_cast(unsigned, acc[i][j][2] + as_f(r[0].z)); a.w = __builtin_bit_cast(unsigned, acc[i][j][3] + as_f(r[0].w));
+          a.x = __builtin_bit_cast(unsigned, acc[i][j][0] + as_f(r[u & 1].x)); a.y = __builtin_bit_cast(unsigned, acc[i][j][1] + as_f(r[u & 1].y));
+          a.z = __builtin_bit_cast(unsigned, acc[i][j][2] + as_f(r[u & 1].z)); a.w = __builtin_bit_cast(unsigned, acc[i][j][3] + as_f(r[u & 1].w));
           a = lane_perm(pa, a);                              // row layout from here on
-          const u32x4 t = r[1 + i];
+          const u32x4 t = r[2 + u];
           const float x0 = as_f(a.x) + as_f(t.x), x1 = as_f(a.y) + as_f(t.y), x2 = as_f(a.z) + as_f(t.z), x3 = as_f(a.w) + as_f(t.w);
-          gst(xo + i * rstep + j * 16, x0, x1, x2, x3, 0);
           acc[i][j] = (f32x4){x0, x1, x2, x3};
           s1[i] += (x0 + x1) + (x2 + x3);
-        }
+          if constexpr ((u & 1) == 0) { h0 = x0; h1 = x1; h2 = x2; h3 = x3; }
+          else {
+            __builtin_amdgcn_sched_barrier(0);
+            gst(xo + i * rstep + (j - 1) * 16, h0, h1, h2, h3, 0);
+            gst(xo + i * rstep + j * 16, x0, x1, x2, x3, 0);
+            __builtin_amdgcn_sched_barrier(0);
+          }
+        }, std::make_integer_sequence<int, 4>{});
       };
-      run_groups<NT, GL, GS>(load, finish);
+      run_groups<NG, GL, GS>(load, finish);
     }
     // row statistics over this wave's 160 columns: mean, then centred squares (4 lanes per row -> quad reduction)
     float mw[MT], m2[MT];
@@ -261,25 +273,44 @@ __global__ void __launch_bounds__(512, 2) k_gemm_ln(const LnArgs p) {
     asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
     bar();                                                  // scratch free again before the next tile's epilogue can write it
     {
-      // pass 2: h = (x - mean) * rstd * gamma + beta, bf16, row layout (4 lanes x 8 bytes = one 32-byte run per row and tile)
-      constexpr int GL = 2, GS = MT;
+      // pass 2: h = (x - mean) * rstd * gamma + beta, bf16.  In the row layout a lane holds 4 consecutive columns of every tile = 8 bytes of h;
+      // neighbouring lanes swap halves of a tile PAIR (even lane: both halves of tile 2a, odd lane: of tile 2a+1) so that every lane stores
+      // 16 bytes and an instruction covers 64 contiguous bytes per row.  A wave block is 2.5 lines of h: the tile pair that shares its line with
+      // the neighbouring wave goes first, the pairs of a whole line follow one another.
+      constexpr int GL = 4, GS = MT, NG = NT / 2;
       const unsigned gb_off = (unsigned)(wc * 160 + rsq * 4) * 4u;
-      bf16_t* ho = p.h_out + o0;
-      auto load = [&](auto gc, u32x4 (&r)[GL]) {
-        constexpr int j = decltype(gc)::value;
-        gload16s<j * 64>(r[0], gb_off, p.gamma); gload16s<j * 64>(r[1], gb_off, p.beta);
-      };
-      auto finish = [&](auto gc, const u32x4 (&r)[GL]) {
-        constexpr int j = decltype(gc)::value;
+      bf16_t* ho = p.h_out + (size_t)(m0 + wm * 64 + rsr) * BN + wc * 160 + (rsq & 1) * 16 + (rsq >> 1) * 8;
+      const bool odd = (rsq & 1) != 0;
+      auto pass2 = [&](auto oddc) {
+        constexpr bool ODDW = decltype(oddc)::value;
+        auto load = [&](auto gc, u32x4 (&r)[GL]) {
+          constexpr int g = decltype(gc)::value, j = 2 * (ODDW ? g : (g + NG - 1) % NG);
+          gload16s<j * 64>(r[0], gb_off, p.gamma); gload16s<j * 64>(r[1], gb_off, p.beta);
+          gload16s<(j + 1) * 64>(r[2], gb_off, p.gamma); gload16s<(j + 1) * 64>(r[3], gb_off, p.beta);
+        };
+        auto finish = [&](auto gc, const u32x4 (&r)[GL]) {
+          constexpr int g = decltype(gc)::value, a = ODDW ? g : (g + NG - 1) % NG, j = 2 * a;
 #pragma unroll
-        for (int i = 0; i < MT; ++i) {
-          const float h0 = (acc[i][j][0] - mean[i]) * rstd[i] * as_f(r[0].x) + as_f(r[1].x), h1 = (acc[i][j][1] - mean[i]) * rstd[i] * as_f(r[0].y) + as_f(r[1].y);
-          const float h2 = (acc[i][j][2] - mean[i]) * rstd[i] * as_f(r[0].z) + as_f(r[1].z), h3 = (acc[i][j][3] - mean[i]) * rstd[i] * as_f(r[0].w) + as_f(r[1].w);
-          u32x2 w; w.x = pack2bf(h0, h1); w.y = pack2bf(h2, h3);
-          gst(reinterpret_cast<u32x2*>(ho + i * rstep + j * 16), w, 0);
-        }
+          for (int i = 0; i < MT; ++i) {
+            u32x2 w[2];
+#pragma unroll
+            for (int t = 0; t < 2; ++t) {
+              const u32x4 ga = r[2 * t], be = r[2 * t + 1];
+              const float h0 = (acc[i][j + t][0] - mean[i]) * rstd[i] * as_f(ga.x) + as_f(be.x), h1 = (acc[i][j + t][1] - mean[i]) * rstd[i] * as_f(ga.y) + as_f(be.y);
+              const float h2 = (acc[i][j + t][2] - mean[i]) * rstd[i] * as_f(ga.z) + as_f(be.z), h3 = (acc[i][j + t][3] - mean[i]) * rstd[i] * as_f(ga.w) + as_f(be.w);
+              w[t].x = pack2bf(h0, h1); w[t].y = pack2bf(h2, h3);
+            }
+            const unsigned sx = odd ? w[0].x : w[1].x, sy = odd ? w[0].y : w[1].y;              // what the neighbour needs
+            const unsigned rx = (unsigned)__builtin_amdgcn_update_dpp(0, (int)sx, 0xB1, 0xF, 0xF, false);      // quad_perm [1, 0, 3, 2]
+            const unsigned ry = (unsigned)__builtin_amdgcn_update_dpp(0, (int)sy, 0xB1, 0xF, 0xF, false);
+            u32x4 o;
+            o.x = odd ? rx : w[0].x; o.y = odd ? ry : w[0].y; o.z = odd ? w[1].x : rx; o.w = odd ? w[1].y : ry;
+            gst(reinterpret_cast<u32x4*>(ho + i * rstep + a * 32), o, 0);
+          }
+        };
+        run_groups<NG, GL, GS>(load, finish);
       };
-      run_groups<NT, GL, GS>(load, finish);
+      if (wc & 1) pass2(std::true_type{}); else pass2(std::false_type{});
     }
     zero_acc();
   }
