@@ -13,8 +13,8 @@ pytestmark = pytest.mark.gpu
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 
 
-def _run(world, out_dir, golden, port, loss_name="CLIP"):
-    procs = [subprocess.Popen([sys.executable, os.path.join(ROOT, "tests", "_gpu_rank_worker.py"), str(r), str(world), str(port), out_dir, golden, loss_name])
+def _run(world, out_dir, golden, port, loss_name="CLIP", transport="gloo"):
+    procs = [subprocess.Popen([sys.executable, os.path.join(ROOT, "tests", "_gpu_rank_worker.py"), str(r), str(world), str(port), out_dir, golden, loss_name, transport])
              for r in range(world)]
     for p in procs:
         assert p.wait(timeout=300) == 0
@@ -59,3 +59,26 @@ def test_two_ranks_equal_single_process(golden_dir, tmp_path, loss_name, port):
         assert torch.equal(r0[k], r1[k]), k                      # replicas stay bit-identical after the all-reduced step
         d = (r0[k] - one[k]).abs()
         assert d.max() < 2.1e-3 and (d > 5e-4).float().mean() < 0.02, (k, d.max())    # same Adam step up to bf16-noise sign flips on tiny gradients
+
+
+@pytest.mark.skipif(torch.cuda.device_count() < 2, reason="needs two GPUs: RCCL refuses two ranks on one device")
+@pytest.mark.parametrize("loss_name,port", [("CLIP", 29761), ("SIGLIP", 29765)])
+def test_whole_substep_over_rccl_two_gpus(golden_dir, tmp_path, loss_name, port):
+    """The sub-step as a node runs it: rank r on GPU r, backend "nccl".  Overlapped arena-gradient all-reduce ranges issued from inside the backward,
+    the packed feature exchange (or the SigLIP peer exchange) and the head-parameter reduce all go through RCCL; result vs the single-process run on
+    the whole batch, replicas bit-identical afterwards.  Skipped on the one-GPU test box; the one-GPU variant above covers the same code with gloo."""
+    golden = os.path.join(golden_dir, "esm_pair_hd16.pt")
+    out = str(tmp_path)
+    _run(1, out, golden, port, loss_name)
+    _run(2, out, golden, port + 1, loss_name, "nccl")
+    one = torch.load(os.path.join(out, f"{loss_name}_w1_rank0.pt"), weights_only=False)
+    r0 = torch.load(os.path.join(out, f"{loss_name}_nccl_w2_rank0.pt"), weights_only=False)
+    r1 = torch.load(os.path.join(out, f"{loss_name}_nccl_w2_rank1.pt"), weights_only=False)
+    assert r0["overlap_calls"] >= 2
+    assert abs(0.5 * (r0["loss"] + r1["loss"]) - one["loss"]) / one["loss"] < 1e-3
+    assert abs(r0["gnorm"] - one["gnorm"]) / one["gnorm"] < 2e-2 and abs(r0["gnorm"] - r1["gnorm"]) < 1e-5 * one["gnorm"] + 1e-6
+    for k in ("w", "emb"):
+        assert torch.equal(r0[k], r1[k]), k
+        d = (r0[k] - one[k]).abs()
+        assert d.max() < 2.1e-3 and (d > 5e-4).float().mean() < 0.02, (k, d.max())
+
