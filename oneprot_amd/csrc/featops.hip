@@ -283,4 +283,4 @@ extern "C" int oneprot_diag_rank(const float* logits, int* rank_row, int* rank_c
   return launch_status();
 }
 
-extern "C" int oneprot_abi_version(void) { return 2; }      // 2: oneprot_gemm_bf16_tn takes workspace_bytes
+extern "C" int oneprot_abi_version(void) { return 3; }      // 2: oneprot_gemm_bf16_tn takes workspace_bytes; 3: fused GEMM + LayerNorm entry points, oneprot_dot_f32

@@ -6,7 +6,7 @@ import ctypes, os, sys
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__)))))
 import torch
 here = os.path.dirname(os.path.abspath(__file__))
-lib = ctypes.CDLL(os.path.join(here, "libg8_stamp.so"))
+lib = ctypes.CDLL(os.path.join(here, os.environ.get("G8_STAMP_LIB", "libg8_stamp.so")))
 P, I, F, L64 = ctypes.c_void_p, ctypes.c_int, ctypes.c_float, ctypes.c_int64
 lib.oneprot_gemm_bf16_nt.argtypes = [P, P, L64, I, I, I, I, I, P, P, P, P, P, P, P, F, I, I, I, P]
 lib.oneprot_gemm_bf16_nt.restype = I
