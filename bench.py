@@ -202,9 +202,9 @@ def summarise_kernels(prof):
         M, N, K, epi = sc[0], sc[1], sc[2], sc[5]
         groups.setdefault((epi, N, K), []).append((ms, 2.0 * M * N * K))
     for (epi, N, K), items in sorted(groups.items()):
-        add(f"k_gemm_nt {epi_names.get(epi, epi)} N={N} K={K}", items, sum(w for _, w in items), "TFLOP/s", PEAK_BF16_TFLOPS)
+        add(f"NT GEMM {epi_names.get(epi, epi)} N={N} K={K}", items, sum(w for _, w in items), "TFLOP/s", PEAK_BF16_TFLOPS)
     tn = [(ms, 2.0 * sc[0] * sc[1] * sc[2]) for ms, sc in prof.get("oneprot_gemm_bf16_tn", [])]
-    add("k_gemm_tn (weight gradients, incl. slab reduce)", tn, sum(w for _, w in tn), "TFLOP/s", PEAK_BF16_TFLOPS)
+    add("TN GEMM (weight gradients, incl. slab reduce)", tn, sum(w for _, w in tn), "TFLOP/s", PEAK_BF16_TFLOPS)
     af = [(ms, 4.0 * sc[-4] * sc[-3] * sc[-2] * sc[-2] * sc[-1]) for ms, sc in prof.get("oneprot_attn_fwd", [])]
     add("k_attn_fwd", af, sum(w for _, w in af), "TFLOP/s", PEAK_BF16_TFLOPS)
     ab = [(ms, 8.0 * sc[-4] * sc[-3] * sc[-2] * sc[-2] * sc[-1]) for ms, sc in prof.get("oneprot_attn_bwd", [])]
