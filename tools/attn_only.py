@@ -5,6 +5,7 @@ import os, sys
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import torch
 from oneprot_amd import hip
+if os.environ.get("G8_LIB"): hip.LIB_PATH = os.path.abspath(os.environ["G8_LIB"])
 iters = int(sys.argv[1]) if len(sys.argv) > 1 else 3
 B = int(sys.argv[2]) if len(sys.argv) > 2 else 256
 L, H, hd = 512, 20, 32
