@@ -4,6 +4,7 @@ import os, sys, statistics
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import torch
 from oneprot_amd import hip
+if os.environ.get("G8_LIB"): hip.LIB_PATH = os.path.abspath(os.environ["G8_LIB"])
 T, d, f = 131072, 640, 2560
 variants = [int(v) for v in sys.argv[1:]] or [0, 1, 2]
 g = torch.Generator(device="cuda").manual_seed(0)
