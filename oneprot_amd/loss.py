@@ -42,11 +42,13 @@ class _PackedAllGatherComm(torch.autograd.Function):
     @staticmethod
     def forward(ctx, packed, comm):
         ctx.comm = comm
-        return comm.all_gather(packed.detach())
+        with _timer_span("feature_all_gather"):
+            return comm.all_gather(packed.detach())
 
     @staticmethod
     def backward(ctx, grad_out):
-        return ctx.comm.reduce_scatter(grad_out.contiguous()), None
+        with _timer_span("feature_reduce_scatter"):
+            return ctx.comm.reduce_scatter(grad_out.contiguous()), None
 
 
 class _PackedAllGather(torch.autograd.Function):
@@ -65,8 +67,9 @@ class _PackedAllGather(torch.autograd.Function):
         grad_out = grad_out.contiguous()
         flat = grad_out.view((W * grad_out.shape[1],) + tuple(grad_out.shape[2:]))
         if dist.get_backend(ctx.group) == "gloo":      # gloo has no reduce_scatter: all-reduce, keep the own slice (CPU tests / rehearsals only)
-            buf = grad_out.clone()
-            dist.all_reduce(buf, op=dist.ReduceOp.SUM, group=ctx.group)
+            with _timer_span("feature_reduce_scatter"):
+                buf = grad_out.clone()
+                dist.all_reduce(buf, op=dist.ReduceOp.SUM, group=ctx.group)
             return buf[ctx.rank].clone(), None, None
         grad_in = torch.empty(grad_out.shape[1:], dtype=grad_out.dtype, device=grad_out.device)
         with _timer_span("feature_reduce_scatter"):

@@ -82,3 +82,26 @@ def test_whole_substep_over_rccl_two_gpus(golden_dir, tmp_path, loss_name, port)
         d = (r0[k] - one[k]).abs()
         assert d.max() < 2.1e-3 and (d > 5e-4).float().mean() < 0.02, (k, d.max())
 
+
+
+def test_bench_two_ranks_prints_per_rank_exchange(tmp_path):
+    """`python bench.py --gpus 2` as the driver starts it (the parent launches its ranks through torch.distributed.run on 127.0.0.1), here with both ranks on
+    the one GPU of the test box over gloo and a small encoder: ONE JSON line from rank 0, whole-job value, weak scaling, and the per-rank `exchange`
+    object (feature all-gather, its reduce-scatter, exposed part of the gradient all-reduce) that a scaling curve is read against."""
+    import json
+    env = dict(os.environ, ONEPROT_DIST_BACKEND="gloo", ONEPROT_ALLOW_RANDOM_INIT="1", MASTER_PORT="29781")
+    for k in ("RANK", "WORLD_SIZE", "LOCAL_RANK"):
+        env.pop(k, None)
+    cmd = [sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2", "--steps", "2", "--warmup", "1", "--model", "facebook/esm2_t6_8M_UR50D", "--batch", "8",
+           "--seq-len", "128", "--no-cpu-baseline", "--no-extras"]
+    out = subprocess.run(cmd, env=env, capture_output=True, text=True, timeout=600)
+    assert out.returncode == 0, out.stderr[-2000:]
+    lines = [l for l in out.stdout.splitlines() if l.startswith("{")]
+    assert len(lines) == 1, out.stdout[-2000:]
+    d = json.loads(lines[0])
+    assert d["n_gpus"] == 2 and d["scaling"] == "weak" and d["config"]["global_batch"] == 16 and d["value"] > 0
+    per = d["exchange"]["per_rank"]
+    assert [p["rank"] for p in per] == [0, 1]
+    for p in per:
+        assert set(p["parts"]) >= {"feature_all_gather", "feature_reduce_scatter", "grad_allreduce_exposed"}, p
+        assert p["exchange_ms"] > 0
