@@ -1056,7 +1056,7 @@ static int launch_gemm(const GemmArgs& a, hipStream_t s) {
     if (shape >> 6) g_pp_ring = shape >> 6;
     shape = 32;
   }
-  if (shape == 40 || shape == 41) {      // 8-phase form (gemm_nt8.hip): 256 x 256 / 256 x 320 tiles; anything it is not built for takes the per-tile forms
+  if (shape >= 40 && shape <= 42) {      // 8-phase form (gemm_nt8.hip): 256 x 256 / 256 x 320 tiles; anything it is not built for takes the per-tile forms
     const int rc = launch_gemm8(EPI, a, shape - 40, 0, s);
     if (rc != G8_NOT_ELIGIBLE) return rc;
     shape = (EPI == ONEPROT_EPI_BIAS_RESID) ? 19 : (a.K >= 1024 ? 3 : (a.N >= 2048 ? 4 : 1));

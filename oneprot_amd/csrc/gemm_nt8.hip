@@ -28,10 +28,12 @@
 
 namespace g8 {
 
-template <int WM_, int WN_, int MTW_, int NTW_, bool XA_, bool Y3_> struct Cfg {
+template <int WM_, int WN_, int MTW_, int NTW_, bool XA_, bool Y3_, bool M2_ = false> struct Cfg {
   static constexpr int WM = WM_, WN = WN_, MTW = MTW_, NTW = NTW_;
   static constexpr bool XA = XA_;                           // major operand: A (activations) or W
   static constexpr bool Y3 = Y3_;                           // ONE register set for the minor operand: Y0 is read again in phase 4 and therefore lives in a 3-slot ring
+  static constexpr bool M2 = M2_;                           // merged phases: two phases of two quadrants per K-tile instead of four of one (both minor-operand sets held; no Y0 ring)
+  static_assert(!(M2 && Y3), "merged phases hold both minor sets");
   static constexpr int MH = MTW / 2, NH = NTW / 2;          // 16-row tiles per quadrant side
   static constexpr int BM = WM * MTW * 16, BN = WN * NTW * 16;
   static constexpr int A_ROWS = BM / 2, B_ROWS = BN / 2;    // rows per unit
@@ -64,9 +66,12 @@ __device__ __forceinline__ void bar() { asm volatile("s_barrier" ::: "memory"); 
     if (lane == 0) reinterpret_cast<unsigned long long*>(p.out2)[(grp * 32 + s) * 8 + (i)] = t_; } } while (0)
 #define STAMP_E(i) do { if (blockIdx.x == 0 && (wave & 3) == 0 && q < 8) { unsigned long long t_; asm volatile("s_memtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(t_) :: "memory"); \
     if (lane == 0) reinterpret_cast<unsigned long long*>(p.out2)[512 + (grp * 8 + q) * 8 + (i)] = t_; } } while (0)
+#define STAMP_M(ph, i) do { if (blockIdx.x == 0 && (wave & 3) == 0 && stamp_s < 32) { unsigned long long t_; asm volatile("s_memtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(t_) :: "memory"); \
+    if (lane == 0) reinterpret_cast<unsigned long long*>(p.out2)[1024 + (grp * 32 + stamp_s) * 8 + (ph) * 2 + (i)] = t_; } } while (0)
 #else
 #define STAMP(i) do { } while (0)
 #define STAMP_E(i) do { } while (0)
+#define STAMP_M(ph, i) do { } while (0)
 #endif
 // One LDS-DMA piece: 64 lanes x 16 bytes from `sbase + voff` (wave-uniform base in SGPRs + 32-bit per-lane offset) to LDS bytes [lds_dst, +1024).
 // Inline asm for two reasons: (i) the saddr + 32-bit-voffset form -- through the builtin hipcc keeps a zero-extended 64-bit offset PAIR per piece
@@ -216,10 +221,12 @@ __global__ void __launch_bounds__(512, 2) k_gemm8(const GemmArgs p, const int g8
   };
   // MFMAs of quadrant (X half xh, Y half yh), operand roles swapped (a = weight fragment, b = activation fragment): lane (c, q) owns
   // C[token c][slots q*4 .. q*4+3] of every tile (gemm_epi.h)
+  int stamp_s = 0, stamp_ph = 0;                           // (diagnostic builds: K-tile / phase the MFMA-run stamps belong to)
   auto quadrant = [&](auto xhc, auto yhc) {
     constexpr int xh = decltype(xhc)::value, yh = decltype(yhc)::value;
     constexpr int mh = XA ? xh : yh, nh = XA ? yh : xh;
     constexpr int yset = C::Y3 ? 0 : yh, aset = XA ? 0 : yset, bset = XA ? yset : 0;
+    STAMP_M(stamp_ph, 0);
     __builtin_amdgcn_s_setprio(1);
 #pragma unroll
     for (int kk = 0; kk < 2; ++kk)
@@ -229,6 +236,8 @@ __global__ void __launch_bounds__(512, 2) k_gemm8(const GemmArgs p, const int g8
         for (int nt = 0; nt < NH; ++nt)
           acc[mh * MH + mt][nh * NH + nt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(fb[bset][nt][kk], fa[aset][mt][kk], acc[mh * MH + mt][nh * NH + nt], 0, 0, 0);
     __builtin_amdgcn_s_setprio(0);
+    STAMP_M(stamp_ph, 1);
+    stamp_ph = (stamp_ph + 1) & 3;
   };
   constexpr int NY = XA ? NH * 2 : MH * 2;                // ds_reads of one Y fragment set
 
@@ -238,6 +247,7 @@ __global__ void __launch_bounds__(512, 2) k_gemm8(const GemmArgs p, const int g8
   constexpr int ST = epilogue_stores<EPI, DUAL, MT, NT>();
   auto ktile = [&](auto bufc, int s, const bool after_epi) {
     constexpr int BUFI = decltype(bufc)::value;
+    stamp_s = s; stamp_ph = 0;
     const unsigned char* bufp = smem + BUFI * C::BUF;
     const unsigned char* y0p = C::Y3 ? smem + C::RING_Y0 + r3 * C::Y_UNIT : bufp + C::OFF_Y0;
     const int r3n2 = r3 == 0 ? 2 : r3 - 1;                 // (s + 2) % 3
@@ -307,6 +317,63 @@ __global__ void __launch_bounds__(512, 2) k_gemm8(const GemmArgs p, const int g8
     r3 = r3 == 2 ? 0 : r3 + 1;
   };
 
+  // ---- merged schedule (C::M2): one K-tile = TWO phases of two quadrants each (twice the MFMAs behind one pair of barriers: the barrier pair and
+  // the wake-up around it cost ~145 cycles per phase however long the MFMA run is -- ablation stamps).
+  //   phase A: read X0, Y0, Y1 | issue X1 of K-tile s+1                 | wait: X1 of K-tile s landed            | MFMAs X0 x (Y0, Y1)
+  //   phase B: read X1         | issue X0, Y0, Y1 of K-tile s+2         | wait: those units of K-tile s+1 landed | MFMAs X1 x (Y1, Y0)
+  // Every read is retired before the phase's first barrier, so the LDS a phase read may be refilled from the next phase on.  Each wait leaves
+  // exactly the units of one K-tile younger than its target in flight: 2 * (x_cnt + y_cnt) operations.
+  int ew = 0;                                               // waits that still have the last epilogue's stores among their younger operations
+  bool x1_ahead = false;                                    // X1 of K-tile s+1 was requested before the epilogue
+  auto vwait2 = [&](bool counted) {
+    constexpr int N0 = 2 * (C::x_cnt(0) + C::y_cnt(0)), N1 = 2 * (C::x_cnt(1) + C::y_cnt(1));
+    if (!counted) wait_vmcnt<0>();
+    else if (ew > 0) { --ew; if (grp == 0) wait_vmcnt<(N0 + ST > 63 ? 63 : N0 + ST)>(); else wait_vmcnt<(N1 + ST > 63 ? 63 : N1 + ST)>(); }
+    else { if (grp == 0) wait_vmcnt<N0>(); else wait_vmcnt<N1>(); }
+  };
+  auto ktile2 = [&](auto bufc, int s) {
+    constexpr int BUFI = decltype(bufc)::value;
+    const unsigned char* bufp = smem + BUFI * C::BUF;
+    const bool more1 = s + 1 < S, more2 = s + 2 < S;
+    // phase A
+    read_x(bufp + C::OFF_X0);
+    read_y(std::integral_constant<int, 0>{}, bufp + C::OFF_Y0);
+    read_y(std::integral_constant<int, 1>{}, bufp + C::OFF_Y1);
+    __builtin_amdgcn_sched_barrier(0);
+    if (more1 && !x1_ahead) issue_unit(std::integral_constant<int, 3>{}, BUFI ^ 1, 0, c1.a, c1.b);
+    x1_ahead = false;
+    vwait2(more1);
+    wait_lgkm<0>();
+    bar();
+    STAMP(0);
+    __builtin_amdgcn_sched_barrier(0);
+    quadrant(std::integral_constant<int, 0>{}, std::integral_constant<int, 0>{});
+    quadrant(std::integral_constant<int, 0>{}, std::integral_constant<int, 1>{});
+    __builtin_amdgcn_sched_barrier(0);
+    bar();
+    STAMP(1);
+    // phase B
+    c2 = c1; cur_next(c2);
+    read_x(bufp + C::OFF_X1);
+    __builtin_amdgcn_sched_barrier(0);
+    if (more2) {
+      issue_unit(std::integral_constant<int, 0>{}, BUFI, 0, c2.a, c2.b);
+      issue_unit(std::integral_constant<int, 1>{}, BUFI, 0, c2.a, c2.b);
+      issue_unit(std::integral_constant<int, 2>{}, BUFI, 0, c2.a, c2.b);
+    }
+    vwait2(more2);
+    wait_lgkm<0>();
+    bar();
+    STAMP(2);
+    __builtin_amdgcn_sched_barrier(0);
+    quadrant(std::integral_constant<int, 1>{}, std::integral_constant<int, 1>{});
+    quadrant(std::integral_constant<int, 1>{}, std::integral_constant<int, 0>{});
+    __builtin_amdgcn_sched_barrier(0);
+    bar();
+    STAMP(3);
+    c1 = c2;
+  };
+
   // ---- prologue: units 0..6 of the stream (K-tile 0 whole, X0 Y0 Y1 of K-tile 1); K-tile 0 landed before the first phase reads it.
   // Accumulators start at zero: the bias is added by the epilogue (gemm_epi8.h).
   // (an opaque zero: with a literal 0 hipcc peels the first K-tiles of every tile off the loop to fold the constant into the first MFMAs, and
@@ -328,7 +395,8 @@ __global__ void __launch_bounds__(512, 2) k_gemm8(const GemmArgs p, const int g8
   issue_unit(std::integral_constant<int, 0>{}, 1, 1, c1.a, c1.b);
   issue_unit(std::integral_constant<int, 1>{}, 1, 1, c1.a, c1.b);
   issue_unit(std::integral_constant<int, 2>{}, 1, 1, c1.a, c1.b);
-  if (grp == 0) wait_vmcnt<C::x_cnt(0) + 2 * C::y_cnt(0)>(); else wait_vmcnt<C::x_cnt(1) + 2 * C::y_cnt(1)>();
+  if constexpr (C::M2) vwait2(true);                       // X0, Y0, Y1 of K-tile 0 landed; X1 of it and three units of K-tile 1 may be in flight
+  else { if (grp == 0) wait_vmcnt<C::x_cnt(0) + 2 * C::y_cnt(0)>(); else wait_vmcnt<C::x_cnt(1) + 2 * C::y_cnt(1)>(); }
   bar();
   // Per output tile: group 1 drops one barrier behind (stagger), the K loop runs, group 0 waits one barrier (both groups aligned again) and
   // the two groups run the epilogue TOGETHER -- two waves per SIMD issue vector instructions at twice the rate of one, so epilogues run one
@@ -342,9 +410,14 @@ __global__ void __launch_bounds__(512, 2) k_gemm8(const GemmArgs p, const int g8
     if (grp == 1) bar();
 #pragma clang loop unroll(disable)
     for (int t = 0; t < nk; t += 2, s += 2) {
-      ktile(std::integral_constant<int, 0>{}, s, after_epi);
-      ktile(std::integral_constant<int, 1>{}, s + 1, false);
-      after_epi = false;
+      if constexpr (C::M2) {
+        ktile2(std::integral_constant<int, 0>{}, s);
+        ktile2(std::integral_constant<int, 1>{}, s + 1);
+      } else {
+        ktile(std::integral_constant<int, 0>{}, s, after_epi);
+        ktile(std::integral_constant<int, 1>{}, s + 1, false);
+        after_epi = false;
+      }
     }
     STAMP_E(0);
     if (grp == 0) bar();
@@ -353,6 +426,7 @@ __global__ void __launch_bounds__(512, 2) k_gemm8(const GemmArgs p, const int g8
     if (q + 1 < Q) {
       issue_unit(std::integral_constant<int, 3>{}, 1, 0, c1.a, c1.b);        // X1 of the next tile's K-tile 1 (c1; s is even: buffer 1)
       after_epi = true;
+      x1_ahead = true; ew = 3;                                               // (merged schedule: the next three waits have the stores behind their targets)
     }
     STAMP_E(2);
     if (p.nt_store != 77) {                                                  // (77: timing-only runs of the main loop, tools/ab)
@@ -404,6 +478,7 @@ static int launch_cfg(GemmArgs a, hipStream_t s) {
   return launch_status();
 }
 
+typedef Cfg<2, 4, 8, 4, true, false, true> C256M;      // 256 x 256 with merged phases (32 MFMAs per barrier pair)
 typedef Cfg<2, 4, 8, 4, true, false> C256;       // 256 x 256, wave tile 128 x 64, X = A (32 registers per quadrant), both W sets held
 typedef Cfg<4, 2, 4, 10, false, true> C320;      // 256 x 320, wave tile 64 x 160, X = W (40 registers), ONE activation set, A0 in a 3-slot ring (160 KB of LDS)
 
@@ -442,12 +517,12 @@ static int launch_epi(int epi, const GemmArgs& a, hipStream_t s) {
 // experiment hook (tools/ab/g8_ab.py): de-phasing of the persistent work-groups
 extern "C" void oneprot_gemm8_dephase(int groups, int sleeps) { g8::g_dph_groups = groups & 0xffff; g8::g_dph_sleeps = sleeps; g8::g_g8n_cap = groups >> 16; }
 
-// cfg 0: 256 x 256, cfg 1: 256 x 320.  Returns G8_NOT_ELIGIBLE when the problem is not made of whole tiles of that configuration or has fewer
+// cfg 0: 256 x 256, cfg 1: 256 x 320, cfg 2: 256 x 256 with merged phases.  Returns G8_NOT_ELIGIBLE when the problem is not made of whole tiles of that configuration or has fewer
 // than `min_tiles` of them (a persistent work-group per CU only pays when most CUs get a tile).
 int launch_gemm8(int epi, const GemmArgs& a, int cfg, long min_tiles, hipStream_t s) {
-  if (cfg == 0) {
+  if (cfg == 0 || cfg == 2) {
     if (!g8::eligible<g8::C256>(a, epi) || (long)(a.M / g8::C256::BM) * (a.N / g8::C256::BN) < min_tiles) return G8_NOT_ELIGIBLE;
-    return g8::launch_epi<g8::C256>(epi, a, s);
+    return cfg == 2 ? g8::launch_epi<g8::C256M>(epi, a, s) : g8::launch_epi<g8::C256>(epi, a, s);
   }
   if (!g8::eligible<g8::C320>(a, epi) || (long)(a.M / g8::C320::BM) * (a.N / g8::C320::BN) < min_tiles) return G8_NOT_ELIGIBLE;
   return g8::launch_epi<g8::C320>(epi, a, s);

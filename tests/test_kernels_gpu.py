@@ -144,9 +144,9 @@ def _gemm_inputs(M, N, K, seed):
     return A, W, bias
 
 
-@pytest.fixture(params=[-1, 0, 1, 2, 3, 4, 5, 6, 7, 8, 17, 19, 20, 32, 40, 41], ids=["auto", "128x128", "256x128", "256x256", "128x128bk64", "256x256bk64", "256x256nopipe", "4w128x128bk64",
+@pytest.fixture(params=[-1, 0, 1, 2, 3, 4, 5, 6, 7, 8, 17, 19, 20, 32, 40, 41, 42], ids=["auto", "128x128", "256x128", "256x256", "128x128bk64", "256x256bk64", "256x256nopipe", "4w128x128bk64",
                                                                                      "4w128x128bk32", "regstaged256x256", "direct256x128", "direct128x128bk64", "direct256x256bk64", "pingpong",
-                                                                                     "8phase256x256", "8phase256x320"])
+                                                                                     "8phase256x256", "8phase256x320", "8phase256x256merged"])
 def gemm_shape(request):
     hip.query("oneprot_gemm_force_shape", request.param)
     yield request.param

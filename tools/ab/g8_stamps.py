@@ -23,7 +23,7 @@ bias = torch.randn(N, device="cuda", generator=g)
 o0 = torch.empty(T, N, dtype=torch.float32 if epi == 3 else torch.bfloat16, device="cuda")
 o1 = torch.empty(T, N, dtype=torch.bfloat16, device="cuda") if epi == 2 else None
 aux = torch.randn(T, N, device="cuda", generator=g).to(torch.float32 if epi == 3 else torch.bfloat16) if epi in (3, 5) else None
-stamps = torch.zeros(1024, dtype=torch.int64, device="cuda")
+stamps = torch.zeros(2048, dtype=torch.int64, device="cuda")
 st = torch.cuda.current_stream().cuda_stream
 ptr = lambda t: t.data_ptr() if t is not None else None
 lib.oneprot_gemm_force_shape(shape)
@@ -50,6 +50,13 @@ for grp in range(2):
         prev = row[7]
         mark = " <- first K-tile of an output tile (gap[0] contains the epilogue)" if kt % nk == 0 and kt > 0 else ""
         print(f"  kt {kt:2d} @{row[0] - t0:8d}: " + " ".join(f"{v:5d}" for v in gaps) + mark)
+
+m = stamps.cpu()[1024:1536].view(2, 32, 4, 2)
+for grp in range(2):
+    print(f"group {grp}: MFMA runs per K-tile, 4 phases: [cycles from the stamp before the first MFMA to the stamp after the last one]")
+    for kt in range(4, 12):
+        if int(m[grp, kt, 0, 0]) == 0: break
+        print(f"  kt {kt:2d}: " + " ".join(f"{int(m[grp, kt, ph, 1] - m[grp, kt, ph, 0]):5d}" for ph in range(4)))
 
 for grp in range(2):
     print(f"group {grp} tile ends: [K-loop end -> resync barrier -> X1 issued -> epilogue issued -> accumulators zeroed]")
