@@ -15,14 +15,17 @@
 //     (X1,Y0): reads are X0+Y0 | Y1 | X1 | none, so a unit's LDS is dead one phase after it was needed and can be refilled for the K-tile after
 //     next: the DMA stream runs 7 units (1.75 K-tiles, up to 126 KB) ahead of the reads behind ONE counted vmcnt per K-tile;
 //   * the unit stream is continuous across the output tiles of the work-group: the first K-tiles of the next tile arrive while the epilogue
-//     of the current one runs, and the epilogue works straight from the accumulators (gemm_epi.h, DIRECT form), never touching LDS;
+//     of the current one runs, and the epilogue works straight from the accumulators (gemm_epi8.h: lane transpose by ds_bpermute, whole
+//     128-byte lines per pair of stores), never touching LDS memory;
 //   * hazards (slot = the interval between two consecutive barriers; group 0 reads phase p in slot 2p and computes in 2p+1, group 1 one slot
 //     later): a DMA may overwrite what phase p read from phase p+2 on -- or from p+1 on when the reads were retired (counted lgkmcnt) before
 //     the first barrier of phase p, which is how X0 is recycled; data waited for (counted vmcnt, before a phase's first barrier) in phase p is
 //     read from phase p+1 on.
 //
-// Configurations:  256 x 256 (waves 2 x 4, wave tile 128 x 64, X = A)  -- N % 256 == 0
-//                  256 x 320 (waves 4 x 2, wave tile  64 x 160, X = W) -- every GEMM of a d = 640 / 1280 / 320 encoder (N = d, 3d, 4d)
+// Configurations:  256 x 256 (waves 2 x 4, wave tile 128 x 64, X = A)  -- N % 256 == 0; also with MERGED phases (two phases of two quadrants per
+//                                                                          K-tile, `ktile2`; forced shape 42: measured equal, kept as a tested variant)
+//                  256 x 320 (waves 4 x 2, wave tile  64 x 160, X = W) -- every GEMM of a d = 640 / 1280 / 320 encoder (N = d, 3d, 4d); ONE
+//                                                                          activation fragment set, its first half re-read from a 3-slot ring (Y3)
 // Whole tiles only, K % 128 == 0; everything else takes the per-tile kernels of gemm_nt.hip.
 #include "gemm_epi8.h"
 
@@ -401,8 +404,9 @@ __global__ void __launch_bounds__(512, 2) k_gemm8(const GemmArgs p, const int g8
   // Per output tile: group 1 drops one barrier behind (stagger), the K loop runs, group 0 waits one barrier (both groups aligned again) and
   // the two groups run the epilogue TOGETHER -- two waves per SIMD issue vector instructions at twice the rate of one, so epilogues run one
   // group after the other would take twice as long -- while the first K-tiles of the next tile keep arriving.
-  // Order at a tile boundary: next tile's bias -> X1 of the next tile's K-tile 1 (now BOTH of its first K-tiles are requested) -> epilogue stores
-  // -> accumulators = bias.  Nothing after the stores waits for them until the K-tile-2 wait, two K-tiles later.
+  // Order at a tile boundary: X1 of the next tile's K-tile 1 (now BOTH of its first K-tiles are requested) -> epilogue (bias / residual / GELU'
+  // loads pipelined ahead of its stores, gemm_epi8.h) -> per-lane constants re-derived -> accumulators = 0.  Nothing after the stores waits for
+  // them until the K-tile-2 wait, two K-tiles later.
   int s = 0;
   bool after_epi = false;
 #pragma clang loop unroll(disable)
