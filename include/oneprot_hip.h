@@ -138,6 +138,8 @@ int oneprot_ce_fwd_bwd(float* logits, float* loss_sum, float* row_loss_ws /* R f
 /* SigLIP block (ref loss.py:229-255) on logits [B,B] = scale*m@s^T: loss_sum += -sum logsigmoid(label*(logit+bias))/B with label +1 on the
    diagonal (-1 everywhere if negative_only); logits are overwritten with dloss/dlogit. */
 int oneprot_siglip_fwd_bwd(float* logits, float* loss_sum, float* row_loss_ws /* B floats */, int B, float logit_bias, int negative_only, void* stream);
+/* the same with the bias read from device memory (a learnable logit_bias tensor, ref loss.py:243-245; NULL = 0): no host synchronisation */
+int oneprot_siglip_fwd_bwd_dev(float* logits, float* loss_sum, float* row_loss_ws /* B floats */, int B, const float* logit_bias_dev, int negative_only, void* stream);
 /* retrieval ranks of the diagonal of logits [N,N] (ref retrieval_metric.py:83-102): rank_row[i] = #{j: logits[i][j] > logits[i][i]}, rank_col likewise on columns. */
 int oneprot_diag_rank(const float* logits, int* rank_row, int* rank_col, int N, void* stream);
 /* sum_abs += coef * sum |x|   (L1 feature regulariser, ref oneprot_module.py:101) */

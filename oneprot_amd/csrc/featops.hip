@@ -238,9 +238,11 @@ extern "C" int oneprot_key_padding_bias(const int64_t* ids, float* bias, int64_t
 
 // SigLIP block (ref loss.py:229-255): logits [B,B] (already scale*m@s^T) -> loss_sum += -sum logsigmoid(label*(logit+bias)) * inv_b,
 // logits <- dloss/dlogit = -label * sigmoid(-label*(logit+bias)) * inv_b;  label = +1 on the diagonal (unless negative_only), else -1.
-__global__ void __launch_bounds__(256) k_siglip_fwd_bwd(float* __restrict__ logits, float* __restrict__ row_loss, int B, float bias, int negative_only, float inv_b) {
+__global__ void __launch_bounds__(256) k_siglip_fwd_bwd(float* __restrict__ logits, float* __restrict__ row_loss, int B, float bias, const float* __restrict__ bias_dev,
+                                                        int negative_only, float inv_b) {
   __shared__ float s4[4];
   const int r = blockIdx.x;
+  if (bias_dev) bias = bias_dev[0];      // a learnable bias stays on the device (ref loss.py:243-245 adds the tensor into the logits)
   float acc = 0.f;
   for (int j = threadIdx.x; j < B; j += 256) {
     const float label = (!negative_only && j == r) ? 1.f : -1.f;
@@ -255,7 +257,13 @@ __global__ void __launch_bounds__(256) k_siglip_fwd_bwd(float* __restrict__ logi
 }
 extern "C" int oneprot_siglip_fwd_bwd(float* logits, float* loss_sum, float* row_loss_ws, int B, float logit_bias, int negative_only, void* stream) {
   if (!logits || !loss_sum || !row_loss_ws || B <= 0) return OP_EINVAL;
-  hipLaunchKernelGGL(k_siglip_fwd_bwd, dim3(B), dim3(256), 0, (hipStream_t)stream, logits, row_loss_ws, B, logit_bias, negative_only, 1.0f / (float)B);
+  hipLaunchKernelGGL(k_siglip_fwd_bwd, dim3(B), dim3(256), 0, (hipStream_t)stream, logits, row_loss_ws, B, logit_bias, (const float*)nullptr, negative_only, 1.0f / (float)B);
+  hipLaunchKernelGGL(k_final_sum, dim3(1), dim3(256), 0, (hipStream_t)stream, (const float*)row_loss_ws, B, loss_sum, 1.0f);
+  return launch_status();
+}
+extern "C" int oneprot_siglip_fwd_bwd_dev(float* logits, float* loss_sum, float* row_loss_ws, int B, const float* logit_bias_dev, int negative_only, void* stream) {
+  if (!logits || !loss_sum || !row_loss_ws || B <= 0) return OP_EINVAL;
+  hipLaunchKernelGGL(k_siglip_fwd_bwd, dim3(B), dim3(256), 0, (hipStream_t)stream, logits, row_loss_ws, B, 0.f, logit_bias_dev, negative_only, 1.0f / (float)B);
   hipLaunchKernelGGL(k_final_sum, dim3(1), dim3(256), 0, (hipStream_t)stream, (const float*)row_loss_ws, B, loss_sum, 1.0f);
   return launch_status();
 }
@@ -283,4 +291,4 @@ extern "C" int oneprot_diag_rank(const float* logits, int* rank_row, int* rank_c
   return launch_status();
 }
 
-extern "C" int oneprot_abi_version(void) { return 3; }      // 2: oneprot_gemm_bf16_tn takes workspace_bytes; 3: fused GEMM + LayerNorm entry points, oneprot_dot_f32
+extern "C" int oneprot_abi_version(void) { return 4; }      // 2: oneprot_gemm_bf16_tn takes workspace_bytes; 3: fused GEMM + LayerNorm entry points, oneprot_dot_f32; 4: oneprot_siglip_fwd_bwd_dev, oneprot_attn_force_fwd_path

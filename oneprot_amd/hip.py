@@ -12,7 +12,7 @@ import torch
 _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.path.join(_HERE, "liboneprot_hip.so")
 
-ABI_VERSION = 3
+ABI_VERSION = 4
 EPI_BF16, EPI_F32, EPI_BIAS_GELU, EPI_BIAS_RESID, EPI_QKV_ROPE, EPI_GELU_BWD = range(6)
 LOG2E = 1.4426950408889634      # the attention kernels take q pre-multiplied by hd^-1/2 * log2(e) (include/oneprot_hip.h)
 
@@ -58,12 +58,14 @@ _SIGS = {
     "oneprot_attn_bwd_workspace": (SZ, [I, I, I]),
     "oneprot_attn_bwd": (I, [P, P, P, P, P, P, P, P, P, F, P, P, I, I, I, I, P]),
     "oneprot_attn_force_bwd_path": (None, [I]),
+    "oneprot_attn_force_fwd_path": (None, [I]),
     "oneprot_gelu_f32": (I, [P, P, L64, P]),
     "oneprot_gelu_bwd_f32": (I, [P, P, P, L64, P]),
     "oneprot_l2norm_fwd": (I, [P, P, P, I, I, F, P]),
     "oneprot_l2norm_bwd": (I, [P, P, P, P, I, I, F, F, P]),
     "oneprot_ce_fwd_bwd": (I, [P, P, P, I, I, I, F, P]),
     "oneprot_siglip_fwd_bwd": (I, [P, P, P, I, F, I, P]),
+    "oneprot_siglip_fwd_bwd_dev": (I, [P, P, P, I, P, I, P]),
     "oneprot_diag_rank": (I, [P, P, P, I, P]),
     "oneprot_abs_sum": (I, [P, P, P, L64, F, P]),
     "oneprot_dot_f32": (I, [P, P, P, P, L64, F, P]),
@@ -89,7 +91,7 @@ _PTR_DTYPES = {
     "oneprot_attnpool_bwd": "fffffffb", "oneprot_layernorm_fwd": "*ffhfff", "oneprot_layernorm_bwd": "*f*fffffhffb", "oneprot_lnpool_fwd": "flffffffhf",
     "oneprot_gemm_bf16_nt": "hhf**h*ff", "oneprot_gemm_ln_pack_weight": "hh", "oneprot_gemm_bf16_nt_resid_ln": "hhfffffhff", "oneprot_gemm_bf16_tn": "hhffb", "oneprot_sgemm": "fff", "oneprot_attn_fwd": "hhhfhf",
     "oneprot_attn_bwd": "hhhfhhfffhb", "oneprot_gelu_f32": "ff", "oneprot_gelu_bwd_f32": "fff", "oneprot_l2norm_fwd": "fff", "oneprot_l2norm_bwd": "ffff",
-    "oneprot_ce_fwd_bwd": "fff", "oneprot_siglip_fwd_bwd": "fff", "oneprot_diag_rank": "fii", "oneprot_abs_sum": "ffb", "oneprot_dot_f32": "fffb", "oneprot_l1_bwd": "fff",
+    "oneprot_ce_fwd_bwd": "fff", "oneprot_siglip_fwd_bwd": "fff", "oneprot_siglip_fwd_bwd_dev": "ffff", "oneprot_diag_rank": "fii", "oneprot_abs_sum": "ffb", "oneprot_dot_f32": "fffb", "oneprot_l1_bwd": "fff",
     "oneprot_scale_by_device_scalar": "ff", "oneprot_key_padding_bias": "lf", "oneprot_sumsq": "ffb", "oneprot_clip_coef": "fff", "oneprot_adam_step": "fffff",
     "oneprot_cast_f32_to_bf16": "fh", "oneprot_transpose_cast_f32_to_bf16": "fh", "oneprot_colsum_bf16": "hfb",
 }

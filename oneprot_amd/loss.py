@@ -217,11 +217,19 @@ class ClipLoss(nn.Module):
 # The blocks are visited, and the loss is summed, in the reference's order (bidirectional: r+1, r-1, r+2, r-2, ...; else r-1, r-2, ...).
 class _PeerExchange:
     """Point-to-point transport of the exchange: the C-ABI communicator (include/oneprot_comm.h: oneprot_comm_send_recv groups) when one is
-    installed with set_feature_comm, else torch.distributed P2P requests."""
+    installed with set_feature_comm, else torch.distributed P2P requests on `group` (None = the default group; peer ranks are ranks OF that
+    group, as in the reference's isend/irecv calls, ref loss.py:116-154)."""
 
-    def __init__(self):
+    def __init__(self, group=None):
         self.comm = _feature_comm
+        self.group = group
         self._side = None
+        if self.comm is not None and group is not None:
+            raise ValueError("a C-ABI feature communicator (set_feature_comm) spans its own ranks: pass group=None, or remove the communicator to exchange on a torch.distributed sub-group")
+
+    def _global(self, peer):
+        """P2POp wants global ranks; the reference passes group-relative neighbours"""
+        return peer if self.group is None else dist.get_global_rank(self.group, peer)
 
     def post(self, pairs):
         """pairs: [(send, to_rank, recv, from_rank), ...]; returns a handle for wait().  Asynchronous with respect to the current stream."""
@@ -238,7 +246,7 @@ class _PeerExchange:
                 snd.record_stream(self._side)
                 r.record_stream(self._side)
             return ("event", ev)
-        staged = dist.get_backend() == "gloo" and pairs[0][0].is_cuda        # gloo moves host memory only (rehearsals with ranks sharing a GPU)
+        staged = dist.get_backend(self.group) == "gloo" and pairs[0][0].is_cuda        # gloo moves host memory only (rehearsals with ranks sharing a GPU)
         ops, back = [], []
         for s_, to, r, frm in pairs:
             snd = s_.detach().contiguous()
@@ -246,8 +254,8 @@ class _PeerExchange:
             if staged:
                 snd, rcv = snd.cpu(), torch.empty(r.shape, dtype=r.dtype)
                 back.append((r, rcv))
-            ops.append(dist.P2POp(dist.isend, snd, to))
-            ops.append(dist.P2POp(dist.irecv, rcv, frm))
+            ops.append(dist.P2POp(dist.isend, snd, self._global(to), group=self.group))
+            ops.append(dist.P2POp(dist.irecv, rcv, self._global(frm), group=self.group))
         return ("reqs", dist.batch_isend_irecv(ops), back)
 
     def wait(self, handle):
@@ -263,18 +271,18 @@ class _PeerExchange:
         """buf [W, B, D] -> sum over ranks of buf[rank]"""
         if self.comm is not None:
             return self.comm.reduce_scatter(buf)
-        if dist.get_backend() == "gloo":
+        if dist.get_backend(self.group) == "gloo":
             tmp = buf.cpu() if buf.is_cuda else buf.clone()
-            dist.all_reduce(tmp, op=dist.ReduceOp.SUM)
+            dist.all_reduce(tmp, op=dist.ReduceOp.SUM, group=self.group)
             return tmp[rank].to(buf.device)
         out = torch.empty(buf.shape[1:], dtype=buf.dtype, device=buf.device)
-        dist.reduce_scatter_tensor(out, buf.view((-1,) + tuple(buf.shape[2:])), op=dist.ReduceOp.SUM)
+        dist.reduce_scatter_tensor(out, buf.view((-1,) + tuple(buf.shape[2:])), op=dist.ReduceOp.SUM, group=self.group)
         return out
 
 
 def neighbour_exchange(from_rank, to_rank, tensor, group=None):
     """ref loss.py:116-132: send `tensor` to `to_rank`, return what `from_rank` sent (one grouped exchange)."""
-    x = _PeerExchange()
+    x = _PeerExchange(group)
     recv = torch.empty_like(tensor)
     x.wait(x.post([(tensor, to_rank, recv, from_rank)]))
     return recv
@@ -282,7 +290,7 @@ def neighbour_exchange(from_rank, to_rank, tensor, group=None):
 
 def neighbour_exchange_bidir(left_rank, right_rank, tensor_to_left, tensor_to_right, group=None):
     """ref loss.py:135-154: returns (tensor_from_right, tensor_from_left); both directions in flight together."""
-    x = _PeerExchange()
+    x = _PeerExchange(group)
     from_right, from_left = torch.empty_like(tensor_to_left), torch.empty_like(tensor_to_right)
     x.wait(x.post([(tensor_to_right, right_rank, from_left, left_rank), (tensor_to_left, left_rank, from_right, right_rank)]))
     return from_right, from_left
@@ -293,24 +301,24 @@ class _ExchangeFn(torch.autograd.Function):
     the roles of the peers swapped (the reference has two classes for this, NeighbourExchange and NeighbourExchangeBidir)."""
 
     @staticmethod
-    def forward(ctx, dst, src, *tensors):
-        ctx.dst, ctx.src = dst, src
-        x = _PeerExchange()
+    def forward(ctx, dst, src, group, *tensors):
+        ctx.dst, ctx.src, ctx.group = dst, src, group
+        x = _PeerExchange(group)
         recv = [torch.empty_like(t) for t in tensors]
         x.wait(x.post([(t, d, r, s_) for t, d, r, s_ in zip(tensors, dst, recv, src)]))
         return tuple(recv)
 
     @staticmethod
     def backward(ctx, *grads):
-        return (None, None) + _ExchangeFn.apply(ctx.src, ctx.dst, *[g.contiguous() for g in grads])
+        return (None, None, None) + _ExchangeFn.apply(ctx.src, ctx.dst, ctx.group, *[g.contiguous() for g in grads])
 
 
 def neighbour_exchange_with_grad(from_rank, to_rank, tensor, group=None):
-    return _ExchangeFn.apply((to_rank,), (from_rank,), tensor)[0]
+    return _ExchangeFn.apply((to_rank,), (from_rank,), group, tensor)[0]
 
 
 def neighbour_exchange_bidir_with_grad(left_rank, right_rank, tensor_to_left, tensor_to_right, group=None):
-    from_left, from_right = _ExchangeFn.apply((right_rank, left_rank), (left_rank, right_rank), tensor_to_right, tensor_to_left)
+    from_left, from_right = _ExchangeFn.apply((right_rank, left_rank), (left_rank, right_rank), group, tensor_to_right, tensor_to_left)
     return from_right, from_left
 
 
@@ -324,29 +332,70 @@ class NeighbourExchangeBidir:
     apply = staticmethod(lambda left_rank, right_rank, group, to_left, to_right: neighbour_exchange_bidir_with_grad(left_rank, right_rank, to_left, to_right, group))
 
 
+def _dev_scalar(x, dev):
+    """a learnable logit scale / bias handed over as a tensor stays on the device: no `float()` (= host synchronisation) on the path"""
+    return x.detach().reshape(1).float().to(dev).contiguous() if isinstance(x, torch.Tensor) else None
+
+
 def _siglip_block_hip(m, c, logit_scale, logit_bias, negative_only, need_grad):
-    """One [B, B] block on the HIP kernels: (loss, dloss/dm, dloss/dc); the pointwise kernel leaves dloss/dlogits in the logits buffer."""
+    """One [B, B] block on the HIP kernels: (loss, dloss/dm, dloss/dc, dloss/dscale, dloss/dbias); the pointwise kernel leaves dloss/dlogits
+    in the logits buffer.  Python-number scale / bias are folded into the GEMM's alpha / passed by value; TENSOR scale / bias (ref
+    loss.py:241-245 multiplies and adds them into the logits) are read from device memory by the kernels and get their gradients:
+    dscale = sum(dlogits * m c^T), dbias = sum(dlogits) -- [1]-shaped device tensors, None for python numbers."""
     B, D = m.shape
-    logits = torch.empty(B, B, device=m.device)
-    hip.call("oneprot_sgemm", m, c, logits, B, B, D, 0, 0, float(logit_scale), 0)
-    loss = torch.zeros(1, device=m.device)
-    rw = torch.empty(B, device=m.device)
-    hip.call("oneprot_siglip_fwd_bwd", logits, loss, rw, B, 0.0 if logit_bias is None else float(logit_bias), 1 if negative_only else 0)
+    dev = m.device
+    scale_t, bias_t = _dev_scalar(logit_scale, dev), _dev_scalar(logit_bias, dev)
+    alpha = 1.0 if scale_t is not None else float(logit_scale)
+    logits = torch.empty(B, B, device=dev)
+    hip.call("oneprot_sgemm", m, c, logits, B, B, D, 0, 0, alpha, 0)
+    raw = None
+    if scale_t is not None:
+        if need_grad:
+            raw = logits.clone()                         # m c^T, for dscale
+        hip.call("oneprot_scale_by_device_scalar", logits, logits.numel(), scale_t)
+    loss = torch.zeros(1, device=dev)
+    rw = torch.empty(B, device=dev)
+    if bias_t is not None:
+        hip.call("oneprot_siglip_fwd_bwd_dev", logits, loss, rw, B, bias_t, 1 if negative_only else 0)
+    else:
+        hip.call("oneprot_siglip_fwd_bwd", logits, loss, rw, B, 0.0 if logit_bias is None else float(logit_bias), 1 if negative_only else 0)
     if not need_grad:
-        return loss.reshape(()), None, None
+        return loss.reshape(()), None, None, None, None
     dm, dc = torch.empty_like(m), torch.empty_like(c)
-    hip.call("oneprot_sgemm", logits, c, dm, B, D, B, 0, 1, float(logit_scale), 0)
-    hip.call("oneprot_sgemm", logits, m, dc, B, D, B, 1, 1, float(logit_scale), 0)
-    return loss.reshape(()), dm, dc
+    hip.call("oneprot_sgemm", logits, c, dm, B, D, B, 0, 1, alpha, 0)
+    hip.call("oneprot_sgemm", logits, m, dc, B, D, B, 1, 1, alpha, 0)
+    dscale = dbias = None
+    if scale_t is not None or bias_t is not None:
+        ws = torch.empty(hip.query("oneprot_sumsq_workspace"), dtype=torch.uint8, device=dev)
+        if scale_t is not None:
+            hip.call("oneprot_scale_by_device_scalar", dm, dm.numel(), scale_t)
+            hip.call("oneprot_scale_by_device_scalar", dc, dc.numel(), scale_t)
+            dscale = torch.zeros(1, device=dev)
+            hip.call("oneprot_dot_f32", logits, raw, dscale, ws, logits.numel(), 1.0)        # chip-wide two-stage reduction, fixed order
+        if bias_t is not None:
+            dbias = torch.zeros(1, device=dev)
+            hip.call("oneprot_dot_f32", logits, torch.ones_like(logits), dbias, ws, logits.numel(), 1.0)
+    return loss.reshape(()), dm, dc, dscale, dbias
+
+
+def _grad_like(g, like, upstream):
+    """gradient accumulated on the device for a scalar tensor argument -> the caller's shape / device, times the upstream gradient"""
+    if g is None or not isinstance(like, torch.Tensor):
+        return None
+    return (g * upstream.to(g)).reshape(like.shape).to(like.device, like.dtype)
+
+
+def _acc(a, b):
+    return b if a is None else (a if b is None else a + b)
 
 
 class _SigLipExchangeFn(torch.autograd.Function):
     """Whole multi-rank SigLIP loss of one rank as ONE autograd node (see the section comment)."""
 
     @staticmethod
-    def forward(ctx, m, s, logit_scale, logit_bias, rank, world, bidir, block):
+    def forward(ctx, m, s, logit_scale, logit_bias, rank, world, bidir, block, group):
         m, s = m.detach().contiguous().float(), s.detach().contiguous().float()
-        need_grad = ctx.needs_input_grad[0] or ctx.needs_input_grad[1]
+        need_grad = any(ctx.needs_input_grad[:4])
         # peers in the reference's order of visits
         if bidir:
             nb, rem = divmod(world - 1, 2)
@@ -355,7 +404,7 @@ class _SigLipExchangeFn(torch.autograd.Function):
                 steps.append([(rank - nb - 1) % world])
         else:
             steps = [[(rank - k) % world] for k in range(1, world)]
-        x = _PeerExchange()
+        x = _PeerExchange(group)
 
         def post(step):
             # receive the chunk of every peer of the step; the own chunk goes to the rank that visits us at the same step (the mirror image)
@@ -363,7 +412,7 @@ class _SigLipExchangeFn(torch.autograd.Function):
             return bufs, x.post([(s, (2 * rank - peer) % world, buf, peer) for peer, buf in zip(step, bufs)])
 
         pending = post(steps[0])
-        loss, dm, ds_local = block(m, s, logit_scale, logit_bias, False, need_grad)
+        loss, dm, ds_local, dscale, dbias = block(m, s, logit_scale, logit_bias, False, need_grad)
         gbuf = None
         if need_grad:
             gbuf = torch.zeros((world,) + tuple(s.shape), device=s.device)
@@ -374,12 +423,16 @@ class _SigLipExchangeFn(torch.autograd.Function):
                 pending = post(steps[i + 1])              # next transfer runs under this step's blocks
             x.wait(handle)
             for peer, chunk in zip(step, bufs):
-                l, dmi, dci = block(m, chunk, logit_scale, logit_bias, True, need_grad)
+                l, dmi, dci, dsc, dbi = block(m, chunk, logit_scale, logit_bias, True, need_grad)
                 loss = loss + l
                 if need_grad:
                     dm = dm + dmi
                     gbuf[peer] = dci
+                    dscale, dbias = _acc(dscale, dsc), _acc(dbias, dbi)
         ctx.rank, ctx.x = rank, x
+        ctx.scale_like = logit_scale if isinstance(logit_scale, torch.Tensor) else None
+        ctx.bias_like = logit_bias if isinstance(logit_bias, torch.Tensor) else None
+        ctx.dscale, ctx.dbias = dscale, dbias
         if need_grad:
             ctx.save_for_backward(dm, gbuf)
         return loss
@@ -389,42 +442,45 @@ class _SigLipExchangeFn(torch.autograd.Function):
         dm, gbuf = ctx.saved_tensors
         g = gout.reshape(()).to(dm)
         ds = ctx.x.reduce_scatter(gbuf * g, ctx.rank)        # every rank scales ITS contributions by ITS upstream gradient
-        return dm * g, ds, None, None, None, None, None, None
+        # scale / bias enter only this rank's blocks: their gradients are rank-local here (the module's gradient all-reduce averages them with the rest)
+        return dm * g, ds, _grad_like(ctx.dscale, ctx.scale_like, g), _grad_like(ctx.dbias, ctx.bias_like, g), None, None, None, None, None
 
 
 class _SigLipBlockFn(torch.autograd.Function):
     """-sum logsigmoid(labels * (scale * m @ s^T + bias)) / B, labels = 2I-1 (or all -1 when negative_only)
-    (ref loss.py:229-255): HIP SGEMM for the logits, one fused kernel for the pointwise loss + its gradient."""
+    (ref loss.py:229-255): HIP SGEMM for the logits, one fused kernel for the pointwise loss + its gradient; both gradients of the block are
+    formed in the forward (the pointwise kernel leaves dloss/dlogits behind), the backward only scales them by the upstream gradient."""
 
     @staticmethod
-    def forward(ctx, m, s, logit_scale, logit_bias, negative_only):
-        m, s = m.contiguous().float(), s.contiguous().float()
-        B, D = m.shape
-        logits = torch.empty(B, B, device=m.device)
-        hip.call("oneprot_sgemm", m, s, logits, B, B, D, 0, 0, float(logit_scale), 0)
-        loss = torch.zeros(1, device=m.device)
-        rw = torch.empty(B, device=m.device)
-        hip.call("oneprot_siglip_fwd_bwd", logits, loss, rw, B, 0.0 if logit_bias is None else float(logit_bias), 1 if negative_only else 0)
-        ctx.save_for_backward(m, s, logits)          # logits now hold dloss/dlogits
-        ctx.logit_scale = float(logit_scale)
-        return loss.reshape(())
+    def forward(ctx, m, s, logit_scale, logit_bias, negative_only, block):
+        m, s = m.detach().contiguous().float(), s.detach().contiguous().float()
+        need_grad = any(ctx.needs_input_grad[:4])
+        loss, dm, ds, dscale, dbias = block(m, s, logit_scale, logit_bias, negative_only, need_grad)
+        ctx.scale_like = logit_scale if isinstance(logit_scale, torch.Tensor) else None
+        ctx.bias_like = logit_bias if isinstance(logit_bias, torch.Tensor) else None
+        ctx.dscale, ctx.dbias = dscale, dbias
+        if need_grad:
+            ctx.save_for_backward(dm, ds)
+        return loss
 
     @staticmethod
     def backward(ctx, gout):
-        m, s, dlog = ctx.saved_tensors
-        B, D = m.shape
-        dm, ds = torch.empty_like(m), torch.empty_like(s)
-        hip.call("oneprot_sgemm", dlog, s, dm, B, D, B, 0, 1, ctx.logit_scale, 0)
-        hip.call("oneprot_sgemm", dlog, m, ds, B, D, B, 1, 1, ctx.logit_scale, 0)
-        g = gout.reshape(1).float().contiguous()
-        hip.call("oneprot_scale_by_device_scalar", dm, dm.numel(), g)
-        hip.call("oneprot_scale_by_device_scalar", ds, ds.numel(), g)
-        return dm, ds, None, None, None
+        dm, ds = ctx.saved_tensors
+        g = gout.reshape(1).to(dm)
+        if dm.is_cuda:
+            dm, ds = dm.clone(), ds.clone()
+            gc = g.float().contiguous()
+            hip.call("oneprot_scale_by_device_scalar", dm, dm.numel(), gc)
+            hip.call("oneprot_scale_by_device_scalar", ds, ds.numel(), gc)
+        else:                   # CPU tests install the oracle's block arithmetic
+            dm, ds = dm * g, ds * g
+        return dm, ds, _grad_like(ctx.dscale, ctx.scale_like, g), _grad_like(ctx.dbias, ctx.bias_like, g), None, None
 
 
 class SigLipLoss(nn.Module):
     """Sigmoid loss (https://arxiv.org/abs/2303.15343), ref loss.py:203-311.  Same constructor and call convention; across ranks the chunks are
-    exchanged directly with their owners and the chunk gradients return in one reduce-scatter (_SigLipExchangeFn)."""
+    exchanged directly with their owners and the chunk gradients return in one reduce-scatter (_SigLipExchangeFn).  `logit_scale` / `logit_bias`
+    may be python numbers or (learnable) tensors; tensors stay on the device and receive their gradients, for any world size."""
 
     def __init__(self, cache_labels=False, rank=0, world_size=1, bidir=True, use_horovod=False):
         super().__init__()
@@ -436,14 +492,15 @@ class SigLipLoss(nn.Module):
         self.bidir = bidir
         self.prev_num_logits = 0
         self.labels = {}
-        self._block = _siglip_block_hip          # (m, chunk, scale, bias, negative_only, need_grad) -> (loss, dm, dchunk); CPU tests install the oracle's
+        self.group = None                        # torch.distributed group of the exchange (None = default group; ref passes group=None everywhere)
+        self._block = _siglip_block_hip          # (m, chunk, scale, bias, negative_only, need_grad) -> (loss, dm, dchunk, dscale, dbias); CPU tests install the oracle's
 
     def _loss(self, modality_features, sequence_features, logit_scale, logit_bias=None, negative_only=False):
-        return _SigLipBlockFn.apply(modality_features, sequence_features, logit_scale, logit_bias, negative_only)
+        return _SigLipBlockFn.apply(modality_features, sequence_features, logit_scale, logit_bias, negative_only, self._block)
 
     def forward(self, modality_features, sequence_features, logit_scale=1.0, logit_bias=None, output_dict=False):
         if self.world_size > 1:
-            loss = _SigLipExchangeFn.apply(modality_features, sequence_features, float(logit_scale), logit_bias, self.rank, self.world_size, self.bidir, self._block)
+            loss = _SigLipExchangeFn.apply(modality_features, sequence_features, logit_scale, logit_bias, self.rank, self.world_size, self.bidir, self._block, self.group)
         else:
             loss = self._loss(modality_features, sequence_features, logit_scale, logit_bias)
         return {"contrastive_loss": loss} if output_dict else loss

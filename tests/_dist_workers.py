@@ -34,6 +34,14 @@ def clip_gather_worker(rank, world, port, golden_path, out_dir):
             loss = O.clip_loss(m, s, 1.0, all_m, all_s, rank, world, ll)
             loss.backward()
             res[f"clip_ll{int(ll)}_gwg{int(gwg)}"] = (loss.detach(), m.grad.clone(), s.grad.clone())
+    # a TENSOR logit scale (ref oneprot_module.py:142 feeds `log_logit_scale.exp()`): its gradient collects over the rank's logit blocks
+    m = g["m"][rank].clone().requires_grad_(True)
+    s = g["s"][rank].clone().requires_grad_(True)
+    scale = torch.tensor(1.3, requires_grad=True)
+    all_m, all_s = gather_features(m, s, local_loss=True, gather_with_grad=True, rank=rank, world_size=world)
+    loss = O.clip_loss(m, s, scale, all_m, all_s, rank, world, True)
+    loss.backward()
+    res["clip_ll1_gwg1_tensor"] = (loss.detach(), m.grad.clone(), s.grad.clone(), scale.grad.clone())
     torch.save(res, os.path.join(out_dir, f"clip_rank{rank}.pt"))
     dist.barrier()
     dist.destroy_process_group()
@@ -53,17 +61,33 @@ def siglip_ring_worker(rank, world, port, golden_path, out_dir):
         def oracle_block(m_, c_, scale, bias, negative_only, need_grad):      # the HIP block arithmetic swapped for the oracle's (no GPU here)
             with torch.enable_grad():                                          # (called from inside an autograd node's forward)
                 mm, cc = m_.detach().requires_grad_(need_grad), c_.detach().requires_grad_(need_grad)
-                l = O.siglip_block(mm, cc, scale, bias, negative_only)
+                tens = [t for t in (scale, bias) if isinstance(t, torch.Tensor)]
+                sc = scale.detach().clone().requires_grad_(need_grad) if isinstance(scale, torch.Tensor) else scale
+                bi = bias.detach().clone().requires_grad_(need_grad) if isinstance(bias, torch.Tensor) else bias
+                l = O.siglip_block(mm, cc, sc, bi, negative_only)
                 if not need_grad:
-                    return l.detach(), None, None
-                dm, dc = torch.autograd.grad(l, (mm, cc))
-            return l.detach(), dm, dc
+                    return l.detach(), None, None, None, None
+                wrt = [mm, cc] + [t for t in (sc, bi) if isinstance(t, torch.Tensor)]
+                grads = list(torch.autograd.grad(l, wrt))
+                dm, dc = grads[0], grads[1]
+                rest = grads[2:]
+                dsc = rest.pop(0).reshape(1) if isinstance(sc, torch.Tensor) else None
+                dbi = rest.pop(0).reshape(1) if isinstance(bi, torch.Tensor) else None
+            return l.detach(), dm, dc, dsc, dbi
         fn._block = oracle_block
         m = g["m"][rank].clone().requires_grad_(True)
         s = g["s"][rank].clone().requires_grad_(True)
         loss = fn(m, s, logit_scale=1.0)
         loss.backward()
         res[f"siglip_bidir{int(bidir)}"] = (loss.detach(), m.grad.clone(), s.grad.clone())
+        # learnable scale and bias as tensors: they stay tensors through the exchange node and get their gradients back
+        m = g["m"][rank].clone().requires_grad_(True)
+        s = g["s"][rank].clone().requires_grad_(True)
+        scale = torch.tensor(1.3, requires_grad=True)
+        bias = torch.tensor(-0.7, requires_grad=True)
+        loss = fn(m, s, logit_scale=scale, logit_bias=bias)
+        loss.backward()
+        res[f"siglip_bidir{int(bidir)}_tensor"] = (loss.detach(), m.grad.clone(), s.grad.clone(), scale.grad.clone(), bias.grad.clone())
     # the helpers other code may import by the reference's names: values and the reverse path of the gradient
     left, right = (rank - 1) % world, (rank + 1) % world
     base = torch.arange(6, dtype=torch.float32).reshape(2, 3)

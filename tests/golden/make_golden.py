@@ -322,6 +322,23 @@ def _rank_worker(rank, world, port, feats, q, REFPATH):
         l = fn(m, s, logit_scale=1.0)
         l.backward()
         res[f"siglip_bidir{int(bidir)}"] = (l.detach().clone(), m.grad.clone(), s.grad.clone())
+        # learnable scale and bias as tensors (SigLIP's usual set-up; ref loss.py:241-245 multiplies / adds them into the logits of EVERY block,
+        # so their gradients collect a term per visited chunk)
+        m = feats["m"][rank].clone().requires_grad_(True)
+        s = feats["s"][rank].clone().requires_grad_(True)
+        scale = torch.tensor(1.3, requires_grad=True)
+        bias = torch.tensor(-0.7, requires_grad=True)
+        l = fn(m, s, logit_scale=scale, logit_bias=bias)
+        l.backward()
+        res[f"siglip_bidir{int(bidir)}_tensor"] = (l.detach().clone(), m.grad.clone(), s.grad.clone(), scale.grad.clone(), bias.grad.clone())
+    # CLIP with a tensor logit scale (ref oneprot_module.py:142 passes `log_logit_scale.exp()` in the test hook)
+    m = feats["m"][rank].clone().requires_grad_(True)
+    s = feats["s"][rank].clone().requires_grad_(True)
+    scale = torch.tensor(1.3, requires_grad=True)
+    fn = lossmod.ClipLoss(local_loss=True, gather_with_grad=True, cache_labels=True, rank=rank, world_size=world)
+    l = fn(m, s, logit_scale=scale)
+    l.backward()
+    res["clip_ll1_gwg1_tensor"] = (l.detach().clone(), m.grad.clone(), s.grad.clone(), scale.grad.clone())
     torch.save(res, q + f".rank{rank}")
     dist.barrier()
     dist.destroy_process_group()
@@ -474,6 +491,8 @@ def main():
     if want("multirank"):
         gen_multirank(2, 29611)
         gen_multirank(3, 29612)
+        gen_multirank(4, 29613)     # bidirectional SigLIP: one two-way step + the remainder step; CLIP label offsets at rank 3
+        gen_multirank(8, 29614)     # the node size of BASELINE cfg-3..5: three two-way steps + remainder, >= 2 pipelined transfers
     if want("distributed"):
         gen_distributed(refdist)
     if want("retrieval"):

@@ -1,4 +1,4 @@
-"""world_size 2 / 3 tests of the N>1 path on CPU (gloo): the packed feature all-gather (+ reduce-scatter backward), the SigLIP ring
+"""world_size 2 / 3 / 4 / 8 tests of the N>1 path on CPU (gloo): the packed feature all-gather (+ reduce-scatter backward), the SigLIP ring
 exchange and the bucketed gradient all-reduce -- checked against goldens the reference produced on real gloo ranks."""
 import json
 import os
@@ -25,30 +25,40 @@ def _close(a, b, tol=2e-6):
     assert (a - b).abs().max() <= tol + 1e-5 * b.abs().max(), (a - b).abs().max()
 
 
-@pytest.mark.parametrize("world,port", [(2, 29721), (3, 29722)])
+# world 4: bidirectional SigLIP = one two-way step + the remainder step, CLIP label offsets at rank 3; world 8 = the node size of BASELINE
+# cfg-3..5: three two-way steps + remainder, more than one transfer posted ahead (ref loss.py:72-83,260-309)
+@pytest.mark.parametrize("world,port", [(2, 29721), (3, 29722), (4, 29731), (8, 29732)])
 def test_gather_features_matches_reference_ranks(golden_dir, tmp_path, world, port):
     gp = os.path.join(golden_dir, f"loss_world{world}.pt")
     _run(W.clip_gather_worker, world, port, gp, str(tmp_path))
     g = torch.load(gp, weights_only=False)
     for r in range(world):
         got = torch.load(os.path.join(str(tmp_path), f"clip_rank{r}.pt"), weights_only=False)
-        for key, (loss, gm, gs) in got.items():
-            rl, rgm, rgs = g["per_rank"][r][key]
+        assert "clip_ll1_gwg1_tensor" in got
+        for key, (loss, gm, gs, *extra) in got.items():
+            rl, rgm, rgs, *rextra = g["per_rank"][r][key]
             assert abs(loss - rl) / abs(rl) < 1e-5, key
             _close(gm, rgm); _close(gs, rgs)
+            assert len(extra) == len(rextra)
+            for a, b in zip(extra, rextra):                      # gradient of a tensor logit scale
+                assert abs(a - b) <= 1e-5 * max(1.0, abs(b)), (key, a, b)
 
 
-@pytest.mark.parametrize("world,port", [(2, 29723), (3, 29724)])
+@pytest.mark.parametrize("world,port", [(2, 29723), (3, 29724), (4, 29733), (8, 29734)])
 def test_siglip_ring_matches_reference_ranks(golden_dir, tmp_path, world, port):
     gp = os.path.join(golden_dir, f"loss_world{world}.pt")
     _run(W.siglip_ring_worker, world, port, gp, str(tmp_path))
     g = torch.load(gp, weights_only=False)
     for r in range(world):
         got = torch.load(os.path.join(str(tmp_path), f"siglip_rank{r}.pt"), weights_only=False)
-        for key, (loss, gm, gs) in got.items():
-            rl, rgm, rgs = g["per_rank"][r][key]
+        assert {"siglip_bidir0_tensor", "siglip_bidir1_tensor"} <= set(got)
+        for key, (loss, gm, gs, *extra) in got.items():
+            rl, rgm, rgs, *rextra = g["per_rank"][r][key]
             assert abs(loss - rl) / abs(rl) < 1e-5, key
             _close(gm, rgm, 1e-5); _close(gs, rgs, 1e-5)
+            assert len(extra) == len(rextra)
+            for a, b in zip(extra, rextra):                      # gradients of the tensor logit scale / bias (ref loss.py:241-245)
+                assert abs(a - b) <= 2e-5 * max(1.0, abs(b)), (key, a, b)
 
 
 def test_bucketed_gradient_allreduce(tmp_path):

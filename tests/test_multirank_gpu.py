@@ -61,6 +61,30 @@ def test_two_ranks_equal_single_process(golden_dir, tmp_path, loss_name, port):
         assert d.max() < 2.1e-3 and (d > 5e-4).float().mean() < 0.02, (k, d.max())    # same Adam step up to bf16-noise sign flips on tiny gradients
 
 
+@pytest.mark.parametrize("loss_name,port", [("CLIP", 29771), ("SIGLIP", 29775)])
+def test_four_ranks_equal_single_process(golden_dir, tmp_path, loss_name, port):
+    """The same at world size 4 (12 pairs of the head-dim-24 fixture, 3 per rank, four processes sharing the one GPU over gloo): CLIP label offsets at
+    ranks 2 and 3; bidirectional SigLIP = one two-way step followed by the remainder step, i.e. a second transfer posted while the first step's
+    blocks run (ref loss.py:72-83,260-309).  Five processes touch the card (the box allows six)."""
+    golden = os.path.join(golden_dir, "esm_pair_hd24.pt")
+    out = str(tmp_path)
+    _run(1, out, golden, port, loss_name)
+    _run(4, out, golden, port + 1, loss_name)
+    one = torch.load(os.path.join(out, f"{loss_name}_w1_rank0.pt"), weights_only=False)
+    rs = [torch.load(os.path.join(out, f"{loss_name}_w4_rank{r}.pt"), weights_only=False) for r in range(4)]
+    assert all(r["overlap_calls"] >= 2 for r in rs)
+    mean_loss = sum(r["loss"] for r in rs) / 4
+    assert abs(mean_loss - one["loss"]) / one["loss"] < 1e-3, ([r["loss"] for r in rs], one["loss"])
+    assert abs(rs[0]["gnorm"] - one["gnorm"]) / one["gnorm"] < 2e-2
+    for r in rs[1:]:
+        assert abs(r["gnorm"] - rs[0]["gnorm"]) < 1e-5 * one["gnorm"] + 1e-6
+        for k in ("w", "emb"):
+            assert torch.equal(r[k], rs[0][k]), k                 # replicas stay bit-identical after the all-reduced step
+    for k in ("w", "emb"):
+        d = (rs[0][k] - one[k]).abs()
+        assert d.max() < 2.1e-3 and (d > 5e-4).float().mean() < 0.02, (k, d.max())
+
+
 @pytest.mark.skipif(torch.cuda.device_count() < 2, reason="needs two GPUs: RCCL refuses two ranks on one device")
 @pytest.mark.parametrize("loss_name,port", [("CLIP", 29761), ("SIGLIP", 29765)])
 def test_whole_substep_over_rccl_two_gpus(golden_dir, tmp_path, loss_name, port):

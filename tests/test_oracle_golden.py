@@ -151,7 +151,7 @@ def test_pooling_and_norm(golden_dir):
     _close(O.logit_scale(x[:, 0], torch.log(torch.tensor(500.0))), g["logit_scale_clip"], atol=1e-4)  # clipped at 100
 
 
-@pytest.mark.parametrize("world", [2, 3])
+@pytest.mark.parametrize("world", [2, 3, 4, 8])
 def test_clip_multirank(golden_dir, world):
     """All four (local_loss, gather_with_grad) combos of ref loss.py:19-114, and SigLIP rings, from real gloo runs."""
     g = _load(golden_dir, f"loss_world{world}.pt")
@@ -184,7 +184,7 @@ def test_clip_multirank(golden_dir, world):
             assert abs(l - res[f"siglip_bidir{bidir}"][0]) / abs(l) < 1e-5
 
 
-@pytest.mark.parametrize("world", [2, 3])
+@pytest.mark.parametrize("world", [2, 3, 4, 8])
 def test_clip_gather_with_grad_gradients(golden_dir, world):
     """gather_with_grad=True: the local gradient = d(sum over ranks of per-rank losses)/d(local features)
     (all_gather backward = reduce_scatter SUM).  Pinned against the gloo goldens."""
