@@ -124,6 +124,10 @@ int oneprot_attn_bwd(const void* q, const void* k, const void* v, const float* k
    Bits 4 and up of a positive value are an ablation mask for timing runs only (tools/attn_only.py: 1 no ticket wait, 4 no tiles, 16 no dQ
    stores, 32 no dK/dV stores) -- results are then wrong by construction. */
 void oneprot_attn_force_bwd_path(int path);
+/* Test / A-B hook for oneprot_attn_fwd: -1 automatic (default), 0 the round-1 kernel (per-tile running maximum), 1 the kernels without a row
+   maximum (persistent LDS-DMA kernel for hd <= 32 and L <= 512, the chunked kernel otherwise; rows whose sums leave [2^-60, 2^60] are repeated
+   with the running maximum), 2 the chunked kernel everywhere.  All three produce the same context / LSE up to the bf16 rounding of P. */
+void oneprot_attn_force_fwd_path(int path);
 
 /* ---------------- small fp32 feature ops (ref base_encoder.py:6-38, loss.py:103-114, oneprot_module.py:99-101) --- */
 int oneprot_gelu_f32(const float* x, float* y, int64_t n, void* stream);

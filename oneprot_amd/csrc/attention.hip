@@ -207,7 +207,7 @@ __global__ void __launch_bounds__(256, 2) k_attn_fwd(const bf16_t* __restrict__ 
       if (first || __any(mx > RESCALE_THR * LOG2E)) {
         float dlt = first ? mx : fmaxf(mx, 0.f);
         if (!(dlt > -1e30f)) dlt = 0.f;                    // fully masked so far: keep m
-        const float alpha = __builtin_amdgcn_exp2f(-dlt);
+        const float alpha = first ? 1.0f : __builtin_amdgcn_exp2f(-dlt);      // (nothing accumulated yet on the first tile; 2^-dlt may be inf there)
         l = (l + lacc[0]) * alpha;
         lacc = zero16();
 #pragma unroll
@@ -265,10 +265,653 @@ static int launch_fwd(const void* q, const void* k, const void* v, const float* 
   return launch_status();
 }
 
+// ---------------------------------------------------------------------------------------------------------
+// forward, round 4: one pass over the keys WITHOUT a row maximum, K/V of a whole (b, h) staged once.
+//
+// The per-tile work of the kernel above is bounded by the vector pipe and by the length of each wave's dependent chain, not by the MFMAs: 16
+// v_exp_f32 (measured 10.6 SIMD-cycles each, profiles/r04_exp_rate_probe.txt) + 8 packs are the arithmetic that has to happen; the 14 v_max, the
+// lane^32 exchange through LDS, the compare-and-branch and the bookkeeping MFMA only serve the running maximum.  exp2 needs no maximum for
+// PRECISION (floating point: the relative error of p = 2^s is the same at every magnitude, and P is rounded to bf16, which has the fp32 exponent
+// range); the maximum is only there against overflow / underflow.  So the fast pass computes p = 2^s as it stands and looks at the row sums once,
+// at the end: a sum within [2^-60, 2^60] proves that no exponential overflowed and that everything that was flushed to zero (< 2^-126) is below
+// 2^-66 of the result.  Any other sum (inf, NaN, tiny: a row whose scores all sit below -60, a fully masked row) sends the rows to the exact
+// pass = the algorithm of k_attn_fwd with the deferred running maximum.  Scores of a trained or randomly initialised encoder sit within a few
+// units of zero, so the second pass is a correctness net, not a working point; tests/test_kernels_gpu.py drives it with scores of +-400.
+// Key tiles whose 32 keys are all padding (bias <= -1e30) are skipped (their P is exactly 0), tiles without any bias take no bookkeeping k-step.
+//
+// Two kernels share the tile steps:
+//   k_attn_fwd3  (hd <= 32, L <= 512: every shipped configuration) -- ONE persistent 8-wave work-group per CU walks the (b, h) slabs; the
+//                K / V / bias images of slab n+1 arrive by LDS-DMA (global_load_lds, no registers) in the second half of the LDS while slab n
+//                is computed, the q fragments of slab n+1 are requested a slab ahead, the outputs of slab n leave after the barrier of slab
+//                n+1: one barrier per slab and no exposed load, stage or store phase (stamps of the per-slab work-group form, k_attn_fwd2:
+//                16 k of its 31 k cycles were entry / staging / bias / barrier / store phases, profiles/r04_fwd2_stamps.txt).  A wave owns
+//                TWO 32-query blocks and runs them interleaved: the K / V fragment reads, their address arithmetic and the loop control are
+//                shared, and each block's exponentials sit in the shadow of the other block's MFMA chain -- with one block per wave and four
+//                waves per SIMD the hardware serves the oldest wave first and the younger ones only fill its stalls (profiles/r04_fwd3_stamps.txt:
+//                waves 0-3 took 18 k cycles per slab, waves 12-15 34 k, 540 SIMD-cycles per tile against 273 for the same dataflow in registers,
+//                profiles/r04_attn_mix_probe.txt);
+//   k_attn_fwd2  (any hd, any L) -- one 8-wave work-group per 256 queries, keys staged through registers in chunks of 512 (256 at hd 64),
+//                the exact pass repeated by the whole work-group (the chunk loop has barriers).
+#define FWD2_BIG 1.0e18f            // ~2^60
+#define FWD2_TINY 8.7e-19f          // ~2^-60
+
+// Row sum of the probabilities.  It has to be the sum of the bf16-ROUNDED values that enter the P.V product: then the rounding errors of the weights
+// cancel in acc / l (the output stays a convex combination); normalising by the fp32 sum of the unrounded values (16 v_add per tile, tried) leaves
+// a common-mode error of ~2^-9 / sqrt(n) on every context row: the loss of the hd-32 reference fixture moved by 1.1e-3.  So the sum is taken by an
+// all-ones MFMA over the packed fragments, as in k_attn_fwd: no vector instructions, 16 accumulator registers per block; same kernel time as the
+// vector form (301 against 293 us, tools/ab/attn_ab.py).
+template <int HD> struct RowState {
+  f32x16 acc[Cfg<HD>::DBLK];
+  f32x16 lacc;                      // every register: sum over the keys so far of the lane's query (since the last scale_sum / finish_sum)
+  float m, l;
+  u32x4 qe;                         // exact pass, query side of the bookkeeping k-step: bf16 [-m split in three, 1, 0, 0, 0, 0] in the lanes with h == 0
+  bool first;
+  __device__ __forceinline__ void reset(int h) {
+    m = 0.f; l = 0.f; first = true;
+    lacc = zero16();
+#pragma unroll
+    for (int d = 0; d < Cfg<HD>::DBLK; ++d) acc[d] = zero16();
+    const u32x4 z = {0u, 0u, 0u, 0u};
+    qe = z;
+    if (h == 0) qe.y = 0x3F800000u;      // -m = 0, slot 3 = 1.0 (picks up the key bias)
+  }
+  // accumulate the row sum of one packed fragment (8 bf16 probabilities)
+  __device__ __forceinline__ void add_frag(const bf8_t& pf) {
+    const u32x4 ones = {0x3F803F80u, 0x3F803F80u, 0x3F803F80u, 0x3F803F80u};
+    lacc = MFMA32(__builtin_bit_cast(bf8_t, ones), pf, lacc);
+  }
+  __device__ __forceinline__ void scale_sum(float alpha) { l = (l + lacc[0]) * alpha; lacc = zero16(); }
+  __device__ __forceinline__ void finish_sum() { l += lacc[0]; lacc = zero16(); }
+  __device__ __forceinline__ bool sums_ok() const { return l >= FWD2_TINY && l <= FWD2_BIG; }
+};
+
+// classes of the key tiles of a chunk from its fp32 bias image in LDS (keys >= nkeys count as masked): bit masks with 4 bits per tile,
+// NZ = some key of the group of 8 has a bias, DEAD = all 8 keys of the group are masked.  class(t): 0 no bias (no bookkeeping k-step),
+// 2 every key masked (tile skipped), 1 mixed.
+__device__ __forceinline__ void tile_class_masks(const float* sBias, int nkeys, bool have_bias, int lane, unsigned long long& NZ, unsigned long long& DEAD) {
+  bool nz = false, dead = true;
+  const int k0 = lane * 8;
+  if (have_bias) {
+    const float4 a = *reinterpret_cast<const float4*>(sBias + k0), b = *reinterpret_cast<const float4*>(sBias + k0 + 4);
+    const float bv[8] = {a.x, a.y, a.z, a.w, b.x, b.y, b.z, b.w};
+#pragma unroll
+    for (int j = 0; j < 8; ++j) {
+      const bool in = k0 + j < nkeys;
+      nz = nz || !in || bv[j] != 0.f;
+      dead = dead && (!in || bv[j] <= -1.0e30f);
+    }
+  } else {
+    nz = k0 + 8 > nkeys;
+    dead = k0 >= nkeys;
+  }
+  NZ = __ballot(nz); DEAD = __ballot(dead);
+}
+__device__ __forceinline__ int tile_class(unsigned long long NZ, unsigned long long DEAD, int t) {
+  const unsigned nzb = (unsigned)(NZ >> (4 * t)) & 15u, ddb = (unsigned)(DEAD >> (4 * t)) & 15u;
+  return nzb == 0u ? 0 : (ddb == 15u ? 2 : 1);
+}
+// K side of the bookkeeping k-step for key tile t: bf16 [1, 1, 1, bias[key], 0, 0, 0, 0] in the lanes with h == 0, zeros in the others
+__device__ __forceinline__ bf8_t key_entry(const float* sBias, bool have_bias, int nkeys, int t, int lane) {
+  const int key = t * 32 + (lane & 31);
+  const float bv = key < nkeys ? (have_bias ? sBias[key] : 0.f) : -INFINITY;
+  u32x4 ke = {0u, 0u, 0u, 0u};
+  if ((lane >> 5) == 0) { ke.x = 0x3F803F80u; ke.y = 0x3F80u | (pack2bf(bv, 0.f) << 16); }
+  return __builtin_bit_cast(bf8_t, ke);
+}
+
+// fast pass, one 32-key tile for NB blocks of 32 queries held by the wave: p = 2^s, no maximum.  BOOK: the tile has key biases (class 1).
+template <int HD, int NB, bool BOOK, class Side>
+__device__ __forceinline__ void fwd_tile_fast(const unsigned char* sK, const unsigned char* sV, const float* sBias, bool have_bias, int nkeys, int t,
+                                              const bf8_t (&qf)[NB][Cfg<HD>::KSTEPS], RowState<HD> (&st)[NB], int lane, Side&& side) {
+  typedef Cfg<HD> C;
+  const int h = lane >> 5, r = lane & 31;
+  const unsigned char* kt = sK + t * 32 * C::ROWB;
+  bf8_t kf[C::KSTEPS];
+#pragma unroll
+  for (int k = 0; k < C::KSTEPS; ++k) kf[k] = rd_row<HD>(kt, r, k, h);
+  f32x16 s[NB];
+#ifdef FWD2_ABL_NOQK
+#pragma unroll
+  for (int b = 0; b < NB; ++b) { s[b] = zero16(); asm volatile("" : "+v"(s[b])); }
+#else
+  if constexpr (BOOK) {
+    const bf8_t ke = key_entry(sBias, have_bias, nkeys, t, lane);
+    u32x4 q1 = {0u, 0u, 0u, 0u};
+    if (h == 0) q1.y = 0x3F800000u;                                    // [0, 0, 0, 1]: picks up the key bias
+#pragma unroll
+    for (int b = 0; b < NB; ++b) s[b] = MFMA32(ke, __builtin_bit_cast(bf8_t, q1), zero16());
+#pragma unroll
+    for (int k = 0; k < C::KSTEPS; ++k)
+#pragma unroll
+      for (int b = 0; b < NB; ++b) s[b] = MFMA32(kf[k], qf[b][k], s[b]);
+  } else {
+#pragma unroll
+    for (int b = 0; b < NB; ++b) s[b] = MFMA32(kf[0], qf[b][0], zero16());
+#pragma unroll
+    for (int k = 1; k < C::KSTEPS; ++k)
+#pragma unroll
+      for (int b = 0; b < NB; ++b) s[b] = MFMA32(kf[k], qf[b][k], s[b]);
+  }
+#endif
+  bf8_t vf[2][C::DBLK];
+#pragma unroll
+  for (int sb = 0; sb < 2; ++sb)
+#pragma unroll
+    for (int d = 0; d < C::DBLK; ++d) vf[sb][d] = rd_tr<HD>(sV, t * 32, sb, d, lane);
+  // all score chains are issued before the first exponential: left alone hipcc reuses one register tile for the blocks' scores and sinks the second
+  // block's chain behind the first block's exponentials (one exposed MFMA latency per block and tile)
+  if (NB > 1) __builtin_amdgcn_sched_barrier(0);
+  side();      // the caller's per-tile share of memory instructions (k_attn_fwd3: LDS-DMA of the next slab, stores of the previous one)
+#pragma unroll
+  for (int b = 0; b < NB; ++b) {
+#ifndef FWD2_ABL_NOEXP
+#pragma unroll
+    for (int e = 0; e < 16; ++e) s[b][e] = __builtin_amdgcn_exp2f(s[b][e]);
+#endif
+#pragma unroll
+    for (int sb = 0; sb < 2; ++sb) {
+      const bf8_t pf = pack8(s[b], sb);
+      st[b].add_frag(pf);
+#ifndef FWD2_ABL_NOPV
+#pragma unroll
+      for (int d = 0; d < C::DBLK; ++d) st[b].acc[d] = MFMA32(vf[sb][d], pf, st[b].acc[d]);
+#else
+      st[b].acc[0][sb] += __builtin_bit_cast(float, __builtin_bit_cast(u32x4, pf).x);
+#endif
+    }
+  }
+}
+
+// exact pass, one 32-key tile for one block of 32 queries: deferred running maximum, subtracted inside the score chain (k_attn_fwd's tile step)
+template <int HD>
+__device__ __forceinline__ void fwd_tile_exact(const unsigned char* sK, const unsigned char* sV, const float* sBias, bool have_bias, int nkeys, int t,
+                                               const bf8_t (&qf)[Cfg<HD>::KSTEPS], RowState<HD>& st, int lane) {
+  typedef Cfg<HD> C;
+  const int h = lane >> 5, r = lane & 31;
+  const unsigned char* kt = sK + t * 32 * C::ROWB;
+  f32x16 s = MFMA32(key_entry(sBias, have_bias, nkeys, t, lane), __builtin_bit_cast(bf8_t, st.qe), zero16());      // bias[key] - m[query]
+#pragma unroll
+  for (int k = 0; k < C::KSTEPS; ++k) s = MFMA32(rd_row<HD>(kt, r, k, h), qf[k], s);
+  float mx = fmaxf(fmaxf(s[0], s[1]), s[2]);
+#pragma unroll
+  for (int e = 3; e < 15; e += 2) mx = fmaxf(fmaxf(mx, s[e]), s[e + 1]);
+  mx = fmaxf(mx, s[15]);
+  mx = fmaxf(mx, __shfl_xor(mx, 32, 64));
+  // deferred rescale (s is already relative to m): the running max moves when a tile exceeds it by more than the threshold, and
+  // unconditionally on the very first tile (m starts at 0, not at the row maximum)
+  if (st.first || __any(mx > RESCALE_THR * LOG2E)) {
+    float dlt = st.first ? mx : fmaxf(mx, 0.f);
+    if (!(dlt > -1e30f)) dlt = 0.f;                    // fully masked so far: keep m
+    const float alpha = st.first ? 1.0f : __builtin_amdgcn_exp2f(-dlt);      // (nothing accumulated yet on the first tile; 2^-dlt may be inf there)
+    st.scale_sum(alpha);
+#pragma unroll
+    for (int d = 0; d < C::DBLK; ++d)
+#pragma unroll
+      for (int e = 0; e < 16; ++e) st.acc[d][e] *= alpha;
+#pragma unroll
+    for (int e = 0; e < 16; ++e) s[e] -= dlt;
+    st.m += dlt;
+    if (h == 0) {
+      unsigned w01, w2;
+      split3_bf16(-st.m, w01, w2);
+      st.qe.x = w01; st.qe.y = w2 | 0x3F800000u;
+    }
+    st.first = false;
+  }
+#pragma unroll
+  for (int e = 0; e < 16; ++e) s[e] = __builtin_amdgcn_exp2f(s[e]);
+#pragma unroll
+  for (int sb = 0; sb < 2; ++sb) {
+    const bf8_t pf = pack8(s, sb);
+    st.add_frag(pf);
+#pragma unroll
+    for (int d = 0; d < C::DBLK; ++d) st.acc[d] = MFMA32(rd_tr<HD>(sV, t * 32, sb, d, lane), pf, st.acc[d]);
+  }
+}
+
+// all key tiles of a chunk.  Runs of bias-free tiles go through a loop of their own that contains nothing else (with both tile forms in one
+// loop body hipcc keeps the accumulators of the two forms in different registers and copies all of them every tile).
+template <int HD, int NB, class Side>
+__device__ __forceinline__ void fwd_chunk_fast(const unsigned char* sK, const unsigned char* sV, const float* sBias, bool have_bias, int nkeys, int nt,
+                                               unsigned long long NZ, unsigned long long DEAD, const bf8_t (&qf)[NB][Cfg<HD>::KSTEPS], RowState<HD> (&st)[NB], int lane,
+                                               Side&& side) {
+  unsigned long long special = (NZ | (NZ >> 1) | (NZ >> 2) | (NZ >> 3)) & 0x1111111111111111ull;      // bit 4 t: tile t has a bias somewhere
+  if (nt < 16) special |= ~0ull << (4 * nt);
+  int t = 0;
+  while (t < nt) {
+    const unsigned long long rest = special >> (4 * t);
+    const int run_end = rest ? t + (__builtin_ctzll(rest) >> 2) : nt;                                  // first tile >= t that is not bias-free
+    for (; t < run_end; ++t) fwd_tile_fast<HD, NB, false>(sK, sV, sBias, have_bias, nkeys, t, qf, st, lane, side);
+    if (t < nt) {
+      if (tile_class(NZ, DEAD, t) == 1) fwd_tile_fast<HD, NB, true>(sK, sV, sBias, have_bias, nkeys, t, qf, st, lane, side);
+      ++t;
+    }
+  }
+}
+template <int HD>
+__device__ __forceinline__ void fwd_chunk_exact(const unsigned char* sK, const unsigned char* sV, const float* sBias, bool have_bias, int nkeys, int nt,
+                                                unsigned long long NZ, unsigned long long DEAD, const bf8_t (&qf)[Cfg<HD>::KSTEPS], RowState<HD>& st, int lane) {
+  for (int t = 0; t < nt; ++t)
+    if (tile_class(NZ, DEAD, t) != 2) fwd_tile_exact<HD>(sK, sV, sBias, have_bias, nkeys, t, qf, st, lane);
+}
+
+// normalised outputs of a block's 32 queries: packed context pieces and the natural-log LSE.  A lane's accumulator registers hold 4 head-dim
+// elements per group g (dd = 8 g + 4 h ...); v_permlane32_swap pairs the groups g, g + 1 across lane ^ 32 so that every lane owns 8 consecutive
+// elements = one 16-byte store (half the store instructions: the per-CU memory pipe, not bandwidth, is what the stores cost here).
+template <int HD> struct RowOut {
+  u32x4 w[Cfg<HD>::DBLK * 2];        // piece (d, pr): head-dim elements 32 d + 16 pr + 8 h ... + 7
+  float lse;
+  __device__ __forceinline__ void from(const RowState<HD>& st) {
+    const float lt = st.l;
+    const float inv = lt > 0.f ? 1.0f / lt : 0.f;
+#pragma unroll
+    for (int d = 0; d < Cfg<HD>::DBLK; ++d)
+#pragma unroll
+      for (int pr = 0; pr < 2; ++pr) {
+        const int g = 2 * pr;
+        unsigned ax = pack2bf(st.acc[d][4 * g] * inv, st.acc[d][4 * g + 1] * inv), ay = pack2bf(st.acc[d][4 * g + 2] * inv, st.acc[d][4 * g + 3] * inv);
+        unsigned bx = pack2bf(st.acc[d][4 * g + 4] * inv, st.acc[d][4 * g + 5] * inv), by = pack2bf(st.acc[d][4 * g + 6] * inv, st.acc[d][4 * g + 7] * inv);
+        // swap(a, b): a's upper half <-> b's lower half.  Lanes h = 0 then hold group g whole (own 4 | lane^32's 4), lanes h = 1 group g + 1
+        const auto sx = __builtin_amdgcn_permlane32_swap(ax, bx, false, false);
+        const auto sy = __builtin_amdgcn_permlane32_swap(ay, by, false, false);
+        w[2 * d + pr].x = sx[0]; w[2 * d + pr].y = sy[0]; w[2 * d + pr].z = sx[1]; w[2 * d + pr].w = sy[1];
+      }
+    lse = (st.m + __log2f(lt)) * 0.6931471805599453f;
+  }
+  static constexpr int NPIECE = (HD + 15) / 16;      // 16-byte pieces per lane that exist (hd 16: one, hd 32: two, hd 64: four)
+  __device__ __forceinline__ void store_piece(int i, bf16_t* dst /* ctx row of the query + head offset */, int h) const {
+    *reinterpret_cast<u32x4*>(dst + 16 * i + 8 * h) = w[i];
+  }
+  __device__ __forceinline__ void store(bf16_t* dst, float* lse_dst, int h) const {
+#pragma unroll
+    for (int i = 0; i < NPIECE; ++i) store_piece(i, dst, h);
+    if (lse_dst && h == 0) *lse_dst = lse;
+  }
+};
+
+#ifdef FWD2_STAMP      // diagnostic build (tools/ab/fwd2_stamps.py): s_memtime at the phase boundaries
+__device__ unsigned long long g_fwd2_stamps[64 * 16 * 8];
+#define FWD2_T(i)                                                                                              \
+  do {                                                                                                         \
+    unsigned long long t_;                                                                                     \
+    asm volatile("s_memtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(t_)::"memory");                                  \
+    if ((threadIdx.x & 63) == 0 && blockIdx.x % 37 == 0 && blockIdx.x / 37 < 64 && ((threadIdx.x >> 6) == 0 || (threadIdx.x >> 6) == 5)) \
+      g_fwd2_stamps[((blockIdx.x / 37) * 2 + ((threadIdx.x >> 6) == 5)) * 8 + (i)] = t_;                       \
+  } while (0)
+#define FWD3_T(i)                                                                                              \
+  do {                                                                                                         \
+    unsigned long long t_;                                                                                     \
+    asm volatile("s_memtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(t_)::"memory");                                  \
+    if ((threadIdx.x & 63) == 0 && blockIdx.x % 4 == 0 && slab_no == 3)                                        \
+      g_fwd2_stamps[((blockIdx.x / 4) * 16 + (threadIdx.x >> 6)) * 8 + (i)] = t_;                              \
+  } while (0)
+extern "C" int oneprot_attn_debug_stamps(unsigned long long* host_out) {
+  return hipMemcpyFromSymbol(host_out, HIP_SYMBOL(g_fwd2_stamps), sizeof(unsigned long long) * 64 * 16 * 8) == hipSuccess ? 0 : -1;
+}
+#else
+#define FWD2_T(i)
+#define FWD3_T(i)
+#endif
+
+// ---- k_attn_fwd2: one work-group per 256 queries, keys in chunks through registers -----------------------------------------------------
+template <int HD> struct Fwd2 {
+  typedef Cfg<HD> C;
+  static constexpr int CK = HD <= 32 ? 512 : 256;                  // keys per LDS chunk
+  static constexpr int TILE = CK * C::ROWB;
+  static constexpr int BIAS_OFF = 2 * TILE;                        // fp32 key bias of the chunk
+  static constexpr int FLAG_OFF = BIAS_OFF + CK * 4;
+  static constexpr int TOTAL = FLAG_OFF + 16;
+};
+
+// one pass over all keys for the wave's 32 queries; EXACT = with the running maximum.  Every wave of the work-group calls it (barriers inside).
+template <int HD, bool EXACT>
+__device__ __forceinline__ void fwd2_pass(unsigned char* smem, const bf16_t* __restrict__ kbase, const bf16_t* __restrict__ vbase, const float* __restrict__ bias_row,
+                                          int L, bool active, const bf8_t (&qf)[1][Cfg<HD>::KSTEPS], RowState<HD> (&st)[1]) {
+  typedef Cfg<HD> C;
+  typedef Fwd2<HD> F;
+  unsigned char* sK = smem;
+  unsigned char* sV = smem + F::TILE;
+  float* sBias = reinterpret_cast<float*>(smem + F::BIAS_OFF);
+  const int nthr = blockDim.x;
+  const int lane = threadIdx.x & 63;
+  st[0].reset(lane >> 5);
+  for (int kc0 = 0; kc0 < L; kc0 += F::CK) {
+    const int nkeys = min(F::CK, L - kc0);
+    const int nrows = (nkeys + 31) & ~31;
+    __syncthreads();
+    if (!EXACT) FWD2_T(1);
+    // ---- stage the chunk: all loads of a round in flight together, then committed to the swizzled images
+    {
+#ifdef FWD2_ABL_NOLOAD
+      const int total = 0;
+#else
+      const int total = nrows * C::NCH;
+#endif
+      for (int base = 0; base < total; base += 4 * nthr) {
+        u32x4 rk[4], rv[4];
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+          const int idx = base + j * nthr + (int)threadIdx.x;
+          const int row = idx / C::NCH, ch = idx - row * C::NCH;
+          const u32x4 z = {0u, 0u, 0u, 0u};
+          rk[j] = z; rv[j] = z;
+          if (idx < total && row < nkeys && ch < HD / 8) {
+            rk[j] = *reinterpret_cast<const u32x4*>(kbase + (size_t)(kc0 + row) * HD + ch * 8);
+            rv[j] = *reinterpret_cast<const u32x4*>(vbase + (size_t)(kc0 + row) * HD + ch * 8);
+          }
+        }
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+          const int idx = base + j * nthr + (int)threadIdx.x;
+          const int row = idx / C::NCH, ch = idx - row * C::NCH;
+          if (idx < total) {
+            const int off = row * C::ROWB + (swz<C::HDP>(row, ch) << 4);
+            *reinterpret_cast<u32x4*>(sK + off) = rk[j];
+            *reinterpret_cast<u32x4*>(sV + off) = rv[j];
+          }
+        }
+      }
+      if (!EXACT) FWD2_T(2);
+      if (bias_row)
+        for (int i = threadIdx.x; i < F::CK; i += nthr) sBias[i] = i < nkeys ? bias_row[kc0 + i] : 0.f;
+    }
+    if (!EXACT) FWD2_T(3);
+    __syncthreads();
+    if (!EXACT) FWD2_T(4);
+    if (!active) continue;
+    unsigned long long NZ, DEAD;
+    tile_class_masks(sBias, nkeys, bias_row != nullptr, lane, NZ, DEAD);
+    if constexpr (EXACT) fwd_chunk_exact<HD>(sK, sV, sBias, bias_row != nullptr, nkeys, nrows >> 5, NZ, DEAD, qf[0], st[0], lane);
+    else fwd_chunk_fast<HD, 1>(sK, sV, sBias, bias_row != nullptr, nkeys, nrows >> 5, NZ, DEAD, qf, st, lane, [] {});
+  }
+}
+
+template <int HD>
+__global__ void __launch_bounds__(512, HD <= 32 ? 4 : 2) k_attn_fwd2(const bf16_t* __restrict__ q, const bf16_t* __restrict__ k, const bf16_t* __restrict__ v,
+                                                                  const float* __restrict__ key_bias, bf16_t* __restrict__ ctx, float* __restrict__ lse_out, int B,
+                                                                  int H, int L, int nqb) {
+  typedef Cfg<HD> C;
+  typedef Fwd2<HD> F;
+  extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+  int* sFlag = reinterpret_cast<int*>(smem + F::FLAG_OFF);
+  int bh, qb;
+  decode_block(nqb, B * H, bh, qb);
+  if (bh >= B * H) return;
+  const int b = bh / H, head = bh - b * H;
+  const int lane = threadIdx.x & 63, wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6), h = lane >> 5, r = lane & 31;
+  const int q0 = qb * 256 + wave * 32;
+  const bool active = q0 < L;
+  const int qidx = q0 + r;
+  const int qrow = qidx < L ? qidx : L - 1;
+  const bf16_t* kbase = k + (size_t)bh * L * HD;
+  const bf16_t* vbase = v + (size_t)bh * L * HD;
+  const float* bias_row = key_bias ? key_bias + (size_t)b * L : nullptr;
+  bf8_t qf[1][C::KSTEPS];
+#pragma unroll
+  for (int st = 0; st < C::KSTEPS; ++st) qf[0][st] = *reinterpret_cast<const bf8_t*>(q + ((size_t)bh * L + qrow) * HD + 16 * st + 8 * h);
+  if (threadIdx.x == 0) *sFlag = 0;
+  FWD2_T(0);
+  RowState<HD> st[1];
+  fwd2_pass<HD, false>(smem, kbase, vbase, bias_row, L, active, qf, st);
+  st[0].finish_sum();
+  FWD2_T(5);
+  {
+#ifdef FWD2_NOFALLBACK      // timing builds of ablated kernels (wrong sums by construction)
+    const bool bad = false;
+#else
+    const bool bad = active && __any(!st[0].sums_ok());
+#endif
+    if (bad && lane == 0) *sFlag = 1;
+    __syncthreads();
+    if (*sFlag != 0) {      // the whole work-group repeats with the running maximum
+      fwd2_pass<HD, true>(smem, kbase, vbase, bias_row, L, active, qf, st);
+      st[0].finish_sum();
+    }
+  }
+  FWD2_T(6);
+  if (!active) return;
+  RowOut<HD> out;
+  out.from(st[0]);
+  if (qidx < L) out.store(ctx + ((size_t)b * L + qidx) * (H * HD) + head * HD, lse_out ? lse_out + (size_t)bh * L + qidx : nullptr, h);
+#ifdef FWD2_STAMP
+  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+#endif
+  FWD2_T(7);
+}
+
+// ---- k_attn_fwd3: persistent, LDS-DMA double buffered, two query blocks per wave (hd <= 32, L <= 512) ------------------------------------
+static __device__ __attribute__((aligned(16))) unsigned int g_attn_zero_page[4] = {0, 0, 0, 0};
+// One LDS-DMA piece: 64 lanes x 16 (or 4) bytes from per-lane global addresses to LDS bytes [lds_dst, +1024) (or +256), lane-linear.  M0 (the
+// LDS destination) is written in the statement that uses it and restored afterwards; these loads are invisible to hipcc's s_waitcnt bookkeeping:
+// the kernel waits for them itself (vmcnt(0) before the slab barrier).
+__device__ __forceinline__ void glds16_addr(const void* src, unsigned lds_dst) {
+  unsigned keep;
+  asm volatile("s_mov_b32 %0, m0\n\ts_mov_b32 m0, %2\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %1, off\n\ts_mov_b32 m0, %0" : "=&s"(keep) : "v"(src), "s"(lds_dst) : "memory");
+}
+__device__ __forceinline__ void glds4_addr(const void* src, unsigned lds_dst) {
+  unsigned keep;
+  asm volatile("s_mov_b32 %0, m0\n\ts_mov_b32 m0, %2\n\ts_nop 0\n\tglobal_load_lds_dword %1, off\n\ts_mov_b32 m0, %0" : "=&s"(keep) : "v"(src), "s"(lds_dst) : "memory");
+}
+
+struct Fwd3 {
+  static constexpr int ROWS = 512;
+  static constexpr int TILE = ROWS * 64;                // 64-byte swizzled rows (hd = 16 zero-padded)
+  static constexpr int BUF = 2 * TILE + ROWS * 4;       // K image, V image, fp32 bias
+  static constexpr int TOTAL = 2 * BUF;                 // 132 KB
+};
+
+template <int HD>
+__global__ void __launch_bounds__(512, 2) k_attn_fwd3(const bf16_t* __restrict__ q, const bf16_t* __restrict__ k, const bf16_t* __restrict__ v,
+                                                   const float* __restrict__ key_bias, bf16_t* __restrict__ ctx, float* __restrict__ lse_out, int B, int H,
+                                                   int L) {
+  typedef Cfg<HD> C;
+  static_assert(C::ROWB == 64, "k_attn_fwd3 stages 64-byte rows");
+  extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+  const unsigned lds0 = (unsigned)(uintptr_t)LDS_PTR(smem);
+  const int lane = threadIdx.x & 63, wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6), h = lane >> 5, r = lane & 31;
+  const int nw = blockDim.x >> 6;
+  // consecutive work-groups go to consecutive XCDs: XCD x takes the x-th eighth of the (b, h) slabs, its work-groups walk that range with a
+  // stride of (work-groups per XCD), so the heads of one batch element -- which share the 128-byte lines of the ctx rows -- meet in one L2
+  const int nbh = B * H, per_xcd = (nbh + 7) >> 3, nslot = gridDim.x >> 3;
+  const int xcd = blockIdx.x & 7;
+  const int bh_end = min(nbh, (xcd + 1) * per_xcd);
+  int bh = xcd * per_xcd + (int)(blockIdx.x >> 3);
+  // the wave's two query blocks: rows [64 w, 64 w + 32) and [64 w + 32, 64 w + 64); the second one may lie beyond L (its rows then repeat row L - 1
+  // and are not stored)
+  const int q0 = wave * 64;
+  const bool active = q0 < L;
+  int qidx[2], qrow[2];
+#pragma unroll
+  for (int b = 0; b < 2; ++b) { qidx[b] = q0 + 32 * b + r; qrow[b] = qidx[b] < L ? qidx[b] : L - 1; }
+  const int nrows = (L + 31) & ~31;
+  const int npieces = nrows >> 4;                           // 1 KiB pieces (16 rows) per image
+  const int dm = H * HD;
+  const unsigned char* zero = reinterpret_cast<const unsigned char*>(g_attn_zero_page);
+
+  // One memory instruction of the slab's list: LDS-DMA pieces of slab `item` (K and V alternating, then the bias piece), its q fragments, the
+  // output stores of slab `pitem`.  The list is worked off one or two entries per key tile INSIDE the tile loop: issued in one burst after the
+  // barrier, the ~180 memory instructions of the 8 waves queued on the CU's one memory pipe for 7-12 k cycles during which no wave computed
+  // (profiles/r04_fwd3_stamps.txt).
+  const int my_pieces = npieces > wave ? (npieces - wave + nw - 1) / nw : 0;
+  const int n_biasp = (nrows + 63) >> 6;
+  auto dma_piece = [&](int item, int buf, int i) {           // i < 2 * my_pieces: K (even) / V (odd) piece i / 2 of this wave; i == 2 * my_pieces: bias
+    const unsigned dst0 = lds0 + buf * Fwd3::BUF;
+    if (i < 2 * my_pieces) {
+      const int p = wave + nw * (i >> 1);
+      const int row = 16 * p + (lane >> 2);
+      const int ch = (lane & 3) ^ ((row >> 2) & 3);         // the chunk that lives at this lane's place of the swizzled image
+      const bool ok = row < L && ch < HD / 8;
+      const unsigned char* base = reinterpret_cast<const unsigned char*>(((i & 1) ? v : k) + (size_t)item * L * HD);
+      glds16_addr(ok ? base + (size_t)row * (HD * 2) + ch * 16 : zero, dst0 + ((i & 1) ? Fwd3::TILE : 0) + p * 1024);
+    } else {
+      const int key = 64 * wave + lane;
+      glds4_addr(key < L ? (const void*)(key_bias + (size_t)(item / H) * L + key) : (const void*)zero, dst0 + 2 * Fwd3::TILE + wave * 256);
+    }
+  };
+  const int n_dma = 2 * my_pieces + ((key_bias && wave < n_biasp) ? 1 : 0);
+  constexpr int NQ = 2 * C::KSTEPS;                          // q fragment loads per slab
+  constexpr int NST = 2 * (RowOut<HD>::NPIECE + 1);          // output stores per slab (context pieces + lse, two blocks)
+  auto load_q1 = [&](int item, bf8_t (&dstq)[2][C::KSTEPS], int i) {
+#pragma unroll
+    for (int b = 0; b < 2; ++b)
+#pragma unroll
+      for (int st = 0; st < C::KSTEPS; ++st)
+        if (i == b * C::KSTEPS + st) dstq[b][st] = *reinterpret_cast<const bf8_t*>(q + ((size_t)item * L + qrow[b]) * HD + 16 * st + 8 * h);
+  };
+  auto store1 = [&](const RowOut<HD> (&o)[2], int item, int i) {
+#pragma unroll
+    for (int b = 0; b < 2; ++b) {
+      bf16_t* dst = ctx + ((size_t)(item / H) * L + qidx[b]) * dm + (item % H) * HD;
+#pragma unroll
+      for (int pc = 0; pc < RowOut<HD>::NPIECE; ++pc)
+        if (i == b * (RowOut<HD>::NPIECE + 1) + pc && qidx[b] < L) o[b].store_piece(pc, dst, h);
+      if (i == b * (RowOut<HD>::NPIECE + 1) + RowOut<HD>::NPIECE && lse_out && h == 0 && qidx[b] < L) lse_out[(size_t)item * L + qidx[b]] = o[b].lse;
+    }
+  };
+
+  bf8_t qf[2][C::KSTEPS], qn[2][C::KSTEPS];
+  if (bh < bh_end) {
+    for (int i = 0; i < n_dma; ++i) dma_piece(bh, 0, i);
+    for (int i = 0; i < NQ; ++i) load_q1(bh, qf, i);
+  }
+  RowOut<HD> pend[2];
+  int pend_bh = -1, buf = 0;
+  int slab_no = 0;
+  while (bh < bh_end) {
+    FWD3_T(0);
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");        // this wave's pieces of slab `bh` have landed (and its q fragments, and older stores)
+    FWD3_T(1);
+    __builtin_amdgcn_s_barrier();                           // ... everybody's have; everybody has left the other half of the LDS
+    FWD3_T(2);
+    // hipcc does not see the wait above: it would put its own vmcnt(0) in front of the first use of the q fragments -- behind the LDS-DMA of the
+    // NEXT slab, i.e. the compute would start only after that transfer.  Consuming the fragments here puts its wait where it is free.
+#pragma unroll
+    for (int b = 0; b < 2; ++b)
+#pragma unroll
+      for (int st = 0; st < C::KSTEPS; ++st) asm volatile("" : "+v"(qf[b][st]));
+    const int nxt = bh + nslot;
+    const bool more = nxt < bh_end;
+    // the q fragments of the next slab in one go (a load whose result registers are written under a condition inside the tile loop makes hipcc wait
+    // for vmcnt(0) -- i.e. for the LDS-DMA too -- in every iteration)
+#ifndef FWD3_ABL_NOQ
+    if (more)
+      for (int i = 0; i < NQ; ++i) load_q1(nxt, qn, i);
+#else
+    for (int b = 0; b < 2; ++b) for (int st = 0; st < C::KSTEPS; ++st) qn[b][st] = qf[b][st];
+#endif
+    // the slab's list of spread memory instructions: [DMA pieces of nxt][stores of pend_bh]
+    const int e_dma = more ? n_dma : 0, e_all = e_dma + ((pend_bh >= 0 && active) ? NST : 0);
+    int vm_i = 0;
+    auto vm_step = [&]() {
+      const int i = vm_i;
+      if (i >= e_all) return;
+      vm_i = i + 1;
+#ifndef FWD3_ABL_NODMA
+      if (i < e_dma) dma_piece(nxt, buf ^ 1, i);
+#else
+      if (i < e_dma) {}
+#endif
+#ifndef FWD3_ABL_NOSTORE
+      else store1(pend, pend_bh, i - e_dma);
+#endif
+    };
+    FWD3_T(3);
+    if (active) {
+      const unsigned char* sK = smem + buf * Fwd3::BUF;
+      const unsigned char* sV = sK + Fwd3::TILE;
+      const float* sBias = reinterpret_cast<const float*>(sK + 2 * Fwd3::TILE);
+      const bool have_bias = key_bias != nullptr;
+      unsigned long long NZ, DEAD;
+      tile_class_masks(sBias, L, have_bias, lane, NZ, DEAD);
+      const int nt = nrows >> 5;
+      RowState<HD> st[2];
+      st[0].reset(h); st[1].reset(h);
+      fwd_chunk_fast<HD, 2>(sK, sV, sBias, have_bias, L, nt, NZ, DEAD, qf, st, lane, [&] { vm_step(); vm_step(); });
+      while (vm_i < e_all) vm_step();                       // (short sequences / skipped tiles: whatever is left of the list)
+      st[0].finish_sum(); st[1].finish_sum();
+      FWD3_T(4);
+#ifndef FWD2_NOFALLBACK
+      // the whole slab is resident: a block whose sums are out of range repeats its own rows with the running maximum, no barrier involved
+#pragma unroll
+      for (int b = 0; b < 2; ++b)
+        if (__any(!st[b].sums_ok())) {
+          st[b].reset(h);
+          fwd_chunk_exact<HD>(sK, sV, sBias, have_bias, L, nt, NZ, DEAD, qf[b], st[b], lane);
+          st[b].finish_sum();
+        }
+#endif
+      pend[0].from(st[0]); pend[1].from(st[1]);
+    } else {
+      while (vm_i < e_all) vm_step();                       // a wave without queries still moves its share of the next slab
+    }
+    FWD3_T(5);
+    ++slab_no;
+    pend_bh = bh;
+    bh = nxt; buf ^= 1;
+#pragma unroll
+    for (int b = 0; b < 2; ++b)
+#pragma unroll
+      for (int st = 0; st < C::KSTEPS; ++st) qf[b][st] = qn[b][st];
+  }
+  if (pend_bh >= 0 && active)
+    for (int i = 0; i < NST; ++i) store1(pend, pend_bh, i);
+}
+
+static int g_attn_fwd_path = -1;      // -1 automatic, 0 k_attn_fwd (per-tile maximum), 1 no-maximum kernels (fwd3 where eligible, else fwd2), 2 k_attn_fwd2 (A/B runs and tests)
+extern "C" void oneprot_attn_force_fwd_path(int path) { g_attn_fwd_path = path < 0 ? -1 : (path > 2 ? 1 : path); }
+
+template <int HD>
+static int launch_fwd2(const void* q, const void* k, const void* v, const float* key_bias, void* ctx, float* lse, int B, int H, int L, hipStream_t s) {
+  static int ok = -1;
+  if (ok < 0) ok = hipFuncSetAttribute((const void*)k_attn_fwd2<HD>, hipFuncAttributeMaxDynamicSharedMemorySize, Fwd2<HD>::TOTAL) == hipSuccess ? 1 : 0;
+  if (!ok) { (void)hipGetLastError(); return OP_EINVAL; }
+  const int nqb = (L + 255) / 256;
+  const int nbh8 = ((B * H + 7) / 8) * 8;
+  const int waves = L >= 256 ? 8 : (L + 31) / 32;
+  hipLaunchKernelGGL(k_attn_fwd2<HD>, dim3(nbh8 * nqb), dim3(64 * waves), Fwd2<HD>::TOTAL, s, (const bf16_t*)q, (const bf16_t*)k, (const bf16_t*)v, key_bias,
+                     (bf16_t*)ctx, lse, B, H, L, nqb);
+  return launch_status();
+}
+
+template <int HD>
+static int launch_fwd3(const void* q, const void* k, const void* v, const float* key_bias, void* ctx, float* lse, int B, int H, int L, hipStream_t s) {
+  static int ok = -1, n_cu = 0;
+  if (ok < 0) {
+    ok = hipFuncSetAttribute((const void*)k_attn_fwd3<HD>, hipFuncAttributeMaxDynamicSharedMemorySize, Fwd3::TOTAL) == hipSuccess ? 1 : 0;
+    int dev = 0; hipDeviceProp_t prop;
+    if (hipGetDevice(&dev) != hipSuccess || hipGetDeviceProperties(&prop, dev) != hipSuccess) ok = 0; else n_cu = prop.multiProcessorCount;
+  }
+  if (!ok) { (void)hipGetLastError(); return launch_fwd2<HD>(q, k, v, key_bias, ctx, lse, B, H, L, s); }
+  const int waves = (L + 63) / 64;                        // <= 8: a wave owns 64 queries
+  const int per_xcd = (B * H + 7) / 8;
+  int nslot = n_cu / 8;                                   // one persistent work-group per CU
+  if (nslot < 1) nslot = 1;
+  if (nslot > per_xcd) nslot = per_xcd;
+  hipLaunchKernelGGL(k_attn_fwd3<HD>, dim3(8 * nslot), dim3(64 * waves), Fwd3::TOTAL, s, (const bf16_t*)q, (const bf16_t*)k, (const bf16_t*)v, key_bias,
+                     (bf16_t*)ctx, lse, B, H, L);
+  return launch_status();
+}
+
+template <int HD>
+static int launch_fwd_nomax(const void* q, const void* k, const void* v, const float* key_bias, void* ctx, float* lse, int B, int H, int L, hipStream_t s) {
+  if constexpr (HD <= 32) {
+    if (L <= Fwd3::ROWS && g_attn_fwd_path != 2) return launch_fwd3<HD>(q, k, v, key_bias, ctx, lse, B, H, L, s);
+  }
+  return launch_fwd2<HD>(q, k, v, key_bias, ctx, lse, B, H, L, s);
+}
+
 extern "C" int oneprot_attn_fwd(const void* q, const void* k, const void* v, const float* key_bias, void* ctx, float* lse, int B, int H, int L, int hd,
                                 void* stream) {
   if (!q || !k || !v || !ctx || B <= 0 || H <= 0 || L <= 0) return OP_EINVAL;
   hipStream_t s = (hipStream_t)stream;
+  if (g_attn_fwd_path != 0) {
+    switch (hd) {
+      case 16: return launch_fwd_nomax<16>(q, k, v, key_bias, ctx, lse, B, H, L, s);
+      case 32: return launch_fwd_nomax<32>(q, k, v, key_bias, ctx, lse, B, H, L, s);
+      case 64: return launch_fwd_nomax<64>(q, k, v, key_bias, ctx, lse, B, H, L, s);
+      default: return OP_EINVAL;
+    }
+  }
   switch (hd) {
     case 16: return launch_fwd<16>(q, k, v, key_bias, ctx, lse, B, H, L, s);
     case 32: return launch_fwd<32>(q, k, v, key_bias, ctx, lse, B, H, L, s);

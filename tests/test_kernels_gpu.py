@@ -346,9 +346,16 @@ def attn_bwd_path(request):
     hip.query("oneprot_attn_force_bwd_path", -1)
 
 
+@pytest.fixture(params=[0, 1, 2], ids=["fwd_rowmax", "fwd_nomax", "fwd_nomax_chunked"])
+def attn_fwd_path(request):
+    hip.query("oneprot_attn_force_fwd_path", request.param)
+    yield request.param
+    hip.query("oneprot_attn_force_fwd_path", -1)
+
+
 @pytest.mark.parametrize("B,H,L,hd", [(2, 3, 37, 32), (1, 2, 128, 16), (2, 2, 300, 32), (1, 2, 70, 64), (1, 1, 513, 32), (2, 2, 512, 32), (1, 3, 256, 32),
-                                      (2, 1, 257, 16), (1, 2, 31, 16), (3, 2, 480, 32)])
-def test_attention_fwd_bwd(B, H, L, hd, attn_bwd_path):
+                                      (2, 1, 257, 16), (1, 2, 31, 16), (3, 2, 480, 32), (1, 2, 300, 64), (1, 1, 1100, 32), (1, 1, 600, 64)])
+def test_attention_fwd_bwd(B, H, L, hd, attn_bwd_path, attn_fwd_path):
     g = torch.Generator().manual_seed(8)
     q = bf(torch.randn(B, H, L, hd, generator=g) * 0.7 * hip.LOG2E).to(DEV)          # the kernels take q x log2(e) (scores in log2 units)
     k = bf(torch.randn(B, H, L, hd, generator=g)).to(DEV)
@@ -376,6 +383,85 @@ def test_attention_fwd_bwd(B, H, L, hd, attn_bwd_path):
     for name, gt, rf in (("dq", got[0], qr.grad), ("dk", got[1], kr.grad), ("dv", got[2], vr.grad)):
         assert rel_err(gt, rf) < 2e-2, f"{name} rel err {rel_err(gt, rf)}"
         assert_close(gt, rf, 5e-2, 5e-2 * rf.abs().max().item(), name)
+
+
+@pytest.mark.parametrize("L", [1, 2, 31, 32, 33, 63, 64, 65, 255, 256, 257, 288, 479, 511, 512, 513, 777])
+@pytest.mark.parametrize("hd", [16, 32, 64])
+def test_attention_fwd_nomax_equals_rowmax_at_block_edges(L, hd):
+    """k_attn_fwd2 (no per-tile maximum, whole (b, h) key range staged once, masked tiles skipped) against k_attn_fwd at every tile / wave / chunk
+    boundary, with ragged key padding that ends inside a tile, on a tile edge, and leaves whole tiles masked.  Both kernels round P to bf16 after the
+    same fp32 arithmetic up to the (here unused) maximum shift, so context and LSE agree to the bf16 rounding of the output."""
+    B, H = 3, 2
+    g = torch.Generator().manual_seed(2000 + L + hd)
+    q = bf(torch.randn(B, H, L, hd, generator=g) * 0.7 * hip.LOG2E).to(DEV)
+    k = bf(torch.randn(B, H, L, hd, generator=g)).to(DEV)
+    v = bf(torch.randn(B, H, L, hd, generator=g)).to(DEV)
+    bias = torch.zeros(B, L)
+    if L > 2:
+        bias[1, L - L // 4:] = torch.finfo(torch.float32).min       # ends inside a tile
+        bias[2, max(1, (L // 2) & ~31):] = float("-inf")            # ends on a tile edge (when L >= 64): the rest are whole masked tiles
+    bias = bias.to(DEV)
+    outs = []
+    for path in (0, 1, 2):           # 1: the persistent LDS-DMA kernel where eligible (hd <= 32, L <= 512); 2: the chunked kernel everywhere
+        hip.query("oneprot_attn_force_fwd_path", path)
+        try:
+            for rep in range(2):     # twice: the persistent kernel alternates LDS halves, a stale half would show on the repeat
+                ctx = torch.full((B * L, H * hd), float("nan"), dtype=torch.bfloat16, device=DEV)
+                lse = torch.full((B, H, L), float("nan"), device=DEV)
+                hip.call("oneprot_attn_fwd", q, k, v, bias, ctx, lse, B, H, L, hd)
+            outs.append((ctx.float(), lse.clone()))
+        finally:
+            hip.query("oneprot_attn_force_fwd_path", -1)
+    (c0, l0) = outs[0]
+    o_ref, lse_ref = _attn_ref(q.float() / hip.LOG2E, k.float(), v.float(), bias)
+    for name, (c1, l1) in zip(("fwd3/fwd2", "fwd2"), outs[1:]):
+        assert torch.isfinite(c1).all() and torch.isfinite(l1).all(), name
+        assert_close(c1, c0, 2 ** -7, 2 ** -8 * float(c0.abs().max()), f"ctx {name}")
+        # the row sum is a sum of bf16-rounded probabilities in both kernels; with the maximum subtracted the largest one is exactly 1, without it
+        # it carries its own 2^-9 rounding: log(l) of a row dominated by few keys differs by up to 2 x 2e-3
+        assert_close(l1, l0, 1e-5, 8e-3, f"lse {name}")
+        assert_close(c1, o_ref.permute(0, 2, 1, 3).reshape(B * L, H * hd), 2 ** -7, 1e-2, f"ctx vs fp32 {name}")
+        assert_close(l1, lse_ref, 1e-4, 5e-3, f"lse vs fp32 {name}")
+
+
+@pytest.mark.parametrize("L,hd", [(512, 32), (300, 16), (700, 32), (400, 64)])
+def test_attention_fwd_nomax_overflow_underflow_net(L, hd):
+    """Scores far outside the range a maximum-free exp2 can hold: every key is u + noise and query row i is alpha_i * u, so row i's scores all sit
+    near alpha_i |u|^2 (log2 units): -400 / -200 (every exponential underflows or is tiny: the row-sum check at the end sends the work-group to the
+    exact pass), 0, +45 / +70 (sums pass 2^40: rescaled in the fast pass, the wave continues with the bookkeeping k-step), +200 / +400 (inf
+    in one tile: exact pass).  Rows of different kinds share waves and work-groups; one batch element keeps ordinary scores throughout (its
+    work-groups must stay in the fast pass and still be right), one mixes padding in."""
+    B, H = 3, 2
+    g = torch.Generator().manual_seed(3000 + L + hd)
+    u = torch.randn(hd, generator=g)
+    u = u / u.norm()
+    k = u[None, None, None, :] * 4.0 + 0.05 * torch.randn(B, H, L, hd, generator=g)
+    kinds = torch.tensor([-400.0, -200.0, 0.0, 45.0, 70.0, 200.0, 400.0])
+    alpha = kinds[torch.randint(0, len(kinds), (B, H, L), generator=g)] / 4.0            # k ~ 4 u, so q = alpha u gives q.k ~ 4 alpha = the kind
+    alpha[0] = 0.0                                                                         # batch element 0: ordinary rows only
+    q = alpha[..., None] * u[None, None, None, :] + 0.3 * torch.randn(B, H, L, hd, generator=g)
+    q, k = bf(q).to(DEV), bf(k).to(DEV)
+    v = bf(torch.randn(B, H, L, hd, generator=g)).to(DEV)
+    bias = torch.zeros(B, L)
+    bias[2, L - L // 3:] = float("-inf")
+    bias = bias.to(DEV)
+    sc = (q.float() @ k.float().transpose(-1, -2))                  # already log2 units
+    assert float(sc.max()) > 300 and float(sc.min()) < -300 and float(sc[0].abs().max()) < 40
+    s = sc * 0.6931471805599453 + bias[:, None, None, :]
+    p = torch.softmax(s, -1)
+    o_ref = (p @ v.float()).permute(0, 2, 1, 3).reshape(B * L, H * hd)
+    lse_ref = torch.logsumexp(s, -1)
+    for path in (0, 1, 2):          # (0: the round-1 kernel with the per-tile maximum must hold the same inputs)
+        hip.query("oneprot_attn_force_fwd_path", path)
+        try:
+            ctx = torch.full((B * L, H * hd), float("nan"), dtype=torch.bfloat16, device=DEV)
+            lse = torch.full((B, H, L), float("nan"), device=DEV)
+            hip.call("oneprot_attn_fwd", q, k, v, bias, ctx, lse, B, H, L, hd)
+        finally:
+            hip.query("oneprot_attn_force_fwd_path", -1)
+        assert torch.isfinite(ctx.float()).all() and torch.isfinite(lse).all(), path
+        assert_close(ctx, o_ref, 2 ** -6, 1.5e-2, f"ctx (extreme scores, path {path})")
+        assert_close(lse, lse_ref, 2e-4, 2e-2, f"lse (extreme scores, path {path})")
 
 
 @pytest.mark.parametrize("L", [1, 2, 31, 32, 33, 63, 64, 65, 255, 256, 257, 288, 479, 511, 512])
@@ -568,11 +654,39 @@ def test_siglip_block(negative_only):
     ref = O.siglip_block(mr, sr, 1.0, -2.5, negative_only)
     (ref * 0.7).backward()
     md, sd = m.to(DEV).requires_grad_(True), s.to(DEV).requires_grad_(True)
-    loss = _SigLipBlockFn.apply(md, sd, 1.0, -2.5, negative_only)
+    from oneprot_amd.loss import _siglip_block_hip
+    loss = _SigLipBlockFn.apply(md, sd, 1.0, -2.5, negative_only, _siglip_block_hip)
     (loss * 0.7).backward()
     assert abs(loss.item() - ref.item()) < 1e-4 * abs(ref.item())
     assert_close(md.grad.cpu(), mr.grad, 1e-4, 1e-6, "siglip dm")
     assert_close(sd.grad.cpu(), sr.grad, 1e-4, 1e-6, "siglip ds")
+
+
+@pytest.mark.parametrize("scale_on", ["cuda", "cpu"])
+def test_siglip_tensor_scale_and_bias_stay_on_device_and_get_gradients(scale_on, golden_dir):
+    """ref loss.py:241-245: `logit_scale * m @ s.T` and `logits += logit_bias` with (learnable) tensors.  SigLipLoss takes them without a host
+    synchronisation and returns their gradients (on the caller's device) -- against the oracle's autograd at world size 1; the multi-rank
+    sums are pinned by the reference's own numbers in tests/test_distributed_cpu.py (`siglip_bidir*_tensor`)."""
+    from oneprot_amd.loss import SigLipLoss
+    g = torch.Generator().manual_seed(21)
+    B, D = 37, 48
+    m = (torch.nn.functional.normalize(torch.randn(B, D, generator=g), dim=-1) * (1 / 0.07))
+    s = torch.nn.functional.normalize(torch.randn(B, D, generator=g), dim=-1)
+    mr, sr = m.clone().requires_grad_(True), s.clone().requires_grad_(True)
+    sc_r, bi_r = torch.tensor(1.3, requires_grad=True), torch.tensor(-0.7, requires_grad=True)
+    ref = O.siglip_block(mr, sr, sc_r, bi_r, False)
+    (ref * 0.7).backward()
+    md, sd = m.to(DEV).requires_grad_(True), s.to(DEV).requires_grad_(True)
+    sc = torch.tensor(1.3, device=scale_on, requires_grad=True)
+    bi = torch.tensor(-0.7, device=scale_on, requires_grad=True)
+    loss = SigLipLoss(rank=0, world_size=1)(md, sd, logit_scale=sc, logit_bias=bi)
+    (loss * 0.7).backward()
+    assert abs(loss.item() - ref.item()) < 1e-4 * abs(ref.item())
+    assert_close(md.grad.cpu(), mr.grad, 1e-4, 1e-6, "siglip dm")
+    assert_close(sd.grad.cpu(), sr.grad, 1e-4, 1e-6, "siglip ds")
+    assert sc.grad.device.type == scale_on and sc.grad.shape == sc.shape
+    assert abs(sc.grad.item() - sc_r.grad.item()) < 1e-4 * abs(sc_r.grad.item()) + 1e-6, (sc.grad, sc_r.grad)
+    assert abs(bi.grad.item() - bi_r.grad.item()) < 1e-4 * abs(bi_r.grad.item()) + 1e-6, (bi.grad, bi_r.grad)
 
 
 def test_retrieval_metric_vs_reference_golden(golden_dir):

@@ -734,8 +734,12 @@ def test_attention1d_pooling_and_learnable_logit_scale(tmp_path, frozen):
     assert cs.min() > 0.999, cs
     assert _cos(enc.pooling.layer.weight.grad.cpu(), leaf["pooling.layer.weight"].grad) > 0.99
     assert abs(enc.pooling.layer.bias.grad.item() - leaf["pooling.layer.bias"].grad.item()) < 2e-2 * (abs(leaf["pooling.layer.bias"].grad.item()) + 1e-3)
+    # d loss / d log_logit_scale = sum_b features_b . tgt_b: three terms of magnitude |features_b| |tgt_b| ~ 14.29 x 8 each that largely cancel (here
+    # to ~6.8), so the tolerance is stated on the terms, not on the cancelled sum: 1e-3 relative feature error (the bf16 compute path's level; the
+    # feature cosine gate above allows 4.5e-2)
     gs, rs_ = enc.norm[1].log_logit_scale.grad.item(), leaf["norm.1.log_logit_scale"].grad.item()
-    assert abs(gs - rs_) < 2e-2 * abs(rs_) + 1e-3, (gs, rs_)
+    term_scale = float((ref.detach().norm(dim=-1) * tgt.norm(dim=-1)).sum())
+    assert abs(gs - rs_) < 1e-3 * term_scale, (gs, rs_, term_scale)
     assert _cos(enc.proj[1].weight.grad.cpu(), leaf["proj.1.weight"].grad) > 0.999
     if frozen:
         assert enc.transformer.flat.grad is None

@@ -31,6 +31,19 @@ def timeit(fn):
 tf, tb = timeit(fwd), timeit(bwd)
 fl = 4.0 * B * H * L * L * hd
 print(f"attn fwd {tf * 1e3:.1f} us ({fl / tf / 1e9:.0f} TFLOP/s)   bwd {tb * 1e3:.1f} us ({2.5 * fl / tb / 1e9:.0f} TFLOP/s)")
+if os.environ.get("ATTN_FWD_AB"):
+    # both forward kernels in one process (box-to-box spread is larger than the difference between variants), with and without key padding
+    nob = torch.zeros_like(key_bias)
+    for name, kb in (("ragged padding (lens L/2..L)", key_bias), ("no padding", nob)):
+        f2 = lambda: hip.call("oneprot_attn_fwd", q, k, v, kb, ctx, lse, B, H, L, hd)
+        res = {0: [], 1: [], 2: []}
+        for rep in range(3):
+            for path in (0, 1, 2):
+                hip.query("oneprot_attn_force_fwd_path", path)
+                res[path].append(timeit(f2))
+        hip.query("oneprot_attn_force_fwd_path", -1)
+        a, b_, c = sorted(res[0])[1], sorted(res[1])[1], sorted(res[2])[1]
+        print(f"fwd, {name}: row-max kernel {a * 1e3:.1f} us, no-max persistent LDS-DMA kernel {b_ * 1e3:.1f} us ({fl / b_ / 1e9:.0f} TFLOP/s), no-max chunked kernel {c * 1e3:.1f} us")
 for abl in [int(x) for x in os.environ.get("ATTN_ABL", "").split(",") if x]:
     # needs a library built with -DONEPROT_ATTN_ABLATE (the hook is not part of the shipped C-ABI: the ablated kernel computes wrong results)
     hip.query("oneprot_attn_force_bwd_path", 1); hip.lib().oneprot_attn_debug_ablate(abl)
