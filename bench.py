@@ -27,6 +27,8 @@ Extra objects on the JSON line:
                the MFMA peak, timed with events after the timed region; MFMA-busy % from the committed PMC pass.
   kernels      per-kernel-family rates from one extra, event-bracketed step after the timed region: MFMA kernels in TFLOP/s, LayerNorm / Adam
                in HBM GB/s against 8 TB/s.
+  other_workloads  cfg-4 (seq <-> text) and the cfg-5-shaped round-robin step (650M anchor, batch 128): pairs/s of 3 steps each, run after the timed
+               region (default workload, N=1 only).
   cpu_baseline the CPU oracle (oracle/oneprot_oracle.py, fp32 torch restatement of the reference) timed on this box's host cores on a
                bounded sample of the same workload (reduced batch; 1 warm-up + 5 timed runs, median), plus the cfg-1 CPU headline point
                (ESM-2-8M x2, L=128, batch 32); rank 0 at N=1 only.
@@ -65,6 +67,7 @@ def parse_args():
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-extras", action="store_true", help="skip the encoder_fwd / kernels measurements after the timed region")
     ap.add_argument("--cpu-sample-pairs", type=int, default=4)
+    ap.add_argument("--no-other-workloads", action="store_true", help="skip the cfg-4 / cfg-5-shaped runs after the timed region")
     return ap.parse_args()
 
 
@@ -268,6 +271,67 @@ def cpu_cfg1(threads):
                 sample=f"cfg-1: ESM-2-8M x2, L=128, batch 32, frozen sequence encoder, oracle training sub-step; 3 warm-up + 5 timed, median {med:.3f}s")
 
 
+def host_cpu_share():
+    """(threads to use, description): the CPU time this process can actually get.  The affinity mask of a GPU box shows every core of the machine
+    (256), but the container's cgroup quota is a fraction of it (16 CPUs per GPU on the pool this was written on): a torch CPU run on 256 threads
+    inside a 16-CPU quota does not finish.  cgroup v2 cpu.max / v1 cfs quota, else the pool's documented share of 16."""
+    aff = len(os.sched_getaffinity(0))
+    quota = None
+    try:
+        with open("/sys/fs/cgroup/cpu.max") as f:
+            q, per = f.read().split()[:2]
+            if q != "max":
+                quota = float(q) / float(per)
+    except Exception:
+        try:
+            with open("/sys/fs/cgroup/cpu/cpu.cfs_quota_us") as f:
+                q = float(f.read())
+            with open("/sys/fs/cgroup/cpu/cpu.cfs_period_us") as f:
+                per = float(f.read())
+            if q > 0:
+                quota = q / per
+        except Exception:
+            pass
+    share = int(quota) if quota and quota >= 1 else None
+    threads = max(1, min(aff, share if share is not None else 16))
+    return threads, {"affinity_mask": aff, "os_cpu_count": os.cpu_count(), "cgroup_cpu_quota": quota,
+                     "threads_used": threads, "rule": "min(affinity, cgroup quota)" if share is not None else "min(affinity, 16): no cgroup quota visible, the pool's CPU share per GPU"}
+
+
+def other_workloads(args, dev, steps=3):
+    """pairs/s of `--pair text` (cfg-4 shape, B pairs) and `--pair roundrobin --batch 128` (cfg-5 shape), 1 warm-up + `steps` timed steps each"""
+    import copy
+    import gc
+    import torch
+    res = {}
+    for tag, pair, batch in (("cfg4_text", "text", args.batch), ("cfg5_roundrobin", "roundrobin", min(args.batch, 128))):
+        a = copy.copy(args)
+        a.pair, a.batch, a.model, a.model_seq, a.model_mod, a.train_seq = pair, batch, None, None, None, False
+        w = build_workload(a, dev, 0)
+        _log(f"{tag} built")
+        mod, bt = w["module"], w["batch"]
+        mod.training_step(bt, 0)
+        torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        for _ in range(steps):
+            ls = mod.training_step(bt, 0)
+        torch.cuda.synchronize()
+        dt = (time.perf_counter() - t0) / steps
+        res[tag] = {"value": round(batch * len(w["subs"]) / dt, 1), "unit": "protein-pairs/sec (1 GPU)", "ms_per_step": round(dt * 1e3, 2), "steps": steps,
+                    "pairs_per_gpu_per_modality": batch, "sub_steps_per_step": len(w["subs"]), "loss": round(float(ls.detach()), 5), "workload": w["desc"]}
+        del mod, bt, w, ls
+        gc.collect(); torch.cuda.empty_cache()
+    return res
+
+
+_T0 = time.perf_counter()
+
+
+def _log(msg):
+    """progress on stderr (the JSON line is the only thing on stdout)"""
+    print(f"[bench {time.perf_counter() - _T0:7.1f}s] {msg}", file=sys.stderr, flush=True)
+
+
 def main():
     args = parse_args()
     if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
@@ -289,6 +353,7 @@ def main():
     warnings.filterwarnings("ignore", message=".*no weight file.*")
     warnings.filterwarnings("ignore", message=".*requires_grad=True to a scalar.*")
     work = build_workload(args, dev, rank)
+    _log("workload built")
     module, batch, subs = work["module"], work["batch"], work["subs"]
     B = args.batch
 
@@ -309,6 +374,7 @@ def main():
     barrier()
     elapsed = time.perf_counter() - t0
     launches = hip.profile_end()["oneprot_gemm_bf16_nt"]
+    _log(f"timed region done: {elapsed / args.steps * 1e3:.1f} ms/step")
     exchange = None
     if xt is not None:        # per-rank exchange time per step: feature all-gather + its reduce-scatter + the un-hidden part of the gradient all-reduce
         parts = {k: round(v / args.steps, 3) for k, v in xt.totals_ms().items()}
@@ -417,9 +483,22 @@ def main():
             out["exchange"] = {"what": "per rank, ms per step on the launch stream: packed feature all-gather + reduce-scatter backward + the part of the gradient all-reduce not hidden under the backward",
                                "per_rank": exchange}
         if world == 1 and not args.no_cpu_baseline:
-            threads = min(len(os.sched_getaffinity(0)), 16)
+            threads, share = host_cpu_share()
+            _log(f"cpu baseline on {threads} threads ({share})")
             out["cpu_baseline"] = cpu_baseline(work, args.cpu_sample_pairs, threads)
+            _log("cpu baseline cfg-1")
+            out["cpu_baseline"]["host_cores"] = share
             out["cpu_baseline"]["cfg1"] = cpu_cfg1(threads)
+        if world == 1 and not args.no_extras and args.pair == "struct_token" and not args.no_other_workloads:
+            # the other single-GPU BASELINE shapes, driver-visible: cfg-4 (seq <-> text) and the cfg-5-shaped 4-modality round-robin step, a few steps
+            # each AFTER the timed region and after the main workload's memory has been released
+            del module, batch, subs, loss
+            work.clear()
+            import gc
+            gc.collect(); torch.cuda.empty_cache()
+            _log("other workloads")
+            out["other_workloads"] = other_workloads(args, dev)
+            _log("done")
         print(json.dumps(out), flush=True)
     if world > 1:
         torch.distributed.barrier()

@@ -1,5 +1,7 @@
 #!/bin/bash
 # Builds liboneprot_hip.so (gfx950) in-tree.  hipcc cross-compiles without a GPU.
+# Every translation unit is compiled with -Rpass-analysis=kernel-resource-usage; check_resources.py then fails the build when a product kernel
+# instantiation carries scratch (a register spill), so that a spill regression cannot reach a bench run unnoticed.
 set -e
 cd "$(dirname "$0")"
 SRCS="rowops.hip gemm_nt.hip gemm_nt8.hip gemm_nt_ln.hip gemm_tn.hip sgemm.hip attention.hip featops.hip"
@@ -7,13 +9,20 @@ OBJS=""
 PIDS=""
 for s in $SRCS; do
   o="${s%.hip}.o"
-  if [ ! -f "$o" ] || [ "$s" -nt "$o" ] || [ common.h -nt "$o" ] || [ gemm_epi.h -nt "$o" ] || [ gemm_epi8.h -nt "$o" ] || [ ../../include/oneprot_hip.h -nt "$o" ]; then
-    ( hipcc --offload-arch=gfx950 -O3 -fPIC -std=c++17 -Wno-unused-value -c "$s" -o "$o.tmp" && mv "$o.tmp" "$o" ) &
+  if [ ! -f "$o" ] || [ ! -f "$o.remarks" ] || [ "$s" -nt "$o" ] || [ common.h -nt "$o" ] || [ gemm_epi.h -nt "$o" ] || [ gemm_epi8.h -nt "$o" ] || [ ../../include/oneprot_hip.h -nt "$o" ]; then
+    ( if hipcc --offload-arch=gfx950 -O3 -fPIC -std=c++17 -Wno-unused-value -Rpass-analysis=kernel-resource-usage -c "$s" -o "$o.tmp" 2> "$o.remarks.tmp"; then
+        mv "$o.tmp" "$o"; mv "$o.remarks.tmp" "$o.remarks"
+      else
+        grep -v "remark:" "$o.remarks.tmp" >&2; rm -f "$o.remarks.tmp"; exit 1
+      fi ) &
     PIDS="$PIDS $!"
   fi
   OBJS="$OBJS $o"
 done
 for p in $PIDS; do wait $p || { echo "compile failed"; exit 1; }; done
+REMARKS=""
+for s in $SRCS; do REMARKS="$REMARKS ${s%.hip}.o.remarks"; done
+python3 check_resources.py $REMARKS || { echo "build refused: register spills in product kernels (see above)"; exit 1; }
 hipcc --offload-arch=gfx950 -shared -fPIC -o ../liboneprot_hip.so $OBJS
 echo "built $(cd .. && pwd)/liboneprot_hip.so"
 # RCCL wrappers (include/oneprot_comm.h) in their own library, so that the kernel library carries no RCCL dependency

@@ -28,6 +28,20 @@ namespace g8 {
 #endif
 
 __device__ __forceinline__ void gload16(u32x4& d, const void* ptr) { asm volatile("global_load_dwordx4 %0, %1, off" : "=v"(d) : "v"(ptr) : "memory"); }
+// saddr forms: wave-uniform 64-bit base in SGPRs + one 32-bit per-lane byte offset + an immediate.  The per-lane 64-bit pointers of the plain forms
+// (one VGPR pair per output / operand tensor and per row block) were what the two-output GELU and the QKV + RoPE epilogues spilled next to 160
+// accumulators -- and a spill reload is a vector-memory load that retires behind the epilogue's own stores.  (No cache-policy variant: the
+// non-temporal store policy of oneprot_gemm_tune never paid on these launches, DESIGN 6b, and is not offered here.)
+template <int IMM> __device__ __forceinline__ void gload16_s(u32x4& d, const void* sbase, unsigned voff) {
+  asm volatile("global_load_dwordx4 %0, %1, %2 offset:%3" : "=v"(d) : "v"(voff), "s"(sbase), "n"(IMM) : "memory");
+}
+template <int IMM> __device__ __forceinline__ void gst16_s(const void* sbase, unsigned voff, const u32x4& v) {
+  // (s_nop 1: a store of more than 8 bytes reads its data registers late; hipcc pads its own stores against the next writer of those registers, not an asm one)
+  asm volatile("global_store_dwordx4 %0, %1, %2 offset:%3\n\ts_nop 1" ::"v"(voff), "v"(v), "s"(sbase), "n"(IMM) : "memory");
+}
+template <int IMM> __device__ __forceinline__ void gst8_s(const void* sbase, unsigned voff, const u32x2& v) {
+  asm volatile("global_store_dwordx2 %0, %1, %2 offset:%3" ::"v"(voff), "v"(v), "s"(sbase), "n"(IMM) : "memory");
+}
 // wait until at most N vector-memory operations are in flight; the loaded registers are defined from here on
 template <int N, int G> __device__ __forceinline__ void wait_vm_pin(u32x4 (&r)[G]) {
   asm volatile("s_waitcnt vmcnt(%1)" : "+v"(r[0]) : "n"(N) : "memory");
@@ -99,22 +113,26 @@ __device__ __forceinline__ void epilogue_pair_body(const GemmArgs& p, f32x4 (&ac
   const int q = lane >> 4;                                  // accumulator layout: lane (c, q) owns columns q*8 .. q*8+7 of the pair, row c
   const int sr = lane >> 2, sq = lane & 3;                  // row layout (stores, GELU' loads): lane owns row sr, columns sq*8 .. sq*8+7
   const int pa = to_rows_addr(lane), pb = to_acc_addr(lane);
-  const size_t o0 = (size_t)(m0 + wr * (MT * 16) + sr) * p.N + n0 + wc * (NT * 16) + sq * 8;     // + i * 16 * N + pp * 32
+  // wave-uniform tile origin (element offset of the wave block's first row / column) + ONE per-lane byte offset shared by out0, out1 and aux:
+  // row layout, lane owns row sr, columns sq*8 .. sq*8+7; row block i adds i * 16 * N elements to the scalar base, column unit pp is an immediate
+  const size_t t0 = (size_t)(m0 + wr * (MT * 16)) * p.N + n0 + wc * (NT * 16);
+  const unsigned voff = (unsigned)(sr * p.N + sq * 8) * 2u;
   const size_t rstep = (size_t)16 * p.N;
-  const float* bcol = HB ? p.bias + n0 + wc * (NT * 16) + q * 8 : nullptr;
-  const bf16_t* aux = AUX ? (const bf16_t*)p.aux + o0 : nullptr;
-  bf16_t* out0 = (bf16_t*)p.out0 + o0;
-  bf16_t* out1 = DUAL ? (bf16_t*)p.out1 + o0 : nullptr;
+  const float* bbase = HB ? p.bias + n0 + wc * (NT * 16) : nullptr;     // accumulator layout: lane (c, q) owns columns q*8 .. q*8+7 of the pair
+  const unsigned boff = (unsigned)q * 32u;
+  const bf16_t* aux0 = AUX ? (const bf16_t*)p.aux + t0 : nullptr;
+  const bf16_t* out0 = (const bf16_t*)p.out0 + t0;
+  const bf16_t* out1 = DUAL ? (const bf16_t*)p.out1 + t0 : nullptr;
   auto load = [&](auto gc, u32x4 (&r)[GL > 0 ? GL : 1]) {
     constexpr int g = decltype(gc)::value;
     if constexpr (HB) {                                     // (a lone-half group fetches its bias twice: the count per group stays uniform)
-      gload16(r[0], bcol + Plan::col(g, 0) * 32); gload16(r[1], bcol + Plan::col(g, 0) * 32 + 4);
-      gload16(r[2], bcol + Plan::col(g, 1) * 32); gload16(r[3], bcol + Plan::col(g, 1) * 32 + 4);
+      gload16_s<Plan::col(g, 0) * 128>(r[0], bbase, boff); gload16_s<Plan::col(g, 0) * 128 + 16>(r[1], bbase, boff);
+      gload16_s<Plan::col(g, 1) * 128>(r[2], bbase, boff); gload16_s<Plan::col(g, 1) * 128 + 16>(r[3], bbase, boff);
     }
     if constexpr (AUX) {
       static_for([&](auto uc) {
         constexpr int u = decltype(uc)::value;
-        gload16(r[(HB ? 4 : 0) + u], aux + Plan::row(g, u) * rstep + Plan::col(g, u) * 32);
+        gload16_s<Plan::col(g, u) * 64>(r[(HB ? 4 : 0) + u], aux0 + Plan::row(g, u) * rstep, voff);
       }, std::make_integer_sequence<int, 4>{});
     }
   };
@@ -137,12 +155,12 @@ __device__ __forceinline__ void epilogue_pair_body(const GemmArgs& p, f32x4 (&ac
           for (int e = 0; e < 8; ++e) gelu_fwd_and_grad(v[e], v[e], dg[e]);
           u32x4 z; z.x = pack2bf(dg[0], dg[1]); z.y = pack2bf(dg[2], dg[3]); z.z = pack2bf(dg[4], dg[5]); z.w = pack2bf(dg[6], dg[7]);
           z = lane_perm(pa, z);
-          if constexpr (!HOLD) gst(reinterpret_cast<u32x4*>(out1 + i * rstep + pp * 32), z, p.nt_store);
+          if constexpr (!HOLD) gst16_s<pp * 64>(out1 + i * rstep, voff, z);
           else if constexpr ((u & 1) == 0) hz = z;
           else {
             __builtin_amdgcn_sched_barrier(0);
-            gst(reinterpret_cast<u32x4*>(out1 + Plan::row(g, u - 1) * rstep + Plan::col(g, u - 1) * 32), hz, p.nt_store);
-            gst(reinterpret_cast<u32x4*>(out1 + i * rstep + pp * 32), z, p.nt_store);
+            gst16_s<Plan::col(g, u - 1) * 64>(out1 + Plan::row(g, u - 1) * rstep, voff, hz);
+            gst16_s<pp * 64>(out1 + i * rstep, voff, z);
             __builtin_amdgcn_sched_barrier(0);
           }
         } else {
@@ -156,13 +174,13 @@ __device__ __forceinline__ void epilogue_pair_body(const GemmArgs& p, f32x4 (&ac
       }
       u32x4 w; w.x = pack2bf(v[0], v[1]); w.y = pack2bf(v[2], v[3]); w.z = pack2bf(v[4], v[5]); w.w = pack2bf(v[6], v[7]);
       w = lane_perm(pa, w);
-      if constexpr (!HOLD) gst(reinterpret_cast<u32x4*>(out0 + i * rstep + pp * 32), w, p.nt_store);
+      if constexpr (!HOLD) gst16_s<pp * 64>(out0 + i * rstep, voff, w);
       else if constexpr ((u & 1) == 0) hw = w;
       else {
         constexpr int pp0 = Plan::col(g, u - 1), i0 = Plan::row(g, u - 1);
         __builtin_amdgcn_sched_barrier(0);
-        gst(reinterpret_cast<u32x4*>(out0 + i0 * rstep + pp0 * 32), hw, p.nt_store);
-        gst(reinterpret_cast<u32x4*>(out0 + i * rstep + pp * 32), w, p.nt_store);
+        gst16_s<pp0 * 64>(out0 + i0 * rstep, voff, hw);
+        gst16_s<pp * 64>(out0 + i * rstep, voff, w);
         __builtin_amdgcn_sched_barrier(0);
       }
     }, std::make_integer_sequence<int, 4>{});
@@ -246,17 +264,22 @@ __device__ __forceinline__ void epilogue_rope32(const GemmArgs& p, f32x4 (&acc)[
   const int dm = p.H * HD;
   const int sec = __builtin_amdgcn_readfirstlane(ncol0 / dm);
   const int head0 = (ncol0 - sec * dm) / HD;
-  bf16_t* dst = (bf16_t*)(sec == 0 ? p.out0 : (sec == 1 ? p.out1 : p.out2));
   const float sc = sec == 0 ? p.q_scale : 1.0f;
-  const float* bcol = HB ? p.bias + ncol0 + q * 4 : nullptr;
+  const float* bbase = HB ? p.bias + ncol0 : nullptr;       // + q * 4 floats per lane (boff), + h * 32 (+ 16) floats as an immediate
+  const unsigned boff = (unsigned)q * 16u;
   float4 cs[MT], sn[MT];
-  size_t roff[MT];                                          // row layout (stores): element offset of (b, head0, l, sq*4) in the head-major output
+  // row layout (stores): the head-major output is addressed as a wave-uniform base -- (batch element of the wave block's first row, head0) -- plus a
+  // 32-bit per-lane byte offset per row block (a wave block of MT*16 rows spans a few batch elements at most), head h adds h * L * HD to the base
+  const int row0 = m0 + wr * (MT * 16);
+  const int b0 = __builtin_amdgcn_readfirstlane(row0 / p.L);
+  const bf16_t* dst = (const bf16_t*)(sec == 0 ? p.out0 : (sec == 1 ? p.out1 : p.out2)) + ((size_t)b0 * p.H + head0) * p.L * HD;
+  unsigned roff[MT];
   const int sr = lane >> 2, sq = lane & 3, pa = to_rows_addr(lane);
 #pragma unroll
   for (int i = 0; i < MT; ++i) {
-    const int gs = m0 + wr * (MT * 16) + i * 16 + sr;
+    const int gs = row0 + i * 16 + sr;
     const int bs = gs / p.L, ls = gs - bs * p.L;
-    roff[i] = (((size_t)bs * p.H + head0) * p.L + ls) * HD + sq * 4;
+    roff[i] = (unsigned)((((bs - b0) * p.H) * p.L + ls) * HD + sq * 4) * 2u;
     const int gm = mrow0 + i * 16;                          // accumulator layout (rotation arithmetic): row c
     const int l = gm % p.L;
     if (sec < 2) {
@@ -269,7 +292,7 @@ __device__ __forceinline__ void epilogue_rope32(const GemmArgs& p, f32x4 (&acc)[
   const size_t hstep = (size_t)p.L * HD;                    // next head of the same token
   auto load = [&](auto gc, u32x4 (&r)[GL > 0 ? GL : 1]) {
     constexpr int h = decltype(gc)::value;
-    if constexpr (HB) { gload16(r[0], bcol + h * 32); gload16(r[1], bcol + h * 32 + 16); }
+    if constexpr (HB) { gload16_s<h * 128>(r[0], bbase, boff); gload16_s<h * 128 + 64>(r[1], bbase, boff); }
   };
   auto finish = [&](auto gc, const u32x4 (&r)[GL > 0 ? GL : 1]) {
     constexpr int h = decltype(gc)::value;
@@ -288,13 +311,13 @@ __device__ __forceinline__ void epilogue_rope32(const GemmArgs& p, f32x4 (&acc)[
         ol[e] = (lo[e] * sc) * cv[e] - (hi[e] * sc) * sv[e];
         oh[e] = (hi[e] * sc) * cv[e] + (lo[e] * sc) * sv[e];
       }
-      bf16_t* d = dst + roff[i] + h * hstep;
+      const bf16_t* d = dst + h * hstep;                    // wave-uniform
       u32x4 w; w.x = pack2bf(ol[0], ol[1]); w.y = pack2bf(ol[2], ol[3]); w.z = pack2bf(oh[0], oh[1]); w.w = pack2bf(oh[2], oh[3]);
       w = lane_perm(pa, w);                                 // row layout: four neighbouring lanes hold the 32 + 32 bytes of one (token, head) row
       u32x2 w0; w0.x = w.x; w0.y = w.y;
       u32x2 w1; w1.x = w.z; w1.y = w.w;
-      gst(reinterpret_cast<u32x2*>(d), w0, p.nt_store);
-      gst(reinterpret_cast<u32x2*>(d + HALF), w1, p.nt_store);
+      gst8_s<0>(d, roff[i], w0);
+      gst8_s<HALF * 2>(d, roff[i], w1);
     }
   };
   run_groups<NG, GL, GS>(load, finish);

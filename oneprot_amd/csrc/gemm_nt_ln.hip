@@ -165,7 +165,10 @@ __global__ void __launch_bounds__(512, 2) k_gemm_ln(const LnArgs p) {
   next_a();
   for (int i = 0; i < 5; ++i) next_w();
   next_a();
-  if (grp == 0) wait_vmcnt<N0>(); else wait_vmcnt<N1>();
+  // the counted wait assumes that all seven requests were issued: a work-group whose whole stream is ONE K-tile (K == 64, one tile) issued only
+  // A(0) and W(0..3) -- fewer pieces than N0 / N1 allow in flight, the wait would return at once and phase 0 would read LDS before anything landed
+  if (Q * nk < 2) wait_vmcnt<0>();
+  else if (grp == 0) wait_vmcnt<N0>(); else wait_vmcnt<N1>();
   bar();
 
   const int c = lane & 15, q4 = lane >> 4;                  // accumulator layout

@@ -534,7 +534,7 @@ extern "C" int oneprot_gemm_bf16_tn(const void* dY, const void* X, int64_t M, in
   if (!dY || !X || !dW || !workspace || M <= 0 || N <= 0 || K <= 0 || M > 0x7fffffff) return OP_EINVAL;
   if ((N & 7) || (K & 7) || (ldy & 7) || (ldx & 7) || ldy < N || ldx < K || ((N * (int64_t)K) & 3)) return OP_EINVAL;
   if (((uintptr_t)dY | (uintptr_t)X | (uintptr_t)dW | (uintptr_t)workspace) & 15) return OP_EINVAL;
-  const int variant = g_tn_variant >= 0 ? g_tn_variant : 2;
+  const int variant = (g_tn_variant < 0 || g_tn_variant == 3) ? 2 : g_tn_variant;      // what runs when the 8-phase form does not take the problem
   hipStream_t s = (hipStream_t)stream;
   if (g_tn_variant < 0 || g_tn_variant == 3) {            // 8-phase form where the problem fits its tiles (every weight gradient of a d = 640 / 1280 / 320 encoder)
     const int cfg = tn8_config(N, K);

@@ -423,22 +423,35 @@ class _EncodeFn(torch.autograd.Function):
         return (None, None, gflat, None) + tuple(eg) + tuple(hg)
 
 
+def _storage_users(t):
+    """number of holders of t's storage (tensors, views, slices, .grad slots ...), or None when this torch build does not expose the count"""
+    f = getattr(torch._C, "_storage_Use_Count", None)
+    return f(t.untyped_storage()._cdata) if f is not None else None
+
+
 def _arena_grad_buffer(tr, dev):
     """The fp32 arena-gradient tensor of a backward pass.  ONE persistent buffer per encoder (592 MB at ESM-2-150M), zero-filled per use: the
     gradient ranges handed to RCCL (distributed.GradOverlap) then sit at the same addresses in every step instead of wherever the caching allocator
-    put a fresh tensor.  Autograd receives a fresh VIEW of it (a view object nobody else holds is adopted as .grad without a copy); while an earlier
-    gradient still lives in the buffer -- a second application of the encoder in the same step (seqsim), or accumulation without zero_grad -- a
-    separate tensor is returned and autograd adds the two."""
+    put a fresh tensor.  Autograd receives a fresh VIEW of it (a view object nobody else holds is adopted as .grad without a copy).
+
+    ALIASING CONTRACT: the gradient of step n lives in this buffer only until the backward of step n+1 zero-fills it -- and it is zero-filled only
+    when NOBODY else holds the buffer's storage: not `flat.grad` (a second application of the encoder in the same step, e.g. seqsim; accumulation
+    without zero_grad), not a tensor a caller kept (`g = p.grad` across `zero_grad(set_to_none=True)`), not a slice or view derived from it (a hook's
+    per-parameter views, a logger's list).  The storage's holder count says so; while there is a holder, a separate tensor is returned (and, where
+    autograd accumulates, added)."""
     buf = getattr(tr, "_gflat_buf", None)
     if buf is not None and (buf.device != dev or buf.numel() != tr._total):
         buf = None
-    g = tr.flat.grad
-    if buf is not None and g is not None and g.data_ptr() == buf.data_ptr():
-        return torch.zeros(tr._total, device=dev)
-    if buf is None:
-        buf = tr._gflat_buf = torch.zeros(tr._total, device=dev)
-    else:
+    if buf is not None:
+        g = tr.flat.grad
+        users = _storage_users(buf)
+        held = users > tr._gflat_base_users if users is not None else (g is not None and g.data_ptr() == buf.data_ptr())
+        if held:
+            return torch.zeros(tr._total, device=dev)
         buf.zero_()
+    else:
+        buf = tr._gflat_buf = torch.zeros(tr._total, device=dev)
+        tr._gflat_base_users = _storage_users(buf)          # the buffer itself (+ the temporary storage handle of the query)
     return buf.view(-1)
 
 

@@ -378,3 +378,106 @@ def test_cfg5_full_depth_650m_anchor_properties():
     l3, g3, f3 = one(0)
     assert l3 == l1 and abs(g3 - g1) / g1 < 1e-3 and _cos(f1, f3) > 0.99999, (l1, l3, g1, g3, _cos(f1, f3))
     assert seq.pooling.layer.weight.grad is not None and seq.transformer.flat.grad is None      # only the pooling conv + head of the frozen anchor train
+
+
+def test_cfg4_full_size_substep_properties():
+    """BASELINE cfg-4 at its FULL single-GPU size: ESM-2-150M sequence tower (L=512) <-> BERT-base text tower (T=256), 256 pairs,
+    both transformers frozen as shipped (sequence.yaml:12, text.yaml:12; ref configs/experiment/train_ddp_1.yaml:12-37) -- too large for the oracle (the
+    B=4 test above carries the oracle parity), so size-independent properties: feature norms 1 and 1/0.07, loss of 256 random pairs near ln 256,
+    and the whole sub-step (forward of both towers, CLIP + L1, head backward, clip, Adam) bit-reproducible from the same state: identical loss,
+    identical gradient norm, identical updated parameters."""
+    _env()
+    import math
+    from src.models.components.sequence_encoder import SequenceEncoder
+    from src.models.components.text_encoder import TextEncoder
+    from src.models.oneprot_module import OneProtLitModule
+    from oneprot_amd.optim import FusedAdam
+    torch.manual_seed(4)
+    seq = SequenceEncoder("facebook/esm2_t30_150M_UR50D", output_dim=1024, pooling_type="mean", proj_type="mlp", use_lora=False, frozen=True)
+    tx = TextEncoder("microsoft/BiomedNLP-BiomedBERT-base-uncased-abstract-fulltext", output_dim=1024, pooling_type="cls", proj_type="mlp", use_logit_scale=True,
+                     learnable_logit_scale=False, frozen=True, use_lora=False)
+    assert (tx.transformer.n_layers, tx.transformer.d, tx.transformer.H) == (12, 768, 12)
+    _randomise_biases(seq, tx)
+    module = OneProtLitModule(components={"sequence": seq, "text": tx}, optimizer=functools.partial(FusedAdam, lr=1e-3), loss_fn="CLIP",
+                              use_l1_regularization=True, local_loss=True, gather_with_grad=True).to(DEV)
+    module.train()
+    gen = torch.Generator().manual_seed(1881)
+    B, L, T = 256, 512, 256
+    lens = [L if i % 3 else int(torch.randint(L // 4, L + 1, (1,), generator=gen)) for i in range(B)]
+    tlens = [T if i % 4 else int(torch.randint(8, T + 1, (1,), generator=gen)) for i in range(B)]
+    seq_ids = _ragged_ids(B, L, 4, 23, lens, gen).to(DEV)
+    tx_ids = _ragged_ids(B, T, 5, 30521, tlens, gen, cls=2, eos=3, pad=0).to(DEV)
+    with torch.no_grad():
+        sf, tf = module(seq_ids, "sequence"), module(tx_ids, "text")
+    assert torch.isfinite(sf).all() and torch.isfinite(tf).all()
+    assert torch.allclose(sf.norm(dim=-1), torch.ones(B, device=DEV), atol=1e-4) and torch.allclose(tf.norm(dim=-1), torch.full((B,), 1 / 0.07, device=DEV), rtol=1e-4)
+    state0 = {k: v.detach().clone() for k, v in module.state_dict().items()}
+    batch = {"text": (seq_ids, tx_ids, "text", None)}
+
+    def one():
+        module.load_state_dict(state0)
+        for opt in [module.optimizers()]:
+            opt.state.clear()                                    # Adam moments restart with the parameters
+        loss = float(module.training_step(batch, 0).detach())
+        after = torch.cat([p.detach().flatten() for p in module.parameters() if p.requires_grad])
+        return loss, float(module.last_grad_norm), after
+
+    l1, g1, p1 = one()
+    l2, g2, p2 = one()
+    assert math.isfinite(l1) and abs(l1 - math.log(B)) < 1.0, l1
+    assert l1 == l2 and g1 == g2 and torch.equal(p1, p2), (l1, l2, g1, g2)
+    assert seq.transformer.flat.grad is None and tx.transformer.flat.grad is None             # frozen towers: only the heads train
+    before = torch.cat([state0[k].flatten() for k, p in module.named_parameters() if p.requires_grad])
+    assert float((p1 - before).abs().max()) > 1e-5                                              # ... and they did move
+
+
+def test_cfg5_roundrobin_full_size_step_properties():
+    """The 4-modality mixed batch of BASELINE cfg-5 at the single-GPU size bench.py reports it at: ESM-2-650M anchor (33 layers,
+    attention1d pooling + linear head, frozen) against struct_token (ESM-2-35M, trainable), text (BERT-base, frozen) and pocket (StructEncoder around the
+    labelled stand-in graph encoder), 128 pairs per modality, L=512 / T=256 -- the workload `bench.py --pair roundrobin --batch 128` builds, taken from
+    bench.build_workload itself.  One training_step = three optimiser sub-steps in the batch's order (ref oneprot_module.py:92-107).  Properties:
+    every sub-step loss finite and near ln 128; the step is bit-reproducible from the same state and RNG seed (the pocket head's dropout draws
+    from the device generator); fused == split attention backward on the one trainable tower."""
+    _env()
+    import argparse
+    import math
+    import bench
+    from oneprot_amd import hip
+    args = argparse.Namespace(batch=128, seq_len=512, text_len=256, pair="roundrobin", model=None, model_seq=None, model_mod=None, train_seq=False)
+    work = bench.build_workload(args, torch.device(DEV), 0)
+    module, batch = work["module"], work["batch"]
+    assert list(batch) == ["struct_token", "text", "pocket"] and module.network["sequence"].transformer.n_layers == 33
+    state0 = {k: v.detach().clone() for k, v in module.state_dict().items()}
+    sub_norms = []
+    orig_clip = module.clip_gradients
+
+    def spy(opt, **kw):                              # one call per optimiser sub-step
+        out = orig_clip(opt, **kw)
+        sub_norms.append(float(module.last_grad_norm))
+        return out
+    module.clip_gradients = spy
+
+    def one(path):
+        hip.query("oneprot_attn_force_bwd_path", path)
+        try:
+            module.load_state_dict(state0)
+            module.optimizers().state.clear()
+            torch.manual_seed(77)
+            loss = float(module.training_step(batch, 0).detach())                    # loss of the last sub-step (pocket)
+            norms = float(module.last_grad_norm)
+            st = module.network["struct_token"].transformer
+            after = torch.cat([st.flat.detach().flatten().cpu(), torch.cat([p.detach().flatten().cpu() for p in module.network["pocket"].parameters()])])
+        finally:
+            hip.query("oneprot_attn_force_bwd_path", -1)
+        return loss, norms, after
+
+    l1, g1, a1 = one(-1)
+    l2, g2, a2 = one(-1)
+    assert math.isfinite(l1) and abs(l1 - math.log(128)) < 1.5, l1
+    assert l1 == l2 and g1 == g2 and torch.equal(a1, a2), (l1, l2, g1, g2)
+    assert len(sub_norms) == 6 and sub_norms[:3] == sub_norms[3:] and all(math.isfinite(x) and x > 0 for x in sub_norms), sub_norms      # 3 sub-steps per step
+    l3, g3, a3 = one(0)                                                                  # split attention backward on the struct_token tower
+    assert abs(l3 - l1) < 1e-3 * abs(l1)
+    d13 = (a1 - a3).abs().max().item()
+    assert d13 < 2.1e-3, d13                                                             # same Adam step up to bf16-noise sign flips on tiny gradients (lr 1e-3)
+    assert module.network["sequence"].transformer.flat.grad is None and module.network["text"].transformer.flat.grad is None

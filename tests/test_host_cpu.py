@@ -176,8 +176,24 @@ def test_config_composer_own_tree():
     assert m["_target_"] == "src.models.oneprot_module.OneProtLitModule"
     assert m["components"]["struct_token"]["output_dim"] == 1024 and m["components"]["sequence"]["frozen"] is True
     assert m["loss_fn"] == "CLIP" and m["local_loss"] and m["gather_with_grad"] and m["use_l1_regularization"]
+    # a drop-in keeps the reference's defaults (ref configs/model/default.yaml:2-6): torch.optim.Adam; the fused optimiser is an opt-in group
     opt = instantiate(m["optimizer"])
-    assert opt.func.__name__ == "FusedAdam" and opt.keywords["lr"] == 0.001
+    assert opt.func is torch.optim.Adam and opt.keywords["lr"] == 0.001 and opt.keywords["weight_decay"] == 0.0
+    cf = compose(os.path.join(ROOT, "configs"), "train", overrides={"model": "oneprot_fused"})
+    optf = instantiate(cf["model"]["optimizer"])
+    assert optf.func.__name__ == "FusedAdam" and optf.keywords["lr"] == 0.001 and cf["model"]["loss_fn"] == "CLIP"
+    # trainer / paths / data-modality mirrors of the reference's files
+    t = c["trainer"]
+    assert t["_target_"] == "pytorch_lightning.trainer.Trainer" and t["accelerator"] == "gpu" and t["devices"] == 1 and t["default_root_dir"] == c["paths"]["output_dir"]
+    sim = compose(os.path.join(ROOT, "configs"), "trainer/ddp_sim", resolve=False)["trainer"]
+    assert sim["accelerator"] == "cpu" and sim["devices"] == 2 and sim["strategy"] == "ddp_spawn" and sim["max_epochs"] == 10
+    cpu = compose(os.path.join(ROOT, "configs"), "trainer/cpu", resolve=False)["trainer"]
+    assert cpu["accelerator"] == "cpu" and cpu["devices"] == 1
+    ddp = compose(os.path.join(ROOT, "configs"), "trainer/ddp", resolve=False)["trainer"]
+    assert ddp["devices"] == 8 and ddp["strategy"] == "ddp_find_unused_parameters_true" and ddp["sync_batchnorm"] is True and ddp["max_epochs"] == 100
+    for name in ("struct_token", "text"):
+        dm = compose(os.path.join(ROOT, "configs"), f"data/modalities/{name}", resolve=False)["data"]["modalities"][name]
+        assert dm["batch_size"] == {"train": 16, "val": 16, "test": 64} and dm["dataset"]["seq_tokenizer"] == "facebook/esm2_t33_650M_UR50D"
     c2 = compose(os.path.join(ROOT, "configs"), "train", overrides={"model": "oneprot_text", "model.components.sequence.output_dim": 256})
     assert c2["model"]["components"]["text"]["output_dim"] == 256 and c2["model"]["components"]["struct_token"]["output_dim"] == 256
 
@@ -195,6 +211,15 @@ def test_config_composer_reads_reference_yaml_unchanged():
     assert t["devices"] == 4 and t["strategy"] == "ddp_find_unused_parameters_true" and t["accelerator"] == "gpu"
     s = compose(os.path.join(REF, "configs"), "model/components/struct_token", resolve=False)
     assert s["model"]["components"]["struct_token"]["use_logit_scale"] is True
+    # the mirrors in this repo carry the reference's keys and values (devices of ddp aside: 8 MI355X per node here, 4 GPUs there)
+    for name in ("default", "cpu", "ddp_sim", "gpu"):
+        ours = compose(os.path.join(ROOT, "configs"), f"trainer/{name}", resolve=False)["trainer"]
+        theirs = compose(os.path.join(REF, "configs"), f"trainer/{name}", resolve=False)["trainer"]
+        for k, v in theirs.items():
+            assert ours[k] == v, (name, k, ours.get(k), v)
+    assert compose(os.path.join(ROOT, "configs"), "model/default", resolve=False)["model"] == compose(os.path.join(REF, "configs"), "model/default", resolve=False)["model"]
+    for name in ("struct_token", "text"):
+        assert compose(os.path.join(ROOT, "configs"), f"data/modalities/{name}", resolve=False) == compose(os.path.join(REF, "configs"), f"data/modalities/{name}", resolve=False)
 
 
 def test_combined_loader_and_synthetic_batches():

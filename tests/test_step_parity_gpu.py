@@ -785,3 +785,32 @@ def test_struct_encoder_adapter_vs_reference(golden_dir):
     batch = {"pocket": (ids.to(DEV), graph.to(DEV), "pocket", None)}
     losses = [float(module.training_step(batch, i).detach()) for i in range(6)]
     assert all(torch.isfinite(torch.tensor(losses))) and losses[-1] < losses[0], losses
+
+
+def test_arena_gradient_buffer_is_not_recycled_under_a_live_reference(tmp_path):
+    """The arena gradient lives in one persistent buffer per encoder (stable addresses for RCCL) that the next backward zero-fills.  A caller that
+    still holds last step's gradient (`g = p.grad` across `zero_grad(set_to_none=True)`) must keep its values: the next backward then takes a fresh
+    tensor; with no outside reference the buffer is reused."""
+    os.environ.update(RANK="0", WORLD_SIZE="1", ONEPROT_ALLOW_RANDOM_INIT="1")
+    from src.models.components.sequence_encoder import SequenceEncoder
+    cfg = dict(vocab=33, hidden=64, layers=2, heads=4, ffn=128, pad=1, mask=32, eps=1e-5)
+    torch.manual_seed(11)
+    enc = SequenceEncoder(_write_cfg(str(tmp_path), cfg, "esm64"), output_dim=16, pooling_type="mean", proj_type="linear", use_lora=False, frozen=False).to(DEV)
+    ids = torch.randint(4, 24, (3, 19), generator=torch.Generator().manual_seed(3)).to(DEV)
+    flat = enc.transformer.flat
+    enc(ids).sum().backward()
+    kept = flat.grad                                   # somebody keeps last step's gradient
+    snap, ptr = kept.clone(), kept.data_ptr()
+    assert float(snap.abs().sum()) > 0
+    enc.zero_grad(set_to_none=True)
+    (enc(ids) * 2).sum().backward()
+    assert torch.equal(kept, snap), "the kept gradient was overwritten by the next backward"
+    assert flat.grad.data_ptr() != ptr
+    assert torch.allclose(flat.grad, 2 * snap, rtol=2e-2, atol=1e-4 * float(snap.abs().max()))
+    del kept
+    enc.zero_grad(set_to_none=True)
+    enc(ids).sum().backward()
+    p1 = flat.grad.data_ptr()
+    enc.zero_grad(set_to_none=True)
+    enc(ids).sum().backward()
+    assert flat.grad.data_ptr() == p1, "without an outside reference the persistent buffer is reused"
