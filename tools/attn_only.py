@@ -48,5 +48,11 @@ for abl in [int(x) for x in os.environ.get("ATTN_ABL", "").split(",") if x]:
     # needs a library built with -DONEPROT_ATTN_ABLATE (the hook is not part of the shipped C-ABI: the ablated kernel computes wrong results)
     hip.query("oneprot_attn_force_bwd_path", 1); hip.lib().oneprot_attn_debug_ablate(abl)
     print(f"fused bwd, ablation mask {abl}: {timeit(bwd) * 1e3:.1f} us")
-hip.query("oneprot_attn_force_bwd_path", 0)
-print(f"split bwd: {timeit(bwd) * 1e3:.1f} us")
+res = {0: [], 1: []}
+for rep in range(3):
+    for path in (0, 1):
+        hip.query("oneprot_attn_force_bwd_path", path)
+        res[path].append(timeit(bwd))
+hip.query("oneprot_attn_force_bwd_path", -1)
+med = {p_: sorted(v)[1] * 1e3 for p_, v in res.items()}
+print(f"bwd: split kernels {med[0]:.1f} us, fused kernel {med[1]:.1f} us ({2.5 * fl / (med[1] * 1e-3) / 1e9:.0f} TFLOP/s)")
