@@ -359,16 +359,47 @@ __device__ __forceinline__ bf8_t key_entry(const float* sBias, bool have_bias, i
   return __builtin_bit_cast(bf8_t, ke);
 }
 
+// per-lane byte offsets of the K row fragments and the V^T transposed fragments inside a 32-key tile of the swizzled images (the swizzle of a row
+// depends on the row modulo 32 at most, so the offsets are the same in every tile: tile t adds the wave-uniform t * 32 * ROWB).  Formed once per
+// wave; left to the tile step, hipcc re-derives the swizzle arithmetic in every tile (14 vector instructions per tile, now 6 additions).
+template <int HD> struct FragOff {
+  int k[Cfg<HD>::KSTEPS];
+  int v[2][Cfg<HD>::DBLK][2];
+  __device__ __forceinline__ void init(int lane) {
+    typedef Cfg<HD> C;
+    const int h = lane >> 5, r = lane & 31, g = lane >> 4, i = lane & 15;
+#pragma unroll
+    for (int st = 0; st < C::KSTEPS; ++st) k[st] = r * C::ROWB + (swz<C::HDP>(r, 2 * st + h) << 4);
+#pragma unroll
+    for (int sb = 0; sb < 2; ++sb)
+#pragma unroll
+      for (int db = 0; db < C::DBLK; ++db) {
+        const int col = 32 * db + 16 * (g & 1) + 4 * (i & 3);
+        const int r0 = 16 * sb + 4 * h + (i >> 2), r1 = r0 + 8;
+        v[sb][db][0] = r0 * C::ROWB + (swz<C::HDP>(r0, col >> 3) << 4) + (col & 7) * 2;
+        v[sb][db][1] = r1 * C::ROWB + (swz<C::HDP>(r1, col >> 3) << 4) + (col & 7) * 2;
+      }
+  }
+  __device__ __forceinline__ bf8_t vt(const unsigned char* tile, int sb, int db) const {
+    const s16x4 a = __builtin_amdgcn_ds_read_tr16_b64_v4i16((__attribute__((address_space(3))) s16x4*)(tile + v[sb][db][0]));
+    const s16x4 b = __builtin_amdgcn_ds_read_tr16_b64_v4i16((__attribute__((address_space(3))) s16x4*)(tile + v[sb][db][1]));
+    s16x8 o;
+    o[0] = a[0]; o[1] = a[1]; o[2] = a[2]; o[3] = a[3]; o[4] = b[0]; o[5] = b[1]; o[6] = b[2]; o[7] = b[3];
+    return __builtin_bit_cast(bf8_t, o);
+  }
+};
+
 // fast pass, one 32-key tile for NB blocks of 32 queries held by the wave: p = 2^s, no maximum.  BOOK: the tile has key biases (class 1).
 template <int HD, int NB, bool BOOK, class Side>
 __device__ __forceinline__ void fwd_tile_fast(const unsigned char* sK, const unsigned char* sV, const float* sBias, bool have_bias, int nkeys, int t,
-                                              const bf8_t (&qf)[NB][Cfg<HD>::KSTEPS], RowState<HD> (&st)[NB], int lane, Side&& side) {
+                                              const bf8_t (&qf)[NB][Cfg<HD>::KSTEPS], RowState<HD> (&st)[NB], int lane, const FragOff<HD>& fo, Side&& side) {
   typedef Cfg<HD> C;
-  const int h = lane >> 5, r = lane & 31;
+  const int h = lane >> 5;
   const unsigned char* kt = sK + t * 32 * C::ROWB;
+  const unsigned char* vt = sV + t * 32 * C::ROWB;
   bf8_t kf[C::KSTEPS];
 #pragma unroll
-  for (int k = 0; k < C::KSTEPS; ++k) kf[k] = rd_row<HD>(kt, r, k, h);
+  for (int k = 0; k < C::KSTEPS; ++k) kf[k] = *reinterpret_cast<const bf8_t*>(kt + fo.k[k]);
   f32x16 s[NB];
 #ifdef FWD2_ABL_NOQK
 #pragma unroll
@@ -397,7 +428,7 @@ __device__ __forceinline__ void fwd_tile_fast(const unsigned char* sK, const uns
 #pragma unroll
   for (int sb = 0; sb < 2; ++sb)
 #pragma unroll
-    for (int d = 0; d < C::DBLK; ++d) vf[sb][d] = rd_tr<HD>(sV, t * 32, sb, d, lane);
+    for (int d = 0; d < C::DBLK; ++d) vf[sb][d] = fo.vt(vt, sb, d);
   // all score chains are issued before the first exponential: left alone hipcc reuses one register tile for the blocks' scores and sinks the second
   // block's chain behind the first block's exponentials (one exposed MFMA latency per block and tile)
   if (NB > 1) __builtin_amdgcn_sched_barrier(0);
@@ -475,15 +506,17 @@ template <int HD, int NB, class Side>
 __device__ __forceinline__ void fwd_chunk_fast(const unsigned char* sK, const unsigned char* sV, const float* sBias, bool have_bias, int nkeys, int nt,
                                                unsigned long long NZ, unsigned long long DEAD, const bf8_t (&qf)[NB][Cfg<HD>::KSTEPS], RowState<HD> (&st)[NB], int lane,
                                                Side&& side) {
+  FragOff<HD> fo;
+  fo.init(lane);
   unsigned long long special = (NZ | (NZ >> 1) | (NZ >> 2) | (NZ >> 3)) & 0x1111111111111111ull;      // bit 4 t: tile t has a bias somewhere
   if (nt < 16) special |= ~0ull << (4 * nt);
   int t = 0;
   while (t < nt) {
     const unsigned long long rest = special >> (4 * t);
     const int run_end = rest ? t + (__builtin_ctzll(rest) >> 2) : nt;                                  // first tile >= t that is not bias-free
-    for (; t < run_end; ++t) fwd_tile_fast<HD, NB, false>(sK, sV, sBias, have_bias, nkeys, t, qf, st, lane, side);
+    for (; t < run_end; ++t) fwd_tile_fast<HD, NB, false>(sK, sV, sBias, have_bias, nkeys, t, qf, st, lane, fo, side);
     if (t < nt) {
-      if (tile_class(NZ, DEAD, t) == 1) fwd_tile_fast<HD, NB, true>(sK, sV, sBias, have_bias, nkeys, t, qf, st, lane, side);
+      if (tile_class(NZ, DEAD, t) == 1) fwd_tile_fast<HD, NB, true>(sK, sV, sBias, have_bias, nkeys, t, qf, st, lane, fo, side);
       ++t;
     }
   }
@@ -693,6 +726,16 @@ __device__ __forceinline__ void glds4_addr(const void* src, unsigned lds_dst) {
   asm volatile("s_mov_b32 %0, m0\n\ts_mov_b32 m0, %2\n\ts_nop 0\n\tglobal_load_lds_dword %1, off\n\ts_mov_b32 m0, %0" : "=&s"(keep) : "v"(src), "s"(lds_dst) : "memory");
 }
 
+// the same with a wave-uniform 64-bit base in SGPRs + one 32-bit per-lane byte offset
+__device__ __forceinline__ void glds16_s(unsigned voff, const void* sbase, unsigned lds_dst) {
+  unsigned keep;
+  asm volatile("s_mov_b32 %0, m0\n\ts_mov_b32 m0, %3\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %1, %2\n\ts_mov_b32 m0, %0" : "=&s"(keep) : "v"(voff), "s"(sbase), "s"(lds_dst) : "memory");
+}
+__device__ __forceinline__ void glds4_s(unsigned voff, const void* sbase, unsigned lds_dst) {
+  unsigned keep;
+  asm volatile("s_mov_b32 %0, m0\n\ts_mov_b32 m0, %3\n\ts_nop 0\n\tglobal_load_lds_dword %1, %2\n\ts_mov_b32 m0, %0" : "=&s"(keep) : "v"(voff), "s"(sbase), "s"(lds_dst) : "memory");
+}
+
 struct Fwd3 {
   static constexpr int ROWS = 512;
   static constexpr int TILE = ROWS * 64;                // 64-byte swizzled rows (hd = 16 zero-padded)
@@ -734,18 +777,27 @@ __global__ void __launch_bounds__(512, 2) k_attn_fwd3(const bf16_t* __restrict__
   // (profiles/r04_fwd3_stamps.txt).
   const int my_pieces = npieces > wave ? (npieces - wave + nw - 1) / nw : 0;
   const int n_biasp = (nrows + 63) >> 6;
+  // A piece that lies wholly inside the slab's L rows is one instruction on a wave-uniform base (slab + piece) and ONE per-lane offset that is the
+  // same for every piece (the swizzle of row 16 p + j depends on j only; the zero-padded chunks of hd = 16 re-read chunk 0: nothing reads their
+  // LDS columns for a value that is kept); only the piece that straddles L forms per-lane 64-bit addresses with the zero page behind rows >= L.
+  const unsigned kv_lane_off = (unsigned)(lane >> 2) * (HD * 2) + (unsigned)((((lane & 3) ^ ((lane >> 4) & 3)) < HD / 8) ? ((lane & 3) ^ ((lane >> 4) & 3)) : 0) * 16u;
   auto dma_piece = [&](int item, int buf, int i) {           // i < 2 * my_pieces: K (even) / V (odd) piece i / 2 of this wave; i == 2 * my_pieces: bias
     const unsigned dst0 = lds0 + buf * Fwd3::BUF;
     if (i < 2 * my_pieces) {
       const int p = wave + nw * (i >> 1);
-      const int row = 16 * p + (lane >> 2);
-      const int ch = (lane & 3) ^ ((row >> 2) & 3);         // the chunk that lives at this lane's place of the swizzled image
-      const bool ok = row < L && ch < HD / 8;
       const unsigned char* base = reinterpret_cast<const unsigned char*>(((i & 1) ? v : k) + (size_t)item * L * HD);
-      glds16_addr(ok ? base + (size_t)row * (HD * 2) + ch * 16 : zero, dst0 + ((i & 1) ? Fwd3::TILE : 0) + p * 1024);
+      const unsigned dst = dst0 + ((i & 1) ? Fwd3::TILE : 0) + p * 1024;
+      if (16 * p + 16 <= L) glds16_s(kv_lane_off, base + (size_t)p * (16 * HD * 2), dst);
+      else {
+        const int row = 16 * p + (lane >> 2);
+        const int ch = (lane & 3) ^ ((row >> 2) & 3);       // the chunk that lives at this lane's place of the swizzled image
+        const bool ok = row < L && ch < HD / 8;
+        glds16_addr(ok ? base + (size_t)row * (HD * 2) + ch * 16 : zero, dst);
+      }
     } else {
-      const int key = 64 * wave + lane;
-      glds4_addr(key < L ? (const void*)(key_bias + (size_t)(item / H) * L + key) : (const void*)zero, dst0 + 2 * Fwd3::TILE + wave * 256);
+      const float* br = key_bias + (size_t)(item / H) * L + 64 * wave;
+      if (64 * wave + 64 <= L) glds4_s((unsigned)lane * 4u, br, dst0 + 2 * Fwd3::TILE + wave * 256);
+      else glds4_addr(64 * wave + lane < L ? (const void*)(br + lane) : (const void*)zero, dst0 + 2 * Fwd3::TILE + wave * 256);
     }
   };
   const int n_dma = 2 * my_pieces + ((key_bias && wave < n_biasp) ? 1 : 0);

@@ -225,6 +225,18 @@ __global__ void __launch_bounds__(256) k_layernorm_bwd(const void* __restrict__ 
     float w = 1.0f;
     if (DY_MODE == 2) w = wrow[row];
     float4 xh[NV], g[NV];
+#ifndef LN_BWD_LATE_ADD
+    // the residual-gradient rows are requested together with x and dy: one exposed round trip per row instead of two (they are only needed after
+    // the two wave reductions, but a load issued there starts a second latency that the 4-5 resident waves per SIMD do not cover)
+    float4 av[NV];
+    if (add_to) {
+#pragma unroll
+      for (int i = 0; i < NV; ++i) {
+        const int c = lane + 64 * i;
+        if (c < nv4) av[i] = reinterpret_cast<const float4*>(add_to + (size_t)row * d)[c];
+      }
+    }
+#endif
     float s1 = 0.f, s2 = 0.f;
 #pragma unroll
     for (int i = 0; i < NV; ++i) {
@@ -267,7 +279,11 @@ __global__ void __launch_bounds__(256) k_layernorm_bwd(const void* __restrict__ 
         o.z = rstd * (g[i].z - m1 - xh[i].z * m2);
         o.w = rstd * (g[i].w - m1 - xh[i].w * m2);
         if (add_to) {
+#ifdef LN_BWD_LATE_ADD
           const float4 a = reinterpret_cast<const float4*>(add_to + (size_t)row * d)[c];
+#else
+          const float4 a = av[i];
+#endif
           o.x += a.x; o.y += a.y; o.z += a.z; o.w += a.w;
         }
         reinterpret_cast<float4*>(dx_out + (size_t)row * d)[c] = o;
