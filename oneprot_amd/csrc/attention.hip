@@ -389,17 +389,33 @@ template <int HD> struct FragOff {
   }
 };
 
+// the K row fragments and V^T fragments of one 32-key tile
+template <int HD> struct TileFrags {
+  bf8_t k[Cfg<HD>::KSTEPS];
+  bf8_t v[2][Cfg<HD>::DBLK];
+  __device__ __forceinline__ void load(const unsigned char* sK, const unsigned char* sV, int t, const FragOff<HD>& fo) {
+    typedef Cfg<HD> C;
+    const unsigned char* kt = sK + t * 32 * C::ROWB;
+    const unsigned char* vt = sV + t * 32 * C::ROWB;
+#pragma unroll
+    for (int st = 0; st < C::KSTEPS; ++st) k[st] = *reinterpret_cast<const bf8_t*>(kt + fo.k[st]);
+#pragma unroll
+    for (int sb = 0; sb < 2; ++sb)
+#pragma unroll
+      for (int d = 0; d < C::DBLK; ++d) v[sb][d] = fo.vt(vt, sb, d);
+  }
+};
+
 // fast pass, one 32-key tile for NB blocks of 32 queries held by the wave: p = 2^s, no maximum.  BOOK: the tile has key biases (class 1).
+// `cur` holds the tile's fragments; when `nxt` is given, the fragments of tile t_next are requested right behind the score chains, so that they
+// land under this tile's exponentials instead of in front of the next tile's first MFMA (two waves per SIMD do not cover an LDS round trip).
 template <int HD, int NB, bool BOOK, class Side>
 __device__ __forceinline__ void fwd_tile_fast(const unsigned char* sK, const unsigned char* sV, const float* sBias, bool have_bias, int nkeys, int t,
-                                              const bf8_t (&qf)[NB][Cfg<HD>::KSTEPS], RowState<HD> (&st)[NB], int lane, const FragOff<HD>& fo, Side&& side) {
+                                              const bf8_t (&qf)[NB][Cfg<HD>::KSTEPS], RowState<HD> (&st)[NB], int lane, const FragOff<HD>& fo,
+                                              const TileFrags<HD>& cur, TileFrags<HD>* nxt, int t_next, Side&& side) {
   typedef Cfg<HD> C;
   const int h = lane >> 5;
-  const unsigned char* kt = sK + t * 32 * C::ROWB;
-  const unsigned char* vt = sV + t * 32 * C::ROWB;
-  bf8_t kf[C::KSTEPS];
-#pragma unroll
-  for (int k = 0; k < C::KSTEPS; ++k) kf[k] = *reinterpret_cast<const bf8_t*>(kt + fo.k[k]);
+  const bf8_t (&kf)[C::KSTEPS] = cur.k;
   f32x16 s[NB];
 #ifdef FWD2_ABL_NOQK
 #pragma unroll
@@ -424,14 +440,11 @@ __device__ __forceinline__ void fwd_tile_fast(const unsigned char* sK, const uns
       for (int b = 0; b < NB; ++b) s[b] = MFMA32(kf[k], qf[b][k], s[b]);
   }
 #endif
-  bf8_t vf[2][C::DBLK];
-#pragma unroll
-  for (int sb = 0; sb < 2; ++sb)
-#pragma unroll
-    for (int d = 0; d < C::DBLK; ++d) vf[sb][d] = fo.vt(vt, sb, d);
+  const bf8_t (&vf)[2][C::DBLK] = cur.v;
+  if (nxt) nxt->load(sK, sV, t_next, fo);
   // all score chains are issued before the first exponential: left alone hipcc reuses one register tile for the blocks' scores and sinks the second
   // block's chain behind the first block's exponentials (one exposed MFMA latency per block and tile)
-  if (NB > 1) __builtin_amdgcn_sched_barrier(0);
+  __builtin_amdgcn_sched_barrier(0);
   side();      // the caller's per-tile share of memory instructions (k_attn_fwd3: LDS-DMA of the next slab, stores of the previous one)
 #pragma unroll
   for (int b = 0; b < NB; ++b) {
@@ -514,9 +527,21 @@ __device__ __forceinline__ void fwd_chunk_fast(const unsigned char* sK, const un
   while (t < nt) {
     const unsigned long long rest = special >> (4 * t);
     const int run_end = rest ? t + (__builtin_ctzll(rest) >> 2) : nt;                                  // first tile >= t that is not bias-free
-    for (; t < run_end; ++t) fwd_tile_fast<HD, NB, false>(sK, sV, sBias, have_bias, nkeys, t, qf, st, lane, fo, side);
+    if (t < run_end) {                                       // a run of bias-free tiles: fragments one tile ahead, two register sets in turn
+      TileFrags<HD> fa, fb;
+      fa.load(sK, sV, t, fo);
+      for (; t + 1 < run_end; t += 2) {
+        fwd_tile_fast<HD, NB, false>(sK, sV, sBias, have_bias, nkeys, t, qf, st, lane, fo, fa, &fb, t + 1, side);
+        fwd_tile_fast<HD, NB, false>(sK, sV, sBias, have_bias, nkeys, t + 1, qf, st, lane, fo, fb, &fa, t + 2, side);      // (t + 2 <= 16: inside the LDS allocation)
+      }
+      if (t < run_end) { fwd_tile_fast<HD, NB, false>(sK, sV, sBias, have_bias, nkeys, t, qf, st, lane, fo, fa, nullptr, 0, side); ++t; }
+    }
     if (t < nt) {
-      if (tile_class(NZ, DEAD, t) == 1) fwd_tile_fast<HD, NB, true>(sK, sV, sBias, have_bias, nkeys, t, qf, st, lane, fo, side);
+      if (tile_class(NZ, DEAD, t) == 1) {
+        TileFrags<HD> f;
+        f.load(sK, sV, t, fo);
+        fwd_tile_fast<HD, NB, true>(sK, sV, sBias, have_bias, nkeys, t, qf, st, lane, fo, f, nullptr, 0, side);
+      }
       ++t;
     }
   }
