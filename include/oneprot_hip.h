@@ -171,6 +171,8 @@ int oneprot_adam_step(float* p, const float* g, float* m, float* v, int64_t n, f
 /* ---------------- casts ------------------------------------------------------------------------------------------ */
 int oneprot_cast_f32_to_bf16(const float* src, void* dst, int64_t n, void* stream);
 int oneprot_transpose_cast_f32_to_bf16(const float* src, void* dst, int R, int C, void* stream);
+/* the same for `count` matrices src + z*src_stride -> dst + z*dst_stride (strides in elements): one launch for a weight of every layer */
+int oneprot_transpose_cast_f32_to_bf16_batched(const float* src, void* dst, int R, int C, int64_t src_stride, int64_t dst_stride, int count, void* stream);
 size_t oneprot_colsum_workspace(int N);
 int oneprot_colsum_bf16(const void* a, float* out, void* workspace, int64_t M, int N, int accumulate, void* stream);
 

@@ -86,17 +86,11 @@ class BertTransformer(ArenaModule):
         if not self._refresh_bf16_mirror():
             return
         if self.flat.requires_grad:          # transposed bf16 weights for the dgrad GEMMs
-            d, f, dev = self.d, self.f, self.flat.device
-            for i in range(self.n_layers):
-                p = f"encoder.layer.{i}."
-                o, n = self.span(p + "attention.self.query.weight", p + "attention.self.value.weight")
-                for key, (src, R, C) in {"qkv": (self._qkv_effective_f32(i), 3 * d, d), "o": (self.view(p + "attention.output.dense.weight"), d, d),
-                                         "w1": (self.view(p + "intermediate.dense.weight"), f, d), "w2": (self.view(p + "output.dense.weight"), d, f)}.items():
-                    t = self._bf16_T.get((i, key))
-                    if t is None:
-                        t = torch.empty(C, R, dtype=torch.bfloat16, device=dev)
-                        self._bf16_T[(i, key)] = t
-                    hip.call("oneprot_transpose_cast_f32_to_bf16", src, t, R, C)
+            d, f = self.d, self.f
+            self._transpose_qkv_weights()
+            self._transpose_layer_weights("o", "encoder.layer.{i}.attention.output.dense.weight", d, d)
+            self._transpose_layer_weights("w1", "encoder.layer.{i}.intermediate.dense.weight", f, d)
+            self._transpose_layer_weights("w2", "encoder.layer.{i}.output.dense.weight", d, f)
 
     @torch.no_grad()
     def run_layers(self, ids, save=False):

@@ -291,4 +291,4 @@ extern "C" int oneprot_diag_rank(const float* logits, int* rank_row, int* rank_c
   return launch_status();
 }
 
-extern "C" int oneprot_abi_version(void) { return 4; }      // 2: oneprot_gemm_bf16_tn takes workspace_bytes; 3: fused GEMM + LayerNorm entry points, oneprot_dot_f32; 4: oneprot_siglip_fwd_bwd_dev, oneprot_attn_force_fwd_path
+extern "C" int oneprot_abi_version(void) { return 4; }      // 2: oneprot_gemm_bf16_tn takes workspace_bytes; 3: fused GEMM + LayerNorm entry points, oneprot_dot_f32; 4: oneprot_siglip_fwd_bwd_dev, oneprot_attn_force_fwd_path, oneprot_transpose_cast_f32_to_bf16_batched

@@ -239,16 +239,20 @@ __global__ void __launch_bounds__(256, MINW) k_gemm_tn(const bf16_t* __restrict_
   }
 }
 
-__global__ void __launch_bounds__(256) k_tn_bias_reduce(const float* __restrict__ bias_slab, float* __restrict__ db, int N, int S, int accumulate) {
-  const int n = blockIdx.x * 256 + threadIdx.x;
-  if (n >= N) return;
-  float s = 0.f;
-  for (int p = 0; p < S; ++p) s += bias_slab[(size_t)p * N + n];
-  db[n] = accumulate ? db[n] + s : s;
-}
-
-__global__ void __launch_bounds__(256) k_tn_reduce(const float* __restrict__ slab, float* __restrict__ dW, size_t n4, size_t stride4, int S, int accumulate) {
-  for (size_t i = (size_t)blockIdx.x * 256 + threadIdx.x; i < n4; i += (size_t)gridDim.x * 256) {
+// Fixed-order sum of the S slabs into dW; the last `bias_blocks` work-groups of the grid do the same for the bias slabs (one launch instead of
+// two: 120 weight gradients per sub-step, and a 7 us launch of 3 work-groups between every two of them)
+__global__ void __launch_bounds__(256) k_tn_reduce(const float* __restrict__ slab, float* __restrict__ dW, size_t n4, size_t stride4, int S, int accumulate,
+                                                   const float* __restrict__ bias_slab, float* __restrict__ db, int N, int bias_blocks) {
+  const int wblocks = (int)gridDim.x - bias_blocks;
+  if ((int)blockIdx.x >= wblocks) {
+    const int n = ((int)blockIdx.x - wblocks) * 256 + threadIdx.x;
+    if (n >= N) return;
+    float s = 0.f;
+    for (int p = 0; p < S; ++p) s += bias_slab[(size_t)p * N + n];
+    db[n] = accumulate ? db[n] + s : s;
+    return;
+  }
+  for (size_t i = (size_t)blockIdx.x * 256 + threadIdx.x; i < n4; i += (size_t)wblocks * 256) {
     float4 s = reinterpret_cast<const float4*>(slab)[i];
     for (int p = 1; p < S; ++p) {
       const float4 v = reinterpret_cast<const float4*>(slab)[i + (size_t)p * stride4];
@@ -556,10 +560,10 @@ extern "C" int oneprot_gemm_bf16_tn(const void* dY, const void* X, int64_t M, in
         const dim3 grid(8 * ((tiles8 * S8 + 7) / 8));
         if (cfg == 1) hipLaunchKernelGGL((k_gemm_tn8<256, 320>), grid, dim3(512), LDS8, s, (const bf16_t*)dY, (const bf16_t*)X, (int)M, N, K, ldy, ldx, (float*)workspace, bias_slab8, tiles_k8, tiles8, S8);
         else hipLaunchKernelGGL((k_gemm_tn8<320, 256>), grid, dim3(512), LDS8, s, (const bf16_t*)dY, (const bf16_t*)X, (int)M, N, K, ldy, ldx, (float*)workspace, bias_slab8, tiles_k8, tiles8, S8);
-        if (dbias) hipLaunchKernelGGL(k_tn_bias_reduce, dim3((N + 255) / 256), dim3(256), 0, s, (const float*)bias_slab8, dbias, N, S8, accumulate);
         const size_t n4_8 = ((size_t)N * K) >> 2;
         size_t blocks8 = (n4_8 + 255) / 256; if (blocks8 > 4096) blocks8 = 4096;
-        hipLaunchKernelGGL(k_tn_reduce, dim3((unsigned)blocks8), dim3(256), 0, s, (const float*)workspace, dW, n4_8, n4_8, S8, accumulate);
+        const int bb8 = dbias ? (N + 255) / 256 : 0;
+        hipLaunchKernelGGL(k_tn_reduce, dim3((unsigned)blocks8 + bb8), dim3(256), 0, s, (const float*)workspace, dW, n4_8, n4_8, S8, accumulate, (const float*)bias_slab8, dbias, N, bb8);
         return launch_status();
       }
     }
@@ -589,9 +593,9 @@ extern "C" int oneprot_gemm_bf16_tn(const void* dY, const void* X, int64_t M, in
     hipLaunchKernelGGL((k_gemm_tn<32, 3, 3, false>), dim3(8 * ((tiles * S + 7) / 8)), dim3(256), 3 * 2 * 32 * 256, s, (const bf16_t*)dY, (const bf16_t*)X, (int)M, N, K, ldy, ldx,
                        (float*)workspace, bias_slab, tiles_k, tiles, S, m_per);
   }
-  if (dbias) hipLaunchKernelGGL(k_tn_bias_reduce, dim3((N + 255) / 256), dim3(256), 0, s, (const float*)bias_slab, dbias, N, S, accumulate);
   const size_t n4 = ((size_t)N * K) >> 2;
   size_t blocks = (n4 + 255) / 256; if (blocks > 4096) blocks = 4096;
-  hipLaunchKernelGGL(k_tn_reduce, dim3((unsigned)blocks), dim3(256), 0, s, (const float*)workspace, dW, n4, n4, S, accumulate);
+  const int bb = dbias ? (N + 255) / 256 : 0;
+  hipLaunchKernelGGL(k_tn_reduce, dim3((unsigned)blocks + bb), dim3(256), 0, s, (const float*)workspace, dW, n4, n4, S, accumulate, (const float*)bias_slab, dbias, N, bb);
   return launch_status();
 }

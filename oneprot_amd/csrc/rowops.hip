@@ -731,9 +731,10 @@ extern "C" int oneprot_cast_f32_to_bf16(const float* src, void* dst, int64_t n, 
 }
 
 // dst[c][r] = bf16(src[r][c]) : 64x64 tiles through LDS (weights only: a few MB per optimizer step)
-__global__ void __launch_bounds__(256) k_transpose_cast(const float* __restrict__ src, bf16_t* __restrict__ dst, int R, int C) {
+__global__ void __launch_bounds__(256) k_transpose_cast(const float* __restrict__ src, bf16_t* __restrict__ dst, int R, int C, int64_t src_stride, int64_t dst_stride) {
   __shared__ float tile[64][65];
   const int r0 = blockIdx.y * 64, c0 = blockIdx.x * 64;
+  src += blockIdx.z * src_stride; dst += blockIdx.z * dst_stride;      // matrix z of a batch (the same weight of every layer)
   for (int i = threadIdx.x; i < 64 * 64; i += 256) {
     const int r = i >> 6, c = i & 63;
     tile[r][c] = (r0 + r < R && c0 + c < C) ? src[(size_t)(r0 + r) * C + c0 + c] : 0.f;
@@ -746,7 +747,13 @@ __global__ void __launch_bounds__(256) k_transpose_cast(const float* __restrict_
 }
 extern "C" int oneprot_transpose_cast_f32_to_bf16(const float* src, void* dst, int R, int C, void* stream) {
   if (!src || !dst || R <= 0 || C <= 0) return OP_EINVAL;
-  hipLaunchKernelGGL(k_transpose_cast, dim3((C + 63) / 64, (R + 63) / 64), dim3(256), 0, (hipStream_t)stream, src, (bf16_t*)dst, R, C);
+  hipLaunchKernelGGL(k_transpose_cast, dim3((C + 63) / 64, (R + 63) / 64), dim3(256), 0, (hipStream_t)stream, src, (bf16_t*)dst, R, C, (int64_t)0, (int64_t)0);
+  return launch_status();
+}
+// `count` matrices src + z * src_stride -> dst + z * dst_stride (strides in elements) in one launch: the same weight of every encoder layer
+extern "C" int oneprot_transpose_cast_f32_to_bf16_batched(const float* src, void* dst, int R, int C, int64_t src_stride, int64_t dst_stride, int count, void* stream) {
+  if (!src || !dst || R <= 0 || C <= 0 || count <= 0 || count > 65535 || src_stride < 0 || dst_stride < (int64_t)R * C) return OP_EINVAL;
+  hipLaunchKernelGGL(k_transpose_cast, dim3((C + 63) / 64, (R + 63) / 64, count), dim3(256), 0, (hipStream_t)stream, src, (bf16_t*)dst, R, C, src_stride, dst_stride);
   return launch_status();
 }
 

@@ -112,6 +112,23 @@ class ArenaModule(nn.Module):
         self._bf16_T = {}
         self._bf16_version = None
 
+    def _transpose_layer_weights(self, key, name, R, C):
+        """self._bf16_T[(i, key)] = bf16 [C, R] transposed copy of the fp32 [R, C] arena block that starts at tensor name.format(i=i), for
+        every layer i, in ONE launch (the layers sit at a constant arena pitch); the copies are views of one [n_layers, C, R] buffer."""
+        offs = [self._spec[name.format(i=i)][0] for i in range(self.n_layers)]
+        pitch = offs[1] - offs[0] if self.n_layers > 1 else 0
+        buf = self._bf16_T.get(("all", key))
+        if buf is None:
+            buf = self._bf16_T[("all", key)] = torch.empty(self.n_layers, C, R, dtype=torch.bfloat16, device=self.flat.device)
+            for i in range(self.n_layers):
+                self._bf16_T[(i, key)] = buf[i]
+        w = self.flat.data
+        if pitch >= 0 and all(o == offs[0] + i * pitch for i, o in enumerate(offs)):
+            hip.call("oneprot_transpose_cast_f32_to_bf16_batched", w[offs[0]:], buf, R, C, pitch, R * C, self.n_layers)
+        else:
+            for i, o in enumerate(offs):
+                hip.call("oneprot_transpose_cast_f32_to_bf16", w[o:o + R * C], buf[i], R, C)
+
     def _add(self, name, shape):
         n = 1
         for s in shape:
@@ -249,6 +266,18 @@ class ArenaModule(nn.Module):
                 hip.call("oneprot_cast_f32_to_bf16", w, self._bf16[o:o + n], n)
         self._bf16_version = ver
         return True
+
+    def _transpose_qkv_weights(self):
+        """the [d, 3d] transposed bf16 copies of the fused q|k|v weights (dgrad operand): one launch over the arena, or per layer from
+        the LoRA-merged scratch"""
+        d = self.d
+        if not self._lora:
+            return self._transpose_layer_weights("qkv", "encoder.layer.{i}.attention.self.query.weight", 3 * d, d)
+        for i in range(self.n_layers):
+            t = self._bf16_T.get((i, "qkv"))
+            if t is None:
+                t = self._bf16_T[(i, "qkv")] = torch.empty(d, 3 * d, dtype=torch.bfloat16, device=self.flat.device)
+            hip.call("oneprot_transpose_cast_f32_to_bf16", self._qkv_effective_f32(i), t, 3 * d, d)
 
     def _qkv_effective_f32(self, i):
         """fp32 [3d, d] fused q|k|v weight of layer i as the GEMMs must see it: the arena view, or (LoRA) a scratch copy with (alpha/r) B A
@@ -423,19 +452,11 @@ class EsmTransformer(ArenaModule):
                 hip.call("oneprot_gemm_ln_pack_weight", self._w16(f"encoder.layer.{i}.attention.output.dense.weight"), t, self.d, self.dp)
         if self.flat.requires_grad:
             d, f = self.d, self.f
-            for i in range(self.n_layers):
-                p = f"encoder.layer.{i}."
-                o, n = self.span(p + "attention.self.query.weight", p + "attention.self.value.weight")
-                plain = {"w1": (self.view(p + "intermediate.dense.weight"), f, d), "w2": (self.view(p + "output.dense.weight"), d, f)}
-                if not self._padded:
-                    plain["qkv"] = (self._qkv_effective_f32(i), 3 * d, d)
-                    plain["o"] = (self.view(p + "attention.output.dense.weight"), d, d)
-                for key, (src, R, C) in plain.items():
-                    t = self._bf16_T.get((i, key))
-                    if t is None:
-                        t = torch.empty(C, R, dtype=torch.bfloat16, device=dev)
-                        self._bf16_T[(i, key)] = t
-                    hip.call("oneprot_transpose_cast_f32_to_bf16", src, t, R, C)
+            self._transpose_layer_weights("w1", "encoder.layer.{i}.intermediate.dense.weight", f, d)
+            self._transpose_layer_weights("w2", "encoder.layer.{i}.output.dense.weight", d, f)
+            if not self._padded:
+                self._transpose_layer_weights("o", "encoder.layer.{i}.attention.output.dense.weight", d, d)
+                self._transpose_qkv_weights()
 
     def _fused_ln_ok(self):
         """the full-row GEMM + LayerNorm kernel is built for 640-wide rows with un-padded heads (ESM-2-150M); ONEPROT_FUSED_LN=0 keeps the pair (A/B runs)"""

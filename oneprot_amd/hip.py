@@ -78,6 +78,7 @@ _SIGS = {
     "oneprot_adam_step": (I, [P, P, P, P, L64, F, F, F, F, F, I, P, P]),
     "oneprot_cast_f32_to_bf16": (I, [P, P, L64, P]),
     "oneprot_transpose_cast_f32_to_bf16": (I, [P, P, I, I, P]),
+    "oneprot_transpose_cast_f32_to_bf16_batched": (I, [P, P, I, I, L64, L64, I, P]),
     "oneprot_colsum_workspace": (SZ, [I]),
     "oneprot_colsum_bf16": (I, [P, P, P, L64, I, I, P]),
 }
@@ -93,7 +94,7 @@ _PTR_DTYPES = {
     "oneprot_attn_bwd": "hhhfhhfffhb", "oneprot_gelu_f32": "ff", "oneprot_gelu_bwd_f32": "fff", "oneprot_l2norm_fwd": "fff", "oneprot_l2norm_bwd": "ffff",
     "oneprot_ce_fwd_bwd": "fff", "oneprot_siglip_fwd_bwd": "fff", "oneprot_siglip_fwd_bwd_dev": "ffff", "oneprot_diag_rank": "fii", "oneprot_abs_sum": "ffb", "oneprot_dot_f32": "fffb", "oneprot_l1_bwd": "fff",
     "oneprot_scale_by_device_scalar": "ff", "oneprot_key_padding_bias": "lf", "oneprot_sumsq": "ffb", "oneprot_clip_coef": "fff", "oneprot_adam_step": "fffff",
-    "oneprot_cast_f32_to_bf16": "fh", "oneprot_transpose_cast_f32_to_bf16": "fh", "oneprot_colsum_bf16": "hfb",
+    "oneprot_cast_f32_to_bf16": "fh", "oneprot_transpose_cast_f32_to_bf16": "fh", "oneprot_transpose_cast_f32_to_bf16_batched": "fh", "oneprot_colsum_bf16": "hfb",
 }
 _DT = {"f": torch.float32, "h": torch.bfloat16, "l": torch.int64, "i": torch.int32, "b": torch.uint8}
 

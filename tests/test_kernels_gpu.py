@@ -615,6 +615,14 @@ def test_casts():
     yt = torch.empty(132, 70, dtype=torch.bfloat16, device=DEV)
     hip.call("oneprot_transpose_cast_f32_to_bf16", x, yt, 70, 132)
     assert torch.equal(yt, x.t().contiguous().to(torch.bfloat16))
+    # the same weight of every layer in one launch: matrices at a constant pitch inside a larger arena
+    arena = torch.randn(5 * 10000 + 64, device=DEV)
+    out = torch.full((5, 132, 70), 7.0, dtype=torch.bfloat16, device=DEV)
+    hip.call("oneprot_transpose_cast_f32_to_bf16_batched", arena[64:], out, 70, 132, 10000, 132 * 70, 5)
+    for z in range(5):
+        assert torch.equal(out[z], arena[64 + z * 10000: 64 + z * 10000 + 70 * 132].view(70, 132).t().contiguous().to(torch.bfloat16))
+    with pytest.raises(hip.HipKernelError):
+        hip.call("oneprot_transpose_cast_f32_to_bf16_batched", arena[64:], out, 70, 132, 10000, 100, 5)      # overlapping outputs
 
 
 @pytest.mark.parametrize("world,local_loss", [(2, True), (3, True), (2, False)])

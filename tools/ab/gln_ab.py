@@ -5,6 +5,7 @@ import os, sys, statistics
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__)))))
 import torch
 from oneprot_amd import hip
+if os.environ.get("ONEPROT_LIB"): hip.LIB_PATH = os.path.abspath(os.environ["ONEPROT_LIB"])
 T, N = 131072, 640
 g = torch.Generator(device="cuda").manual_seed(0)
 rnd = lambda *s: torch.randn(*s, device="cuda", generator=g)
