@@ -25,10 +25,11 @@ torch.cuda.synchronize()
 buf = (ctypes.c_ulonglong * 1024)()
 assert lib.oneprot_tn8_debug_read(buf) == 0
 for grp in range(2):
-    print(f"group {grp}: per phase cycles [prev MFMA-slot end -> gathers issued | DMA issued | gathers landed (lgkmcnt 0; note: each stamp drains lgkmcnt itself) | unit landed (vmcnt) | barrier passed | MFMAs issued | wait at the closing barrier]")
+    print(f"group {grp}: cycles per 32-token unit, in time order [gathers issued | gathers landed (lgkmcnt 0) | unit p+1 landed (vmcnt) | opening barrier | 40 MFMAs + 5 LDS-DMA issued | bias MFMAs | closing barrier | SUM]")
     prev = None
     for p in range(8, 20):
         r = [buf[(grp * 64 + p) * 8 + i] for i in range(8)]
         if prev is not None:
-            print(f"  p{p:2d}: {r[2] - prev:6d} {r[3] - r[2]:6d} {r[4] - r[3]:6d} {r[5] - r[4]:6d} {r[0] - r[5]:6d} {r[6] - r[0]:6d} {r[1] - r[6]:6d}")
+            d = [r[2] - prev, r[4] - r[2], r[5] - r[4], r[0] - r[5], r[3] - r[0], r[6] - r[3], r[1] - r[6]]
+            print(f"  p{p:2d}: " + " ".join(f"{v:6d}" for v in d) + f"   {sum(d):6d}")
         prev = r[1]
