@@ -119,10 +119,11 @@ size_t oneprot_attn_bwd_workspace(int B, int H, int L);
 int oneprot_attn_bwd(const void* q, const void* k, const void* v, const float* key_bias, const void* ctx, const void* dctx, const float* lse,
                      const float* rope_cos, const float* rope_sin, float q_scale, void* dqkv, void* workspace, int B, int H, int L, int hd,
                      void* stream);
-/* Test / A-B hook: -1 automatic (default), 0 the two split kernels (dQ, then dK/dV), 1 the fused short-sequence kernel where eligible
-   (L <= 512, hd <= 32: S, P, dP, dS formed once per tile; dQ summed in LDS in a fixed ticket order: deterministic like the split kernels).
-   Bits 4 and up of a positive value are an ablation mask for timing runs only (tools/attn_only.py: 1 no ticket wait, 4 no tiles, 16 no dQ
-   stores, 32 no dK/dV stores) -- results are then wrong by construction. */
+/* Test / A-B hook: -1 automatic (default: by sequence length -- the split kernels up to L = 288, the 16-wave fused kernel up to 416, the
+   8-wave fused kernel up to 512), 0 the two split kernels (dQ, then dK/dV), 1 the fused short-sequence kernel with 16 waves of 32 keys where
+   eligible (L <= 512, hd <= 32: S, P, dP, dS formed once per tile; dQ summed in LDS in a fixed ticket order: deterministic like the split
+   kernels), 2 the fused kernel with 8 waves of 64 keys (two key blocks per wave: Q / dO fragments read once per two tiles, one ticketed
+   read-add-write of dQ per two tiles, deferred under the next step's MFMA chains). */
 void oneprot_attn_force_bwd_path(int path);
 /* Test / A-B hook for oneprot_attn_fwd: -1 automatic (default), 0 the round-1 kernel (per-tile running maximum), 1 the kernels without a row
    maximum (persistent LDS-DMA kernel for hd <= 32 and L <= 512, the chunked kernel otherwise; rows whose sums leave [2^-60, 2^60] are repeated

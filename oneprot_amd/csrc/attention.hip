@@ -1475,8 +1475,324 @@ __global__ void __launch_bounds__(1024, 1) k_attn_bwd_fused(const bf16_t* __rest
   }
 }
 
-static int g_attn_bwd_path = -1;      // -1 automatic, 0 split kernels, 1 fused where eligible (A/B runs and tests)
-extern "C" void oneprot_attn_force_bwd_path(int path) { g_attn_bwd_path = path < 0 ? -1 : (path ? 1 : 0); }
+#ifdef BWD64_STAMP      // diagnostic build (tools/ab/bwd64_stamps.py): s_memtime at the stage boundaries of every step of one work-group's eight waves
+__device__ unsigned long long g_bwd64_stamps[8 * 16 * 8];
+extern "C" int oneprot_attn_debug_bwd64_stamps(unsigned long long* host_out) {
+  return hipMemcpyFromSymbol(host_out, HIP_SYMBOL(g_bwd64_stamps), sizeof(g_bwd64_stamps)) == hipSuccess ? 0 : -2;
+}
+#define BWD64_T(i)                                                                                   \
+  do {                                                                                               \
+    __builtin_amdgcn_sched_barrier(0);                                                               \
+    unsigned long long t_;                                                                           \
+    asm volatile("s_memtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(t_)::"memory");                        \
+    if (lane == 0 && blockIdx.x == 2053) g_bwd64_stamps[(wave * 16 + (blk0 + t)) * 8 + (i)] = t_;   \
+    __builtin_amdgcn_sched_barrier(0);                                                               \
+  } while (0)
+#else
+#define BWD64_T(i) do { } while (0)
+#endif
+
+// ---- the fused backward with TWO key blocks per wave (round 4): eight waves of 64 keys ----------------------------------------------
+// The 16-wave kernel above spends, per (query block, key block) tile, about as long as its MFMAs (12 x 32 cycles), its vector work (16
+// exponentials + ~100 others), its LDS reads (15 KB) and its LDS stores (6 KB) take ONE AFTER THE OTHER (5 760 cycles per round of sixteen
+// tiles per CU: profiles/r04_*): a wave's tile is one dependent chain and the ticket order keeps the sixteen waves in step.  Here a wave owns
+// 64 keys = two key blocks and walks the same query blocks: (i) the Q / dO row fragments and transposed fragments of a query block are read
+// once for two tiles; (ii) the dQ contributions of both key blocks accumulate in ONE 32 x 32 result -- one read-add-write of the block's LDS
+// buffer and one ticket per TWO tiles; (iii) the two tiles are independent chains inside one wave, so the exponentials of one run under the
+// MFMAs of the other without relying on the other waves of the SIMD.  Arithmetic per tile and the order of every accumulation into dK / dV
+// are those of the 16-wave kernel; dQ adds its key blocks pairwise first ((kb0 + kb1) + ...), so dQ differs from it by fp32 rounding only.
+template <int HD>
+__global__ void __launch_bounds__(512, 1) k_attn_bwd_fused64(const bf16_t* __restrict__ q, const bf16_t* __restrict__ k, const bf16_t* __restrict__ v,
+                                                           const float* __restrict__ key_bias, const bf16_t* __restrict__ ctx, const bf16_t* __restrict__ dctx,
+                                                           const float* __restrict__ lse, const float* __restrict__ cosT, const float* __restrict__ sinT,
+                                                           float q_scale, bf16_t* __restrict__ dqkv, int B, int H, int L, int dph) {
+  typedef Cfg<HD> C;
+  typedef FusedLds<HD> F;
+  extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+  unsigned char* sQ = smem;
+  unsigned char* sdO = sQ + F::TILE;
+  u32x4* sQE = reinterpret_cast<u32x4*>(sdO + F::TILE);
+  lds_vint* sTicket = (lds_vint*)LDS_PTR(sdO + F::TILE + (F::ROWS + 1) * 16);
+  float* sdQ = reinterpret_cast<float*>(sdO + F::TILE + F::QE);
+  const int lane = threadIdx.x & 63, wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6), h = lane >> 5, r = lane & 31;
+  unsigned char* sT = reinterpret_cast<unsigned char*>(sdQ) + F::DQ + wave * 2 * F::SLAB;      // this wave's two transpose slabs (64 rows of 64 B)
+  const int dm = H * HD;
+  const int nbh = B * H, per_xcd = (nbh + 7) >> 3;
+  const int bh = (int)(blockIdx.x & 7) * per_xcd + (int)(blockIdx.x >> 3);
+  if (bh >= nbh) return;
+  const int b = bh / H, head = bh - b * H;
+  const int key0 = wave * 64;
+  const bool active = key0 < L;
+
+  u32x4 kr[4], vr[4];
+#pragma unroll
+  for (int it = 0; it < 4; ++it) {
+    const int idx = lane + 64 * it, row = idx >> 2, ch = idx & 3;
+    const u32x4 z = {0u, 0u, 0u, 0u};
+    kr[it] = z; vr[it] = z;
+    if (key0 + row < L && ch < HD / 8) {
+      kr[it] = *reinterpret_cast<const u32x4*>(k + ((size_t)bh * L + key0 + row) * HD + ch * 8);
+      vr[it] = *reinterpret_cast<const u32x4*>(v + ((size_t)bh * L + key0 + row) * HD + ch * 8);
+    }
+  }
+  float bias_k[2];
+#pragma unroll
+  for (int kb = 0; kb < 2; ++kb) {
+    const int kidx = key0 + 32 * kb + r;
+    bias_k[kb] = kidx < L ? (key_bias ? key_bias[(size_t)b * L + kidx] : 0.f) : -INFINITY;
+  }
+  {
+    const bf16_t* qrow0 = q + (size_t)bh * L * HD;
+    const bf16_t* dorow0 = dctx + (size_t)b * L * dm + head * HD;
+    const bf16_t* orow0 = ctx + (size_t)b * L * dm + head * HD;
+    const int nrows = (L + 31) & ~31;
+    {                                                       // four (row, chunk) items per thread, all requested before the first is used: one exposed round trip
+      u32x4 rq[4], rdo[4], ro[4];
+      float rl[4];
+#pragma unroll
+      for (int it = 0; it < 4; ++it) {
+        const int idx = threadIdx.x + 512 * it, row = idx >> 2, ch = idx & 3;
+        const u32x4 z = {0u, 0u, 0u, 0u};
+        rq[it] = z; rdo[it] = z; ro[it] = z; rl[it] = 0.f;
+        if (row < L) {
+          if (ch < HD / 8) {
+            rq[it] = *reinterpret_cast<const u32x4*>(qrow0 + (size_t)row * HD + ch * 8);
+            rdo[it] = *reinterpret_cast<const u32x4*>(dorow0 + (size_t)row * dm + ch * 8);
+            ro[it] = *reinterpret_cast<const u32x4*>(orow0 + (size_t)row * dm + ch * 8);
+          }
+          if (ch == 0) rl[it] = lse[(size_t)bh * L + row];
+        }
+      }
+#pragma unroll
+      for (int it = 0; it < 4; ++it) {
+        const int idx = threadIdx.x + 512 * it, row = idx >> 2, ch = idx & 3;
+        float part = dot8_bf16(rdo[it], ro[it]);
+        part += __shfl_xor(part, 1, 64);
+        part += __shfl_xor(part, 2, 64);
+        if (row < nrows) {
+          const int off = row * 64 + (swz<32>(row, ch) << 4);
+          *reinterpret_cast<u32x4*>(sQ + off) = rq[it];
+          *reinterpret_cast<u32x4*>(sdO + off) = rdo[it];
+          if (ch == 0) {
+            u32x4 e;
+            unsigned w01, w2;
+            split3_bf16(row < L ? -rl[it] * LOG2E : -1.0e30f, w01, w2);
+            e.x = w01; e.y = w2 | 0x3F800000u;
+            split3_bf16(row < L ? -part : 0.f, w01, w2);
+            e.z = w01; e.w = w2;
+            sQE[row] = e;
+          }
+        }
+      }
+    }
+    const u32x4 z = {0u, 0u, 0u, 0u};
+    if (threadIdx.x == 0) sQE[F::ROWS] = z;
+    if (threadIdx.x < FQB) sTicket[threadIdx.x] = 0;
+  }
+
+  // ---- the wave's own K / V rows through its slabs (row fragments; K^T fragments for dQ)
+  bf8_t kf[2][C::KSTEPS], vf[2][C::KSTEPS], ktf[2][2];
+  {
+#pragma unroll
+    for (int it = 0; it < 4; ++it) {
+      const int idx = lane + 64 * it, row = idx >> 2, ch = idx & 3;
+      *reinterpret_cast<u32x4*>(sT + row * 64 + (swz<32>(row, ch) << 4)) = kr[it];
+    }
+#pragma unroll
+    for (int kb = 0; kb < 2; ++kb) {
+#pragma unroll
+      for (int st = 0; st < C::KSTEPS; ++st) kf[kb][st] = rd_row<HD>(sT + kb * F::SLAB, r, st, h);
+      ktf[kb][0] = rd_tr<HD>(sT + kb * F::SLAB, 0, 0, 0, lane);
+      ktf[kb][1] = rd_tr<HD>(sT + kb * F::SLAB, 0, 1, 0, lane);
+    }
+    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+#pragma unroll
+    for (int it = 0; it < 4; ++it) {
+      const int idx = lane + 64 * it, row = idx >> 2, ch = idx & 3;
+      *reinterpret_cast<u32x4*>(sT + row * 64 + (swz<32>(row, ch) << 4)) = vr[it];
+    }
+#pragma unroll
+    for (int kb = 0; kb < 2; ++kb)
+#pragma unroll
+      for (int st = 0; st < C::KSTEPS; ++st) vf[kb][st] = rd_row<HD>(sT + kb * F::SLAB, r, st, h);
+    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+  }
+  // bookkeeping k-step operands (bias[key] - lse[query] into the scores, -delta[query] into dP): rebuilt from three registers where they are used
+  // rather than held as two 4-register fragments next to the accumulators
+  unsigned ky[2];
+#pragma unroll
+  for (int kb = 0; kb < 2; ++kb) ky[kb] = h == 0 ? (0x3F80u | (pack2bf(bias_k[kb], 0.f) << 16)) : 0u;
+  const unsigned hm = h == 0 ? 0x3F803F80u : 0u;
+  f32x16 adk[2] = {zero16(), zero16()}, adv[2] = {zero16(), zero16()};
+
+  const int sw = (r >> 2) & 3;
+  int row_off[C::KSTEPS];
+#pragma unroll
+  for (int st = 0; st < C::KSTEPS; ++st) row_off[st] = r * 64 + (((2 * st + h) ^ sw) << 4);
+  int tr_off[2][2];
+  {
+    const int g = lane >> 4, i = lane & 15;
+    const int col = 16 * (g & 1) + 4 * (i & 3);
+#pragma unroll
+    for (int sb = 0; sb < 2; ++sb) {
+      const int r0 = 16 * sb + 4 * h + (i >> 2), r1 = r0 + 8;
+      tr_off[sb][0] = r0 * 64 + (swz<32>(r0, col >> 3) << 4) + (col & 7) * 2;
+      tr_off[sb][1] = r1 * 64 + (swz<32>(r1, col >> 3) << 4) + (col & 7) * 2;
+    }
+  }
+  const int wr_off = r * 64 + 8 * h;
+  auto tr_frag = [&](const unsigned char* base, int sb) -> bf8_t {
+    const s16x4 a = __builtin_amdgcn_ds_read_tr16_b64_v4i16((__attribute__((address_space(3))) s16x4*)(base + tr_off[sb][0]));
+    const s16x4 c = __builtin_amdgcn_ds_read_tr16_b64_v4i16((__attribute__((address_space(3))) s16x4*)(base + tr_off[sb][1]));
+    s16x8 o;
+    o[0] = a[0]; o[1] = a[1]; o[2] = a[2]; o[3] = a[3]; o[4] = c[0]; o[5] = c[1]; o[6] = c[2]; o[7] = c[3];
+    return __builtin_bit_cast(bf8_t, o);
+  };
+  __syncthreads();
+
+  // the two waves of a SIMD (w and w + 4) run the same recipe: started together they want the matrix pipe together and the vector pipe together.
+  // The second one starts `dph` x 64 cycles late, so that its MFMA phases fall into the first one's exponentials; the ticket order leaves
+  // four steps of slack between them.
+  if (wave >= 4) for (int i = 0; i < dph; ++i) __builtin_amdgcn_s_sleep(1);
+  if (active) {
+    const int nkw = (L + 63) >> 6;                          // waves that own keys = visits per query block
+    const int nqb = (L + 31) >> 5;                          // query blocks
+    // The dQ half of a step -- dS^T fragments back from the slabs, the four dQ MFMAs, the ticketed read-add-write -- is DEFERRED into the next
+    // step: its MFMAs are issued behind the next step's score / dP chains and its LDS round trips (ticket, read, add, write: ~450 cycles of
+    // latency, no arithmetic) run while those chains execute, instead of standing between two steps with the matrix pipe idle.
+    int p_i = -1, p_turn = 0, p_ticket = 0, p_qblk = 0;     // the deferred step: buffer, turn, rank among the block's visitors, query block
+    auto dq_mfmas = [&]() -> f32x16 {
+      f32x16 dq = MFMA32(ktf[0][0], tr_frag(sT, 0), zero16());       // dQ^T[d][query] = K^T dS^T, both key blocks
+      dq = MFMA32(ktf[1][0], tr_frag(sT + F::SLAB, 0), dq);
+      dq = MFMA32(ktf[0][1], tr_frag(sT, 1), dq);
+      dq = MFMA32(ktf[1][1], tr_frag(sT + F::SLAB, 1), dq);
+      return dq;
+    };
+    auto dq_commit = [&](f32x16& dq) {
+      if (lane == 0)
+        while (sTicket[p_i] != p_turn) __builtin_amdgcn_s_sleep(1);
+      asm volatile("" ::: "memory");
+      float4* drow = reinterpret_cast<float4*>(sdQ + (p_i * 32 + r) * F::DQP + 4 * h);
+      if (p_ticket != 0) {
+#pragma unroll
+        for (int g = 0; g < 4; ++g) {
+          const float4 o = drow[2 * g];
+          dq[4 * g] += o.x; dq[4 * g + 1] += o.y; dq[4 * g + 2] += o.z; dq[4 * g + 3] += o.w;
+        }
+      }
+      if (p_ticket != nkw - 1) {
+#pragma unroll
+        for (int g = 0; g < 4; ++g) drow[2 * g] = make_float4(dq[4 * g], dq[4 * g + 1], dq[4 * g + 2], dq[4 * g + 3]);
+      }
+      asm volatile("" ::: "memory");
+      if (lane == 0) sTicket[p_i] = p_turn + 1;          // LDS operations of a wave complete in order: the sums land before the counter moves
+      if (p_ticket == nkw - 1) {                         // last visitor: the block's dQ rows leave from registers
+        const int qidx = p_qblk * 32 + r;
+        f32x16 a0[1] = {dq};
+        if (qidx < L) unrope_store<HD>(a0, cosT, sinT, qidx, h, q_scale, cosT != nullptr, dqkv + ((size_t)b * L + qidx) * (3 * dm) + head * HD);
+      }
+    };
+    int tbase = 0;
+    for (int blk0 = 0; blk0 < nqb; blk0 += FQB) {
+      const int nblk = min(FQB, nqb - blk0);
+      const int vq = nkw / nblk, vr_ = nkw - vq * nblk;
+      auto visits = [&](int blk) { return vq + (blk < vr_ ? 1 : 0); };      // waves that start their walk at block blk (< nblk): #{w < nkw : w % nblk == blk}
+      int ticket = wave / nblk;
+      int i = wave - ticket * nblk;
+      for (int t = 0; t < (dph >= 1000 ? 0 : nblk); ++t) {      // (dph >= 1000: timing-only runs without the walk, ablation builds)
+        const int qblk = blk0 + i;
+        BWD64_T(0);
+        const unsigned char* tQ = sQ + qblk * 2048;
+        const unsigned char* tdO = sdO + qblk * 2048;
+        const bf8_t qe_row = __builtin_bit_cast(bf8_t, sQE[h ? F::ROWS : qblk * 32 + r]);
+        bf8_t qf[C::KSTEPS], dof[C::KSTEPS];
+#pragma unroll
+        for (int st = 0; st < C::KSTEPS; ++st) {
+          qf[st] = *reinterpret_cast<const bf8_t*>(tQ + row_off[st]);
+          dof[st] = *reinterpret_cast<const bf8_t*>(tdO + row_off[st]);
+        }
+        f32x16 sc[2], dp[2];
+#pragma unroll
+        for (int kb = 0; kb < 2; ++kb) {
+          const u32x4 kS = {hm, ky[kb], 0u, 0u}, kD = {0u, 0u, hm, hm >> 16};
+          sc[kb] = MFMA32(qe_row, __builtin_bit_cast(bf8_t, kS), zero16());           // bias[key] - lse[query]
+          dp[kb] = MFMA32(qe_row, __builtin_bit_cast(bf8_t, kD), zero16());           // -delta[query]
+#pragma unroll
+          for (int st = 0; st < C::KSTEPS; ++st) {
+            sc[kb] = MFMA32(qf[st], kf[kb][st], sc[kb]);
+            dp[kb] = MFMA32(dof[st], vf[kb][st], dp[kb]);
+          }
+        }
+        BWD64_T(1);
+        // the previous step's dQ: fragments of its dS^T (still in the slabs) and MFMAs behind this step's chains ...
+        f32x16 dqp = zero16();
+        if (p_i >= 0) dqp = dq_mfmas();
+        __builtin_amdgcn_sched_barrier(0);
+        // ... its read-add-write while they execute
+        if (p_i >= 0) dq_commit(dqp);
+        BWD64_T(2);
+        __builtin_amdgcn_sched_barrier(0);
+        const bf8_t tdo0 = tr_frag(tdO, 0), tdo1 = tr_frag(tdO, 1), tq0 = tr_frag(tQ, 0), tq1 = tr_frag(tQ, 1);      // (requested here, not with the row fragments: 16 registers less across the deferred dQ)
+#pragma unroll
+        for (int kb = 0; kb < 2; ++kb) {
+          f32x16 p;
+#pragma unroll
+          for (int e = 0; e < 16; ++e) { p[e] = __builtin_amdgcn_exp2f(sc[kb][e]); sc[kb][e] = p[e] * dp[kb][e]; }      // P, dS
+          const bf8_t pf0 = pack8(p, 0), pf1 = pack8(p, 1);
+          const bf8_t ds0 = pack8(sc[kb], 0), ds1 = pack8(sc[kb], 1);
+          adv[kb] = MFMA32(tdo0, pf0, adv[kb]);                 // dV^T += dO^T P
+          adk[kb] = MFMA32(tq0, ds0, adk[kb]);                  // dK^T += Q^T dS
+          adv[kb] = MFMA32(tdo1, pf1, adv[kb]);
+          adk[kb] = MFMA32(tq1, ds1, adk[kb]);
+          // dS^T through the wave's slab kb
+          const u32x4 w0 = __builtin_bit_cast(u32x4, ds0), w1 = __builtin_bit_cast(u32x4, ds1);
+          u32x2 g0 = {w0.x, w0.y}, g1 = {w0.z, w0.w}, g2 = {w1.x, w1.y}, g3 = {w1.z, w1.w};
+          unsigned char* slab = sT + kb * F::SLAB;
+          *reinterpret_cast<u32x2*>(slab + wr_off + ((0 ^ sw) << 4)) = g0;
+          *reinterpret_cast<u32x2*>(slab + wr_off + ((1 ^ sw) << 4)) = g1;
+          *reinterpret_cast<u32x2*>(slab + wr_off + ((2 ^ sw) << 4)) = g2;
+          *reinterpret_cast<u32x2*>(slab + wr_off + ((3 ^ sw) << 4)) = g3;
+        }
+        asm volatile("" ::: "memory");
+        BWD64_T(3);
+        p_i = i; p_turn = tbase + ticket; p_ticket = ticket; p_qblk = qblk;
+        i = i + 1 == nblk ? 0 : i + 1;
+        ticket += visits(i);
+      }
+      tbase += nkw;
+    }
+    if (p_i >= 0) {
+      f32x16 dql = dq_mfmas();
+      dq_commit(dql);
+    }
+  }
+  if (active) {
+#pragma unroll
+    for (int kb = 0; kb < 2; ++kb) {
+      const int kidx = key0 + 32 * kb + r;
+      f32x16 a1[1] = {adk[kb]}, a2[1] = {adv[kb]};
+      unsigned char* slab = sT + kb * F::SLAB;
+#pragma unroll
+      for (int which = 0; which < 2; ++which) {
+        bf16_t* img = reinterpret_cast<bf16_t*>(slab + r * 64);
+        if (which == 0) unrope_store<HD>(a1, cosT, sinT, kidx < L ? kidx : 0, h, 0.6931471805599453f, cosT != nullptr, img);
+        else unrope_store<HD>(a2, cosT, sinT, 0, h, 1.0f, false, img);
+        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+#pragma unroll
+        for (int it = 0; it < 2; ++it) {
+          const int idx = lane + 64 * it, row = idx >> 2, ch = idx & 3;
+          const u32x4 w = *reinterpret_cast<const u32x4*>(slab + row * 64 + ch * 16);
+          if (key0 + 32 * kb + row < L && ch < HD / 8)
+            *reinterpret_cast<u32x4*>(dqkv + ((size_t)b * L + key0 + 32 * kb + row) * (3 * dm) + (which + 1) * dm + head * HD + ch * 8) = w;
+        }
+        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+      }
+    }
+  }
+}
+
+static int g_attn_bwd_path = -1;      // -1 automatic, 0 split kernels, 1 fused 16-wave kernel, 2 fused 8-wave kernel (two key blocks per wave) where eligible (A/B runs and tests)
+extern "C" void oneprot_attn_force_bwd_path(int path) { g_attn_bwd_path = path < 0 ? -1 : (path > 2 ? 2 : path); }
 #ifdef ONEPROT_ATTN_ABLATE
 static int g_attn_bwd_ablate = 0;      // timing builds only (tools/attn_only.py with a library built -DONEPROT_ATTN_ABLATE): skips parts of the fused kernel, results are wrong by construction
 extern "C" void oneprot_attn_debug_ablate(int mask) { g_attn_bwd_ablate = mask; }
@@ -1488,14 +1804,28 @@ template <int HD>
 static int launch_bwd(const void* q, const void* k, const void* v, const float* key_bias, const void* ctx, const void* dctx, const float* lse, float* delta,
                       const float* cosT, const float* sinT, float q_scale, void* dqkv, int B, int H, int L, hipStream_t s) {
   if constexpr (HD <= 32) {
-    if (L <= 512 && g_attn_bwd_path != 0) {
+    // automatic choice (tools/attn_only.py with ATTN_L, 256 x 20 heads, us per launch: L = 128 / 256 / 320 / 384 / 448 / 512 -- split 151 / 354 / 555 /
+    // 642 / 876 / 1004, fused 16 waves 174 / 366 / 510 / 619 / 769 / 885, fused 8 waves 240 / 429 / 547 / 638 / 748 / 845): the fused kernels pay
+    // once their work-group has a key block for most of its waves
+    const int path = g_attn_bwd_path >= 0 ? g_attn_bwd_path : (L <= 288 ? 0 : (L <= 416 ? 1 : 2));
+    if (L <= 512 && path != 0) {
       // the fused kernel needs the 143 KB dynamic-LDS opt-in; a device / driver that refuses it takes the split kernels from then on (forced
       // fused path: the refusal is the caller's error)
       static int fused_ok = -1;
       if (fused_ok < 0)
         fused_ok = hipFuncSetAttribute((const void*)k_attn_bwd_fused<HD>, hipFuncAttributeMaxDynamicSharedMemorySize, FusedLds<HD>::TOTAL) == hipSuccess ? 1 : 0;
       if (!fused_ok) { (void)hipGetLastError(); if (g_attn_bwd_path > 0) return OP_EINVAL; }
-      else {
+      else if (path == 2) {
+        static int f64_ok = -1;
+        if (f64_ok < 0)
+          f64_ok = hipFuncSetAttribute((const void*)k_attn_bwd_fused64<HD>, hipFuncAttributeMaxDynamicSharedMemorySize, FusedLds<HD>::TOTAL) == hipSuccess ? 1 : 0;
+        if (!f64_ok) { (void)hipGetLastError(); if (g_attn_bwd_path > 0) return OP_EINVAL; }
+        else {
+        hipLaunchKernelGGL(k_attn_bwd_fused64<HD>, dim3(((B * H + 7) / 8) * 8), dim3(512), FusedLds<HD>::TOTAL, s, (const bf16_t*)q, (const bf16_t*)k, (const bf16_t*)v, key_bias,
+                           (const bf16_t*)ctx, (const bf16_t*)dctx, lse, cosT, sinT, q_scale, (bf16_t*)dqkv, B, H, L, g_attn_bwd_ablate);
+        return launch_status();
+        }
+      } else {
       hipLaunchKernelGGL(k_attn_bwd_fused<HD>, dim3(((B * H + 7) / 8) * 8), dim3(1024), FusedLds<HD>::TOTAL, s, (const bf16_t*)q, (const bf16_t*)k, (const bf16_t*)v, key_bias,
                          (const bf16_t*)ctx, (const bf16_t*)dctx, lse, cosT, sinT, q_scale, (bf16_t*)dqkv, B, H, L, g_attn_bwd_ablate);
       return launch_status();

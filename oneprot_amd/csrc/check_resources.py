@@ -15,6 +15,7 @@ RULES = [
     (r"^void k_attn_fwd3<", 0),                 # persistent attention forward
     (r"^void k_attn_fwd2<", 16),                # (long-sequence / hd 64 path: the output address computed at entry is parked in scratch until the final store -- outside every loop)
     (r"^void k_attn_bwd_fused<\(int\)32>", 0),
+    (r"^void k_attn_bwd_fused64<\(int\)32>", 0),   # 8-wave fused backward (two key blocks per wave): 254 of 256 registers, see the kernel's comments before adding a live value
     (r"^void k_layernorm_(fwd|bwd)", 0),
 ]
 

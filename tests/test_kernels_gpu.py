@@ -339,7 +339,7 @@ def _attn_ref(q, k, v, bias):
     return p @ v.float(), torch.logsumexp(s, -1)
 
 
-@pytest.fixture(params=[0, 1], ids=["bwd_split", "bwd_fused"])
+@pytest.fixture(params=[0, 1, 2], ids=["bwd_split", "bwd_fused", "bwd_fused_64keys"])
 def attn_bwd_path(request):
     hip.query("oneprot_attn_force_bwd_path", request.param)
     yield request.param
@@ -486,7 +486,7 @@ def test_attention_bwd_fused_equals_split_at_block_edges(L, hd):
     cos, sin = O.rope_tables(L, hd)
     cosd, sind = cos[:, : hd // 2].contiguous().to(DEV), sin[:, : hd // 2].contiguous().to(DEV)
     outs = []
-    for path in (0, 1, 1):           # the fused kernel twice: its dQ sums run in ticket order, so a repeat is bit-identical
+    for path in (0, 1, 1, 2, 2):     # the fused kernels twice: their dQ sums run in ticket order, so a repeat is bit-identical
         hip.query("oneprot_attn_force_bwd_path", path)
         try:
             dqkv = torch.full((B * L, 3 * H * hd), float("nan"), dtype=torch.bfloat16, device=DEV)
@@ -495,9 +495,16 @@ def test_attention_bwd_fused_equals_split_at_block_edges(L, hd):
             outs.append(dqkv.float().view(B * L, 3, H * hd))
         finally:
             hip.query("oneprot_attn_force_bwd_path", -1)
-    split, fused, fused2 = outs
-    assert torch.isfinite(fused).all()
+    split, fused, fused2, f64, f64b = outs
+    assert torch.isfinite(fused).all() and torch.isfinite(f64).all()
     assert torch.equal(fused, fused2)
+    assert torch.equal(f64, f64b)
+    if L > 2:      # masked keys (probability exactly 0) receive exactly zero dK / dV -- also from the waves that skip their all-padding key blocks
+        assert float(f64[L + L - L // 4: 2 * L, 1:].abs().max()) == 0.0 and float(fused[L + L - L // 4: 2 * L, 1:].abs().max()) == 0.0
+    # two key blocks per wave: the walks start at other query blocks and dQ adds its two key blocks first -- the same sums in yet another order
+    for part, name in enumerate(("dQ", "dK", "dV")):
+        assert_close(f64[:, part], split[:, part], 2 ** -7, 2 ** -7 * float(split[:, part].abs().max()), name + " (64 keys per wave)")
+        assert rel_err(f64[:, part], split[:, part]) < 3e-3, name
     for part, name in enumerate(("dQ", "dK", "dV")):
         assert_close(fused[:, part], split[:, part], 2 ** -7, 2 ** -7 * float(split[:, part].abs().max()), name)
         assert rel_err(fused[:, part], split[:, part]) < 3e-3, name

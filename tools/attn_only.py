@@ -8,7 +8,7 @@ from oneprot_amd import hip
 if os.environ.get("G8_LIB"): hip.LIB_PATH = os.path.abspath(os.environ["G8_LIB"])
 iters = int(sys.argv[1]) if len(sys.argv) > 1 else 3
 B = int(sys.argv[2]) if len(sys.argv) > 2 else 256
-L, H, hd = 512, 20, 32
+L, H, hd = int(os.environ.get("ATTN_L", "512")), 20, 32
 g = torch.Generator(device="cuda").manual_seed(0)
 mk = lambda: (torch.randn(B, H, L, hd, device="cuda", generator=g) * 0.7).to(torch.bfloat16)
 q, k, v = mk(), mk(), mk()
@@ -44,15 +44,26 @@ if os.environ.get("ATTN_FWD_AB"):
         hip.query("oneprot_attn_force_fwd_path", -1)
         a, b_, c = sorted(res[0])[1], sorted(res[1])[1], sorted(res[2])[1]
         print(f"fwd, {name}: row-max kernel {a * 1e3:.1f} us, no-max persistent LDS-DMA kernel {b_ * 1e3:.1f} us ({fl / b_ / 1e9:.0f} TFLOP/s), no-max chunked kernel {c * 1e3:.1f} us")
+dphs = [int(x) for x in os.environ.get("ATTN_DPH", "").split(",") if x]
+if dphs:
+    # (ablation build) start offset of the second wave of each SIMD in the 8-wave fused backward, in units of 64 cycles; interleaved rounds
+    hip.query("oneprot_attn_force_bwd_path", 2)
+    rr = {d_: [] for d_ in dphs}
+    for rep in range(5):
+        for d_ in dphs:
+            hip.lib().oneprot_attn_debug_ablate(d_)
+            rr[d_].append(timeit(bwd))
+    hip.lib().oneprot_attn_debug_ablate(0)
+    print("fused 8-wave bwd, second wave of a SIMD d x 64 cycles late (median of 5 interleaved rounds): " + "  ".join(f"d={d_}: {sorted(v)[2] * 1e3:.1f} us" for d_, v in rr.items()))
 for abl in [int(x) for x in os.environ.get("ATTN_ABL", "").split(",") if x]:
     # needs a library built with -DONEPROT_ATTN_ABLATE (the hook is not part of the shipped C-ABI: the ablated kernel computes wrong results)
     hip.query("oneprot_attn_force_bwd_path", 1); hip.lib().oneprot_attn_debug_ablate(abl)
     print(f"fused bwd, ablation mask {abl}: {timeit(bwd) * 1e3:.1f} us")
-res = {0: [], 1: []}
+res = {0: [], 1: [], 2: []}
 for rep in range(3):
-    for path in (0, 1):
+    for path in (0, 1, 2):
         hip.query("oneprot_attn_force_bwd_path", path)
         res[path].append(timeit(bwd))
 hip.query("oneprot_attn_force_bwd_path", -1)
 med = {p_: sorted(v)[1] * 1e3 for p_, v in res.items()}
-print(f"bwd: split kernels {med[0]:.1f} us, fused kernel {med[1]:.1f} us ({2.5 * fl / (med[1] * 1e-3) / 1e9:.0f} TFLOP/s)")
+print(f"bwd: split kernels {med[0]:.1f} us, fused 16-wave kernel {med[1]:.1f} us ({2.5 * fl / (med[1] * 1e-3) / 1e9:.0f} TFLOP/s), fused 8-wave kernel (64 keys per wave) {med[2]:.1f} us ({2.5 * fl / (med[2] * 1e-3) / 1e9:.0f} TFLOP/s)")
