@@ -159,6 +159,16 @@ int oneprot_scale_by_device_scalar(float* x, int64_t n, const float* s, void* st
 /* bias[i] = ids[i]==pad ? -FLT_MAX : 0  (additive key-padding mask, hf masking_utils.create_bidirectional_mask) */
 int oneprot_key_padding_bias(const int64_t* ids, float* bias, int64_t n, int pad_id, void* stream);
 
+/* y = dropout(x) on a bf16 operand of n elements (n % 8 == 0), keep probability 1 - p, kept values scaled by the inverse keep probability; the mask
+   is a pure function of (seed, stream_id, element index) -- Philox4x32-10 -- and is never stored.  Replaces the `lora_dropout` module peft 0.5.0
+   applies to the adapter branch's input (ref src/models/components/sequence_encoder.py:61-74, text_encoder.py:39-52: LoraConfig(lora_dropout=...)).
+   The generator is not torch's: same distribution, different stream. */
+int oneprot_dropout_bf16(const void* x, void* y, int64_t n, float p, uint64_t seed, uint64_t stream_id, void* stream);
+/* dx += mask(seed, stream_id) * dy / keep: the backward of the call above with the same (p, seed, stream_id), added into an existing bf16 gradient. */
+int oneprot_dropout_bwd_add_bf16(const void* dy, void* dx, int64_t n, float p, uint64_t seed, uint64_t stream_id, void* stream);
+/* the same into an fp32 gradient (the post-LN BERT tower keeps the layer-input gradient in fp32; ref text_encoder.py:39-52). */
+int oneprot_dropout_bwd_add_f32(const void* dy, float* dx, int64_t n, float p, uint64_t seed, uint64_t stream_id, void* stream);
+
 /* ---------------- optimiser (torch.optim.Adam, ref configs/model/default.yaml:2-6; clip: oneprot_module.py:106) -- */
 /* sumsq[0] += sum x^2 (two-stage deterministic reduction through workspace of oneprot_sumsq_workspace() bytes). */
 size_t oneprot_sumsq_workspace(void);

@@ -118,6 +118,12 @@ class BertTransformer(ArenaModule):
         saved = dict(ids=ids, key_bias=key_bias, layers=[], B=B, L=L) if save else None
         q, k, v, ctx, u = b16(B, H, L, hd), b16(B, H, L, hd), b16(B, H, L, hd), b16(T, d), b16(T, f)
         eps = cfg.layer_norm_eps
+        lora_two = self._lora_two_branch()
+        if lora_two:
+            lora_call = self._lora_calls
+            self._lora_calls += 1
+            if save:
+                saved["lora_call"] = lora_call
         for i in range(self.n_layers):
             p = f"encoder.layer.{i}."
             if save:     # per layer: input (bf16), attention operands, the two pre-LN sums with their statistics, FFN intermediates
@@ -133,8 +139,16 @@ class BertTransformer(ArenaModule):
             o, n = self.span(p + "attention.self.query.weight", p + "attention.self.value.weight")
             ob, nb = self.span(p + "attention.self.query.bias", p + "attention.self.value.bias")
             # rotary tables (1, 0) turn the QKV epilogue into "q *= 1/sqrt(hd), head-major q/k/v" (scores scaled inside attention in HF: same product)
-            hip.call("oneprot_gemm_bf16_nt", h, self._bf16[o:o + n], T, 3 * d, d, d, d, hip.EPI_QKV_ROPE, self.flat.data[ob:ob + nb], q, k, v, None,
-                     one, zero, hd ** -0.5 * hip.LOG2E, L, H, hd)
+            if lora_two:      # peft's two branches in one launch: [h | dropout(h) A^T] x [W | s B]^T  (esm.py, enable_lora)
+                xc, lora_u = self._lora_branch_operand(i, h, T, lora_call)
+                kc = self._lora_ops["Kc"]
+                hip.call("oneprot_gemm_bf16_nt", xc, self._lora_ops["Wc"][i], T, 3 * d, kc, kc, kc, hip.EPI_QKV_ROPE, self.flat.data[ob:ob + nb], q, k, v, None,
+                         one, zero, hd ** -0.5 * hip.LOG2E, L, H, hd)
+                if save:
+                    st["lora_u"] = lora_u
+            else:
+                hip.call("oneprot_gemm_bf16_nt", h, self._bf16[o:o + n], T, 3 * d, d, d, d, hip.EPI_QKV_ROPE, self.flat.data[ob:ob + nb], q, k, v, None,
+                         one, zero, hd ** -0.5 * hip.LOG2E, L, H, hd)
             hip.call("oneprot_attn_fwd", q, k, v, key_bias, ctx, lse, B, H, L, hd)
             hip.call("oneprot_gemm_bf16_nt", ctx, self._w16(p + "attention.output.dense.weight"), T, d, d, d, d, hip.EPI_BIAS_RESID,
                      self.view(p + "attention.output.dense.bias"), s1, None, None, x, None, None, 1.0, 0, 0, 0)
@@ -164,7 +178,12 @@ class BertTransformer(ArenaModule):
         f32 = lambda *s: torch.empty(*s, dtype=torch.float32, device=dev)
         b16 = lambda *s: torch.empty(*s, dtype=torch.bfloat16, device=dev)
         ws_ln = torch.empty(hip.query("oneprot_layernorm_bwd_workspace", d), dtype=torch.uint8, device=dev)
-        ws_tn = self._tn_workspace(((3 * d, d), (f, d), (d, f), (d, d)), dev)
+        lora_raw = None
+        tn_shapes = ((3 * d, d), (f, d), (d, f), (d, d))
+        if "lora_call" in saved:                          # the forward ran peft's two-branch form (train mode, lora_dropout > 0)
+            lora_raw = self._lora_raw = self._lora_raw_buffers(dev)
+            tn_shapes += ((3 * d, self._lora_ops["Rp"]), (self._lora_ops["rp"], d))
+        ws_tn = self._tn_workspace(tn_shapes, dev)
         ws_at = torch.empty(hip.query("oneprot_attn_bwd_workspace", B, H, L), dtype=torch.uint8, device=dev)
         ds, ds16, gy = f32(T, d), b16(T, d), f32(T, d)
         dz, dctx, dqkv = b16(T, f), b16(T, d), b16(T, 3 * d)
@@ -194,6 +213,8 @@ class BertTransformer(ArenaModule):
             hip.call("oneprot_gemm_bf16_tn", dqkv, st["x16"], T, 3 * d, d, 3 * d, d, gflat[o:o + n], gflat[ob:ob + nb], ws_tn, ws_tn.numel(), 0)
             hip.call("oneprot_gemm_bf16_nt", dqkv, self._bf16_T[(i, "qkv")], T, d, 3 * d, 3 * d, 3 * d, hip.EPI_BIAS_RESID, None, g, None, None, ds, None, None,
                      1.0, 0, 0, 0)
+            if lora_raw is not None:      # two-branch LoRA: adapter gradients, and g += mask * (du A) / keep
+                self._lora_branch_backward(i, st["x16"], st["lora_u"], dqkv, T, saved["lora_call"], ws_tn, lora_raw, dh32=g)
             saved["layers"][i] = None
         self._embedding_backward(saved["ids"], g, gflat)
         if on_ready is not None:

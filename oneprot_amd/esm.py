@@ -163,9 +163,13 @@ class ArenaModule(nn.Module):
     # target_modules=[query,key,value], bias="all")).  peft's lora.Linear computes  y = x W^T + b + (alpha/r) * (dropout(x) A^T) B^T  with
     # A ~ kaiming_uniform(a=sqrt(5)), B = 0; only lora_A / lora_B and every parameter whose name contains "bias" stay trainable; the wrapped
     # model's keys gain the prefix "base_model.model." and the adapters are "<linear>.lora_{A,B}.default.weight".
-    # Here: the adapters are two stacked parameters, the bf16 GEMM operand of a target is the merged W + (alpha/r) B A (equal to the
-    # two-branch form at dropout p = 0, which is how every dropout of this path runs), the hand-written backward yields d(W_eff) from
-    # which dA = s B^T dW and dB = s dW A^T follow, and the arena gradient is masked down to its "bias" entries.
+    # Here: the adapters are two stacked parameters.  In eval mode (and with lora_dropout = 0) the bf16 GEMM operand of a target is the merged
+    # W + (alpha/r) B A -- peft's forward at dropout 0 -- and the hand-written backward yields d(W_eff), from which dA = s B^T dW and
+    # dB = s dW A^T follow.  In TRAIN mode with lora_dropout > 0 the two branches stay apart, as in peft: the fused QKV GEMM runs on the
+    # K-concatenated operands [h | dropout(h) A^T] x [W | s B]^T (one launch, the rotary epilogue unchanged), the mask comes from a counter-based
+    # generator (oneprot_dropout_bf16: a pure function of seed, call, layer, element) and is regenerated in the backward, where
+    # du = dqkv (sB), dB = s dqkv^T u, dA = du^T dropout(h) and the layer-input gradient gains mask * (du A) / keep.
+    # Either way the arena gradient is masked down to its "bias" entries (peft bias="all").
     LORA_TARGETS = ("query", "key", "value")
     _lora = None
 
@@ -179,11 +183,10 @@ class ArenaModule(nn.Module):
         self.lora_A = nn.Parameter(A)
         self.lora_B = nn.Parameter(torch.zeros(n, len(targets), d, r))
         self._lora = dict(r=r, alpha=alpha, scaling=alpha / r, targets=targets, dropout=dropout)
-        if dropout and dropout > 0:
-            # peft applies dropout to the adapter branch's input in train mode (the reference default is lora_dropout 0.1); the merged-weight
-            # form W + (alpha/r) B A used here equals peft's two-branch form only at p = 0.  Say so instead of silently training another model.
-            warnings.warn(f"lora_dropout={dropout} is not applied: the HIP path merges the adapters into the GEMM operand, which is peft's forward at dropout 0 "
-                          "(deviation from the reference's train-mode behaviour; INTEGRATION.md, 'Deviations')", stacklevel=2)
+        if not 0.0 <= float(dropout) < 1.0:
+            raise ValueError(f"lora_dropout must be in [0, 1), got {dropout}")
+        self._lora_seed = int(torch.initial_seed()) & 0x7FFFFFFFFFFFFFFF      # masks follow torch.manual_seed; every call / layer draws its own stream
+        self._lora_calls = 0
         for p in self.parameters():
             p.requires_grad = False
         self.lora_A.requires_grad = True
@@ -251,7 +254,8 @@ class ArenaModule(nn.Module):
 
     def _refresh_bf16_mirror(self):
         """returns True when the mirror was rebuilt"""
-        ver = (self.flat._version, self.flat.data_ptr()) + ((self.lora_A._version, self.lora_B._version) if self._lora else ())
+        two = self._lora_two_branch()
+        ver = (self.flat._version, self.flat.data_ptr()) + ((self.lora_A._version, self.lora_B._version, two) if self._lora else ())
         if self._bf16_version == ver:
             return False
         dev = self.flat.device
@@ -259,7 +263,9 @@ class ArenaModule(nn.Module):
             self._bf16 = torch.empty(self._total, dtype=torch.bfloat16, device=dev)
             self._bf16_T = {}
         hip.call("oneprot_cast_f32_to_bf16", self.flat.data, self._bf16, self._total)
-        if self._lora:          # merged operands W + (alpha/r) B A for the target projections
+        if two:                 # train mode with lora_dropout: the mirror keeps the base weights, the adapters ride in the concatenated operands
+            self._lora_refresh_branch_operands()
+        elif self._lora:        # merged operands W + (alpha/r) B A for the target projections
             for i in range(self.n_layers):
                 w = self._qkv_effective_f32(i)
                 o, n = self.span(f"encoder.layer.{i}.attention.self.query.weight", f"encoder.layer.{i}.attention.self.value.weight")
@@ -284,7 +290,7 @@ class ArenaModule(nn.Module):
         added to the target blocks."""
         o, n = self.span(f"encoder.layer.{i}.attention.self.query.weight", f"encoder.layer.{i}.attention.self.value.weight")
         w = self.flat.data[o:o + n]
-        if not self._lora:
+        if not self._lora or self._lora_two_branch():
             return w
         d, r = self.d, self._lora["r"]
         if getattr(self, "_lora_scratch", None) is None or self._lora_scratch.device != w.device:
@@ -309,18 +315,114 @@ class ArenaModule(nn.Module):
         return torch.empty(max(hip.query("oneprot_gemm_bf16_tn_workspace", N, K) for N, K in shapes), dtype=torch.uint8, device=dev)
 
     def lora_backward(self, gflat):
-        """(dA, dB) from the gradient w.r.t. the merged weights left in `gflat`, then `gflat` reduced to its "bias" entries (peft bias="all")."""
+        """(dA, dB) and `gflat` reduced to its "bias" entries (peft bias="all").  Merged form: from the gradient w.r.t. the merged weights left in
+        `gflat`; two-branch form: from the per-layer adapter gradients backward_layers left in self._lora_raw."""
         d, r, s_ = self.d, self._lora["r"], self._lora["scaling"]
         dA, dB = torch.empty_like(self.lora_A), torch.empty_like(self.lora_B)
-        for i in range(self.n_layers):
+        raw = getattr(self, "_lora_raw", None)
+        if raw is not None:
+            self._lora_raw = None
+            dA_raw, dB_raw = raw                                             # [n, Rp, d], [n, 3d, Rp]; target ti at rows / columns ti * rp .. + r
+            rp = self._lora_ops["rp"]
             for ti, t in enumerate(self._lora["targets"]):
-                dW = self.view(f"encoder.layer.{i}.attention.self.{t}.weight", gflat)
-                hip.call("oneprot_sgemm", dW, self.lora_A.data[i, ti], dB[i, ti], d, r, d, 0, 0, s_, 0)        # dB = s dW A^T
-                hip.call("oneprot_sgemm", self.lora_B.data[i, ti], dW, dA[i, ti], r, d, d, 1, 1, s_, 0)        # dA = s B^T dW
+                blk = self.LORA_TARGETS.index(t)
+                dA[:, ti] = dA_raw[:, ti * rp:ti * rp + r]
+                dB[:, ti] = s_ * dB_raw[:, blk * d:(blk + 1) * d, ti * rp:ti * rp + r]
+        else:
+            for i in range(self.n_layers):
+                for ti, t in enumerate(self._lora["targets"]):
+                    dW = self.view(f"encoder.layer.{i}.attention.self.{t}.weight", gflat)
+                    hip.call("oneprot_sgemm", dW, self.lora_A.data[i, ti], dB[i, ti], d, r, d, 0, 0, s_, 0)        # dB = s dW A^T
+                    hip.call("oneprot_sgemm", self.lora_B.data[i, ti], dW, dA[i, ti], r, d, d, 1, 1, s_, 0)        # dA = s B^T dW
         masked = torch.zeros_like(gflat)
         idx = self._lora_bias_index
         masked[idx] = gflat[idx]
         return dA, dB, masked
+
+    # ---- LoRA in train mode with lora_dropout > 0: peft's two-branch form (see the comment above enable_lora)
+    def _lora_two_branch(self):
+        return bool(self._lora) and self._lora["dropout"] > 0 and self.training and not getattr(self, "_padded", False)
+
+    def _lora_refresh_branch_operands(self):
+        """bf16 operands of the two-branch form for every layer: Wc [n, 3d, Kc] = [W | s B (block-diagonal over the targets) | 0] for the
+        K-concatenated QKV GEMM, Acat [n, Rp, d] (the targets' A stacked, each padded to rp = ceil8(r) rows), AtT [n, targets, d, rp] and BsT [n, Rp, 3d] for the backward."""
+        lo, n, d, dev = self._lora, self.n_layers, self.d, self.flat.device
+        r, nt, s_ = lo["r"], len(lo["targets"]), lo["scaling"]
+        rp = -(-r // 8) * 8
+        Rp = nt * rp
+        Kc = -(-(d + Rp) // 128) * 128
+        bf = torch.bfloat16
+        Acat = torch.zeros(n, Rp, d, device=dev)
+        Bs = torch.zeros(n, 3 * d, Rp, device=dev)
+        for ti, t in enumerate(lo["targets"]):
+            blk = self.LORA_TARGETS.index(t)
+            Acat[:, ti * rp:ti * rp + r] = self.lora_A.data[:, ti]
+            Bs[:, blk * d:(blk + 1) * d, ti * rp:ti * rp + r] = s_ * self.lora_B.data[:, ti]
+        Wc = torch.zeros(n, 3 * d, Kc, dtype=bf, device=dev)
+        for i in range(n):
+            o, cnt = self.span(f"encoder.layer.{i}.attention.self.query.weight", f"encoder.layer.{i}.attention.self.value.weight")
+            Wc[i, :, :d] = self._bf16[o:o + cnt].view(3 * d, d)
+        Wc[:, :, d:d + Rp] = Bs.to(bf)
+        self._lora_ops = dict(rp=rp, Rp=Rp, Kc=Kc, Wc=Wc, Acat=Acat.to(bf).contiguous(), AtT=Acat.view(n, nt, rp, d).transpose(2, 3).to(bf).contiguous(),
+                              BsT=Bs.transpose(1, 2).to(bf).contiguous())
+
+    def _lora_scratch_for(self, T, dev):
+        sc = getattr(self, "_lora_branch_scratch", None)
+        if sc is None or sc["key"] != (T, dev, self._lora_ops["Kc"]):
+            sc = dict(key=(T, dev, self._lora_ops["Kc"]), hd=torch.empty(T, self.d, dtype=torch.bfloat16, device=dev),
+                      ut=torch.empty(T, self._lora_ops["rp"], dtype=torch.bfloat16, device=dev),
+                      Xc=torch.zeros(T, self._lora_ops["Kc"], dtype=torch.bfloat16, device=dev))      # columns past d + Rp stay zero
+            self._lora_branch_scratch = sc
+        return sc
+
+    def _lora_stream(self, call_id, i, ti):
+        """dropout stream of target ti in layer i of forward call call_id: peft gives every wrapped Linear its own dropout module, so q, k and v
+        see independent masks of the same input"""
+        return (call_id * self.n_layers + i) * 4 + ti
+
+    def _lora_branch_operand(self, i, h, T, call_id):
+        """A operand of layer i's QKV GEMM in the two-branch form: [h | dropout_q(h) A_q^T | dropout_k(h) A_k^T | dropout_v(h) A_v^T | 0] bf16
+        [T, Kc]; also returns u = the adapter columns [T, Rp] (kept for the backward; the dropped inputs are regenerated there)."""
+        ops, d = self._lora_ops, self.d
+        rp, Rp = ops["rp"], ops["Rp"]
+        sc = self._lora_scratch_for(T, h.device)
+        u = torch.empty(T, Rp, dtype=torch.bfloat16, device=h.device)
+        for ti in range(len(self._lora["targets"])):
+            hip.call("oneprot_dropout_bf16", h, sc["hd"], T * d, float(self._lora["dropout"]), self._lora_seed, self._lora_stream(call_id, i, ti))
+            hip.call("oneprot_gemm_bf16_nt", sc["hd"], ops["Acat"][i, ti * rp:(ti + 1) * rp], T, rp, d, d, d, hip.EPI_BF16, None, sc["ut"], None, None, None, None, None,
+                     1.0, 0, 0, 0)
+            u[:, ti * rp:(ti + 1) * rp].copy_(sc["ut"])
+        Xc = sc["Xc"]
+        Xc[:, :d].copy_(h.view(T, d))
+        Xc[:, d:d + Rp].copy_(u)
+        return Xc, u
+
+    def _lora_branch_backward(self, i, h, u, dqkv, T, call_id, ws_tn, raw, dh16=None, dh32=None):
+        """adapter gradients of layer i into raw = (dA_raw [n, Rp, d], dB_raw [n, 3d, Rp]) and the branches' share of the layer-input gradient,
+        sum_t mask_t * (du_t A_t) / keep, added into dh16 (bf16) or dh32 (fp32)."""
+        ops, d = self._lora_ops, self.d
+        rp, Rp, dev = ops["rp"], ops["Rp"], dqkv.device
+        p_ = float(self._lora["dropout"])
+        sc = self._lora_scratch_for(T, dev)
+        du = torch.empty(T, Rp, dtype=torch.bfloat16, device=dev)
+        hip.call("oneprot_gemm_bf16_nt", dqkv, ops["BsT"][i], T, Rp, 3 * d, 3 * d, 3 * d, hip.EPI_BF16, None, du, None, None, None, None, None, 1.0, 0, 0, 0)
+        hip.call("oneprot_gemm_bf16_tn", dqkv, u, T, 3 * d, Rp, 3 * d, Rp, raw[1][i], None, ws_tn, ws_tn.numel(), 0)            # dqkv^T u
+        dhd = torch.empty(T, d, dtype=torch.bfloat16, device=dev)
+        dut = sc["ut"]
+        for ti in range(len(self._lora["targets"])):
+            stream_id = self._lora_stream(call_id, i, ti)
+            dut.copy_(du[:, ti * rp:(ti + 1) * rp])
+            hip.call("oneprot_dropout_bf16", h, sc["hd"], T * d, p_, self._lora_seed, stream_id)                                  # the forward's dropout_t(h) again
+            hip.call("oneprot_gemm_bf16_tn", dut, sc["hd"], T, rp, d, rp, d, raw[0][i, ti * rp:(ti + 1) * rp], None, ws_tn, ws_tn.numel(), 0)      # du_t^T dropout_t(h)
+            hip.call("oneprot_gemm_bf16_nt", dut, ops["AtT"][i, ti], T, d, rp, rp, rp, hip.EPI_BF16, None, dhd, None, None, None, None, None, 1.0, 0, 0, 0)
+            if dh16 is not None:
+                hip.call("oneprot_dropout_bwd_add_bf16", dhd, dh16, T * d, p_, self._lora_seed, stream_id)
+            else:
+                hip.call("oneprot_dropout_bwd_add_f32", dhd, dh32, T * d, p_, self._lora_seed, stream_id)
+
+    def _lora_raw_buffers(self, dev):
+        ops = self._lora_ops
+        return (torch.zeros(self.n_layers, ops["Rp"], self.d, device=dev), torch.zeros(self.n_layers, 3 * self.d, ops["Rp"], device=dev))
 
     def save_pretrained(self, path):
         """HF-style directory (config.json + model.safetensors) -- used by ref peft_checkpoint.py:20."""
@@ -549,6 +651,12 @@ class EsmTransformer(ArenaModule):
         u = b16(T, f)
         eps = cfg.layer_norm_eps
         fused_ln = self._fused_ln_ok() and T % 128 == 0
+        lora_two = self._lora_two_branch()
+        if lora_two:      # every call draws its own dropout masks; the backward regenerates them from (seed, call, layer)
+            lora_call = self._lora_calls
+            self._lora_calls += 1
+            if save:
+                saved["lora_call"] = lora_call
         for i in range(self.n_layers):
             p = f"encoder.layer.{i}."
             if save:
@@ -562,7 +670,15 @@ class EsmTransformer(ArenaModule):
             hip.call("oneprot_layernorm_fwd", x, 0, self.view(p + "attention.LayerNorm.weight"), self.view(p + "attention.LayerNorm.bias"), h1, None,
                      m1, r1, T, d, eps)
             w_qkv, b_qkv, w_o = self._qkv_operands(i)
-            hip.call("oneprot_gemm_bf16_nt", h1, w_qkv, T, 3 * dp, d, d, d, hip.EPI_QKV_ROPE, b_qkv, q, k, v, None, cos, sin, q_scale * hip.LOG2E, L, H, hd)
+            if lora_two:      # peft's two branches in one launch: [h1 | dropout(h1) A^T] x [W | s B]^T  (K = Kc)
+                xc, lora_u = self._lora_branch_operand(i, h1, T, lora_call)
+                kc = self._lora_ops["Kc"]
+                hip.call("oneprot_gemm_bf16_nt", xc, self._lora_ops["Wc"][i], T, 3 * dp, kc, kc, kc, hip.EPI_QKV_ROPE, b_qkv, q, k, v, None, cos, sin,
+                         q_scale * hip.LOG2E, L, H, hd)
+                if save:
+                    st["lora_u"] = lora_u
+            else:
+                hip.call("oneprot_gemm_bf16_nt", h1, w_qkv, T, 3 * dp, d, d, d, hip.EPI_QKV_ROPE, b_qkv, q, k, v, None, cos, sin, q_scale * hip.LOG2E, L, H, hd)
             hip.call("oneprot_attn_fwd", q, k, v, key_bias, ctx_, lse, B, H, L, hd)
             x_mid = f32(T, d) if save else x
             if fused_ln:
@@ -604,7 +720,12 @@ class EsmTransformer(ArenaModule):
         gv = lambda name: self.view(name, gflat)
         b16 = lambda *s: torch.empty(*s, dtype=torch.bfloat16, device=dev)
         ws_ln = torch.empty(hip.query("oneprot_layernorm_bwd_workspace", d), dtype=torch.uint8, device=dev)
-        ws_tn = self._tn_workspace(((3 * dp, d), (f, d), (d, f), (d, dp)), dev)
+        lora_raw = None
+        tn_shapes = ((3 * dp, d), (f, d), (d, f), (d, dp))
+        if "lora_call" in saved:                          # the forward ran peft's two-branch form (train mode, lora_dropout > 0)
+            lora_raw = self._lora_raw = self._lora_raw_buffers(dev)
+            tn_shapes += ((3 * d, self._lora_ops["Rp"]), (self._lora_ops["rp"], d))
+        ws_tn = self._tn_workspace(tn_shapes, dev)
         ws_at = torch.empty(hip.query("oneprot_attn_bwd_workspace", B, H, L), dtype=torch.uint8, device=dev)
         dz = b16(T, f)
         dh = b16(T, d)
@@ -644,6 +765,8 @@ class EsmTransformer(ArenaModule):
                 gflat[ob:ob + nb].copy_(gb_qkv[rowmap])
             hip.call("oneprot_gemm_bf16_nt", dqkv, self._bf16_T[(i, "qkv")], T, d, 3 * dp, 3 * dp, 3 * dp, hip.EPI_BF16, None, dh, None, None, None, None, None,
                      1.0, 0, 0, 0)
+            if lora_raw is not None:      # two-branch LoRA: adapter gradients, and dh += mask * (du A) / keep
+                self._lora_branch_backward(i, st["h1"], st["lora_u"], dqkv, T, saved["lora_call"], ws_tn, lora_raw, dh16=dh)
             # ---- LN1 (input x_in)
             hip.call("oneprot_layernorm_bwd", dh, 0, None, 0, st["x_in"], 0, self.view(p + "attention.LayerNorm.weight"), st["mean1"], st["rstd1"], g, g, g16,
                      gv(p + "attention.LayerNorm.weight"), gv(p + "attention.LayerNorm.bias"), ws_ln, T, d, 0)

@@ -51,16 +51,18 @@ def linear(x: Tensor, w: Tensor, b: Optional[Tensor] = None) -> Tensor:
 
 
 
-def lora_proj(x: Tensor, sd: Dict[str, Tensor], key: str, scaling: Optional[float]) -> Tensor:
+def lora_proj(x: Tensor, sd: Dict[str, Tensor], key: str, scaling: Optional[float], keep: Optional[Tensor] = None) -> Tensor:
     """A query/key/value projection, optionally wrapped by a LoRA adapter as peft 0.5.0's `lora.Linear.forward` computes it (ref
     sequence_encoder.py:61-74, text_encoder.py:39-52 call `get_peft_model`; peft is a third-party dependency pinned at 0.5.0 in ref
     requirements.txt:8 and ABSENT here, so this branch restates its published algorithm and is *parity unpinned*):
-        y = x W^T + b + (lora_alpha / r) * (dropout(x) A^T) B^T       (dropout p = 0: eval mode)
-    with A = `<key>lora_A.default.weight` [r, d], B = `<key>lora_B.default.weight` [d, r]."""
+        y = x W^T + b + (lora_alpha / r) * (dropout(x) A^T) B^T
+    with A = `<key>lora_A.default.weight` [r, d], B = `<key>lora_B.default.weight` [d, r].  `keep` is this module's dropout mask already
+    divided by the keep probability (nn.Dropout in train mode: x * mask / (1 - p)); None = eval mode / p = 0."""
     y = linear(x, sd[key + "weight"], sd[key + "bias"])
     a = sd.get(key + "lora_A.default.weight")
     if a is not None:
-        y = y + scaling * ((x @ a.t()) @ sd[key + "lora_B.default.weight"].t())
+        xd = x if keep is None else x * keep
+        y = y + scaling * ((xd @ a.t()) @ sd[key + "lora_B.default.weight"].t())
     return y
 
 
@@ -118,14 +120,16 @@ def additive_key_mask(attn_mask: Tensor) -> Tensor:
 
 
 def esm_layer(x: Tensor, sd: Dict[str, Tensor], pre: str, heads: int, key_mask: Tensor, cos: Tensor, sin: Tensor,
-              eps: float, lora_scaling: Optional[float] = None) -> Tensor:
-    """One pre-LN EsmLayer (hf: modeling_esm.py:340-521)."""
+              eps: float, lora_scaling: Optional[float] = None, lora_keep: Optional[Dict[str, Tensor]] = None) -> Tensor:
+    """One pre-LN EsmLayer (hf: modeling_esm.py:340-521).  lora_keep: {"query" | "key" | "value": dropout mask / keep probability} of the
+    adapters' own dropout modules in train mode (peft 0.5.0: one nn.Dropout per wrapped Linear)."""
     B, L, d = x.shape
     hd = d // heads
+    lk = lora_keep or {}
     h = layer_norm(x, sd[pre + "attention.LayerNorm.weight"], sd[pre + "attention.LayerNorm.bias"], eps)
-    q = lora_proj(h, sd, pre + "attention.self.query.", lora_scaling)
-    k = lora_proj(h, sd, pre + "attention.self.key.", lora_scaling)
-    v = lora_proj(h, sd, pre + "attention.self.value.", lora_scaling)
+    q = lora_proj(h, sd, pre + "attention.self.query.", lora_scaling, lk.get("query"))
+    k = lora_proj(h, sd, pre + "attention.self.key.", lora_scaling, lk.get("key"))
+    v = lora_proj(h, sd, pre + "attention.self.value.", lora_scaling, lk.get("value"))
     q = q.view(B, L, heads, hd).transpose(1, 2)
     k = k.view(B, L, heads, hd).transpose(1, 2)
     v = v.view(B, L, heads, hd).transpose(1, 2)
@@ -151,7 +155,7 @@ def esm_forward(ids: Tensor, sd: Dict[str, Tensor], cfg: dict, pre: str = "trans
     cos, sin = rope_tables(L, cfg["hidden"] // cfg["heads"])
     km = additive_key_mask(attn_mask)
     for i in range(cfg["layers"]):
-        x = esm_layer(x, sd, f"{pre}encoder.layer.{i}.", cfg["heads"], km, cos, sin, cfg["eps"], cfg.get("lora_scaling"))
+        x = esm_layer(x, sd, f"{pre}encoder.layer.{i}.", cfg["heads"], km, cos, sin, cfg["eps"], cfg.get("lora_scaling"), (cfg.get("lora_keep") or {}).get(i))
         if taps is not None:
             taps[f"layer{i}"] = x
     x = layer_norm(x, sd[pre + "encoder.emb_layer_norm_after.weight"], sd[pre + "encoder.emb_layer_norm_after.bias"], cfg["eps"])
@@ -177,9 +181,10 @@ def bert_forward(ids: Tensor, sd: Dict[str, Tensor], cfg: dict, pre: str = "tran
     km = additive_key_mask(attn_mask)
     for i in range(cfg["layers"]):
         p = f"{pre}encoder.layer.{i}."
-        q = lora_proj(x, sd, p + "attention.self.query.", cfg.get("lora_scaling")).view(B, T, heads, hd).transpose(1, 2)
-        k = lora_proj(x, sd, p + "attention.self.key.", cfg.get("lora_scaling")).view(B, T, heads, hd).transpose(1, 2)
-        v = lora_proj(x, sd, p + "attention.self.value.", cfg.get("lora_scaling")).view(B, T, heads, hd).transpose(1, 2)
+        lk = (cfg.get("lora_keep") or {}).get(i) or {}      # train-mode dropout masks of the adapters (see lora_proj)
+        q = lora_proj(x, sd, p + "attention.self.query.", cfg.get("lora_scaling"), lk.get("query")).view(B, T, heads, hd).transpose(1, 2)
+        k = lora_proj(x, sd, p + "attention.self.key.", cfg.get("lora_scaling"), lk.get("key")).view(B, T, heads, hd).transpose(1, 2)
+        v = lora_proj(x, sd, p + "attention.self.value.", cfg.get("lora_scaling"), lk.get("value")).view(B, T, heads, hd).transpose(1, 2)
         s = (q @ k.transpose(-1, -2)) * hd ** -0.5 + km
         a = (torch.softmax(s, -1) @ v).transpose(1, 2).reshape(B, T, d)
         a = linear(a, sd[p + "attention.output.dense.weight"], sd[p + "attention.output.dense.bias"])

@@ -632,6 +632,49 @@ def test_casts():
         hip.call("oneprot_transpose_cast_f32_to_bf16_batched", arena[64:], out, 70, 132, 10000, 100, 5)      # overlapping outputs
 
 
+def test_dropout_bf16_mask_is_a_function_of_seed_stream_and_element():
+    """oneprot_dropout_bf16 (peft's lora_dropout on the adapter branch's input): keep probability, exact values, determinism, independent streams,
+    and the two backward forms regenerate the forward's mask."""
+    g = torch.Generator().manual_seed(5)
+    n = 96 * 320
+    x = torch.randn(n, generator=g).to(torch.bfloat16).to(DEV)
+    p_, seed = 0.1, 0x1234ABCD5678
+    thr = int(p_ * 65536 + 0.5)
+    scale = 65536.0 / (65536 - thr)
+    y, y2, y3 = torch.empty_like(x), torch.empty_like(x), torch.empty_like(x)
+    hip.call("oneprot_dropout_bf16", x, y, n, p_, seed, 7)
+    hip.call("oneprot_dropout_bf16", x, y2, n, p_, seed, 7)
+    hip.call("oneprot_dropout_bf16", x, y3, n, p_, seed, 8)
+    assert torch.equal(y, y2) and not torch.equal(y, y3)
+    keep = y != 0
+    kept_or_zero_input = keep | (x == 0)
+    assert abs(float(kept_or_zero_input.float().mean()) - (1 - thr / 65536)) < 4 * (0.1 * 0.9 / n) ** 0.5 + 1e-3
+    assert torch.equal(y[keep], (x[keep].float() * scale).to(torch.bfloat16))
+    k3 = y3 != 0
+    agree = float((keep == k3).float().mean())
+    assert abs(agree - (0.9 * 0.9 + 0.1 * 0.1)) < 0.01, agree            # two streams: independent masks
+    # lag-1 correlation of the mask along the element index is that of independent draws
+    m = keep.float() - keep.float().mean()
+    assert abs(float((m[1:] * m[:-1]).mean() / m.var())) < 0.02
+    dy = torch.randn(n, generator=g).to(torch.bfloat16).to(DEV)
+    base = torch.randn(n, generator=g)
+    d16 = base.to(torch.bfloat16).to(DEV)
+    hip.call("oneprot_dropout_bwd_add_bf16", dy, d16, n, p_, seed, 7)
+    ones = torch.ones(n, dtype=torch.bfloat16, device=DEV)
+    mk = torch.empty_like(ones)
+    hip.call("oneprot_dropout_bf16", ones, mk, n, p_, seed, 7)
+    mask = (mk > 0).float()
+    ref16 = (base.to(torch.bfloat16).float().to(DEV) + mask * scale * dy.float()).to(torch.bfloat16)
+    assert torch.equal(d16, ref16)
+    d32 = base.clone().to(DEV)
+    hip.call("oneprot_dropout_bwd_add_f32", dy, d32, n, p_, seed, 7)
+    assert_close(d32.cpu(), (base.to(DEV) + mask * scale * dy.float()).cpu(), 1e-6, 1e-6, "dropout bwd add f32")
+    with pytest.raises(hip.HipKernelError):
+        hip.call("oneprot_dropout_bf16", x, y, n - 4, p_, seed, 7)            # whole 16-byte pieces only
+    with pytest.raises(hip.HipKernelError):
+        hip.call("oneprot_dropout_bf16", x, y, n, 1.0, seed, 7)
+
+
 @pytest.mark.parametrize("world,local_loss", [(2, True), (3, True), (2, False)])
 def test_clip_loss_node_multirank_semantics(golden_dir, world, local_loss):
     """The fused CLIP node (SGEMM logits + fused CE fwd/bwd) on gathered features, per rank, vs the losses/gradients the reference

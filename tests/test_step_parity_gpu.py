@@ -481,7 +481,7 @@ def test_lora_sequence_encoder_vs_oracle():
     from src.models.components.sequence_encoder import SequenceEncoder
     from oneprot_amd.optim import FusedAdam
     torch.manual_seed(21)
-    enc = SequenceEncoder("facebook/esm2_t6_8M_UR50D", output_dim=256, pooling_type="mean", proj_type="mlp")       # use_lora=True, frozen=True by default
+    enc = SequenceEncoder("facebook/esm2_t6_8M_UR50D", output_dim=256, pooling_type="mean", proj_type="mlp", lora_dropout=0.0)       # use_lora=True, frozen=True by default; the dropout branch has its own test below
     tr = enc.transformer
     with torch.no_grad():
         tr.lora_B.normal_(0, 0.05)                       # peft initialises B = 0 (adapter inactive); make it count
@@ -495,7 +495,7 @@ def test_lora_sequence_encoder_vs_oracle():
     trainable = sorted(n for n, p_ in enc.named_parameters() if p_.requires_grad)
     assert trainable == sorted(["transformer.flat", "transformer.lora_A", "transformer.lora_B"] + ["proj." + n for n, _ in enc.proj.named_parameters()])
     # a second instance loads the PeftModel-style state dict strictly
-    enc2 = SequenceEncoder("facebook/esm2_t6_8M_UR50D", output_dim=256, pooling_type="mean", proj_type="mlp")
+    enc2 = SequenceEncoder("facebook/esm2_t6_8M_UR50D", output_dim=256, pooling_type="mean", proj_type="mlp", lora_dropout=0.0)
     enc2.load_state_dict(sd, strict=True)
     assert torch.equal(enc2.transformer.lora_B, tr.lora_B.cpu()) and torch.equal(enc2.transformer.flat, tr.flat.cpu())
 
@@ -548,8 +548,96 @@ def test_lora_sequence_encoder_vs_oracle():
     assert not torch.allclose(f2, feats.detach().cpu(), atol=1e-4)
 
 
-def test_lora_text_encoder_vs_oracle(golden_dir, tmp_path):
-    """TextEncoder(use_lora=True, frozen=True) (ref text_encoder.py:39-52): BERT tower with q/k/v adapters -- features and adapter gradients vs the oracle."""
+def _lora_keep_masks(tr, call_id, B, L):
+    """{layer: {target: keep multiplier [B, L, d]}} of forward call `call_id` of a LoRA transformer in train mode: the mask the HIP path drew for
+    every adapter's dropout module (regenerated from (seed, call, layer, target) by running the dropout kernel on ones), times 1 / keep probability."""
+    from oneprot_amd import hip
+    d, p_ = tr.d, float(tr._lora["dropout"])
+    thr = int(p_ * 65536 + 0.5)
+    ones = torch.ones(B * L, d, dtype=torch.bfloat16, device=DEV)
+    out = torch.empty_like(ones)
+    keep = {}
+    for i in range(tr.n_layers):
+        keep[i] = {}
+        for ti, t in enumerate(tr._lora["targets"]):
+            hip.call("oneprot_dropout_bf16", ones, out, ones.numel(), p_, tr._lora_seed, tr._lora_stream(call_id, i, ti))
+            keep[i][t] = ((out.float() > 0).float() * (65536.0 / (65536 - thr))).view(B, L, d).cpu()
+    return keep
+
+
+def test_lora_dropout_two_branch_sequence_encoder_vs_oracle():
+    """Train mode with lora_dropout > 0 (the reference's configuration when use_lora is on: sequence.yaml:10, ref sequence_encoder.py:61-74): peft keeps
+    the adapter branch apart and feeds it dropout(x), one dropout module per wrapped Linear.  The HIP path's masks are exported and handed to the
+    oracle's restatement of peft's forward: features, loss and adapter / bias gradients must agree; eval mode is the merged (mask-free) form."""
+    os.environ.update(RANK="0", WORLD_SIZE="1", ONEPROT_ALLOW_RANDOM_INIT="1")
+    from src.models.components.sequence_encoder import SequenceEncoder
+    from src.models.components.loss import ClipLoss
+    torch.manual_seed(22)
+    enc = SequenceEncoder("facebook/esm2_t6_8M_UR50D", output_dim=256, pooling_type="mean", proj_type="mlp", lora_r=4, lora_alpha=8, lora_dropout=0.25)
+    tr = enc.transformer
+    with torch.no_grad():
+        tr.lora_B.normal_(0, 0.08)
+        tr.lora_A.mul_(3.0)                               # a branch large enough for its masks to matter
+        for k, v in tr.named_views().items():
+            if k.endswith(".bias"):
+                v.normal_(0, 0.02)
+    sd = {k: v.detach().clone() for k, v in enc.state_dict().items()}
+    gen = torch.Generator().manual_seed(1882)
+    B, L = 6, 96
+    ids = torch.randint(4, 24, (B, L), generator=gen)
+    ids[:, 0] = 0
+    for b, n in enumerate([96, 40, 96, 17, 70, 96]):
+        ids[b, n - 1] = 2
+        ids[b, n:] = 1
+    other = torch.nn.functional.normalize(torch.randn(B, 256, generator=gen), dim=-1) * (1 / 0.07)
+    enc = enc.to(DEV).train()
+    call = tr._lora_calls
+    feats = enc(ids.to(DEV))
+    assert tr._lora_calls == call + 1
+    keep = _lora_keep_masks(tr, call, B, L)
+    frac = torch.stack([m.gt(0).float().mean() for lay in keep.values() for m in lay.values()])
+    assert (frac - 0.75).abs().max() < 0.01, frac                         # keep probability 1 - p
+    assert not torch.equal(keep[0]["query"], keep[0]["key"]) and not torch.equal(keep[0]["query"], keep[1]["query"])      # one mask per wrapped Linear
+    cfg = dict(layers=6, hidden=320, heads=20, ffn=1280, pad=1, mask=32, eps=1e-5, lora_scaling=8 / 4, lora_keep=keep)
+    osd = {k: (v.clone().requires_grad_(True) if v.is_floating_point() and ("lora_" in k or "bias" in k or k.startswith("proj.")) else v) for k, v in sd.items()}
+    rf = O.encoder_features("esm", ids, osd, cfg, "mean", "mlp", False)
+    rloss = O.clip_loss(rf, other)
+    rloss.backward()
+    cs = torch.nn.functional.cosine_similarity(feats.detach().cpu(), rf.detach(), dim=-1)
+    assert cs.min() > 0.999, cs
+    # the masks matter: the mask-free forward of the same weights is measurably elsewhere
+    r0 = O.encoder_features("esm", ids, {k: v.detach() for k, v in osd.items()}, dict(cfg, lora_keep=None), "mean", "mlp", False)
+    assert torch.nn.functional.cosine_similarity(r0, rf.detach(), dim=-1).min() < 0.9995
+    loss = ClipLoss()(feats, other.to(DEV))
+    assert abs(float(loss) - float(rloss)) / float(rloss) < 2e-3, (float(loss), float(rloss))
+    loss.backward()
+    P = "transformer.base_model.model.encoder.layer."
+    for i in (0, 3, 5):
+        for ti, t in enumerate(("query", "key", "value")):
+            for which, got in (("A", tr.lora_A.grad[i, ti]), ("B", tr.lora_B.grad[i, ti])):
+                ref = osd[f"{P}{i}.attention.self.{t}.lora_{which}.default.weight"].grad
+                assert _cos(got.cpu(), ref) > 0.98, (i, t, which, _cos(got.cpu(), ref))
+    gflat = tr.flat.grad
+    idx = tr._lora_bias_index
+    mask = torch.zeros_like(gflat, dtype=torch.bool); mask[idx] = True
+    assert float(gflat[~mask].abs().max()) == 0.0
+    for name in ("encoder.layer.0.attention.self.query.bias", "encoder.layer.3.intermediate.dense.bias", "encoder.layer.5.LayerNorm.bias"):
+        ref = osd["transformer.base_model.model." + name].grad
+        assert _cos(tr.view(name, gflat).cpu(), ref) > 0.98, name
+    # a second train-mode call draws new masks; eval mode is deterministic and equals the oracle without masks
+    with torch.no_grad():
+        f2 = enc(ids.to(DEV)).cpu()
+        assert not torch.allclose(f2, feats.detach().cpu(), atol=1e-3)
+        enc.eval()
+        e1, e2 = enc(ids.to(DEV)).cpu(), enc(ids.to(DEV)).cpu()
+    assert torch.equal(e1, e2)
+    assert torch.nn.functional.cosine_similarity(e1, r0, dim=-1).min() > 0.999
+
+
+@pytest.mark.parametrize("lora_dropout", [0.0, 0.2], ids=["merged", "two_branch_dropout"])
+def test_lora_text_encoder_vs_oracle(golden_dir, tmp_path, lora_dropout):
+    """TextEncoder(use_lora=True, frozen=True) (ref text_encoder.py:39-52): BERT tower with q/k/v adapters -- features and adapter gradients vs the oracle;
+    with lora_dropout > 0 in train mode through peft's two-branch form, the oracle fed the masks the HIP path drew."""
     os.environ.update(RANK="0", WORLD_SIZE="1", ONEPROT_ALLOW_RANDOM_INIT="1")
     from src.models.components.text_encoder import TextEncoder
     from src.models.components.loss import ClipLoss
@@ -561,17 +649,20 @@ def test_lora_text_encoder_vs_oracle(golden_dir, tmp_path):
         json.dump(dict(model_type="bert", vocab_size=cfg["vocab"], hidden_size=cfg["hidden"], num_hidden_layers=cfg["layers"], num_attention_heads=cfg["heads"],
                        intermediate_size=cfg["ffn"], max_position_embeddings=cfg["max_pos"], pad_token_id=cfg["pad"], layer_norm_eps=cfg["eps"]), f)
     enc = TextEncoder(path, output_dim=cfg["output_dim"], pooling_type="mean", proj_type="linear", use_logit_scale=True, frozen=True, use_lora=True, lora_r=4,
-                      lora_alpha=16)
+                      lora_alpha=16, lora_dropout=lora_dropout)
     enc.load_state_dict(g["sd"], strict=False)           # base weights from the (adapter-free) fixture; adapters stay at their init
     with torch.no_grad():
         enc.transformer.lora_B.normal_(0, 0.05)
     sd = {k: v.detach().clone() for k, v in enc.state_dict().items()}
     osd = {k: (v.clone().requires_grad_(True) if "lora_" in k else v) for k, v in sd.items()}
+    enc = enc.to(DEV).train()
+    call = enc.transformer._lora_calls
+    feats = enc(g["ids"].to(DEV))
+    if lora_dropout > 0:
+        cfg = dict(cfg, lora_keep=_lora_keep_masks(enc.transformer, call, *g["ids"].shape))
     rf = O.encoder_features("bert", g["ids"], osd, cfg, "mean", "linear", True)
     rloss = O.clip_loss(g["seq_features"], rf)
     rloss.backward()
-    enc = enc.to(DEV)
-    feats = enc(g["ids"].to(DEV))
     assert torch.nn.functional.cosine_similarity(feats.detach().cpu(), rf.detach(), dim=-1).min() > 0.999
     ClipLoss()(g["seq_features"].to(DEV), feats).backward()
     tr = enc.transformer
