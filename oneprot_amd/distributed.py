@@ -130,14 +130,51 @@ class ExchangeTimer:
         return {k: sum(a.elapsed_time(b) for a, b in v) for k, v in self.spans.items()}
 
 
+def grad_comm_dtype(name=None):
+    """wire dtype of the gradient all-reduce: None / "fp32" (default; the reference's DDP reduces fp32 gradients) or "bf16" (half the bytes over
+    xGMI: buckets are rounded to bf16, reduced, and written back into the fp32 gradient -- an option, not the default: the sum then runs in
+    bf16).  `name` None reads ONEPROT_GRAD_COMM_DTYPE."""
+    name = (name or os.environ.get("ONEPROT_GRAD_COMM_DTYPE") or "fp32").lower()
+    if name in ("fp32", "float32", "f32"):
+        return None
+    if name in ("bf16", "bfloat16"):
+        return torch.bfloat16
+    raise ValueError(f"gradient communication dtype {name!r}: fp32 or bf16")
+
+
+class _Pending:
+    """an asynchronous all-reduce of `src` (a gradient range, or its bf16 copy `wire` that is written back into `src` once the collective is done)"""
+
+    def __init__(self, handle, src=None, wire=None):
+        self.handle, self.src, self.wire = handle, src, wire
+
+    def wait(self):
+        self.handle.wait()
+        if self.wire is not None:
+            self.src.copy_(self.wire)
+            self.wire = None
+
+
+def _reduce_async(chunk, world, use_avg, average, wire_dtype):
+    """mean (or sum) all-reduce of the fp32 range `chunk`, asynchronous; returns a _Pending"""
+    op = dist.ReduceOp.AVG if (use_avg and average) else dist.ReduceOp.SUM
+    if wire_dtype is None:
+        if average and not use_avg:
+            chunk.div_(world)
+        return _Pending(dist.all_reduce(chunk, op=op, async_op=True))
+    wire = (chunk / world if (average and not use_avg) else chunk).to(wire_dtype)
+    return _Pending(dist.all_reduce(wire, op=op, async_op=True), chunk, wire)
+
+
 class GradOverlap:
     """Asynchronous mean-all-reduce of arena-gradient ranges issued from inside an encoder's backward (one RCCL call per ~6 layers), so
     the reduction of the upper layers runs under the backward of the lower ones.  `allreduce_gradients` waits for the handles of a
     parameter that was reduced this way instead of reducing it again.  Attach with `attach(encoder.transformer)`."""
 
-    def __init__(self):
+    def __init__(self, comm_dtype=None):
         self.world = get_world_size()
         self.use_avg = is_dist_avail_and_initialized() and dist.get_backend() == "nccl"
+        self.wire = grad_comm_dtype(comm_dtype)
         self.calls = 0
 
     def attach(self, transformer):
@@ -148,28 +185,24 @@ class GradOverlap:
         self.calls += 1
         # the reduction operator is chosen once from the backend (RCCL has ncclAvg; gloo does not): an asynchronous collective reports
         # its errors at wait(), so there is nothing to catch and fall back from here
-        if self.use_avg:
-            h = dist.all_reduce(chunk, op=dist.ReduceOp.AVG, async_op=True)
-        else:
-            chunk.div_(self.world)
-            h = dist.all_reduce(chunk, op=dist.ReduceOp.SUM, async_op=True)
+        h = _reduce_async(chunk, self.world, self.use_avg, True, self.wire)
         pend = getattr(param, "_oneprot_pending_reduce", None)
         if pend is None:
             pend = param._oneprot_pending_reduce = []
         pend.append(h)
 
 
-def allreduce_gradients(parameters, bucket_bytes=256 << 20, average=True):
+def allreduce_gradients(parameters, bucket_bytes=256 << 20, average=True, comm_dtype=None):
     """Mean-all-reduce the gradients of `parameters` (only those with a .grad) in large flat buckets.
     The encoder arena gradient is already one contiguous tensor, so the 148 M-parameter encoder is reduced in place with a
     handful of RCCL calls sized for the per-link xGMI bandwidth (bucket_bytes), issued asynchronously and waited once."""
     if not is_dist_avail_and_initialized() or get_world_size() == 1:
         return
     with ExchangeTimer.span("grad_allreduce_exposed"):
-        _allreduce_gradients(parameters, bucket_bytes, average)
+        _allreduce_gradients(parameters, bucket_bytes, average, grad_comm_dtype(comm_dtype))
 
 
-def _allreduce_gradients(parameters, bucket_bytes, average):
+def _allreduce_gradients(parameters, bucket_bytes, average, wire=None):
     world = get_world_size()
     use_avg = average and dist.get_backend() == "nccl"           # RCCL: ncclAvg inside the collective; gloo: divide, then SUM
     op = dist.ReduceOp.AVG if use_avg else dist.ReduceOp.SUM
@@ -187,10 +220,7 @@ def _allreduce_gradients(parameters, bucket_bytes, average):
             flat = g.view(-1)
             step = max(bucket_bytes // g.element_size(), 1)
             for o in range(0, flat.numel(), step):
-                chunk = flat[o:o + step]
-                if average and not use_avg:
-                    chunk.div_(world)
-                handles.append(dist.all_reduce(chunk, op=op, async_op=True))
+                handles.append(_reduce_async(flat[o:o + step], world, use_avg, average, wire))
         else:
             small.append(g)
     if small:

@@ -121,6 +121,30 @@ def allreduce_worker(rank, world, port, out_dir):
     dist.destroy_process_group()
 
 
+def allreduce_bf16_worker(rank, world, port, out_dir):
+    """the optional bf16 wire format of the gradient all-reduce (ONEPROT_GRAD_COMM_DTYPE=bf16): large buckets and the ranges reduced from inside
+    an encoder's backward travel as bf16 and come back into the fp32 gradient; small parameters stay fp32"""
+    os.environ["ONEPROT_GRAD_COMM_DTYPE"] = "bf16"
+    D = _init(rank, world, port)
+    torch.manual_seed(rank)
+    big = torch.nn.Parameter(torch.zeros(600_000))
+    small = torch.nn.Parameter(torch.zeros(7))
+    arena = torch.nn.Parameter(torch.zeros(300_000))
+    for p in (big, small, arena):
+        p.grad = torch.randn_like(p)
+    mine = [p.grad.clone() for p in (big, small, arena)]
+    ov = D.GradOverlap()
+    assert ov.wire is torch.bfloat16
+    ov.reduce_range(arena, arena.grad, 0, 100_000)            # two ranges, as an encoder backward hands them over
+    ov.reduce_range(arena, arena.grad, 100_000, 300_000)
+    D.allreduce_gradients([big, small, arena], bucket_bytes=1 << 20)
+    assert not getattr(arena, "_oneprot_pending_reduce")
+    torch.save({"mine": mine, "reduced": [p.grad.clone() for p in (big, small, arena)]}, os.path.join(out_dir, f"arbf_rank{rank}.pt"))
+    os.environ.pop("ONEPROT_GRAD_COMM_DTYPE")
+    dist.barrier()
+    dist.destroy_process_group()
+
+
 def val_plateau_worker(rank, world, port, out_dir):
     """Standalone (no Trainer) validation epochs on two ranks whose LOCAL losses differ: the monitored value must be the global mean, the
     ReduceLROnPlateau decisions -- hence the learning rates -- identical on every rank, and the running mean must restart every epoch."""

@@ -70,6 +70,23 @@ def test_bucketed_gradient_allreduce(tmp_path):
         _close(a["reduced"][i], mean); _close(b["reduced"][i], mean)
 
 
+def test_bf16_wire_format_of_the_gradient_allreduce(tmp_path):
+    """ONEPROT_GRAD_COMM_DTYPE=bf16: the mean of the ranks' gradients to bf16 precision for the large tensors (buckets and overlapped arena ranges),
+    exactly as before for the small ones."""
+    _run(W.allreduce_bf16_worker, 2, 29727, str(tmp_path))
+    a = torch.load(os.path.join(str(tmp_path), "arbf_rank0.pt"), weights_only=False)
+    b = torch.load(os.path.join(str(tmp_path), "arbf_rank1.pt"), weights_only=False)
+    for i in range(3):
+        mean = (a["mine"][i] + b["mine"][i]) / 2
+        assert torch.equal(a["reduced"][i], b["reduced"][i])
+        if i == 1:
+            _close(a["reduced"][i], mean)                                        # small parameters: fp32 on the wire
+        else:
+            err = (a["reduced"][i] - mean).abs()
+            assert float(err.max()) <= 2 ** -7 * float(mean.abs().max()) and float(err.max()) > 1e-6       # bf16 on the wire (two roundings: each rank's share, the sum)
+            assert torch.equal(a["reduced"][i], a["reduced"][i].to(torch.bfloat16).float())              # what came back is a bf16 value
+
+
 def test_validation_loss_is_global_before_the_plateau_scheduler(tmp_path):
     """without a Trainer the monitored validation loss was rank-local, so ReduceLROnPlateau could decide differently per rank."""
     _run(W.val_plateau_worker, 2, 29726, str(tmp_path))
