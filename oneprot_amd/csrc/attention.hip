@@ -1711,10 +1711,13 @@ __global__ void __launch_bounds__(512, 1) k_attn_bwd_fused64(const bf16_t* __res
           qf[st] = *reinterpret_cast<const bf8_t*>(tQ + row_off[st]);
           dof[st] = *reinterpret_cast<const bf8_t*>(tdO + row_off[st]);
         }
+        // Order of a step (one wave, in-order issue): chains of key block 0 | dQ chain of the PREVIOUS step | its ticketed read-add-write |
+        // chains of key block 1 dealt between the exponentials / products / packs of key block 0 | dV / dK MFMAs of key block 0 dealt between the
+        // vector work of key block 1 | dV / dK MFMAs of key block 1: the vector pipe works while the matrix pipe drains the chains.
         f32x16 sc[2], dp[2];
-#pragma unroll
-        for (int kb = 0; kb < 2; ++kb) {
-          const u32x4 kS = {hm, ky[kb], 0u, 0u}, kD = {0u, 0u, hm, hm >> 16};
+        const u32x4 kD = {0u, 0u, hm, hm >> 16};
+        auto chains = [&](int kb) {
+          const u32x4 kS = {hm, ky[kb], 0u, 0u};
           sc[kb] = MFMA32(qe_row, __builtin_bit_cast(bf8_t, kS), zero16());           // bias[key] - lse[query]
           dp[kb] = MFMA32(qe_row, __builtin_bit_cast(bf8_t, kD), zero16());           // -delta[query]
 #pragma unroll
@@ -1722,37 +1725,56 @@ __global__ void __launch_bounds__(512, 1) k_attn_bwd_fused64(const bf16_t* __res
             sc[kb] = MFMA32(qf[st], kf[kb][st], sc[kb]);
             dp[kb] = MFMA32(dof[st], vf[kb][st], dp[kb]);
           }
-        }
+        };
+        chains(0);
         BWD64_T(1);
-        // the previous step's dQ: fragments of its dS^T (still in the slabs) and MFMAs behind this step's chains ...
         f32x16 dqp = zero16();
         if (p_i >= 0) dqp = dq_mfmas();
         __builtin_amdgcn_sched_barrier(0);
-        // ... its read-add-write while they execute
         if (p_i >= 0) dq_commit(dqp);
         BWD64_T(2);
         __builtin_amdgcn_sched_barrier(0);
         const bf8_t tdo0 = tr_frag(tdO, 0), tdo1 = tr_frag(tdO, 1), tq0 = tr_frag(tQ, 0), tq1 = tr_frag(tQ, 1);      // (requested here, not with the row fragments: 16 registers less across the deferred dQ)
-#pragma unroll
-        for (int kb = 0; kb < 2; ++kb) {
+        bf8_t pf[2], dsf[2];
+        auto vector_part = [&](int kb) {      // P = 2^s, dS = P * dP', both packed to bf16 fragments
           f32x16 p;
 #pragma unroll
-          for (int e = 0; e < 16; ++e) { p[e] = __builtin_amdgcn_exp2f(sc[kb][e]); sc[kb][e] = p[e] * dp[kb][e]; }      // P, dS
-          const bf8_t pf0 = pack8(p, 0), pf1 = pack8(p, 1);
-          const bf8_t ds0 = pack8(sc[kb], 0), ds1 = pack8(sc[kb], 1);
-          adv[kb] = MFMA32(tdo0, pf0, adv[kb]);                 // dV^T += dO^T P
-          adk[kb] = MFMA32(tq0, ds0, adk[kb]);                  // dK^T += Q^T dS
-          adv[kb] = MFMA32(tdo1, pf1, adv[kb]);
-          adk[kb] = MFMA32(tq1, ds1, adk[kb]);
-          // dS^T through the wave's slab kb
-          const u32x4 w0 = __builtin_bit_cast(u32x4, ds0), w1 = __builtin_bit_cast(u32x4, ds1);
+          for (int e = 0; e < 16; ++e) { p[e] = __builtin_amdgcn_exp2f(sc[kb][e]); sc[kb][e] = p[e] * dp[kb][e]; }
+          pf[0] = pack8(p, 0); pf[1] = pack8(p, 1);
+          dsf[0] = pack8(sc[kb], 0); dsf[1] = pack8(sc[kb], 1);
+        };
+        auto matrix_part = [&](int kb) {      // dV^T += dO^T P, dK^T += Q^T dS; dS^T through the wave's slab kb
+          adv[kb] = MFMA32(tdo0, pf[0], adv[kb]);
+          adk[kb] = MFMA32(tq0, dsf[0], adk[kb]);
+          adv[kb] = MFMA32(tdo1, pf[1], adv[kb]);
+          adk[kb] = MFMA32(tq1, dsf[1], adk[kb]);
+          const u32x4 w0 = __builtin_bit_cast(u32x4, dsf[0]), w1 = __builtin_bit_cast(u32x4, dsf[1]);
           u32x2 g0 = {w0.x, w0.y}, g1 = {w0.z, w0.w}, g2 = {w1.x, w1.y}, g3 = {w1.z, w1.w};
           unsigned char* slab = sT + kb * F::SLAB;
           *reinterpret_cast<u32x2*>(slab + wr_off + ((0 ^ sw) << 4)) = g0;
           *reinterpret_cast<u32x2*>(slab + wr_off + ((1 ^ sw) << 4)) = g1;
           *reinterpret_cast<u32x2*>(slab + wr_off + ((2 ^ sw) << 4)) = g2;
           *reinterpret_cast<u32x2*>(slab + wr_off + ((3 ^ sw) << 4)) = g3;
+        };
+        // key block 1's chains (6 MFMAs) between key block 0's vector instructions (~56)
+        chains(1);
+        vector_part(0);
+#pragma unroll
+        for (int n = 0; n < 6; ++n) {
+          __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);
+          __builtin_amdgcn_sched_group_barrier(0x002, 9, 0);
         }
+        __builtin_amdgcn_sched_barrier(0);
+        // key block 0's dV / dK MFMAs (4) between key block 1's vector instructions
+        matrix_part(0);
+        vector_part(1);
+#pragma unroll
+        for (int n = 0; n < 4; ++n) {
+          __builtin_amdgcn_sched_group_barrier(0x008, 1, 1);
+          __builtin_amdgcn_sched_group_barrier(0x002, 14, 1);
+        }
+        __builtin_amdgcn_sched_barrier(0);
+        matrix_part(1);
         asm volatile("" ::: "memory");
         BWD64_T(3);
         p_i = i; p_turn = tbase + ticket; p_ticket = ticket; p_qblk = qblk;
