@@ -1499,8 +1499,10 @@ extern "C" int oneprot_attn_debug_bwd64_stamps(unsigned long long* host_out) {
 // 64 keys = two key blocks and walks the same query blocks: (i) the Q / dO row fragments and transposed fragments of a query block are read
 // once for two tiles; (ii) the dQ contributions of both key blocks accumulate in ONE 32 x 32 result -- one read-add-write of the block's LDS
 // buffer and one ticket per TWO tiles; (iii) the two tiles are independent chains inside one wave, so the exponentials of one run under the
-// MFMAs of the other without relying on the other waves of the SIMD.  Arithmetic per tile and the order of every accumulation into dK / dV
-// are those of the 16-wave kernel; dQ adds its key blocks pairwise first ((kb0 + kb1) + ...), so dQ differs from it by fp32 rounding only.
+// MFMAs of the other without relying on the other waves of the SIMD (sched_group_barrier patterns in the step body); (iv) the dQ half of a
+// step (dS^T back from the slabs, four dependent MFMAs, ticket, read-add-write: latency, no arithmetic) is deferred into the next step, behind
+// its first chains.  Arithmetic per tile is that of the 16-wave kernel; the sums into dK / dV / dQ run in another fixed order (other start
+// blocks of the walks, dQ adds its two key blocks first), so the results differ from it by fp32 rounding only and repeat bit for bit.
 template <int HD>
 __global__ void __launch_bounds__(512, 1) k_attn_bwd_fused64(const bf16_t* __restrict__ q, const bf16_t* __restrict__ k, const bf16_t* __restrict__ v,
                                                            const float* __restrict__ key_bias, const bf16_t* __restrict__ ctx, const bf16_t* __restrict__ dctx,
@@ -1650,9 +1652,8 @@ __global__ void __launch_bounds__(512, 1) k_attn_bwd_fused64(const bf16_t* __res
   };
   __syncthreads();
 
-  // the two waves of a SIMD (w and w + 4) run the same recipe: started together they want the matrix pipe together and the vector pipe together.
-  // The second one starts `dph` x 64 cycles late, so that its MFMA phases fall into the first one's exponentials; the ticket order leaves
-  // four steps of slack between them.
+  // (experiment hook, ablation builds only -- dph is 0 in the product: the second wave of every SIMD starts dph x 64 cycles late.  Measured: 0 is best,
+  // the waves drift apart by themselves; tools/attn_only.py ATTN_DPH)
   if (wave >= 4) for (int i = 0; i < dph; ++i) __builtin_amdgcn_s_sleep(1);
   if (active) {
     const int nkw = (L + 63) >> 6;                          // waves that own keys = visits per query block
