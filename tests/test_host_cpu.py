@@ -313,3 +313,15 @@ def test_comm_library_exports_every_declared_symbol():
     exported = sorted(l.split()[-1] for l in out.splitlines() if " T " in l and "oneprot_comm_" in l)
     assert exported == declared
     comm.lib()          # loads and binds every symbol
+
+
+def test_gradient_wire_dtype_option(monkeypatch):
+    """ONEPROT_GRAD_COMM_DTYPE / distributed.grad_comm_dtype: fp32 (the reference's DDP) by default, bf16 on request, anything else refused"""
+    from oneprot_amd import distributed as D
+    monkeypatch.delenv("ONEPROT_GRAD_COMM_DTYPE", raising=False)
+    assert D.grad_comm_dtype() is None and D.grad_comm_dtype("fp32") is None and D.grad_comm_dtype("float32") is None
+    assert D.grad_comm_dtype("bf16") is torch.bfloat16 and D.grad_comm_dtype("BFloat16") is torch.bfloat16
+    monkeypatch.setenv("ONEPROT_GRAD_COMM_DTYPE", "bf16")
+    assert D.grad_comm_dtype() is torch.bfloat16 and D.grad_comm_dtype("fp32") is None
+    with pytest.raises(ValueError):
+        D.grad_comm_dtype("fp8")
