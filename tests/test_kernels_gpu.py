@@ -510,6 +510,34 @@ def test_attention_bwd_fused_equals_split_at_block_edges(L, hd):
         assert rel_err(fused[:, part], split[:, part]) < 3e-3, name
 
 
+@pytest.mark.parametrize("L,expected", [(256, 0), (288, 0), (320, 1), (416, 1), (448, 2), (512, 2)])
+def test_attention_bwd_automatic_path_by_length(L, expected):
+    """The launcher picks the backward kernel by sequence length (split pair up to 288, 16-wave fused up to 416, 8-wave fused up to 512: measured
+    crossovers, attention.hip launch_bwd): the automatic result is bit-identical to the forced path it should have taken."""
+    B, H, hd = 2, 2, 32
+    g = torch.Generator().manual_seed(77 + L)
+    q = bf(torch.randn(B, H, L, hd, generator=g) * 0.7 * hip.LOG2E).to(DEV)
+    k = bf(torch.randn(B, H, L, hd, generator=g)).to(DEV)
+    v = bf(torch.randn(B, H, L, hd, generator=g)).to(DEV)
+    ctx = torch.empty(B * L, H * hd, dtype=torch.bfloat16, device=DEV)
+    lse = torch.empty(B, H, L, device=DEV)
+    hip.call("oneprot_attn_fwd", q, k, v, None, ctx, lse, B, H, L, hd)
+    dctx = bf(torch.randn(B * L, H * hd, generator=g)).to(DEV)
+    outs = {}
+    for path in (-1, 0, 1, 2):
+        hip.query("oneprot_attn_force_bwd_path", path)
+        try:
+            dqkv = torch.full((B * L, 3 * H * hd), float("nan"), dtype=torch.bfloat16, device=DEV)
+            w = ws(hip.query("oneprot_attn_bwd_workspace", B, H, L))
+            hip.call("oneprot_attn_bwd", q, k, v, None, ctx, dctx, lse, None, None, hd ** -0.5, dqkv, w, B, H, L, hd)
+            outs[path] = dqkv.float()
+        finally:
+            hip.query("oneprot_attn_force_bwd_path", -1)
+    assert torch.equal(outs[-1], outs[expected])
+    others = [p for p in (0, 1, 2) if p != expected]
+    assert any(not torch.equal(outs[-1], outs[p]) for p in others)      # (the paths do differ in their rounding: the equality above is not vacuous)
+
+
 @pytest.mark.parametrize("L,hd", [(45, 32), (300, 32), (77, 16)])
 def test_attention_bwd_rope_chain(L, hd, attn_bwd_path):
     """dqkv must be the gradient w.r.t. the un-rotated, un-scaled projections (transpose of q-scale + RoPE)."""
