@@ -119,6 +119,14 @@ size_t oneprot_attn_bwd_workspace(int B, int H, int L);
 int oneprot_attn_bwd(const void* q, const void* k, const void* v, const float* key_bias, const void* ctx, const void* dctx, const float* lse,
                      const float* rope_cos, const float* rope_sin, float q_scale, void* dqkv, void* workspace, int B, int H, int L, int hd,
                      void* stream);
+/* The forward with attention-probability dropout (hf modeling_bert.py BertSelfAttention: softmax -> nn.Dropout(attention_probs_dropout_prob) -> @ V;
+   the reference leaves it active whenever the text tower is in train mode, text_encoder.py:59).  keep(b, h, q, k) is a pure function of
+   (seed, stream_id, b*H+h, q, k) through Philox4x32-10 (8-bit threshold: keep probability 1 - round(256 p) / 256, kept probabilities scaled by its
+   inverse); ctx = (keep * softmax / keep_prob) @ V, lse = that of the undropped softmax.  Same arguments as oneprot_attn_fwd otherwise. */
+int oneprot_attn_fwd_dropout(const void* q, const void* k, const void* v, const float* key_bias, void* ctx, float* lse, int B, int H, int L, int hd,
+                             float p, uint64_t seed, uint64_t stream_id, void* stream);
+/* keep[B][H][L][L] (one byte each, 0 / 1): the mask the call above applies -- for tests and for a reference that is handed the mask. */
+int oneprot_attn_dropout_keep(void* keep, int B, int H, int L, float p, uint64_t seed, uint64_t stream_id, void* stream);
 /* Test / A-B hook: -1 automatic (default: by sequence length -- the split kernels up to L = 288, the 16-wave fused kernel up to 416, the
    8-wave fused kernel up to 512), 0 the two split kernels (dQ, then dK/dV), 1 the fused short-sequence kernel with 16 waves of 32 keys where
    eligible (L <= 512, hd <= 32: S, P, dP, dS formed once per tile; dQ summed in LDS in a fixed ticket order: deterministic like the split
@@ -164,6 +172,8 @@ int oneprot_key_padding_bias(const int64_t* ids, float* bias, int64_t n, int pad
    applies to the adapter branch's input (ref src/models/components/sequence_encoder.py:61-74, text_encoder.py:39-52: LoraConfig(lora_dropout=...)).
    The generator is not torch's: same distribution, different stream. */
 int oneprot_dropout_bf16(const void* x, void* y, int64_t n, float p, uint64_t seed, uint64_t stream_id, void* stream);
+/* the same on fp32 (hidden-state dropout of the BERT tower: hf modeling_bert.py BertEmbeddings / BertSelfOutput / BertOutput); y may alias x. */
+int oneprot_dropout_f32(const float* x, float* y, int64_t n, float p, uint64_t seed, uint64_t stream_id, void* stream);
 /* dx += mask(seed, stream_id) * dy / keep: the backward of the call above with the same (p, seed, stream_id), added into an existing bf16 gradient. */
 int oneprot_dropout_bwd_add_bf16(const void* dy, void* dx, int64_t n, float p, uint64_t seed, uint64_t stream_id, void* stream);
 /* the same into an fp32 gradient (the post-LN BERT tower keeps the layer-input gradient in fp32; ref text_encoder.py:39-52). */

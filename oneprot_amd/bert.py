@@ -92,6 +92,29 @@ class BertTransformer(ArenaModule):
             self._transpose_layer_weights("w1", "encoder.layer.{i}.intermediate.dense.weight", f, d)
             self._transpose_layer_weights("w2", "encoder.layer.{i}.output.dense.weight", d, f)
 
+    # ---- hf's train-mode dropout (hidden_dropout_prob / attention_probs_dropout_prob, 0.1 in bert-base).  The reference never switches its text tower
+    # to eval mode (text_encoder.py:59), so even the frozen tower of the shipped configuration is stochastic there.  Here it is an OPTION, off by
+    # default (parity is defined against eval mode, INTEGRATION.md "Deviations"): ONEPROT_BERT_DROPOUT=1 or `transformer.train_dropout = True`
+    # applies all four dropouts in train mode to a FROZEN tower (forward only; a trainable tower keeps p = 0 -- the attention backward with a mask is
+    # not built).  Masks come from the counter-based generator of the LoRA dropout (Philox4x32-10 of seed, call, layer, site, element).
+    train_dropout = None
+
+    def _train_dropout(self):
+        on = self.train_dropout if self.train_dropout is not None else os.environ.get("ONEPROT_BERT_DROPOUT", "0") == "1"
+        cfg = self.config
+        if not (on and self.training and not self.flat.requires_grad):
+            return False
+        if not (float(cfg.hidden_dropout_prob) > 0 or float(cfg.attention_probs_dropout_prob) > 0):
+            return False
+        if getattr(self, "_drop_seed", None) is None:
+            self._drop_seed = int(torch.initial_seed()) & 0x7FFFFFFFFFFFFFFF
+            self._drop_calls = 0
+        return True
+
+    def _drop_stream(self, call_id, layer, site):
+        """stream id of a dropout site: layer -1 = embeddings; site 0 = attention probabilities, 1 = attention output dense, 2 = FFN output dense"""
+        return (call_id * (self.n_layers + 1) + (layer + 1)) * 4 + site
+
     @torch.no_grad()
     def run_layers(self, ids, save=False):
         """Embeddings + n post-LN layers.  Returns (last hidden state fp32 [T,d], saved-dict or None)."""
@@ -115,6 +138,14 @@ class BertTransformer(ArenaModule):
         hip.call("oneprot_bert_embed_fwd", ids, self.view(e + "word_embeddings.weight"), self.view(e + "position_embeddings.weight"),
                  self.view(e + "token_type_embeddings.weight"), self.view(e + "LayerNorm.weight"), self.view(e + "LayerNorm.bias"), x, h, B, L, d,
                  cfg.vocab_size, cfg.layer_norm_eps)
+        drop = self._train_dropout() and not save
+        if drop:      # hf's train-mode dropouts (frozen tower, forward only): embeddings, attention probabilities, the two dense outputs of every layer
+            drop_call = self._drop_calls
+            self._drop_calls += 1
+            p_h, p_a = float(cfg.hidden_dropout_prob), float(cfg.attention_probs_dropout_prob)
+            y_drop = f32(T, d)
+            hip.call("oneprot_dropout_f32", x, x, T * d, p_h, self._drop_seed, self._drop_stream(drop_call, -1, 0))
+            hip.call("oneprot_cast_f32_to_bf16", x, h, T * d)
         saved = dict(ids=ids, key_bias=key_bias, layers=[], B=B, L=L) if save else None
         q, k, v, ctx, u = b16(B, H, L, hd), b16(B, H, L, hd), b16(B, H, L, hd), b16(T, d), b16(T, f)
         eps = cfg.layer_norm_eps
@@ -149,15 +180,29 @@ class BertTransformer(ArenaModule):
             else:
                 hip.call("oneprot_gemm_bf16_nt", h, self._bf16[o:o + n], T, 3 * d, d, d, d, hip.EPI_QKV_ROPE, self.flat.data[ob:ob + nb], q, k, v, None,
                          one, zero, hd ** -0.5 * hip.LOG2E, L, H, hd)
-            hip.call("oneprot_attn_fwd", q, k, v, key_bias, ctx, lse, B, H, L, hd)
-            hip.call("oneprot_gemm_bf16_nt", ctx, self._w16(p + "attention.output.dense.weight"), T, d, d, d, d, hip.EPI_BIAS_RESID,
-                     self.view(p + "attention.output.dense.bias"), s1, None, None, x, None, None, 1.0, 0, 0, 0)
+            if drop:
+                hip.call("oneprot_attn_fwd_dropout", q, k, v, key_bias, ctx, lse, B, H, L, hd, p_a, self._drop_seed, self._drop_stream(drop_call, i, 0))
+                # s1 = x + dropout(ctx Wo^T + bo): the residual add leaves the GEMM epilogue so that the mask can sit between the two
+                hip.call("oneprot_gemm_bf16_nt", ctx, self._w16(p + "attention.output.dense.weight"), T, d, d, d, d, hip.EPI_F32,
+                         self.view(p + "attention.output.dense.bias"), y_drop, None, None, None, None, None, 1.0, 0, 0, 0)
+                hip.call("oneprot_dropout_f32", y_drop, y_drop, T * d, p_h, self._drop_seed, self._drop_stream(drop_call, i, 1))
+                torch.add(x, y_drop, out=s1)
+            else:
+                hip.call("oneprot_attn_fwd", q, k, v, key_bias, ctx, lse, B, H, L, hd)
+                hip.call("oneprot_gemm_bf16_nt", ctx, self._w16(p + "attention.output.dense.weight"), T, d, d, d, d, hip.EPI_BIAS_RESID,
+                         self.view(p + "attention.output.dense.bias"), s1, None, None, x, None, None, 1.0, 0, 0, 0)
             hip.call("oneprot_layernorm_fwd", s1, 0, self.view(p + "attention.output.LayerNorm.weight"), self.view(p + "attention.output.LayerNorm.bias"), y16, y1,
                      m1, r1, T, d, eps)
             hip.call("oneprot_gemm_bf16_nt", y16, self._w16(p + "intermediate.dense.weight"), T, f, d, d, d, hip.EPI_BIAS_GELU,
                      self.view(p + "intermediate.dense.bias"), u, z, None, None, None, None, 1.0, 0, 0, 0)
-            hip.call("oneprot_gemm_bf16_nt", u, self._w16(p + "output.dense.weight"), T, d, f, f, f, hip.EPI_BIAS_RESID, self.view(p + "output.dense.bias"),
-                     s2, None, None, y1, None, None, 1.0, 0, 0, 0)
+            if drop:
+                hip.call("oneprot_gemm_bf16_nt", u, self._w16(p + "output.dense.weight"), T, d, f, f, f, hip.EPI_F32, self.view(p + "output.dense.bias"),
+                         y_drop, None, None, None, None, None, 1.0, 0, 0, 0)
+                hip.call("oneprot_dropout_f32", y_drop, y_drop, T * d, p_h, self._drop_seed, self._drop_stream(drop_call, i, 2))
+                torch.add(y1, y_drop, out=s2)
+            else:
+                hip.call("oneprot_gemm_bf16_nt", u, self._w16(p + "output.dense.weight"), T, d, f, f, f, hip.EPI_BIAS_RESID, self.view(p + "output.dense.bias"),
+                         s2, None, None, y1, None, None, 1.0, 0, 0, 0)
             hip.call("oneprot_layernorm_fwd", s2, 0, self.view(p + "output.LayerNorm.weight"), self.view(p + "output.LayerNorm.bias"), h_out, x_out, m2, r2, T, d, eps)
             if save:
                 saved["layers"].append(st)

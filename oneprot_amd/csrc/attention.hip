@@ -144,10 +144,25 @@ __device__ __forceinline__ void decode_block(int nblk_per_bh, int nbh, int& bh, 
 // =========================================================================================================
 // forward
 // =========================================================================================================
-template <int HD>
+// DROP: attention-probability dropout (hf modeling_bert.py BertSelfAttention: softmax -> dropout -> @ V; active in the reference whenever the text
+// tower is in train mode, text_encoder.py:59).  keep(b, h, q, k) is a pure function of (seed, stream, b*H+h, q, k): byte e of
+// Philox4x32-10(counter = (q, 2 * (k >> 5) + ((k >> 2) & 1), b*H+h, stream), key = seed), e = ((k & 31) >> 3) * 4 + (k & 3) -- the 16 keys a lane
+// holds of one 32-key tile share one call -- kept iff byte >= thr8 = round(p * 256); kept probabilities are scaled by 256 / (256 - thr8) (folded into
+// the final normalisation).  The row sum and the log-sum-exp are those of the undropped softmax.  oneprot_attn_dropout_keep writes the same mask
+// out for tests.
+__device__ __forceinline__ unsigned attn_keep_bits(int qidx, int tile, int h, int bh, unsigned long long seed, unsigned long long stream_id, unsigned thr8) {
+  unsigned rnd[4];
+  philox4x32_10((unsigned)qidx, (unsigned)(2 * tile + h), (unsigned)bh, (unsigned)stream_id, (unsigned)seed, (unsigned)(seed >> 32) ^ (unsigned)(stream_id >> 32), rnd);
+  unsigned bits = 0;
+#pragma unroll
+  for (int e = 0; e < 16; ++e) bits |= (((rnd[e >> 2] >> (8 * (e & 3))) & 0xffu) >= thr8 ? 1u : 0u) << e;
+  return bits;
+}
+
+template <int HD, bool DROP = false>
 __global__ void __launch_bounds__(256, 2) k_attn_fwd(const bf16_t* __restrict__ q, const bf16_t* __restrict__ k, const bf16_t* __restrict__ v,
                                                   const float* __restrict__ key_bias, bf16_t* __restrict__ ctx, float* __restrict__ lse_out, int B, int H,
-                                                  int L, int nqb) {
+                                                  int L, int nqb, unsigned thr8 = 0, unsigned long long seed = 0, unsigned long long stream_id = 0) {
   typedef Cfg<HD> C;
   extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
   unsigned char* sK = smem;
@@ -227,17 +242,25 @@ __global__ void __launch_bounds__(256, 2) k_attn_fwd(const bf16_t* __restrict__ 
       }
 #pragma unroll
       for (int r = 0; r < 16; ++r) s[r] = __builtin_amdgcn_exp2f(s[r]);
+      f32x16 sd = s;
+      if constexpr (DROP) {
+        const unsigned bits = attn_keep_bits(qidx, (kc0 >> 5) + t, h, bh, seed, stream_id, thr8);
+#pragma unroll
+        for (int r = 0; r < 16; ++r) sd[r] = ((bits >> r) & 1u) ? s[r] : 0.f;
+      }
 #pragma unroll
       for (int sb = 0; sb < 2; ++sb) {
         const bf8_t pf = pack8(s, sb);
         lacc = MFMA32(__builtin_bit_cast(bf8_t, ones), pf, lacc);
+        const bf8_t pv = DROP ? pack8(sd, sb) : pf;
 #pragma unroll
-        for (int d = 0; d < C::DBLK; ++d) acc[d] = MFMA32(rd_tr<HD>(sV, t * 32, sb, d, lane), pf, acc[d]);
+        for (int d = 0; d < C::DBLK; ++d) acc[d] = MFMA32(rd_tr<HD>(sV, t * 32, sb, d, lane), pv, acc[d]);
       }
     }
   }
   const float lt = l + lacc[0];
-  const float inv = lt > 0.f ? 1.0f / lt : 0.f;
+  float inv = lt > 0.f ? 1.0f / lt : 0.f;
+  if constexpr (DROP) inv *= 256.0f / (float)(256u - thr8);
   if (qidx < L) {
     bf16_t* dst = ctx + ((size_t)b * L + qidx) * (H * HD) + head * HD;
 #pragma unroll
@@ -255,6 +278,38 @@ __global__ void __launch_bounds__(256, 2) k_attn_fwd(const bf16_t* __restrict__ 
 }
 
 template <int HD> static size_t fwd_lds() { return (size_t)2 * KC * Cfg<HD>::ROWB + (KC + 1) * 16; }
+
+template <int HD>
+static int launch_fwd_dropout(const void* q, const void* k, const void* v, const float* key_bias, void* ctx, float* lse, int B, int H, int L, unsigned thr8,
+                              uint64_t seed, uint64_t stream_id, hipStream_t s) {
+  const int nqb = (L + 127) / 128;
+  const int nbh8 = ((B * H + 7) / 8) * 8;
+  hipLaunchKernelGGL((k_attn_fwd<HD, true>), dim3(nbh8 * nqb), dim3(256), fwd_lds<HD>(), s, (const bf16_t*)q, (const bf16_t*)k, (const bf16_t*)v, key_bias,
+                     (bf16_t*)ctx, lse, B, H, L, nqb, thr8, (unsigned long long)seed, (unsigned long long)stream_id);
+  return launch_status();
+}
+// keep[b][h][q][k] (one byte each, 0 / 1) of the mask k_attn_fwd<HD, true> applies: for tests and for an oracle that is handed the mask
+__global__ void __launch_bounds__(256) k_attn_dropout_keep(unsigned char* __restrict__ keep, int BH, int L, unsigned thr8, unsigned long long seed, unsigned long long stream_id) {
+  const size_t n = (size_t)BH * L * L;
+  for (size_t i = (size_t)blockIdx.x * 256 + threadIdx.x; i < n; i += (size_t)gridDim.x * 256) {
+    const int kk = (int)(i % L), qq = (int)((i / L) % L), bh = (int)(i / ((size_t)L * L));
+    const unsigned bits = attn_keep_bits(qq, kk >> 5, (kk >> 2) & 1, bh, seed, stream_id, thr8);
+    keep[i] = (unsigned char)((bits >> ((((kk & 31) >> 3) << 2) | (kk & 3))) & 1u);
+  }
+}
+static int attn_drop_thr8(float p, unsigned& thr8) {
+  if (!(p >= 0.f) || !(p < 1.f)) return OP_EINVAL;
+  thr8 = (unsigned)(p * 256.f + 0.5f);
+  return thr8 < 256u ? OP_OK : OP_EINVAL;
+}
+extern "C" int oneprot_attn_dropout_keep(void* keep, int B, int H, int L, float p, uint64_t seed, uint64_t stream_id, void* stream) {
+  unsigned thr8;
+  if (!keep || B <= 0 || H <= 0 || L <= 0 || attn_drop_thr8(p, thr8) != OP_OK) return OP_EINVAL;
+  const size_t n = (size_t)B * H * L * L;
+  size_t blocks = (n + 255) / 256; if (blocks > 8192) blocks = 8192;
+  hipLaunchKernelGGL(k_attn_dropout_keep, dim3((unsigned)blocks), dim3(256), 0, (hipStream_t)stream, (unsigned char*)keep, B * H, L, thr8, (unsigned long long)seed, (unsigned long long)stream_id);
+  return launch_status();
+}
 
 template <int HD>
 static int launch_fwd(const void* q, const void* k, const void* v, const float* key_bias, void* ctx, float* lse, int B, int H, int L, hipStream_t s) {
@@ -993,6 +1048,19 @@ extern "C" int oneprot_attn_fwd(const void* q, const void* k, const void* v, con
     case 16: return launch_fwd<16>(q, k, v, key_bias, ctx, lse, B, H, L, s);
     case 32: return launch_fwd<32>(q, k, v, key_bias, ctx, lse, B, H, L, s);
     case 64: return launch_fwd<64>(q, k, v, key_bias, ctx, lse, B, H, L, s);
+    default: return OP_EINVAL;
+  }
+}
+
+extern "C" int oneprot_attn_fwd_dropout(const void* q, const void* k, const void* v, const float* key_bias, void* ctx, float* lse, int B, int H, int L, int hd, float p,
+                                        uint64_t seed, uint64_t stream_id, void* stream) {
+  unsigned thr8;
+  if (!q || !k || !v || !ctx || B <= 0 || H <= 0 || L <= 0 || attn_drop_thr8(p, thr8) != OP_OK) return OP_EINVAL;
+  hipStream_t s = (hipStream_t)stream;
+  switch (hd) {
+    case 16: return launch_fwd_dropout<16>(q, k, v, key_bias, ctx, lse, B, H, L, thr8, seed, stream_id, s);
+    case 32: return launch_fwd_dropout<32>(q, k, v, key_bias, ctx, lse, B, H, L, thr8, seed, stream_id, s);
+    case 64: return launch_fwd_dropout<64>(q, k, v, key_bias, ctx, lse, B, H, L, thr8, seed, stream_id, s);
     default: return OP_EINVAL;
   }
 }

@@ -70,4 +70,18 @@ __device__ __forceinline__ void gelu_fwd_and_grad(float x, float& g, float& dg) 
   dg = fmaf(x * e, 0.3989422804014327f, cdf);
 }
 
+// Philox4x32-10 (Salmon et al., SC'11): counter (c0..c3), key (k0, k1) -> four 32-bit words.  The dropout masks of this library are pure functions of
+// (seed, stream id, element index) through this generator and are never stored (featops.hip: oneprot_dropout_*; attention.hip: the BERT tower's
+// attention-probability dropout).
+__device__ __forceinline__ void philox4x32_10(unsigned c0, unsigned c1, unsigned c2, unsigned c3, unsigned k0, unsigned k1, unsigned (&out)[4]) {
+#pragma unroll
+  for (int r = 0; r < 10; ++r) {
+    const unsigned long long p0 = (unsigned long long)0xD2511F53u * c0, p1 = (unsigned long long)0xCD9E8D57u * c2;
+    const unsigned n0 = (unsigned)(p1 >> 32) ^ c1 ^ k0, n1 = (unsigned)p1, n2 = (unsigned)(p0 >> 32) ^ c3 ^ k1, n3 = (unsigned)p0;
+    c0 = n0; c1 = n1; c2 = n2; c3 = n3;
+    k0 += 0x9E3779B9u; k1 += 0xBB67AE85u;
+  }
+  out[0] = c0; out[1] = c1; out[2] = c2; out[3] = c3;
+}
+
 static inline int launch_status() { return hipGetLastError() == hipSuccess ? OP_OK : OP_ELAUNCH; }

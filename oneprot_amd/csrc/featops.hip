@@ -241,16 +241,6 @@ extern "C" int oneprot_key_padding_bias(const int64_t* ids, float* bias, int64_t
 // never stored: element e keeps iff the 16-bit slice e & 7 of Philox4x32-10(counter = (e >> 3, stream), key = seed) is >= thr = round(p * 65536),
 // so the backward kernel regenerates the forward's mask from (seed, stream).  Kept values are scaled by 65536 / (65536 - thr), the inverse of
 // the keep probability actually used.  torch's own Philox stream is not reproduced (a different generator of the same distribution).
-__device__ __forceinline__ void philox4x32_10(unsigned c0, unsigned c1, unsigned c2, unsigned c3, unsigned k0, unsigned k1, unsigned (&out)[4]) {
-#pragma unroll
-  for (int r = 0; r < 10; ++r) {
-    const unsigned long long p0 = (unsigned long long)0xD2511F53u * c0, p1 = (unsigned long long)0xCD9E8D57u * c2;
-    const unsigned n0 = (unsigned)(p1 >> 32) ^ c1 ^ k0, n1 = (unsigned)p1, n2 = (unsigned)(p0 >> 32) ^ c3 ^ k1, n3 = (unsigned)p0;
-    c0 = n0; c1 = n1; c2 = n2; c3 = n3;
-    k0 += 0x9E3779B9u; k1 += 0xBB67AE85u;
-  }
-  out[0] = c0; out[1] = c1; out[2] = c2; out[3] = c3;
-}
 // MODE 0: y = dropout(x);  MODE 1: y += dropout'(x) = mask * scale * x  (y, x bf16; the adapter branch's input gradient added to the direct one)
 template <int MODE>
 __global__ void __launch_bounds__(256) k_dropout_bf16(const u32x4* __restrict__ x, u32x4* __restrict__ y, size_t n8, unsigned thr, float scale, unsigned long long seed,
@@ -293,6 +283,22 @@ __global__ void __launch_bounds__(256) k_dropout_bwd_add_f32(const u32x4* __rest
     dx[2 * i] = a; dx[2 * i + 1] = b;
   }
 }
+// y = dropout(x) on fp32 (hidden-state dropout of the BERT tower: hf modeling_bert.py BertEmbeddings / BertSelfOutput / BertOutput), in place allowed
+__global__ void __launch_bounds__(256) k_dropout_f32(const float4* __restrict__ x, float4* __restrict__ y, size_t n8, unsigned thr, float scale, unsigned long long seed,
+                                                     unsigned long long stream_id) {
+  for (size_t i = (size_t)blockIdx.x * 256 + threadIdx.x; i < n8; i += (size_t)gridDim.x * 256) {
+    unsigned rnd[4];
+    philox4x32_10((unsigned)i, (unsigned)(i >> 32), (unsigned)stream_id, (unsigned)(stream_id >> 32), (unsigned)seed, (unsigned)(seed >> 32), rnd);
+    float4 a = x[2 * i], b = x[2 * i + 1];
+    float* o[8] = {&a.x, &a.y, &a.z, &a.w, &b.x, &b.y, &b.z, &b.w};
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+      *o[2 * j] = ((rnd[j] & 0xffffu) >= thr) ? *o[2 * j] * scale : 0.f;
+      *o[2 * j + 1] = ((rnd[j] >> 16) >= thr) ? *o[2 * j + 1] * scale : 0.f;
+    }
+    y[2 * i] = a; y[2 * i + 1] = b;
+  }
+}
 static int launch_dropout(int mode, const void* x, void* y, int64_t n, float p, uint64_t seed, uint64_t stream_id, void* stream) {
   if (!x || !y || n <= 0 || (n & 7) || !(p >= 0.f) || !(p < 1.f)) return OP_EINVAL;
   if (((uintptr_t)x | (uintptr_t)y) & 15) return OP_EINVAL;
@@ -300,7 +306,8 @@ static int launch_dropout(int mode, const void* x, void* y, int64_t n, float p, 
   if (thr >= 65536u) return OP_EINVAL;
   const float scale = 65536.f / (float)(65536u - thr);
   const size_t n8 = (size_t)n >> 3;
-  if (mode == 2) hipLaunchKernelGGL(k_dropout_bwd_add_f32, dim3(ew_grid(n8)), dim3(256), 0, (hipStream_t)stream, (const u32x4*)x, (float4*)y, n8, thr, scale, (unsigned long long)seed, (unsigned long long)stream_id);
+  if (mode == 3) hipLaunchKernelGGL(k_dropout_f32, dim3(ew_grid(n8)), dim3(256), 0, (hipStream_t)stream, (const float4*)x, (float4*)y, n8, thr, scale, (unsigned long long)seed, (unsigned long long)stream_id);
+  else if (mode == 2) hipLaunchKernelGGL(k_dropout_bwd_add_f32, dim3(ew_grid(n8)), dim3(256), 0, (hipStream_t)stream, (const u32x4*)x, (float4*)y, n8, thr, scale, (unsigned long long)seed, (unsigned long long)stream_id);
   else if (mode == 0) hipLaunchKernelGGL(k_dropout_bf16<0>, dim3(ew_grid(n8)), dim3(256), 0, (hipStream_t)stream, (const u32x4*)x, (u32x4*)y, n8, thr, scale, (unsigned long long)seed, (unsigned long long)stream_id);
   else hipLaunchKernelGGL(k_dropout_bf16<1>, dim3(ew_grid(n8)), dim3(256), 0, (hipStream_t)stream, (const u32x4*)x, (u32x4*)y, n8, thr, scale, (unsigned long long)seed, (unsigned long long)stream_id);
   return launch_status();
@@ -310,6 +317,9 @@ extern "C" int oneprot_dropout_bf16(const void* x, void* y, int64_t n, float p, 
 }
 extern "C" int oneprot_dropout_bwd_add_bf16(const void* dy, void* dx, int64_t n, float p, uint64_t seed, uint64_t stream_id, void* stream) {
   return launch_dropout(1, dy, dx, n, p, seed, stream_id, stream);
+}
+extern "C" int oneprot_dropout_f32(const float* x, float* y, int64_t n, float p, uint64_t seed, uint64_t stream_id, void* stream) {
+  return launch_dropout(3, x, y, n, p, seed, stream_id, stream);
 }
 extern "C" int oneprot_dropout_bwd_add_f32(const void* dy, float* dx, int64_t n, float p, uint64_t seed, uint64_t stream_id, void* stream) {
   return launch_dropout(2, dy, dx, n, p, seed, stream_id, stream);

@@ -176,21 +176,35 @@ def bert_forward(ids: Tensor, sd: Dict[str, Tensor], cfg: dict, pre: str = "tran
     x = sd[e + "word_embeddings.weight"][ids] + sd[e + "token_type_embeddings.weight"][0][None, None] \
         + sd[e + "position_embeddings.weight"][:T][None]
     x = layer_norm(x, sd[e + "LayerNorm.weight"], sd[e + "LayerNorm.bias"], eps)
+    # train mode (hf modeling_bert.py: BertEmbeddings.dropout, BertSelfAttention.dropout on the probabilities, BertSelfOutput.dropout, BertOutput.dropout;
+    # the reference leaves them active whenever the tower is in train mode, text_encoder.py:59): cfg["bert_keep"] = {"emb": m, "layers": [{"attn": m
+    # [B, H, T, T], "out1": m, "out2": m}, ...]}, every m a dropout mask already divided by its keep probability; absent = eval mode
+    bk = cfg.get("bert_keep")
+    if bk is not None:
+        x = x * bk["emb"]
     if taps is not None:
         taps["embeddings"] = x
     km = additive_key_mask(attn_mask)
     for i in range(cfg["layers"]):
         p = f"{pre}encoder.layer.{i}."
         lk = (cfg.get("lora_keep") or {}).get(i) or {}      # train-mode dropout masks of the adapters (see lora_proj)
+        dk = bk["layers"][i] if bk is not None else None
         q = lora_proj(x, sd, p + "attention.self.query.", cfg.get("lora_scaling"), lk.get("query")).view(B, T, heads, hd).transpose(1, 2)
         k = lora_proj(x, sd, p + "attention.self.key.", cfg.get("lora_scaling"), lk.get("key")).view(B, T, heads, hd).transpose(1, 2)
         v = lora_proj(x, sd, p + "attention.self.value.", cfg.get("lora_scaling"), lk.get("value")).view(B, T, heads, hd).transpose(1, 2)
         s = (q @ k.transpose(-1, -2)) * hd ** -0.5 + km
-        a = (torch.softmax(s, -1) @ v).transpose(1, 2).reshape(B, T, d)
+        pr = torch.softmax(s, -1)
+        if dk is not None:
+            pr = pr * dk["attn"]
+        a = (pr @ v).transpose(1, 2).reshape(B, T, d)
         a = linear(a, sd[p + "attention.output.dense.weight"], sd[p + "attention.output.dense.bias"])
+        if dk is not None:
+            a = a * dk["out1"]
         x = layer_norm(a + x, sd[p + "attention.output.LayerNorm.weight"], sd[p + "attention.output.LayerNorm.bias"], eps)
         u = gelu_erf(linear(x, sd[p + "intermediate.dense.weight"], sd[p + "intermediate.dense.bias"]))
         o = linear(u, sd[p + "output.dense.weight"], sd[p + "output.dense.bias"])
+        if dk is not None:
+            o = o * dk["out2"]
         x = layer_norm(o + x, sd[p + "output.LayerNorm.weight"], sd[p + "output.LayerNorm.bias"], eps)
     return x
 

@@ -510,6 +510,38 @@ def test_attention_bwd_fused_equals_split_at_block_edges(L, hd):
         assert rel_err(fused[:, part], split[:, part]) < 3e-3, name
 
 
+@pytest.mark.parametrize("B,H,L,hd", [(2, 3, 70, 64), (1, 2, 300, 64), (2, 2, 96, 32)])
+def test_attention_fwd_probability_dropout(B, H, L, hd):
+    """oneprot_attn_fwd_dropout (hf BertSelfAttention in train mode: softmax -> dropout -> @ V): against torch on the same bf16 inputs with the mask
+    the kernel drew (exported by oneprot_attn_dropout_keep), keep rate, independence across heads / streams, undropped log-sum-exp."""
+    g = torch.Generator().manual_seed(11 + L)
+    q = bf(torch.randn(B, H, L, hd, generator=g) * hd ** -0.5)
+    k, v = bf(torch.randn(B, H, L, hd, generator=g)), bf(torch.randn(B, H, L, hd, generator=g))
+    bias = torch.zeros(B, L)
+    bias[-1, L - L // 5:] = -3.0e38
+    p_, seed, stream = 0.1, 0xABCDEF0123, 5
+    keep = torch.empty(B, H, L, L, dtype=torch.uint8, device=DEV)
+    hip.call("oneprot_attn_dropout_keep", keep, B, H, L, p_, seed, stream)
+    keep2 = torch.empty_like(keep)
+    hip.call("oneprot_attn_dropout_keep", keep2, B, H, L, p_, seed, stream + 1)
+    kf = keep.float().cpu()
+    thr8 = int(p_ * 256 + 0.5)
+    assert abs(float(kf.mean()) - (1 - thr8 / 256)) < 0.01
+    assert abs(float((keep == keep2).float().mean()) - ((1 - thr8 / 256) ** 2 + (thr8 / 256) ** 2)) < 0.01          # another stream: an independent mask
+    assert not torch.equal(keep[0, 0], keep[0, 1])                                                                  # heads differ
+    ctx = torch.empty(B * L, H * hd, dtype=torch.bfloat16, device=DEV)
+    lse = torch.empty(B, H, L, device=DEV)
+    hip.call("oneprot_attn_fwd_dropout", (q * hip.LOG2E).to(torch.bfloat16).to(DEV), k.to(DEV), v.to(DEV), bias.to(DEV), ctx, lse, B, H, L, hd, p_, seed, stream)
+    ql = (q * hip.LOG2E).to(torch.bfloat16).float() / hip.LOG2E
+    s_ = ql @ k.float().transpose(-1, -2) + bias[:, None, None, :]
+    pr = torch.softmax(s_, -1)
+    ref = ((pr * kf * (256.0 / (256 - thr8))) @ v.float()).permute(0, 2, 1, 3).reshape(B * L, H * hd)
+    assert_close(ctx.float().cpu(), ref, 2 ** -6, 2e-2, "ctx with probability dropout")
+    assert_close(lse.cpu(), torch.logsumexp(s_, -1), 2e-3, 2e-2, "lse (undropped)")
+    nodrop = (pr @ v.float()).permute(0, 2, 1, 3).reshape(B * L, H * hd)
+    assert rel_err(ctx.float().cpu(), nodrop) > 5 * rel_err(ctx.float().cpu(), ref)          # the mask matters
+
+
 @pytest.mark.parametrize("L,expected", [(256, 0), (288, 0), (320, 1), (416, 1), (448, 2), (512, 2)])
 def test_attention_bwd_automatic_path_by_length(L, expected):
     """The launcher picks the backward kernel by sequence length (split pair up to 288, 16-wave fused up to 416, 8-wave fused up to 512: measured

@@ -251,6 +251,66 @@ def test_text_encoder_vs_reference(golden_dir, tmp_path):
     assert abs(feats.norm(dim=-1) - 1 / 0.07).max() < 1e-3
 
 
+def test_text_encoder_train_mode_dropout_vs_oracle(golden_dir, tmp_path):
+    """hf's train-mode dropout of the frozen BERT tower (embeddings, attention probabilities, the two dense outputs per layer; the reference leaves it
+    on in train mode: text_encoder.py:59), behind `transformer.train_dropout = True`: last hidden state and features against the oracle handed the masks
+    the HIP path drew; off by default; eval mode untouched; a second call draws new masks."""
+    os.environ.update(RANK="0", WORLD_SIZE="1", ONEPROT_ALLOW_RANDOM_INIT="1")
+    from oneprot_amd import hip
+    from src.models.components.text_encoder import TextEncoder
+    g = torch.load(os.path.join(golden_dir, "bert_text.pt"), weights_only=False)
+    cfg = g["cfg"]
+    path = os.path.join(str(tmp_path), "bert")
+    os.makedirs(path)
+    with open(os.path.join(path, "config.json"), "w") as f:
+        json.dump(dict(model_type="bert", vocab_size=cfg["vocab"], hidden_size=cfg["hidden"], num_hidden_layers=cfg["layers"], num_attention_heads=cfg["heads"],
+                       intermediate_size=cfg["ffn"], max_position_embeddings=cfg["max_pos"], pad_token_id=cfg["pad"], layer_norm_eps=cfg["eps"]), f)
+    torch.manual_seed(5)
+    enc = TextEncoder(path, output_dim=cfg["output_dim"], pooling_type="cls", proj_type="mlp", use_logit_scale=True, learnable_logit_scale=False, frozen=True,
+                      use_lora=False)
+    enc.load_state_dict(g["sd"], strict=True)
+    enc = enc.to(DEV).train()
+    tr = enc.transformer
+    ids = g["ids"]
+    B, T = ids.shape
+    with torch.no_grad():
+        plain = enc(ids.to(DEV)).cpu()                                   # the option is off by default: train mode == eval mode
+    assert torch.nn.functional.cosine_similarity(plain, g["features"], dim=-1).min() > 0.999
+    tr.train_dropout = True
+    assert (float(tr.config.hidden_dropout_prob), float(tr.config.attention_probs_dropout_prob)) == (0.1, 0.1)
+    with torch.no_grad():
+        feats = enc(ids.to(DEV)).cpu()
+    call = tr._drop_calls - 1
+    d, H, n = tr.d, tr.H, tr.n_layers
+    thr16, thr8 = int(0.1 * 65536 + 0.5), int(0.1 * 256 + 0.5)
+
+    def hidden_keep(layer, site):
+        ones = torch.ones(B * T, d, device=DEV)
+        out = torch.empty_like(ones)
+        hip.call("oneprot_dropout_f32", ones, out, ones.numel(), 0.1, tr._drop_seed, tr._drop_stream(call, layer, site))
+        return ((out > 0).float() * (65536.0 / (65536 - thr16))).view(B, T, d).cpu()
+
+    layers = []
+    for i in range(n):
+        kp = torch.empty(B, H, T, T, dtype=torch.uint8, device=DEV)
+        hip.call("oneprot_attn_dropout_keep", kp, B, H, T, 0.1, tr._drop_seed, tr._drop_stream(call, i, 0))
+        layers.append(dict(attn=kp.float().cpu() * (256.0 / (256 - thr8)), out1=hidden_keep(i, 1), out2=hidden_keep(i, 2)))
+    keep = dict(emb=hidden_keep(-1, 0), layers=layers)
+    assert abs(float(keep["emb"].gt(0).float().mean()) - 0.9) < 0.02 and abs(float(layers[0]["attn"].gt(0).float().mean()) - (1 - thr8 / 256)) < 0.02
+    ocfg = dict(cfg, bert_keep=keep)
+    rf = O.encoder_features("bert", ids, g["sd"], ocfg, "cls", "mlp", True)
+    cs = torch.nn.functional.cosine_similarity(feats, rf, dim=-1)
+    assert cs.min() > 0.999, cs
+    r0 = O.encoder_features("bert", ids, g["sd"], cfg, "cls", "mlp", True)
+    assert torch.nn.functional.cosine_similarity(r0, rf, dim=-1).min() < 0.999          # the masks move the features by more than the parity tolerance
+    with torch.no_grad():
+        again = enc(ids.to(DEV)).cpu()
+        assert not torch.allclose(again, feats, atol=1e-3)                               # new masks on every call
+        enc.eval()
+        e1 = enc(ids.to(DEV)).cpu()
+    assert torch.allclose(e1, plain, atol=1e-6)
+
+
 def test_trainable_text_encoder_gradients_vs_reference(golden_dir, tmp_path):
     """TextEncoder(frozen=False) (the signature default, ref text_encoder.py:9-37): loss and the gradient of every BERT / head parameter vs the
     reference's autograd, through the hand-written BERT backward (post-LN layers, embedding LayerNorm, sorted embedding-row reduction)."""
