@@ -121,9 +121,14 @@ int oneprot_attn_bwd(const void* q, const void* k, const void* v, const float* k
                      void* stream);
 /* The forward with attention-probability dropout (hf modeling_bert.py BertSelfAttention: softmax -> nn.Dropout(attention_probs_dropout_prob) -> @ V;
    the reference leaves it active whenever the text tower is in train mode, text_encoder.py:59).  keep(b, h, q, k) is a pure function of
-   (seed, stream_id, b*H+h, q, k) through Philox4x32-10 (8-bit threshold: keep probability 1 - round(256 p) / 256, kept probabilities scaled by its
-   inverse); ctx = (keep * softmax / keep_prob) @ V, lse = that of the undropped softmax.  Same arguments as oneprot_attn_fwd otherwise. */
+   (seed, stream_id, b*H+h, q, k) -- one integer hash per element, 16-bit threshold, kept probabilities scaled by the inverse keep probability;
+   ctx = (keep * softmax / keep_prob) @ V, lse = that of the undropped softmax.  Same arguments as oneprot_attn_fwd otherwise. */
 int oneprot_attn_fwd_dropout(const void* q, const void* k, const void* v, const float* key_bias, void* ctx, float* lse, int B, int H, int L, int hd,
+                             float p, uint64_t seed, uint64_t stream_id, void* stream);
+/* Its backward (the two split kernels, any hd / L): dV = (keep * P / keep_prob)^T dO, dS = P * (keep * dP / keep_prob - delta), the mask regenerated
+   from the same (p, seed, stream_id).  Same arguments as oneprot_attn_bwd otherwise. */
+int oneprot_attn_bwd_dropout(const void* q, const void* k, const void* v, const float* key_bias, const void* ctx, const void* dctx, const float* lse,
+                             const float* rope_cos, const float* rope_sin, float q_scale, void* dqkv, void* workspace, int B, int H, int L, int hd,
                              float p, uint64_t seed, uint64_t stream_id, void* stream);
 /* keep[B][H][L][L] (one byte each, 0 / 1): the mask the call above applies -- for tests and for a reference that is handed the mask. */
 int oneprot_attn_dropout_keep(void* keep, int B, int H, int L, float p, uint64_t seed, uint64_t stream_id, void* stream);

@@ -95,14 +95,15 @@ class BertTransformer(ArenaModule):
     # ---- hf's train-mode dropout (hidden_dropout_prob / attention_probs_dropout_prob, 0.1 in bert-base).  The reference never switches its text tower
     # to eval mode (text_encoder.py:59), so even the frozen tower of the shipped configuration is stochastic there.  Here it is an OPTION, off by
     # default (parity is defined against eval mode, INTEGRATION.md "Deviations"): ONEPROT_BERT_DROPOUT=1 or `transformer.train_dropout = True`
-    # applies all four dropouts in train mode to a FROZEN tower (forward only; a trainable tower keeps p = 0 -- the attention backward with a mask is
-    # not built).  Masks come from the counter-based generator of the LoRA dropout (Philox4x32-10 of seed, call, layer, site, element).
+    # applies all four dropouts in train mode, to a frozen tower (forward only) and to a trainable one (the backward regenerates every mask: the dense
+    # outputs' gradients pass through the same hidden masks, the attention backward runs its masked form, oneprot_attn_bwd_dropout).  Hidden masks come
+    # from the counter-based generator of the LoRA dropout (Philox4x32-10 of seed, call, layer, site, element), the attention masks from a per-element hash.
     train_dropout = None
 
     def _train_dropout(self):
         on = self.train_dropout if self.train_dropout is not None else os.environ.get("ONEPROT_BERT_DROPOUT", "0") == "1"
         cfg = self.config
-        if not (on and self.training and not self.flat.requires_grad):
+        if not (on and self.training):
             return False
         if not (float(cfg.hidden_dropout_prob) > 0 or float(cfg.attention_probs_dropout_prob) > 0):
             return False
@@ -138,8 +139,8 @@ class BertTransformer(ArenaModule):
         hip.call("oneprot_bert_embed_fwd", ids, self.view(e + "word_embeddings.weight"), self.view(e + "position_embeddings.weight"),
                  self.view(e + "token_type_embeddings.weight"), self.view(e + "LayerNorm.weight"), self.view(e + "LayerNorm.bias"), x, h, B, L, d,
                  cfg.vocab_size, cfg.layer_norm_eps)
-        drop = self._train_dropout() and not save
-        if drop:      # hf's train-mode dropouts (frozen tower, forward only): embeddings, attention probabilities, the two dense outputs of every layer
+        drop = self._train_dropout()
+        if drop:      # hf's train-mode dropouts: embeddings, attention probabilities, the two dense outputs of every layer
             drop_call = self._drop_calls
             self._drop_calls += 1
             p_h, p_a = float(cfg.hidden_dropout_prob), float(cfg.attention_probs_dropout_prob)
@@ -147,6 +148,8 @@ class BertTransformer(ArenaModule):
             hip.call("oneprot_dropout_f32", x, x, T * d, p_h, self._drop_seed, self._drop_stream(drop_call, -1, 0))
             hip.call("oneprot_cast_f32_to_bf16", x, h, T * d)
         saved = dict(ids=ids, key_bias=key_bias, layers=[], B=B, L=L) if save else None
+        if drop and save:
+            saved["drop_call"] = drop_call
         q, k, v, ctx, u = b16(B, H, L, hd), b16(B, H, L, hd), b16(B, H, L, hd), b16(T, d), b16(T, f)
         eps = cfg.layer_norm_eps
         lora_two = self._lora_two_branch()
@@ -232,6 +235,10 @@ class BertTransformer(ArenaModule):
         ws_at = torch.empty(hip.query("oneprot_attn_bwd_workspace", B, H, L), dtype=torch.uint8, device=dev)
         ds, ds16, gy = f32(T, d), b16(T, d), f32(T, d)
         dz, dctx, dqkv = b16(T, f), b16(T, d), b16(T, 3 * d)
+        drop_call = saved.get("drop_call")                 # the forward ran hf's train-mode dropouts: every mask is regenerated from (seed, call, layer, site)
+        if drop_call is not None:
+            p_h, p_a = float(cfg.hidden_dropout_prob), float(cfg.attention_probs_dropout_prob)
+            dm16 = b16(T, d)                                # gradient of a dense output = the pre-LN sum's gradient through that output's mask
         for i in reversed(range(self.n_layers)):
             st = saved["layers"][i]
             p = f"encoder.layer.{i}."
@@ -239,8 +246,12 @@ class BertTransformer(ArenaModule):
             hip.call("oneprot_layernorm_bwd", g, 1, None, 0, st["s2"], 0, self.view(p + "output.LayerNorm.weight"), st["mean2"], st["rstd2"], None, ds, ds16,
                      gv(p + "output.LayerNorm.weight"), gv(p + "output.LayerNorm.bias"), ws_ln, T, d, 0)
             # ---- FFN2 (weight + bias grads in one TN launch), then du * gelu'(z) in the dgrad epilogue
-            self._wgrad(ds16, st["u"], T, d, f, d, f, gv(p + "output.dense.weight"), gv(p + "output.dense.bias"), ws_tn)
-            hip.call("oneprot_gemm_bf16_nt", ds16, self._bf16_T[(i, "w2")], T, f, d, d, d, hip.EPI_GELU_BWD, None, dz, None, None, st["z"], None, None, 1.0, 0, 0, 0)
+            do16 = ds16
+            if drop_call is not None:
+                hip.call("oneprot_dropout_bf16", ds16, dm16, T * d, p_h, self._drop_seed, self._drop_stream(drop_call, i, 2))
+                do16 = dm16
+            self._wgrad(do16, st["u"], T, d, f, d, f, gv(p + "output.dense.weight"), gv(p + "output.dense.bias"), ws_tn)
+            hip.call("oneprot_gemm_bf16_nt", do16, self._bf16_T[(i, "w2")], T, f, d, d, d, hip.EPI_GELU_BWD, None, dz, None, None, st["z"], None, None, 1.0, 0, 0, 0)
             # ---- FFN1; gy = ds (residual branch) + dz W1
             self._wgrad(dz, st["y16"], T, f, d, f, d, gv(p + "intermediate.dense.weight"), gv(p + "intermediate.dense.bias"), ws_tn)
             hip.call("oneprot_gemm_bf16_nt", dz, self._bf16_T[(i, "w1")], T, d, f, f, f, hip.EPI_BIAS_RESID, None, gy, None, None, ds, None, None, 1.0, 0, 0, 0)
@@ -248,10 +259,18 @@ class BertTransformer(ArenaModule):
             hip.call("oneprot_layernorm_bwd", gy, 1, None, 0, st["s1"], 0, self.view(p + "attention.output.LayerNorm.weight"), st["mean1"], st["rstd1"], None, ds, ds16,
                      gv(p + "attention.output.LayerNorm.weight"), gv(p + "attention.output.LayerNorm.bias"), ws_ln, T, d, 0)
             # ---- out-proj
-            self._wgrad(ds16, st["ctx"], T, d, d, d, d, gv(p + "attention.output.dense.weight"), gv(p + "attention.output.dense.bias"), ws_tn)
-            hip.call("oneprot_gemm_bf16_nt", ds16, self._bf16_T[(i, "o")], T, d, d, d, d, hip.EPI_BF16, None, dctx, None, None, None, None, None, 1.0, 0, 0, 0)
+            da16 = ds16
+            if drop_call is not None:
+                hip.call("oneprot_dropout_bf16", ds16, dm16, T * d, p_h, self._drop_seed, self._drop_stream(drop_call, i, 1))
+                da16 = dm16
+            self._wgrad(da16, st["ctx"], T, d, d, d, d, gv(p + "attention.output.dense.weight"), gv(p + "attention.output.dense.bias"), ws_tn)
+            hip.call("oneprot_gemm_bf16_nt", da16, self._bf16_T[(i, "o")], T, d, d, d, d, hip.EPI_BF16, None, dctx, None, None, None, None, None, 1.0, 0, 0, 0)
             # ---- attention (no rotary: cos/sin = null)
-            hip.call("oneprot_attn_bwd", st["q"], st["k"], st["v"], saved["key_bias"], st["ctx"], dctx, st["lse"], None, None, hd ** -0.5, dqkv, ws_at, B, H, L, hd)
+            if drop_call is not None:
+                hip.call("oneprot_attn_bwd_dropout", st["q"], st["k"], st["v"], saved["key_bias"], st["ctx"], dctx, st["lse"], None, None, hd ** -0.5, dqkv, ws_at,
+                         B, H, L, hd, p_a, self._drop_seed, self._drop_stream(drop_call, i, 0))
+            else:
+                hip.call("oneprot_attn_bwd", st["q"], st["k"], st["v"], saved["key_bias"], st["ctx"], dctx, st["lse"], None, None, hd ** -0.5, dqkv, ws_at, B, H, L, hd)
             # ---- QKV projection; g = ds (residual branch) + dqkv Wqkv
             o, n = self.span(p + "attention.self.query.weight", p + "attention.self.value.weight")
             ob, nb = self.span(p + "attention.self.query.bias", p + "attention.self.value.bias")
@@ -261,6 +280,8 @@ class BertTransformer(ArenaModule):
             if lora_raw is not None:      # two-branch LoRA: adapter gradients, and g += mask * (du A) / keep
                 self._lora_branch_backward(i, st["x16"], st["lora_u"], dqkv, T, saved["lora_call"], ws_tn, lora_raw, dh32=g)
             saved["layers"][i] = None
+        if drop_call is not None:                          # x0 = dropout(LN(embeddings))
+            hip.call("oneprot_dropout_f32", g, g, T * d, p_h, self._drop_seed, self._drop_stream(drop_call, -1, 0))
         self._embedding_backward(saved["ids"], g, gflat)
         if on_ready is not None:
             on_ready(0, self._total)

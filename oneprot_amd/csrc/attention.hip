@@ -145,24 +145,45 @@ __device__ __forceinline__ void decode_block(int nblk_per_bh, int nbh, int& bh, 
 // forward
 // =========================================================================================================
 // DROP: attention-probability dropout (hf modeling_bert.py BertSelfAttention: softmax -> dropout -> @ V; active in the reference whenever the text
-// tower is in train mode, text_encoder.py:59).  keep(b, h, q, k) is a pure function of (seed, stream, b*H+h, q, k): byte e of
-// Philox4x32-10(counter = (q, 2 * (k >> 5) + ((k >> 2) & 1), b*H+h, stream), key = seed), e = ((k & 31) >> 3) * 4 + (k & 3) -- the 16 keys a lane
-// holds of one 32-key tile share one call -- kept iff byte >= thr8 = round(p * 256); kept probabilities are scaled by 256 / (256 - thr8) (folded into
-// the final normalisation).  The row sum and the log-sum-exp are those of the undropped softmax.  oneprot_attn_dropout_keep writes the same mask
-// out for tests.
-__device__ __forceinline__ unsigned attn_keep_bits(int qidx, int tile, int h, int bh, unsigned long long seed, unsigned long long stream_id, unsigned thr8) {
-  unsigned rnd[4];
-  philox4x32_10((unsigned)qidx, (unsigned)(2 * tile + h), (unsigned)bh, (unsigned)stream_id, (unsigned)seed, (unsigned)(seed >> 32) ^ (unsigned)(stream_id >> 32), rnd);
+// tower is in train mode, text_encoder.py:59).  keep(b, h, q, k) is a pure function of (seed, stream, b*H+h, q, k), one 32-bit integer hash per
+// ELEMENT (lowbias32 finaliser over a multiplicative mix of the indices), so that the forward (a lane holds 1 query x 16 keys), the dQ kernel
+// (the same) and the dK / dV kernel (a lane holds 16 queries x 1 key) regenerate the same mask from their own layouts; kept iff the upper 16 bits
+// >= thr16 = round(p * 65536), kept probabilities scaled by 65536 / (65536 - thr16).  The row sum, the log-sum-exp and delta = rowsum(dO * O) are
+// untouched by the mask.  oneprot_attn_dropout_keep writes the mask out for tests.  (The hidden-state dropouts use Philox, featops.hip; here a
+// Philox call per element would cost ten times the tile's own vector work.)
+struct AttnDrop { unsigned thr16, s0, s1; float scale; };
+__device__ __forceinline__ bool attn_keep(unsigned qi, unsigned ki, unsigned bh, const AttnDrop& dr) {
+  unsigned x = (qi * 0x9E3779B1u) ^ (ki * 0x85EBCA77u + dr.s0) ^ (bh * 0xC2B2AE3Du + dr.s1);
+  x ^= x >> 16; x *= 0x7feb352du; x ^= x >> 15; x *= 0x846ca68bu; x ^= x >> 16;
+  return (x >> 16) >= dr.thr16;
+}
+// the 16 elements of a 32 x 32 accumulator tile a lane holds: index 8 * (e >> 2) + 4 * h + (e & 3) along the tile's row axis
+__device__ __forceinline__ unsigned attn_keep_bits_q(int qidx, int key0, int h, int bh, const AttnDrop& dr) {      // lane = query, rows = keys
   unsigned bits = 0;
 #pragma unroll
-  for (int e = 0; e < 16; ++e) bits |= (((rnd[e >> 2] >> (8 * (e & 3))) & 0xffu) >= thr8 ? 1u : 0u) << e;
+  for (int e = 0; e < 16; ++e) bits |= (attn_keep((unsigned)qidx, (unsigned)(key0 + 8 * (e >> 2) + 4 * h + (e & 3)), (unsigned)bh, dr) ? 1u : 0u) << e;
   return bits;
+}
+__device__ __forceinline__ unsigned attn_keep_bits_k(int kidx, int q0, int h, int bh, const AttnDrop& dr) {        // lane = key, rows = queries
+  unsigned bits = 0;
+#pragma unroll
+  for (int e = 0; e < 16; ++e) bits |= (attn_keep((unsigned)(q0 + 8 * (e >> 2) + 4 * h + (e & 3)), (unsigned)kidx, (unsigned)bh, dr) ? 1u : 0u) << e;
+  return bits;
+}
+static int attn_drop_make(float p, uint64_t seed, uint64_t stream_id, AttnDrop& dr) {
+  if (!(p >= 0.f) || !(p < 1.f)) return OP_EINVAL;
+  dr.thr16 = (unsigned)(p * 65536.f + 0.5f);
+  if (dr.thr16 >= 65536u) return OP_EINVAL;
+  dr.scale = 65536.f / (float)(65536u - dr.thr16);
+  const uint64_t m = (seed ^ (stream_id * 0x9E3779B97F4A7C15ull)) * 0xD6E8FEB86659FD93ull;
+  dr.s0 = (unsigned)m; dr.s1 = (unsigned)(m >> 32) ^ (unsigned)(stream_id * 0x2545F491u);
+  return OP_OK;
 }
 
 template <int HD, bool DROP = false>
 __global__ void __launch_bounds__(256, 2) k_attn_fwd(const bf16_t* __restrict__ q, const bf16_t* __restrict__ k, const bf16_t* __restrict__ v,
                                                   const float* __restrict__ key_bias, bf16_t* __restrict__ ctx, float* __restrict__ lse_out, int B, int H,
-                                                  int L, int nqb, unsigned thr8 = 0, unsigned long long seed = 0, unsigned long long stream_id = 0) {
+                                                  int L, int nqb, const AttnDrop dr = AttnDrop{0u, 0u, 0u, 1.0f}) {
   typedef Cfg<HD> C;
   extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
   unsigned char* sK = smem;
@@ -244,7 +265,7 @@ __global__ void __launch_bounds__(256, 2) k_attn_fwd(const bf16_t* __restrict__ 
       for (int r = 0; r < 16; ++r) s[r] = __builtin_amdgcn_exp2f(s[r]);
       f32x16 sd = s;
       if constexpr (DROP) {
-        const unsigned bits = attn_keep_bits(qidx, (kc0 >> 5) + t, h, bh, seed, stream_id, thr8);
+        const unsigned bits = attn_keep_bits_q(qidx, kc0 + t * 32, h, bh, dr);
 #pragma unroll
         for (int r = 0; r < 16; ++r) sd[r] = ((bits >> r) & 1u) ? s[r] : 0.f;
       }
@@ -260,7 +281,7 @@ __global__ void __launch_bounds__(256, 2) k_attn_fwd(const bf16_t* __restrict__ 
   }
   const float lt = l + lacc[0];
   float inv = lt > 0.f ? 1.0f / lt : 0.f;
-  if constexpr (DROP) inv *= 256.0f / (float)(256u - thr8);
+  if constexpr (DROP) inv *= dr.scale;
   if (qidx < L) {
     bf16_t* dst = ctx + ((size_t)b * L + qidx) * (H * HD) + head * HD;
 #pragma unroll
@@ -280,43 +301,37 @@ __global__ void __launch_bounds__(256, 2) k_attn_fwd(const bf16_t* __restrict__ 
 template <int HD> static size_t fwd_lds() { return (size_t)2 * KC * Cfg<HD>::ROWB + (KC + 1) * 16; }
 
 template <int HD>
-static int launch_fwd_dropout(const void* q, const void* k, const void* v, const float* key_bias, void* ctx, float* lse, int B, int H, int L, unsigned thr8,
-                              uint64_t seed, uint64_t stream_id, hipStream_t s) {
-  const int nqb = (L + 127) / 128;
-  const int nbh8 = ((B * H + 7) / 8) * 8;
-  hipLaunchKernelGGL((k_attn_fwd<HD, true>), dim3(nbh8 * nqb), dim3(256), fwd_lds<HD>(), s, (const bf16_t*)q, (const bf16_t*)k, (const bf16_t*)v, key_bias,
-                     (bf16_t*)ctx, lse, B, H, L, nqb, thr8, (unsigned long long)seed, (unsigned long long)stream_id);
-  return launch_status();
-}
-// keep[b][h][q][k] (one byte each, 0 / 1) of the mask k_attn_fwd<HD, true> applies: for tests and for an oracle that is handed the mask
-__global__ void __launch_bounds__(256) k_attn_dropout_keep(unsigned char* __restrict__ keep, int BH, int L, unsigned thr8, unsigned long long seed, unsigned long long stream_id) {
-  const size_t n = (size_t)BH * L * L;
-  for (size_t i = (size_t)blockIdx.x * 256 + threadIdx.x; i < n; i += (size_t)gridDim.x * 256) {
-    const int kk = (int)(i % L), qq = (int)((i / L) % L), bh = (int)(i / ((size_t)L * L));
-    const unsigned bits = attn_keep_bits(qq, kk >> 5, (kk >> 2) & 1, bh, seed, stream_id, thr8);
-    keep[i] = (unsigned char)((bits >> ((((kk & 31) >> 3) << 2) | (kk & 3))) & 1u);
-  }
-}
-static int attn_drop_thr8(float p, unsigned& thr8) {
-  if (!(p >= 0.f) || !(p < 1.f)) return OP_EINVAL;
-  thr8 = (unsigned)(p * 256.f + 0.5f);
-  return thr8 < 256u ? OP_OK : OP_EINVAL;
-}
-extern "C" int oneprot_attn_dropout_keep(void* keep, int B, int H, int L, float p, uint64_t seed, uint64_t stream_id, void* stream) {
-  unsigned thr8;
-  if (!keep || B <= 0 || H <= 0 || L <= 0 || attn_drop_thr8(p, thr8) != OP_OK) return OP_EINVAL;
-  const size_t n = (size_t)B * H * L * L;
-  size_t blocks = (n + 255) / 256; if (blocks > 8192) blocks = 8192;
-  hipLaunchKernelGGL(k_attn_dropout_keep, dim3((unsigned)blocks), dim3(256), 0, (hipStream_t)stream, (unsigned char*)keep, B * H, L, thr8, (unsigned long long)seed, (unsigned long long)stream_id);
-  return launch_status();
-}
-
-template <int HD>
 static int launch_fwd(const void* q, const void* k, const void* v, const float* key_bias, void* ctx, float* lse, int B, int H, int L, hipStream_t s) {
   const int nqb = (L + 127) / 128;
   const int nbh8 = ((B * H + 7) / 8) * 8;
   hipLaunchKernelGGL(k_attn_fwd<HD>, dim3(nbh8 * nqb), dim3(256), fwd_lds<HD>(), s, (const bf16_t*)q, (const bf16_t*)k, (const bf16_t*)v, key_bias,
                      (bf16_t*)ctx, lse, B, H, L, nqb);
+  return launch_status();
+}
+
+template <int HD>
+static int launch_fwd_dropout(const void* q, const void* k, const void* v, const float* key_bias, void* ctx, float* lse, int B, int H, int L, const AttnDrop& dr,
+                              hipStream_t s) {
+  const int nqb = (L + 127) / 128;
+  const int nbh8 = ((B * H + 7) / 8) * 8;
+  hipLaunchKernelGGL((k_attn_fwd<HD, true>), dim3(nbh8 * nqb), dim3(256), fwd_lds<HD>(), s, (const bf16_t*)q, (const bf16_t*)k, (const bf16_t*)v, key_bias,
+                     (bf16_t*)ctx, lse, B, H, L, nqb, dr);
+  return launch_status();
+}
+// keep[b][h][q][k] (one byte each, 0 / 1) of the mask the DROP kernels apply: for tests and for an oracle that is handed the mask
+__global__ void __launch_bounds__(256) k_attn_dropout_keep(unsigned char* __restrict__ keep, int BH, int L, const AttnDrop dr) {
+  const size_t n = (size_t)BH * L * L;
+  for (size_t i = (size_t)blockIdx.x * 256 + threadIdx.x; i < n; i += (size_t)gridDim.x * 256) {
+    const unsigned kk = (unsigned)(i % L), qq = (unsigned)((i / L) % L), bh = (unsigned)(i / ((size_t)L * L));
+    keep[i] = attn_keep(qq, kk, bh, dr) ? 1 : 0;
+  }
+}
+extern "C" int oneprot_attn_dropout_keep(void* keep, int B, int H, int L, float p, uint64_t seed, uint64_t stream_id, void* stream) {
+  AttnDrop dr;
+  if (!keep || B <= 0 || H <= 0 || L <= 0 || attn_drop_make(p, seed, stream_id, dr) != OP_OK) return OP_EINVAL;
+  const size_t n = (size_t)B * H * L * L;
+  size_t blocks = (n + 255) / 256; if (blocks > 8192) blocks = 8192;
+  hipLaunchKernelGGL(k_attn_dropout_keep, dim3((unsigned)blocks), dim3(256), 0, (hipStream_t)stream, (unsigned char*)keep, B * H, L, dr);
   return launch_status();
 }
 
@@ -1054,13 +1069,13 @@ extern "C" int oneprot_attn_fwd(const void* q, const void* k, const void* v, con
 
 extern "C" int oneprot_attn_fwd_dropout(const void* q, const void* k, const void* v, const float* key_bias, void* ctx, float* lse, int B, int H, int L, int hd, float p,
                                         uint64_t seed, uint64_t stream_id, void* stream) {
-  unsigned thr8;
-  if (!q || !k || !v || !ctx || B <= 0 || H <= 0 || L <= 0 || attn_drop_thr8(p, thr8) != OP_OK) return OP_EINVAL;
+  AttnDrop dr;
+  if (!q || !k || !v || !ctx || B <= 0 || H <= 0 || L <= 0 || attn_drop_make(p, seed, stream_id, dr) != OP_OK) return OP_EINVAL;
   hipStream_t s = (hipStream_t)stream;
   switch (hd) {
-    case 16: return launch_fwd_dropout<16>(q, k, v, key_bias, ctx, lse, B, H, L, thr8, seed, stream_id, s);
-    case 32: return launch_fwd_dropout<32>(q, k, v, key_bias, ctx, lse, B, H, L, thr8, seed, stream_id, s);
-    case 64: return launch_fwd_dropout<64>(q, k, v, key_bias, ctx, lse, B, H, L, thr8, seed, stream_id, s);
+    case 16: return launch_fwd_dropout<16>(q, k, v, key_bias, ctx, lse, B, H, L, dr, s);
+    case 32: return launch_fwd_dropout<32>(q, k, v, key_bias, ctx, lse, B, H, L, dr, s);
+    case 64: return launch_fwd_dropout<64>(q, k, v, key_bias, ctx, lse, B, H, L, dr, s);
     default: return OP_EINVAL;
   }
 }
@@ -1114,11 +1129,13 @@ __device__ __forceinline__ void unrope_store(f32x16 (&acc)[Cfg<HD>::DBLK], const
 }
 
 // ---- dQ: one wave = 32 queries, loops over all keys -------------------------------------------------------------
-template <int HD>
+// DROP (both split kernels): the forward ran with probability dropout, O = (keep * P / keep_prob) V.  Then dV = (keep * P / keep_prob)^T dO and
+// dS = P * (keep * dP / keep_prob - delta) with the SAME delta = rowsum(dO * O); the mask is regenerated from (seed, stream, b*H+h, q, k).
+template <int HD, bool DROP = false>
 __global__ void __launch_bounds__(256, 2) k_attn_bwd_dq(const bf16_t* __restrict__ q, const bf16_t* __restrict__ k, const bf16_t* __restrict__ v,
                                                      const float* __restrict__ key_bias, const bf16_t* __restrict__ ctx, const bf16_t* __restrict__ dctx,
                                                      const float* __restrict__ lse, float* __restrict__ delta, const float* __restrict__ cosT, const float* __restrict__ sinT,
-                                                     float q_scale, bf16_t* __restrict__ dqkv, int B, int H, int L, int nqb) {
+                                                     float q_scale, bf16_t* __restrict__ dqkv, int B, int H, int L, int nqb, const AttnDrop dr = AttnDrop{0u, 0u, 0u, 1.0f}) {
   typedef Cfg<HD> C;
   extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
   unsigned char* sK = smem;
@@ -1181,11 +1198,16 @@ __global__ void __launch_bounds__(256, 2) k_attn_bwd_dq(const bf16_t* __restrict
     for (int t = 0; t < nrows / 32; ++t) {
       const u32x4 ke = sE[h ? KC : t * 32 + (lane & 31)];
       f32x16 s = MFMA32(__builtin_bit_cast(bf8_t, ke), __builtin_bit_cast(bf8_t, qe), zero16());          // bias[key] - lse[query]
-      f32x16 dp = MFMA32(__builtin_bit_cast(bf8_t, ones3), __builtin_bit_cast(bf8_t, de), zero16());      // -delta[query]
+      f32x16 dp = DROP ? zero16() : MFMA32(__builtin_bit_cast(bf8_t, ones3), __builtin_bit_cast(bf8_t, de), zero16());      // -delta[query] (DROP: subtracted after the mask)
 #pragma unroll
       for (int st = 0; st < C::KSTEPS; ++st) {
         s = MFMA32(rd_row<HD>(sK, t * 32 + (lane & 31), st, h), qf[st], s);
         dp = MFMA32(rd_row<HD>(sV, t * 32 + (lane & 31), st, h), dof[st], dp);
+      }
+      if constexpr (DROP) {
+        const unsigned bits = attn_keep_bits_q(qidx, kc0 + t * 32, h, bh, dr);
+#pragma unroll
+        for (int r = 0; r < 16; ++r) dp[r] = (((bits >> r) & 1u) ? dp[r] * dr.scale : 0.f) - delta_q;
       }
 #pragma unroll
       for (int r = 0; r < 16; ++r) s[r] = __builtin_amdgcn_exp2f(s[r]) * dp[r];          // dS^T = P * (dP - delta)
@@ -1201,11 +1223,11 @@ __global__ void __launch_bounds__(256, 2) k_attn_bwd_dq(const bf16_t* __restrict
 }
 
 // ---- dK, dV: one wave = 32 keys, loops over all queries -----------------------------------------------------------
-template <int HD>
+template <int HD, bool DROP = false>
 __global__ void __launch_bounds__(256, 2) k_attn_bwd_dkv(const bf16_t* __restrict__ q, const bf16_t* __restrict__ k, const bf16_t* __restrict__ v,
                                                       const float* __restrict__ key_bias, const bf16_t* __restrict__ dctx, const float* __restrict__ lse,
                                                       const float* __restrict__ delta, const float* __restrict__ cosT, const float* __restrict__ sinT,
-                                                      bf16_t* __restrict__ dqkv, int B, int H, int L, int nkb) {
+                                                      bf16_t* __restrict__ dqkv, int B, int H, int L, int nkb, const AttnDrop dr = AttnDrop{0u, 0u, 0u, 1.0f}) {
   typedef Cfg<HD> C;
   extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
   unsigned char* sQ = smem;
@@ -1253,17 +1275,30 @@ __global__ void __launch_bounds__(256, 2) k_attn_bwd_dkv(const bf16_t* __restric
       const bf8_t qe_row = __builtin_bit_cast(bf8_t, sQE[h ? KC : t * 32 + (lane & 31)]);
       f32x16 s = MFMA32(qe_row, __builtin_bit_cast(bf8_t, kS), zero16());            // bias[key] - lse[query]
       f32x16 dp = MFMA32(qe_row, __builtin_bit_cast(bf8_t, kD), zero16());           // -delta[query]
+      f32x16 dpr = zero16();                                                          // (DROP) the raw dP, masked before -delta joins it
 #pragma unroll
       for (int st = 0; st < C::KSTEPS; ++st) {
         s = MFMA32(rd_row<HD>(sQ, t * 32 + (lane & 31), st, h), kf[st], s);          // S[query][key] + bias - lse
-        dp = MFMA32(rd_row<HD>(sdO, t * 32 + (lane & 31), st, h), vf[st], dp);       // dP[query][key] - delta
+        if constexpr (DROP) dpr = MFMA32(rd_row<HD>(sdO, t * 32 + (lane & 31), st, h), vf[st], dpr);
+        else dp = MFMA32(rd_row<HD>(sdO, t * 32 + (lane & 31), st, h), vf[st], dp);  // dP[query][key] - delta
       }
-      f32x16 p;
+      f32x16 p, pm;
+      if constexpr (DROP) {
+        const unsigned bits = attn_keep_bits_k(kidx, qc0 + t * 32, h, bh, dr);
 #pragma unroll
-      for (int r = 0; r < 16; ++r) { p[r] = __builtin_amdgcn_exp2f(s[r]); s[r] = p[r] * dp[r]; }      // P, dS
+        for (int r = 0; r < 16; ++r) {
+          const bool kp = (bits >> r) & 1u;
+          p[r] = __builtin_amdgcn_exp2f(s[r]);
+          pm[r] = kp ? p[r] * dr.scale : 0.f;                                          // what multiplied V in the forward
+          s[r] = p[r] * ((kp ? dpr[r] * dr.scale : 0.f) + dp[r]);                      // dS = P * (keep dP / keep_prob - delta)
+        }
+      } else {
+#pragma unroll
+        for (int r = 0; r < 16; ++r) { p[r] = __builtin_amdgcn_exp2f(s[r]); s[r] = p[r] * dp[r]; }      // P, dS
+      }
 #pragma unroll
       for (int sb = 0; sb < 2; ++sb) {
-        const bf8_t pf = pack8(p, sb), dsf = pack8(s, sb);
+        const bf8_t pf = pack8(DROP ? pm : p, sb), dsf = pack8(s, sb);
 #pragma unroll
         for (int d = 0; d < C::DBLK; ++d) {
           adv[d] = MFMA32(rd_tr<HD>(sdO, t * 32, sb, d, lane), pf, adv[d]);           // dV^T += dO^T P
@@ -1935,6 +1970,34 @@ static int launch_bwd(const void* q, const void* k, const void* v, const float* 
 }
 
 extern "C" size_t oneprot_attn_bwd_workspace(int B, int H, int L) { return (size_t)B * H * L * sizeof(float); }
+
+template <int HD>
+static int launch_bwd_dropout(const void* q, const void* k, const void* v, const float* key_bias, const void* ctx, const void* dctx, const float* lse, float* delta,
+                              const float* cosT, const float* sinT, float q_scale, void* dqkv, int B, int H, int L, const AttnDrop& dr, hipStream_t s) {
+  const int nb = (L + 127) / 128;
+  const int nbh8 = ((B * H + 7) / 8) * 8;
+  const size_t lds = (size_t)2 * KC * Cfg<HD>::ROWB + (KC + 1) * 16;
+  hipLaunchKernelGGL((k_attn_bwd_dq<HD, true>), dim3(nbh8 * nb), dim3(256), lds, s, (const bf16_t*)q, (const bf16_t*)k, (const bf16_t*)v, key_bias,
+                     (const bf16_t*)ctx, (const bf16_t*)dctx, lse, delta, cosT, sinT, q_scale, (bf16_t*)dqkv, B, H, L, nb, dr);
+  hipLaunchKernelGGL((k_attn_bwd_dkv<HD, true>), dim3(nbh8 * nb), dim3(256), lds, s, (const bf16_t*)q, (const bf16_t*)k, (const bf16_t*)v, key_bias,
+                     (const bf16_t*)dctx, lse, (const float*)delta, cosT, sinT, (bf16_t*)dqkv, B, H, L, nb, dr);
+  return launch_status();
+}
+extern "C" int oneprot_attn_bwd_dropout(const void* q, const void* k, const void* v, const float* key_bias, const void* ctx, const void* dctx, const float* lse,
+                                        const float* rope_cos, const float* rope_sin, float q_scale, void* dqkv, void* workspace, int B, int H, int L, int hd,
+                                        float p, uint64_t seed, uint64_t stream_id, void* stream) {
+  AttnDrop dr;
+  if (!q || !k || !v || !ctx || !dctx || !lse || !dqkv || !workspace || B <= 0 || H <= 0 || L <= 0 || attn_drop_make(p, seed, stream_id, dr) != OP_OK) return OP_EINVAL;
+  if ((rope_cos == nullptr) != (rope_sin == nullptr)) return OP_EINVAL;
+  hipStream_t s = (hipStream_t)stream;
+  float* delta = (float*)workspace;
+  switch (hd) {
+    case 16: return launch_bwd_dropout<16>(q, k, v, key_bias, ctx, dctx, lse, delta, rope_cos, rope_sin, q_scale, dqkv, B, H, L, dr, s);
+    case 32: return launch_bwd_dropout<32>(q, k, v, key_bias, ctx, dctx, lse, delta, rope_cos, rope_sin, q_scale, dqkv, B, H, L, dr, s);
+    case 64: return launch_bwd_dropout<64>(q, k, v, key_bias, ctx, dctx, lse, delta, rope_cos, rope_sin, q_scale, dqkv, B, H, L, dr, s);
+    default: return OP_EINVAL;
+  }
+}
 
 extern "C" int oneprot_attn_bwd(const void* q, const void* k, const void* v, const float* key_bias, const void* ctx, const void* dctx, const float* lse,
                                 const float* rope_cos, const float* rope_sin, float q_scale, void* dqkv, void* workspace, int B, int H, int L, int hd,

@@ -511,9 +511,10 @@ def test_attention_bwd_fused_equals_split_at_block_edges(L, hd):
 
 
 @pytest.mark.parametrize("B,H,L,hd", [(2, 3, 70, 64), (1, 2, 300, 64), (2, 2, 96, 32)])
-def test_attention_fwd_probability_dropout(B, H, L, hd):
-    """oneprot_attn_fwd_dropout (hf BertSelfAttention in train mode: softmax -> dropout -> @ V): against torch on the same bf16 inputs with the mask
-    the kernel drew (exported by oneprot_attn_dropout_keep), keep rate, independence across heads / streams, undropped log-sum-exp."""
+def test_attention_probability_dropout_fwd_bwd(B, H, L, hd):
+    """oneprot_attn_fwd_dropout / oneprot_attn_bwd_dropout (hf BertSelfAttention in train mode: softmax -> dropout -> @ V): forward and the gradients
+    w.r.t. q, k, v against torch autograd on the same bf16 inputs with the mask the kernels drew (exported by oneprot_attn_dropout_keep); keep rate,
+    independence across heads / streams, undropped log-sum-exp."""
     g = torch.Generator().manual_seed(11 + L)
     q = bf(torch.randn(B, H, L, hd, generator=g) * hd ** -0.5)
     k, v = bf(torch.randn(B, H, L, hd, generator=g)), bf(torch.randn(B, H, L, hd, generator=g))
@@ -525,21 +526,43 @@ def test_attention_fwd_probability_dropout(B, H, L, hd):
     keep2 = torch.empty_like(keep)
     hip.call("oneprot_attn_dropout_keep", keep2, B, H, L, p_, seed, stream + 1)
     kf = keep.float().cpu()
-    thr8 = int(p_ * 256 + 0.5)
-    assert abs(float(kf.mean()) - (1 - thr8 / 256)) < 0.01
-    assert abs(float((keep == keep2).float().mean()) - ((1 - thr8 / 256) ** 2 + (thr8 / 256) ** 2)) < 0.01          # another stream: an independent mask
-    assert not torch.equal(keep[0, 0], keep[0, 1])                                                                  # heads differ
+    thr = int(p_ * 65536 + 0.5)
+    kp = 1 - thr / 65536
+    assert abs(float(kf.mean()) - kp) < 0.01
+    assert abs(float((keep == keep2).float().mean()) - (kp ** 2 + (1 - kp) ** 2)) < 0.01          # another stream: an independent mask
+    assert not torch.equal(keep[0, 0], keep[0, 1])                                               # heads differ
+    m = kf[0, 0] - kf[0, 0].mean()
+    assert abs(float((m[1:] * m[:-1]).mean() / m.var())) < 0.03 and abs(float((m[:, 1:] * m[:, :-1]).mean() / m.var())) < 0.03      # neighbours along q and along k: uncorrelated
+    qd = (q * hip.LOG2E).to(torch.bfloat16).to(DEV)
     ctx = torch.empty(B * L, H * hd, dtype=torch.bfloat16, device=DEV)
     lse = torch.empty(B, H, L, device=DEV)
-    hip.call("oneprot_attn_fwd_dropout", (q * hip.LOG2E).to(torch.bfloat16).to(DEV), k.to(DEV), v.to(DEV), bias.to(DEV), ctx, lse, B, H, L, hd, p_, seed, stream)
-    ql = (q * hip.LOG2E).to(torch.bfloat16).float() / hip.LOG2E
-    s_ = ql @ k.float().transpose(-1, -2) + bias[:, None, None, :]
+    hip.call("oneprot_attn_fwd_dropout", qd, k.to(DEV), v.to(DEV), bias.to(DEV), ctx, lse, B, H, L, hd, p_, seed, stream)
+    ql = (qd.float().cpu() / hip.LOG2E).requires_grad_(True)
+    kr, vr = k.float().requires_grad_(True), v.float().requires_grad_(True)
+    s_ = ql @ kr.transpose(-1, -2) + bias[:, None, None, :]
     pr = torch.softmax(s_, -1)
-    ref = ((pr * kf * (256.0 / (256 - thr8))) @ v.float()).permute(0, 2, 1, 3).reshape(B * L, H * hd)
-    assert_close(ctx.float().cpu(), ref, 2 ** -6, 2e-2, "ctx with probability dropout")
-    assert_close(lse.cpu(), torch.logsumexp(s_, -1), 2e-3, 2e-2, "lse (undropped)")
-    nodrop = (pr @ v.float()).permute(0, 2, 1, 3).reshape(B * L, H * hd)
-    assert rel_err(ctx.float().cpu(), nodrop) > 5 * rel_err(ctx.float().cpu(), ref)          # the mask matters
+    ref = ((pr * kf / kp) @ vr).permute(0, 2, 1, 3).reshape(B * L, H * hd)
+    assert_close(ctx.float().cpu(), ref.detach(), 2 ** -6, 2e-2, "ctx with probability dropout")
+    assert_close(lse.cpu(), torch.logsumexp(s_, -1).detach(), 2e-3, 2e-2, "lse (undropped)")
+    nodrop = (pr @ vr).permute(0, 2, 1, 3).reshape(B * L, H * hd).detach()
+    assert rel_err(ctx.float().cpu(), nodrop) > 5 * rel_err(ctx.float().cpu(), ref.detach())          # the mask matters
+    dctx = bf(torch.randn(B * L, H * hd, generator=g))
+    ref.backward(dctx.float())
+    dqkv = torch.zeros(B * L, 3 * H * hd, dtype=torch.bfloat16, device=DEV)
+    w = ws(hip.query("oneprot_attn_bwd_workspace", B, H, L))
+    hip.call("oneprot_attn_bwd_dropout", qd, k.to(DEV), v.to(DEV), bias.to(DEV), ctx, dctx.to(DEV), lse, None, None, 1.0, dqkv, w, B, H, L, hd, p_, seed, stream)
+    got = dqkv.float().cpu().view(B, L, 3, H, hd).permute(2, 0, 3, 1, 4)
+    # q was stored x log2(e): the kernel returns d/d(unscaled q) with q_scale = 1 applied to ... the gradient w.r.t. the stored q / log2(e)
+    for i, (name, r_) in enumerate((("dq", ql.grad), ("dk", kr.grad), ("dv", vr.grad))):
+        assert rel_err(got[i], r_) < 2e-2, f"{name}: {rel_err(got[i], r_)}"
+    # and the masked backward is not the plain one
+    dq0 = torch.zeros_like(dqkv)
+    hip.query("oneprot_attn_force_bwd_path", 0)
+    try:
+        hip.call("oneprot_attn_bwd", qd, k.to(DEV), v.to(DEV), bias.to(DEV), ctx, dctx.to(DEV), lse, None, None, 1.0, dq0, w, B, H, L, hd)
+    finally:
+        hip.query("oneprot_attn_force_bwd_path", -1)
+    assert rel_err(dq0.float().cpu().view(B, L, 3, H, hd).permute(2, 0, 3, 1, 4)[2], vr.grad) > 5 * rel_err(got[2], vr.grad)
 
 
 @pytest.mark.parametrize("L,expected", [(256, 0), (288, 0), (320, 1), (416, 1), (448, 2), (512, 2)])

@@ -251,6 +251,28 @@ def test_text_encoder_vs_reference(golden_dir, tmp_path):
     assert abs(feats.norm(dim=-1) - 1 / 0.07).max() < 1e-3
 
 
+def _bert_keep_masks(tr, call, B, T):
+    """the masks (already divided by the keep probability) the HIP path drew in forward call `call` of a BERT tower running hf's train-mode dropout:
+    {"emb": [B, T, d], "layers": [{"attn": [B, H, T, T], "out1": [B, T, d], "out2": [B, T, d]}, ...]} -- the oracle's cfg["bert_keep"]"""
+    from oneprot_amd import hip
+    d, H, n = tr.d, tr.H, tr.n_layers
+    p_h, p_a = float(tr.config.hidden_dropout_prob), float(tr.config.attention_probs_dropout_prob)
+    sc = lambda p_: 65536.0 / (65536 - int(p_ * 65536 + 0.5))
+
+    def hidden_keep(layer, site):
+        ones = torch.ones(B * T, d, device=DEV)
+        out = torch.empty_like(ones)
+        hip.call("oneprot_dropout_f32", ones, out, ones.numel(), p_h, tr._drop_seed, tr._drop_stream(call, layer, site))
+        return ((out > 0).float() * sc(p_h)).view(B, T, d).cpu()
+
+    layers = []
+    for i in range(n):
+        kp = torch.empty(B, H, T, T, dtype=torch.uint8, device=DEV)
+        hip.call("oneprot_attn_dropout_keep", kp, B, H, T, p_a, tr._drop_seed, tr._drop_stream(call, i, 0))
+        layers.append(dict(attn=kp.float().cpu() * sc(p_a), out1=hidden_keep(i, 1), out2=hidden_keep(i, 2)))
+    return dict(emb=hidden_keep(-1, 0), layers=layers)
+
+
 def test_text_encoder_train_mode_dropout_vs_oracle(golden_dir, tmp_path):
     """hf's train-mode dropout of the frozen BERT tower (embeddings, attention probabilities, the two dense outputs per layer; the reference leaves it
     on in train mode: text_encoder.py:59), behind `transformer.train_dropout = True`: last hidden state and features against the oracle handed the masks
@@ -280,23 +302,8 @@ def test_text_encoder_train_mode_dropout_vs_oracle(golden_dir, tmp_path):
     assert (float(tr.config.hidden_dropout_prob), float(tr.config.attention_probs_dropout_prob)) == (0.1, 0.1)
     with torch.no_grad():
         feats = enc(ids.to(DEV)).cpu()
-    call = tr._drop_calls - 1
-    d, H, n = tr.d, tr.H, tr.n_layers
-    thr16, thr8 = int(0.1 * 65536 + 0.5), int(0.1 * 256 + 0.5)
-
-    def hidden_keep(layer, site):
-        ones = torch.ones(B * T, d, device=DEV)
-        out = torch.empty_like(ones)
-        hip.call("oneprot_dropout_f32", ones, out, ones.numel(), 0.1, tr._drop_seed, tr._drop_stream(call, layer, site))
-        return ((out > 0).float() * (65536.0 / (65536 - thr16))).view(B, T, d).cpu()
-
-    layers = []
-    for i in range(n):
-        kp = torch.empty(B, H, T, T, dtype=torch.uint8, device=DEV)
-        hip.call("oneprot_attn_dropout_keep", kp, B, H, T, 0.1, tr._drop_seed, tr._drop_stream(call, i, 0))
-        layers.append(dict(attn=kp.float().cpu() * (256.0 / (256 - thr8)), out1=hidden_keep(i, 1), out2=hidden_keep(i, 2)))
-    keep = dict(emb=hidden_keep(-1, 0), layers=layers)
-    assert abs(float(keep["emb"].gt(0).float().mean()) - 0.9) < 0.02 and abs(float(layers[0]["attn"].gt(0).float().mean()) - (1 - thr8 / 256)) < 0.02
+    keep = _bert_keep_masks(tr, tr._drop_calls - 1, B, T)
+    assert abs(float(keep["emb"].gt(0).float().mean()) - 0.9) < 0.02 and abs(float(keep["layers"][0]["attn"].gt(0).float().mean()) - 0.9) < 0.02
     ocfg = dict(cfg, bert_keep=keep)
     rf = O.encoder_features("bert", ids, g["sd"], ocfg, "cls", "mlp", True)
     cs = torch.nn.functional.cosine_similarity(feats, rf, dim=-1)
@@ -353,6 +360,56 @@ def test_trainable_text_encoder_gradients_vs_reference(golden_dir, tmp_path):
     unused = [r for r in range(cfg["vocab"]) if r not in set(g["ids"].flatten().tolist())]
     assert float(wg[unused].abs().max()) == 0.0
     allg = torch.cat([got[k].flatten() for k in g["grads"]]); allr = torch.cat([v.flatten() for v in g["grads"].values()])
+    assert _cos(allg, allr) > 0.9995
+
+
+def test_trainable_text_encoder_train_mode_dropout_gradients_vs_oracle(golden_dir, tmp_path):
+    """the same option on a TRAINABLE text tower: loss and the gradient of every BERT / head parameter through the four dropouts (hidden masks on the
+    dense outputs' gradients, the masked attention backward, the embedding mask) against the oracle's autograd with the exported masks."""
+    os.environ.update(RANK="0", WORLD_SIZE="1", ONEPROT_ALLOW_RANDOM_INIT="1")
+    from src.models.components.text_encoder import TextEncoder
+    from src.models.components.loss import ClipLoss
+    g = torch.load(os.path.join(golden_dir, "bert_text_train.pt"), weights_only=False)
+    cfg = g["cfg"]
+    path = os.path.join(str(tmp_path), "bert")
+    os.makedirs(path)
+    with open(os.path.join(path, "config.json"), "w") as f:
+        json.dump(dict(model_type="bert", vocab_size=cfg["vocab"], hidden_size=cfg["hidden"], num_hidden_layers=cfg["layers"], num_attention_heads=cfg["heads"],
+                       intermediate_size=cfg["ffn"], max_position_embeddings=cfg["max_pos"], pad_token_id=cfg["pad"], layer_norm_eps=cfg["eps"]), f)
+    torch.manual_seed(6)
+    enc = TextEncoder(path, output_dim=cfg["output_dim"], pooling_type="mean", proj_type="linear", use_logit_scale=True, learnable_logit_scale=False, frozen=False,
+                      use_lora=False)
+    enc.load_state_dict(g["sd"], strict=True)
+    enc = enc.to(DEV).train()
+    tr = enc.transformer
+    tr.train_dropout = True
+    ids = g["ids"]
+    feats = enc(ids.to(DEV))
+    keep = _bert_keep_masks(tr, tr._drop_calls - 1, *ids.shape)
+    osd = {k: (v.clone().requires_grad_(True) if v.is_floating_point() else v) for k, v in g["sd"].items()}
+    rf = O.encoder_features("bert", ids, osd, dict(cfg, bert_keep=keep), "mean", "linear", True)
+    rloss = O.clip_loss(g["seq_features"], rf)
+    rloss.backward()
+    assert torch.nn.functional.cosine_similarity(feats.detach().cpu(), rf.detach(), dim=-1).min() > 0.999
+    loss = ClipLoss()(g["seq_features"].to(DEV), feats)
+    assert abs(float(loss.detach()) - float(rloss)) / float(rloss) < 2e-3, (float(loss.detach()), float(rloss))
+    assert abs(float(rloss) - float(g["loss"])) / float(g["loss"]) > 2e-3          # the masks move the loss by more than the parity tolerance
+    loss.backward()
+    got = {"transformer." + k: tr.view(k, tr.flat.grad).detach().cpu() for k in tr._spec}
+    got.update({"proj." + k: p_.grad.detach().cpu() for k, p_ in enc.proj.named_parameters()})
+    refs = {k: v.grad for k, v in osd.items() if v.is_floating_point() and v.grad is not None and k in got}
+    big = max(float(v.norm()) for v in refs.values())
+    n = 0
+    for k, ref in refs.items():
+        if float(ref.norm()) < 1e-6:
+            continue
+        c = _cos(got[k], ref)
+        assert c > 0.98, (k, c)
+        if float(ref.norm()) > 0.05 * big:
+            assert c > 0.999, (k, c)
+        n += 1
+    assert n >= 38
+    allg = torch.cat([got[k].flatten() for k in refs]); allr = torch.cat([v.flatten() for v in refs.values()])
     assert _cos(allg, allr) > 0.9995
 
 
