@@ -79,9 +79,25 @@ __global__ void __launch_bounds__(256) k_embed_bwd_small(const long long* __rest
   for (int v = 0; v < vocab; ++v) s_acc[v * 256 + threadIdx.x] = 0.f;
   const int t0 = chunk * tok_per_block, t1 = min(T, t0 + tok_per_block);
   if (col < d) {
-    for (int t = t0; t < t1; ++t) {
+    // eight tokens' loads are in flight before the first LDS add (one token per iteration was one exposed memory latency per token: 607 us at cfg-2)
+    int t = t0;
+    for (; t + 7 < t1; t += 8) {
+      long long id[8]; float v[8], sc[8];
+#pragma unroll
+      for (int j = 0; j < 8; ++j) {
+        id[j] = ids[t + j];
+        v[j] = dx[(size_t)(t + j) * d + col];
+        sc[j] = row_scale ? row_scale[(t + j) / L] : 1.0f;
+      }
+#pragma unroll
+      for (int j = 0; j < 8; ++j) {
+        if (id[j] == pad_id || (token_dropout && id[j] == mask_id) || id[j] < 0 || id[j] >= vocab) continue;   // block-uniform branch
+        s_acc[(int)id[j] * 256 + threadIdx.x] += sc[j] * v[j];
+      }
+    }
+    for (; t < t1; ++t) {
       const long long id = ids[t];
-      if (id == pad_id || (token_dropout && id == mask_id) || id < 0 || id >= vocab) continue;   // block-uniform branch
+      if (id == pad_id || (token_dropout && id == mask_id) || id < 0 || id >= vocab) continue;
       const float sc = row_scale ? row_scale[t / L] : 1.0f;
       s_acc[(int)id * 256 + threadIdx.x] += sc * dx[(size_t)t * d + col];
     }
@@ -98,8 +114,26 @@ __global__ void __launch_bounds__(256) k_reduce_partials(const float* __restrict
   out[j] = accumulate ? out[j] + s : s;
 }
 
+#define EMBED_BWD_CHUNKS 512      // token chunks = blocks per 256-column slab (128 left the 256 CUs with 1.5 blocks each, every block a serial walk over 1 024 tokens)
+// the same for many partials: 8 threads per output, each sums every 8th partial (64 loads in flight per output instead of one dependent walk over
+// all of them), then a fixed-order combination through LDS -- deterministic
+__global__ void __launch_bounds__(256) k_reduce_partials_wide(const float* __restrict__ partial, float* __restrict__ out, int nparts, size_t n, int accumulate) {
+  __shared__ float sh[8][32];
+  const int jj = threadIdx.x & 31, pg = threadIdx.x >> 5;
+  const size_t j = (size_t)blockIdx.x * 32 + jj;
+  float s = 0.f;
+  if (j < n)
+    for (int p = pg; p < nparts; p += 8) s += partial[(size_t)p * n + j];
+  sh[pg][jj] = s;
+  __syncthreads();
+  if (pg == 0 && j < n) {
+    const float t = ((sh[0][jj] + sh[1][jj]) + (sh[2][jj] + sh[3][jj])) + ((sh[4][jj] + sh[5][jj]) + (sh[6][jj] + sh[7][jj]));
+    out[j] = accumulate ? out[j] + t : t;
+  }
+}
+
 extern "C" size_t oneprot_esm_embed_bwd_workspace(int T, int d, int vocab) {
-  const int chunks = 128;
+  const int chunks = EMBED_BWD_CHUNKS;
   (void)T;
   return (size_t)chunks * vocab * d * sizeof(float);
 }
@@ -107,7 +141,7 @@ extern "C" size_t oneprot_esm_embed_bwd_workspace(int T, int d, int vocab) {
 extern "C" int oneprot_esm_embed_bwd(const int64_t* ids, const float* dx, const float* row_scale, float* dtable, void* workspace, int B, int L, int d,
                                      int vocab, int pad_id, int mask_id, int token_dropout, int accumulate, void* stream) {
   if (!ids || !dx || !dtable || !workspace || (d & 3) || vocab <= 0 || vocab > 160) return OP_EINVAL;   // 160*256*4 = 160 KiB of LDS
-  const int T = B * L, chunks = 128;
+  const int T = B * L, chunks = EMBED_BWD_CHUNKS;
   const int tpb = (T + chunks - 1) / chunks;
   dim3 grid((d + 255) / 256, chunks);
   const size_t lds = (size_t)vocab * 256 * sizeof(float);
@@ -115,7 +149,7 @@ extern "C" int oneprot_esm_embed_bwd(const int64_t* ids, const float* dx, const 
   hipLaunchKernelGGL(k_embed_bwd_small, grid, dim3(256), lds, (hipStream_t)stream, (const long long*)ids, dx, row_scale, (float*)workspace, T, L, d,
                      vocab, pad_id, mask_id, token_dropout, tpb);
   const size_t n = (size_t)vocab * d;
-  hipLaunchKernelGGL(k_reduce_partials, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, (hipStream_t)stream, (const float*)workspace, dtable, chunks, n, accumulate);
+  hipLaunchKernelGGL(k_reduce_partials_wide, dim3((unsigned)((n + 31) / 32)), dim3(256), 0, (hipStream_t)stream, (const float*)workspace, dtable, chunks, n, accumulate);
   return launch_status();
 }
 
@@ -390,17 +424,34 @@ __global__ void __launch_bounds__(512) k_lnpool_fwd(const float* __restrict__ x,
 #pragma unroll
   for (int i = 0; i < MAXV; ++i) acc[i] = make_float4(0, 0, 0, 0);
   const int lend = (mode == 1 && !hidden_bf16 && !hidden_f32 && !mean_out) ? 1 : L;
+  // the NEXT row of the wave is requested before this row's two wave reductions (a wave walks 64 rows of its sequence one after the other: without
+  // the prefetch every row paid a memory round trip on top of the reductions -- 260 us per launch at cfg-2)
+  float4 vn[MAXV];
+  bool validn = false;
+  auto request = [&](int l) {
+    if (l < lend) {
+      const size_t row = (size_t)b * L + l;
+      validn = ids[row] != pad_id;
+#pragma unroll
+      for (int i = 0; i < MAXV; ++i) {
+        const int c = lane + 64 * i;
+        if (c < nv4) vn[i] = reinterpret_cast<const float4*>(x + row * d)[c];
+      }
+    }
+  };
+  request(wave);
   for (int l = wave; l < lend; l += 8) {
     const size_t row = (size_t)b * L + l;
-    const bool valid = ids[row] != pad_id;
+    const bool valid = validn;
     const float wt = (mode == 0) ? (valid ? inv_n : 0.f) : (l == 0 ? 1.f : 0.f);
     float4 v[MAXV];
     float s = 0.f;
 #pragma unroll
     for (int i = 0; i < MAXV; ++i) {
       const int c = lane + 64 * i;
-      if (c < nv4) { v[i] = reinterpret_cast<const float4*>(x + row * d)[c]; s += (v[i].x + v[i].y) + (v[i].z + v[i].w); }
+      if (c < nv4) { v[i] = vn[i]; s += (v[i].x + v[i].y) + (v[i].z + v[i].w); }
     }
+    request(l + 8);
     const float mean = wave_sum(s) * inv_d;
     float q = 0.f;
 #pragma unroll
