@@ -342,7 +342,7 @@ __global__ void __launch_bounds__(256) k_layernorm_bwd(const void* __restrict__ 
   }
 }
 
-#define LN_BWD_BLOCKS 2048
+#define LN_BWD_BLOCKS 1024      // 4 blocks per CU: 259 us against 261-273 with 2048 (half the partial matrix for k_ln_reduce), 272 with 768, 324 with 512 (tools/ab/ln_time.py)
 extern "C" size_t oneprot_layernorm_bwd_workspace(int d) { return (size_t)LN_BWD_BLOCKS * 2 * d * sizeof(float); }
 
 // dgamma_dbeta: [2][d] laid out as dgamma then dbeta (the two may be non-adjacent: pass both pointers)
