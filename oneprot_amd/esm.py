@@ -341,7 +341,15 @@ class ArenaModule(nn.Module):
 
     # ---- LoRA in train mode with lora_dropout > 0: peft's two-branch form (see the comment above enable_lora)
     def _lora_two_branch(self):
-        return bool(self._lora) and self._lora["dropout"] > 0 and self.training and not getattr(self, "_padded", False)
+        if not (bool(self._lora) and self._lora["dropout"] > 0 and self.training):
+            return False
+        if getattr(self, "_padded", False):      # head_dim 24 models run their QKV operands in a padded layout: the concatenated form is not built for it
+            if not getattr(self, "_lora_pad_warned", False):
+                self._lora_pad_warned = True
+                warnings.warn("lora_dropout is not applied to this padded-head model (head_dim not in 16/32/64): the adapters run merged into the weights, "
+                              "which is peft's forward at dropout 0 (INTEGRATION.md, 'Deviations')", stacklevel=3)
+            return False
+        return True
 
     def _lora_refresh_branch_operands(self):
         """bf16 operands of the two-branch form for every layer: Wc [n, 3d, Kc] = [W | s B (block-diagonal over the targets) | 0] for the
