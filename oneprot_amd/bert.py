@@ -1,8 +1,9 @@
 """BERT text tower on the HIP kernels -- what the reference obtains from `AutoModel.from_pretrained` in TextEncoder
 (ref text_encoder.py:33) i.e. transformers' BertModel (hf modeling_bert.py:53-108 embeddings, 139-204 attention, 354-417 layer;
 post-LN, 1/sqrt(hd) inside attention, erf-GELU).  State-dict keys are BertModel's.  Forward and hand-written backward
-(`frozen=False`, the TextEncoder signature default); dropout runs at p = 0 (the reference keeps HF's 0.1 active in train mode even
-for the frozen tower, which makes its outputs non-deterministic -- SURVEY.md section 8 a7; parity is defined against eval mode)."""
+(`frozen=False`, the TextEncoder signature default); dropout runs at p = 0 by default (the reference keeps HF's 0.1 active in train mode even
+for the frozen tower, which makes its outputs non-deterministic -- SURVEY.md section 8 a7; parity is defined against eval mode).  HF's four
+train-mode dropouts are available as an option (`train_dropout` / ONEPROT_BERT_DROPOUT=1, see _train_dropout below)."""
 import os
 import warnings
 
