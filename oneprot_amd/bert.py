@@ -115,7 +115,7 @@ class BertTransformer(ArenaModule):
 
     def _drop_stream(self, call_id, layer, site):
         """stream id of a dropout site: layer -1 = embeddings; site 0 = attention probabilities, 1 = attention output dense, 2 = FFN output dense"""
-        return (call_id * (self.n_layers + 1) + (layer + 1)) * 4 + site
+        return self._rng_stream(self.RNG_DOMAIN_BERT, (call_id * (self.n_layers + 1) + (layer + 1)) * 4 + site)
 
     @torch.no_grad()
     def run_layers(self, ids, save=False):

@@ -398,10 +398,11 @@ template <int HD> struct RowState {
 // classes of the key tiles of a chunk from its fp32 bias image in LDS (keys >= nkeys count as masked): bit masks with 4 bits per tile,
 // NZ = some key of the group of 8 has a bias, DEAD = all 8 keys of the group are masked.  class(t): 0 no bias (no bookkeeping k-step),
 // 2 every key masked (tile skipped), 1 mixed.
-__device__ __forceinline__ void tile_class_masks(const float* sBias, int nkeys, bool have_bias, int lane, unsigned long long& NZ, unsigned long long& DEAD) {
+// `ck` = floats in the bias image (the chunk size): lanes whose group of 8 lies beyond it (256-key chunks of the hd-64 kernel) never touch LDS.
+__device__ __forceinline__ void tile_class_masks(const float* sBias, int ck, int nkeys, bool have_bias, int lane, unsigned long long& NZ, unsigned long long& DEAD) {
   bool nz = false, dead = true;
   const int k0 = lane * 8;
-  if (have_bias) {
+  if (have_bias && k0 < ck) {
     const float4 a = *reinterpret_cast<const float4*>(sBias + k0), b = *reinterpret_cast<const float4*>(sBias + k0 + 4);
     const float bv[8] = {a.x, a.y, a.z, a.w, b.x, b.y, b.z, b.w};
 #pragma unroll
@@ -748,7 +749,7 @@ __device__ __forceinline__ void fwd2_pass(unsigned char* smem, const bf16_t* __r
     if (!EXACT) FWD2_T(4);
     if (!active) continue;
     unsigned long long NZ, DEAD;
-    tile_class_masks(sBias, nkeys, bias_row != nullptr, lane, NZ, DEAD);
+    tile_class_masks(sBias, F::CK, nkeys, bias_row != nullptr, lane, NZ, DEAD);
     if constexpr (EXACT) fwd_chunk_exact<HD>(sK, sV, sBias, bias_row != nullptr, nkeys, nrows >> 5, NZ, DEAD, qf[0], st[0], lane);
     else fwd_chunk_fast<HD, 1>(sK, sV, sBias, bias_row != nullptr, nkeys, nrows >> 5, NZ, DEAD, qf, st, lane, [] {});
   }
@@ -969,7 +970,7 @@ __global__ void __launch_bounds__(512, 2) k_attn_fwd3(const bf16_t* __restrict__
       const float* sBias = reinterpret_cast<const float*>(sK + 2 * Fwd3::TILE);
       const bool have_bias = key_bias != nullptr;
       unsigned long long NZ, DEAD;
-      tile_class_masks(sBias, L, have_bias, lane, NZ, DEAD);
+      tile_class_masks(sBias, Fwd3::ROWS, L, have_bias, lane, NZ, DEAD);
       const int nt = nrows >> 5;
       RowState<HD> st[2];
       st[0].reset(h); st[1].reset(h);

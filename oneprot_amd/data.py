@@ -90,7 +90,10 @@ class StandInGraphEncoder(torch.nn.Module):
 
 
 def save_checkpoint(module, path):
-    torch.save({"state_dict": {k: v.detach().cpu() for k, v in module.state_dict().items()}, "global_step": getattr(module, "global_step", 0)}, path)
+    checkpoint = {"state_dict": {k: v.detach().cpu() for k, v in module.state_dict().items()}, "global_step": getattr(module, "global_step", 0)}
+    if hasattr(module, "on_save_checkpoint"):
+        module.on_save_checkpoint(checkpoint)            # dropout stream positions (plain ints), outside the state dict
+    torch.save(checkpoint, path)
 
 
 def load_weights_only(module, path):
@@ -99,4 +102,7 @@ def load_weights_only(module, path):
     sd = checkpoint["state_dict"]
     if "model." in next(iter(sd.keys())):
         sd = {k.replace("model.", ""): v for k, v in sd.items() if k.startswith("model.")}
-    return module.load_state_dict(sd, strict=True)
+    result = module.load_state_dict(sd, strict=True)
+    if hasattr(module, "on_load_checkpoint"):
+        module.on_load_checkpoint(checkpoint)            # no-op for checkpoints written by the reference
+    return result

@@ -97,10 +97,31 @@ class ArenaModule(nn.Module):
     """Parameters of a whole encoder in one fp32 arena (`flat`) with named views, a bf16 mirror for the MFMA GEMMs, and
     state-dict hooks that expose / accept the HF key names."""
 
+    # Counter-based dropout streams (Philox key = seed, counter high words = stream id): every consumer gets a domain of its own so that no two
+    # of them can draw the same mask -- bits 60..63 the purpose (1: BERT hidden / attention dropout, 2: LoRA dropout), bits 44..59 the tower
+    # (construction order within the process), bits 0..43 the consumer's own (call, layer, site) numbering.
+    RNG_DOMAIN_BERT, RNG_DOMAIN_LORA = 1, 2
+    _next_rng_uid = 0
+
     def _init_arena(self):
         self._spec = OrderedDict()
         self._cursor = 0
         self._extra = OrderedDict()
+        self._rng_uid = ArenaModule._next_rng_uid & 0xFFFF
+        ArenaModule._next_rng_uid += 1
+
+    def _rng_stream(self, domain, local):
+        return (int(domain) << 60) | (self._rng_uid << 44) | (int(local) & ((1 << 44) - 1))
+
+    def rng_state(self):
+        """Seeds and call counters of the dropout streams (plain ints): what a checkpoint has to carry for a resumed run to continue the mask
+        sequence instead of replaying it from call 0 (OneProtLitModule.on_save_checkpoint / on_load_checkpoint)."""
+        return {k: int(getattr(self, k)) for k in ("_lora_seed", "_lora_calls", "_drop_seed", "_drop_calls") if getattr(self, k, None) is not None}
+
+    def set_rng_state(self, state):
+        for k in ("_lora_seed", "_lora_calls", "_drop_seed", "_drop_calls"):
+            if k in state:
+                setattr(self, k, int(state[k]))
 
     def _finish_arena(self):
         self._total = self._cursor
@@ -353,26 +374,32 @@ class ArenaModule(nn.Module):
 
     def _lora_refresh_branch_operands(self):
         """bf16 operands of the two-branch form for every layer: Wc [n, 3d, Kc] = [W | s B (block-diagonal over the targets) | 0] for the
-        K-concatenated QKV GEMM, Acat [n, Rp, d] (the targets' A stacked, each padded to rp = ceil8(r) rows), AtT [n, targets, d, rp] and BsT [n, Rp, 3d] for the backward."""
+        K-concatenated QKV GEMM, Acat [n, Rp, d] (the targets' A stacked, each padded to rp = ceil8(r) rows), AtT [n, targets, d, rp] and BsT [n, Rp, 3d] for the backward.
+        Runs after every optimizer step (the adapters moved): the buffers are allocated once and refilled in place -- the frozen base weights as ONE
+        strided copy out of the bf16 mirror (the q|k|v block sits at the same offset in every layer of the arena), the r-wide adapter columns by
+        slice assignment; the zero padding is written once, at allocation."""
         lo, n, d, dev = self._lora, self.n_layers, self.d, self.flat.device
         r, nt, s_ = lo["r"], len(lo["targets"]), lo["scaling"]
         rp = -(-r // 8) * 8
         Rp = nt * rp
         Kc = -(-(d + Rp) // 128) * 128
         bf = torch.bfloat16
-        Acat = torch.zeros(n, Rp, d, device=dev)
-        Bs = torch.zeros(n, 3 * d, Rp, device=dev)
+        ops = getattr(self, "_lora_ops", None)
+        if ops is None or ops["Wc"].device != dev or ops["Kc"] != Kc or ops["rp"] != rp:
+            ops = self._lora_ops = dict(rp=rp, Rp=Rp, Kc=Kc, Wc=torch.zeros(n, 3 * d, Kc, dtype=bf, device=dev), Acat=torch.zeros(n, Rp, d, dtype=bf, device=dev),
+                                        AtT=torch.zeros(n, nt, d, rp, dtype=bf, device=dev), BsT=torch.zeros(n, Rp, 3 * d, dtype=bf, device=dev))
+        o0, cnt = self.span("encoder.layer.0.attention.self.query.weight", "encoder.layer.0.attention.self.value.weight")
+        stride = self.span("encoder.layer.1.attention.self.query.weight", "encoder.layer.1.attention.self.value.weight")[0] - o0 if n > 1 else cnt
+        assert cnt == 3 * d * d
+        ops["Wc"][:, :, :d].copy_(torch.as_strided(self._bf16, (n, 3 * d, d), (stride, d, 1), o0))
         for ti, t in enumerate(lo["targets"]):
             blk = self.LORA_TARGETS.index(t)
-            Acat[:, ti * rp:ti * rp + r] = self.lora_A.data[:, ti]
-            Bs[:, blk * d:(blk + 1) * d, ti * rp:ti * rp + r] = s_ * self.lora_B.data[:, ti]
-        Wc = torch.zeros(n, 3 * d, Kc, dtype=bf, device=dev)
-        for i in range(n):
-            o, cnt = self.span(f"encoder.layer.{i}.attention.self.query.weight", f"encoder.layer.{i}.attention.self.value.weight")
-            Wc[i, :, :d] = self._bf16[o:o + cnt].view(3 * d, d)
-        Wc[:, :, d:d + Rp] = Bs.to(bf)
-        self._lora_ops = dict(rp=rp, Rp=Rp, Kc=Kc, Wc=Wc, Acat=Acat.to(bf).contiguous(), AtT=Acat.view(n, nt, rp, d).transpose(2, 3).to(bf).contiguous(),
-                              BsT=Bs.transpose(1, 2).to(bf).contiguous())
+            a16 = self.lora_A.data[:, ti].to(bf)                                  # [n, r, d]
+            b16 = (s_ * self.lora_B.data[:, ti]).to(bf)                           # [n, d, r]
+            ops["Acat"][:, ti * rp:ti * rp + r] = a16
+            ops["AtT"][:, ti, :, :r] = a16.transpose(1, 2)
+            ops["Wc"][:, blk * d:(blk + 1) * d, d + ti * rp:d + ti * rp + r] = b16
+            ops["BsT"][:, ti * rp:ti * rp + r, blk * d:(blk + 1) * d] = b16.transpose(1, 2)
 
     def _lora_scratch_for(self, T, dev):
         sc = getattr(self, "_lora_branch_scratch", None)
@@ -386,7 +413,7 @@ class ArenaModule(nn.Module):
     def _lora_stream(self, call_id, i, ti):
         """dropout stream of target ti in layer i of forward call call_id: peft gives every wrapped Linear its own dropout module, so q, k and v
         see independent masks of the same input"""
-        return (call_id * self.n_layers + i) * 4 + ti
+        return self._rng_stream(self.RNG_DOMAIN_LORA, (call_id * self.n_layers + i) * 4 + ti)
 
     def _lora_branch_operand(self, i, h, T, call_id):
         """A operand of layer i's QKV GEMM in the two-branch form: [h | dropout_q(h) A_q^T | dropout_k(h) A_k^T | dropout_v(h) A_v^T | 0] bf16

@@ -315,6 +315,21 @@ class OneProtLitModule(_Base):
             return {"optimizer": optimizer, "lr_scheduler": {"scheduler": scheduler, "monitor": "val/loss_best", "interval": "epoch", "frequency": 1}}
         return {"optimizer": optimizer}
 
+    # ------------------------------------------------------------------------------------------- checkpoint hooks
+    # (LightningModule hook names: a Trainer calls them around torch.save / ckpt_path=...; oneprot_amd.data.save_checkpoint / load_weights_only call
+    # them too.)  The dropout streams of the towers (LoRA dropout, the BERT tower's train-mode dropout) are counter-based -- (seed, call counter)
+    # -- and live outside the state dict, whose key set is the reference's on-disk contract: they travel in a checkpoint entry of their own, so that
+    # a resumed run continues the mask sequence instead of replaying it from call 0.
+    def on_save_checkpoint(self, checkpoint):
+        checkpoint["oneprot_amd_dropout_rng"] = {m: enc.transformer.rng_state() for m, enc in self.network.items()
+                                                 if hasattr(getattr(enc, "transformer", None), "rng_state")}
+
+    def on_load_checkpoint(self, checkpoint):
+        for m, state in (checkpoint.get("oneprot_amd_dropout_rng") or {}).items():
+            tr = getattr(self.network[m], "transformer", None) if m in self.network else None
+            if hasattr(tr, "set_rng_state"):
+                tr.set_rng_state(state)
+
     # ------------------------------------------------------------------------------------------- minimal driver
     def fit_steps(self, batches):
         """Drive training_step over an iterable of CombinedLoader-style batches ({modality: (seq_ids, mod_ids, name, raw)})."""

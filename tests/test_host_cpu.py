@@ -270,6 +270,27 @@ def test_checkpoint_wire_format(golden_dir, tmp_path, monkeypatch):
     load_weights_only(m2, ck)
     for k, v in m1.state_dict().items():
         assert torch.equal(v, m2.state_dict()[k]), k
+    # dropout stream positions ride along outside the state dict and are restored (a resumed run continues the mask sequence)
+    tr1 = m1.network["struct_token"].transformer
+    tr1.enable_lora(4, 8, ["query", "key", "value"], dropout=0.1)
+    tr1._lora_calls = 17
+    save_checkpoint(m1, ck)
+    assert torch.load(ck, weights_only=True)["oneprot_amd_dropout_rng"]["struct_token"] == {"_lora_seed": tr1._lora_seed, "_lora_calls": 17}
+    m3 = make()
+    tr3 = m3.network["struct_token"].transformer
+    tr3.enable_lora(4, 8, ["query", "key", "value"], dropout=0.1)
+    tr3._lora_seed = 1
+    load_weights_only(m3, ck)
+    assert (tr3._lora_seed, tr3._lora_calls) == (tr1._lora_seed, 17)
+    # every consumer of the counter-based generator has a stream domain of its own: purpose and tower enter the stream id
+    seq_tr = m1.network["sequence"].transformer
+    assert tr1._rng_uid != seq_tr._rng_uid
+    assert tr1._lora_stream(0, 0, 0) != seq_tr._lora_stream(0, 0, 0)
+    assert tr1._lora_stream(0, 0, 0) != tr1._rng_stream(tr1.RNG_DOMAIN_BERT, 0)
+    assert tr1._lora_stream(3, 2, 1) & ((1 << 44) - 1) == (3 * tr1.n_layers + 2) * 4 + 1
+    m1 = make()
+    m1.network["sequence"].load_state_dict(g["sd_seq"]); m1.network["struct_token"].load_state_dict(g["sd_st"])
+    save_checkpoint(m1, ck)
     # Lightning-wrapped variant with the 'model.' prefix the reference strips (src/train.py:77-79)
     sd = torch.load(ck, weights_only=True)["state_dict"]
     torch.save({"state_dict": {"model." + k: v for k, v in sd.items()}}, ck)

@@ -715,6 +715,30 @@ def test_casts():
         hip.call("oneprot_transpose_cast_f32_to_bf16_batched", arena[64:], out, 70, 132, 10000, 100, 5)      # overlapping outputs
 
 
+def test_dropout_streams_of_different_consumers_and_towers_are_independent():
+    """The BERT tower's hidden dropout and the LoRA dropout draw from the same generator with the same seed (torch.initial_seed): purpose and tower
+    are part of the stream id (ArenaModule._rng_stream), so the embedding mask of call 0 is NOT the layer-0 query-adapter mask, and two towers'
+    LoRA masks differ."""
+    from oneprot_amd.esm import ArenaModule
+    towers = []
+    for uid in (0, 1):
+        t = ArenaModule.__new__(ArenaModule)
+        t._rng_uid = uid
+        towers.append(t)
+    n, p_, seed = 64 * 768, 0.1, 0x5EED
+    ones = torch.ones(n, dtype=torch.bfloat16, device=DEV)
+    def mask(stream):
+        out = torch.empty_like(ones)
+        hip.call("oneprot_dropout_bf16", ones, out, n, p_, seed, stream)
+        return out != 0
+    bert_emb = mask(towers[0]._rng_stream(ArenaModule.RNG_DOMAIN_BERT, 0))
+    lora_q0 = mask(towers[0]._rng_stream(ArenaModule.RNG_DOMAIN_LORA, 0))
+    lora_q0_other = mask(towers[1]._rng_stream(ArenaModule.RNG_DOMAIN_LORA, 0))
+    for a, b in ((bert_emb, lora_q0), (lora_q0, lora_q0_other)):
+        agree = float((a == b).float().mean())
+        assert abs(agree - (0.9 * 0.9 + 0.1 * 0.1)) < 0.01, agree
+
+
 def test_dropout_bf16_mask_is_a_function_of_seed_stream_and_element():
     """oneprot_dropout_bf16 (peft's lora_dropout on the adapter branch's input): keep probability, exact values, determinism, independent streams,
     and the two backward forms regenerate the forward's mask."""

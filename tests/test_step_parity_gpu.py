@@ -505,7 +505,7 @@ def test_multi_step_training_tracks_oracle(golden_dir, tmp_path, frozen_seq):
 
 
 def test_cfg1_shape_train_step_vs_oracle():
-    """BASELINE cfg-1 shape (ESM-2-8M x2, L=128, reduced batch 8, ragged padding): full sub-step loss + gradient norm vs the CPU oracle."""
+    """BASELINE cfg-1 at its own size (ESM-2-8M x2, L=128, batch 32, ragged padding): full sub-step loss + gradient norm vs the CPU oracle."""
     os.environ.update(RANK="0", WORLD_SIZE="1", ONEPROT_ALLOW_RANDOM_INIT="1")
     from src.models.components.sequence_encoder import SequenceEncoder
     from src.models.components.struct_token_encoder import StructTokenEncoder
@@ -518,11 +518,12 @@ def test_cfg1_shape_train_step_vs_oracle():
     sd_seq = {k: v.detach().clone() for k, v in seq.state_dict().items()}
     sd_st = {k: v.detach().clone() for k, v in st.state_dict().items()}
     gen = torch.Generator().manual_seed(1881)
-    B, L = 8, 128
+    B, L = 32, 128
     seq_ids = torch.randint(4, 24, (B, L), generator=gen); st_ids = torch.randint(33, 53, (B, L), generator=gen)
+    lens = [128, 90, 128, 31, 128, 128, 64, 100] + [int(n) for n in torch.randint(L // 4, L + 1, (B - 8,), generator=gen)]
     for ids in (seq_ids, st_ids):
         ids[:, 0] = 0
-        for b, n in enumerate([128, 90, 128, 31, 128, 128, 64, 100]):
+        for b, n in enumerate(lens):
             ids[b, n - 1] = 2
             ids[b, n:] = 1
     cfg = dict(layers=6, hidden=320, heads=20, ffn=1280, pad=1, mask=32, eps=1e-5)
