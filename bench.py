@@ -480,7 +480,9 @@ def main():
         }
         out.update(extras)
         if exchange is not None:
+            from oneprot_amd.distributed import grad_overlap_enabled
             out["exchange"] = {"what": "per rank, ms per step on the launch stream: packed feature all-gather + reduce-scatter backward + the part of the gradient all-reduce not hidden under the backward",
+                               "grad_overlap": int(grad_overlap_enabled()), "grad_overlap_switch": "ONEPROT_GRAD_OVERLAP=0/1 (1: arena ranges all-reduced from inside the backward; 0: bucketed after it)",
                                "per_rank": exchange}
         if world == 1 and not args.no_cpu_baseline:
             threads, share = host_cpu_share()

@@ -39,9 +39,6 @@ template <int IMM> __device__ __forceinline__ void gst16_s(const void* sbase, un
   // (s_nop 1: a store of more than 8 bytes reads its data registers late; hipcc pads its own stores against the next writer of those registers, not an asm one)
   asm volatile("global_store_dwordx4 %0, %1, %2 offset:%3\n\ts_nop 1" ::"v"(voff), "v"(v), "s"(sbase), "n"(IMM) : "memory");
 }
-template <int IMM> __device__ __forceinline__ void gst8_s(const void* sbase, unsigned voff, const u32x2& v) {
-  asm volatile("global_store_dwordx2 %0, %1, %2 offset:%3" ::"v"(voff), "v"(v), "s"(sbase), "n"(IMM) : "memory");
-}
 // wait until at most N vector-memory operations are in flight; the loaded registers are defined from here on
 template <int N, int G> __device__ __forceinline__ void wait_vm_pin(u32x4 (&r)[G]) {
   asm volatile("s_waitcnt vmcnt(%1)" : "+v"(r[0]) : "n"(N) : "memory");
@@ -164,8 +161,7 @@ __device__ __forceinline__ void epilogue_pair_body(const GemmArgs& p, f32x4 (&ac
             __builtin_amdgcn_sched_barrier(0);
           }
         } else {
-#pragma unroll
-          for (int e = 0; e < 8; ++e) v[e] = gelu_fwd_only(v[e]);
+          gelu_fwd_only8(v);
         }
       } else if constexpr (AUX) {
         const u32x4 t = lane_perm(pb, r[(HB ? 4 : 0) + u]);
@@ -258,7 +254,7 @@ __device__ __forceinline__ void epilogue_f32(const GemmArgs& p, f32x4 (&acc)[MT]
 // register of the other tile).  Group = one head.  The RoPE table rows of the wave's MT row groups are fetched once, before any store.
 template <bool HB, int MT, int NT>
 __device__ __forceinline__ void epilogue_rope32(const GemmArgs& p, f32x4 (&acc)[MT][NT], int m0, int n0, int wr, int wc, int lane) {
-  constexpr int HD = 32, HALF = 16, NG = NT / 2, GL = HB ? 2 : 0, GS = MT * 2;
+  constexpr int HD = 32, HALF = 16, NG = NT / 2, GL = HB ? 2 : 0, GS = MT;
   const int c = lane & 15, q = lane >> 4;
   const int mrow0 = m0 + wr * (MT * 16) + c, ncol0 = n0 + wc * (NT * 16);
   const int dm = p.H * HD;
@@ -275,11 +271,14 @@ __device__ __forceinline__ void epilogue_rope32(const GemmArgs& p, f32x4 (&acc)[
   const bf16_t* dst = (const bf16_t*)(sec == 0 ? p.out0 : (sec == 1 ? p.out1 : p.out2)) + ((size_t)b0 * p.H + head0) * p.L * HD;
   unsigned roff[MT];
   const int sr = lane >> 2, sq = lane & 3, pa = to_rows_addr(lane);
+  const bool odd = (sq & 1) != 0;
 #pragma unroll
   for (int i = 0; i < MT; ++i) {
     const int gs = row0 + i * 16 + sr;
     const int bs = gs / p.L, ls = gs - bs * p.L;
-    roff[i] = (unsigned)((((bs - b0) * p.H) * p.L + ls) * HD + sq * 4) * 2u;
+    // one 16-byte store per lane: neighbouring lanes swap halves below, the even lane of a pair then holds columns sq*4 .. sq*4+7 of the head's first
+    // half, the odd lane columns 16 + (sq-1)*4 .. +7 of its second half (two 8-byte stores per lane ran the store path at 4.2 TB/s)
+    roff[i] = (unsigned)((((bs - b0) * p.H) * p.L + ls) * HD + ((sq & 1) ? HALF + (sq - 1) * 4 : sq * 4)) * 2u;
     const int gm = mrow0 + i * 16;                          // accumulator layout (rotation arithmetic): row c
     const int l = gm % p.L;
     if (sec < 2) {
@@ -314,10 +313,12 @@ __device__ __forceinline__ void epilogue_rope32(const GemmArgs& p, f32x4 (&acc)[
       const bf16_t* d = dst + h * hstep;                    // wave-uniform
       u32x4 w; w.x = pack2bf(ol[0], ol[1]); w.y = pack2bf(ol[2], ol[3]); w.z = pack2bf(oh[0], oh[1]); w.w = pack2bf(oh[2], oh[3]);
       w = lane_perm(pa, w);                                 // row layout: four neighbouring lanes hold the 32 + 32 bytes of one (token, head) row
-      u32x2 w0; w0.x = w.x; w0.y = w.y;
-      u32x2 w1; w1.x = w.z; w1.y = w.w;
-      gst8_s<0>(d, roff[i], w0);
-      gst8_s<HALF * 2>(d, roff[i], w1);
+      const unsigned sx = odd ? w.x : w.z, sy = odd ? w.y : w.w;                                        // what the neighbour stores
+      const unsigned rx = (unsigned)__builtin_amdgcn_update_dpp(0, (int)sx, 0xB1, 0xF, 0xF, false);      // quad_perm [1, 0, 3, 2]
+      const unsigned ry = (unsigned)__builtin_amdgcn_update_dpp(0, (int)sy, 0xB1, 0xF, 0xF, false);
+      u32x4 o;
+      o.x = odd ? rx : w.x; o.y = odd ? ry : w.y; o.z = odd ? w.z : rx; o.w = odd ? w.w : ry;
+      gst16_s<0>(d, roff[i], o);
     }
   };
   run_groups<NG, GL, GS>(load, finish);
@@ -326,7 +327,8 @@ __device__ __forceinline__ void epilogue_rope32(const GemmArgs& p, f32x4 (&acc)[
 // vector-memory stores one wave issues per tile (for the store-tolerant wait that follows the epilogue)
 template <int EPI, bool DUAL, int MT, int NT> constexpr int epilogue_stores() {
   if (EPI == ONEPROT_EPI_BF16 || EPI == ONEPROT_EPI_GELU_BWD || EPI == ONEPROT_EPI_BIAS_GELU) return MT * NT / 2 * (DUAL ? 2 : 1);
-  return MT * NT * (DUAL ? 2 : 1);      // F32, BIAS_RESID (fp32 + optional bf16 copy), QKV_ROPE (8-byte stores, one per tile)
+  if (EPI == ONEPROT_EPI_QKV_ROPE) return MT * NT / 2;      // head_dim 32: one 16-byte store per head and row block (head_dim 64 issues twice as many: the smaller count is the safe one)
+  return MT * NT * (DUAL ? 2 : 1);      // F32, BIAS_RESID (fp32 + optional bf16 copy)
 }
 
 }  // namespace g8

@@ -668,8 +668,7 @@ __device__ __forceinline__ void pp_chunk(const GemmArgs& p, f32x4 (&acc)[MT][NTW
         u32x4 z; z.x = pack2bf(dg[0], dg[1]); z.y = pack2bf(dg[2], dg[3]); z.z = pack2bf(dg[4], dg[5]); z.w = pack2bf(dg[6], dg[7]);
         *reinterpret_cast<u32x4*>(reinterpret_cast<unsigned char*>((bf16_t*)p.out1 + uo) + lane_off) = z;
       } else {
-#pragma unroll
-        for (int e = 0; e < 8; ++e) v[e] = gelu_fwd_only(v[e]);
+        gelu_fwd_only8(v);
       }
     } else if (EPI == ONEPROT_EPI_GELU_BWD) {
       v[0] *= bflo(aux16.x); v[1] *= bfhi(aux16.x); v[2] *= bflo(aux16.y); v[3] *= bfhi(aux16.y);

@@ -225,6 +225,18 @@ __global__ void __launch_bounds__(512, 2) k_gemm8(const GemmArgs p, const int g8
   // MFMAs of quadrant (X half xh, Y half yh), operand roles swapped (a = weight fragment, b = activation fragment): lane (c, q) owns
   // C[token c][slots q*4 .. q*4+3] of every tile (gemm_epi.h)
   int stamp_s = 0, stamp_ph = 0;                           // (diagnostic builds: K-tile / phase the MFMA-run stamps belong to)
+#ifdef G8_DUMMY_VALU      // experiment (tools/ab): G8_DUMMY_VALU plain + G8_DUMMY_EXP transcendental vector instructions in every READ slot -- how much epilogue work hides there?
+  float dv[4] = {0.1f, 0.2f, 0.3f, 0.4f};
+  asm volatile("" : "+v"(dv[0]), "+v"(dv[1]), "+v"(dv[2]), "+v"(dv[3]));
+  auto dummy_valu = [&]() {
+#pragma unroll
+    for (int i = 0; i < G8_DUMMY_VALU; ++i) asm volatile("v_fma_f32 %0, %0, 0.5, 0.5" : "+v"(dv[i & 3]));
+#pragma unroll
+    for (int i = 0; i < G8_DUMMY_EXP; ++i) asm volatile("v_exp_f32 %0, -%0" : "+v"(dv[i & 3]));
+  };
+#else
+  auto dummy_valu = [&]() {};
+#endif
   auto quadrant = [&](auto xhc, auto yhc) {
     constexpr int xh = decltype(xhc)::value, yh = decltype(yhc)::value;
     constexpr int mh = XA ? xh : yh, nh = XA ? yh : xh;
@@ -261,6 +273,7 @@ __global__ void __launch_bounds__(512, 2) k_gemm8(const GemmArgs p, const int g8
     read_y(std::integral_constant<int, 0>{}, y0p);
     __builtin_amdgcn_sched_barrier(0);
     if (more1 && !after_epi) issue_unit(std::integral_constant<int, 3>{}, BUFI ^ 1, 0, c1.a, c1.b);          // X1 of K-tile s+1 (issued ahead of the epilogue at a tile start)
+    dummy_valu();
     wait_lgkm<NY>();
     bar();
     STAMP(0);
@@ -275,6 +288,7 @@ __global__ void __launch_bounds__(512, 2) k_gemm8(const GemmArgs p, const int g8
     read_y(std::integral_constant<int, 1>{}, bufp + C::OFF_Y1);
     __builtin_amdgcn_sched_barrier(0);
     if (more2) issue_unit(std::integral_constant<int, 0>{}, BUFI, 0, c2.a, c2.b);              // X0 of K-tile s+2
+    dummy_valu();
     bar();
     STAMP(2);
     wait_lgkm<0>();
@@ -287,6 +301,7 @@ __global__ void __launch_bounds__(512, 2) k_gemm8(const GemmArgs p, const int g8
     read_x(bufp + C::OFF_X1);
     __builtin_amdgcn_sched_barrier(0);
     if (more2) issue_unit(std::integral_constant<int, 1>{}, BUFI, r3n2, c2.a, c2.b);           // Y0 of K-tile s+2
+    dummy_valu();
     bar();
     STAMP(4);
     wait_lgkm<0>();
@@ -308,6 +323,7 @@ __global__ void __launch_bounds__(512, 2) k_gemm8(const GemmArgs p, const int g8
     } else {
       wait_vmcnt<0>();
     }
+    dummy_valu();
     bar();
     STAMP(6);
     if constexpr (C::Y3) wait_lgkm<0>();
@@ -457,6 +473,9 @@ __global__ void __launch_bounds__(512, 2) k_gemm8(const GemmArgs p, const int g8
     zero_acc();
     STAMP_E(4);
   }
+#ifdef G8_DUMMY_VALU
+  asm volatile("" :: "v"(dv[0]), "v"(dv[1]), "v"(dv[2]), "v"(dv[3]));
+#endif
 }
 
 static int g_dph_groups = 1, g_dph_sleeps = 0, g_g8n_cap = 0;

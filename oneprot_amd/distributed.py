@@ -142,6 +142,18 @@ def grad_comm_dtype(name=None):
     raise ValueError(f"gradient communication dtype {name!r}: fp32 or bf16")
 
 
+def grad_overlap_enabled(value=None):
+    """ONEPROT_GRAD_OVERLAP (default 1): issue the arena-gradient all-reduce in ranges from inside the backward (GradOverlap) -- 0: one bucketed
+    all-reduce after the backward, nothing co-resident with the backward's kernels.  Why a switch: every hot kernel of the step is ONE persistent
+    work-group per CU with a static tile list, so a collective's channel work-groups that hold a few CUs through a GEMM make the displaced
+    work-groups run after the others (tools/ab/cu_occupier.py, profiles/r05_cu_occupier.txt measures that with a stand-in on one GPU); which side
+    wins on a real 8-GPU node is for the first multi-GPU run to decide with this switch -- bench.py prints the setting in its `exchange` block."""
+    v = os.environ.get("ONEPROT_GRAD_OVERLAP", "1") if value is None else str(value)
+    if v not in ("0", "1"):
+        raise ValueError(f"ONEPROT_GRAD_OVERLAP={v!r}: 0 or 1")
+    return v == "1"
+
+
 class _Pending:
     """an asynchronous all-reduce of `src` (a gradient range, or its bf16 copy `wire` that is written back into `src` once the collective is done)"""
 

@@ -236,6 +236,9 @@ class OneProtLitModule(_Base):
         if getattr(self, "_overlap_attached", False) or not self._owns_gradient_sync() or getattr(self.loss_fn, "world_size", 1) <= 1:
             return
         if D.is_dist_avail_and_initialized():
+            if not D.grad_overlap_enabled():         # ONEPROT_GRAD_OVERLAP=0: allreduce_gradients reduces the arenas in buckets after the backward
+                self._overlap_attached = True
+                return
             ov = D.GradOverlap()
             for enc in self.network.values():
                 ov.attach(enc.transformer)

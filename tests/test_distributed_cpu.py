@@ -111,3 +111,16 @@ def test_first_node_and_env_mapping(golden_dir, monkeypatch):
             assert os.environ[k] == c[k], (k, c)
     import src.distributed as SD      # the reference's import path
     assert SD.init_distributed_mode is D.init_distributed_mode
+
+
+def test_gradient_overlap_switch(monkeypatch):
+    """ONEPROT_GRAD_OVERLAP: 1 (default) attaches distributed.GradOverlap to the towers, 0 leaves the arena gradients to the bucketed all-reduce after
+    the backward; anything else is refused."""
+    from oneprot_amd import distributed as D
+    monkeypatch.delenv("ONEPROT_GRAD_OVERLAP", raising=False)
+    assert D.grad_overlap_enabled() is True
+    monkeypatch.setenv("ONEPROT_GRAD_OVERLAP", "0")
+    assert D.grad_overlap_enabled() is False
+    monkeypatch.setenv("ONEPROT_GRAD_OVERLAP", "yes")
+    with pytest.raises(ValueError):
+        D.grad_overlap_enabled()

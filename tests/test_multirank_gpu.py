@@ -13,8 +13,9 @@ pytestmark = pytest.mark.gpu
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 
 
-def _run(world, out_dir, golden, port, loss_name="CLIP", transport="gloo"):
-    procs = [subprocess.Popen([sys.executable, os.path.join(ROOT, "tests", "_gpu_rank_worker.py"), str(r), str(world), str(port), out_dir, golden, loss_name, transport])
+def _run(world, out_dir, golden, port, loss_name="CLIP", transport="gloo", env=None):
+    procs = [subprocess.Popen([sys.executable, os.path.join(ROOT, "tests", "_gpu_rank_worker.py"), str(r), str(world), str(port), out_dir, golden, loss_name, transport],
+                              env=dict(os.environ, **(env or {})))
              for r in range(world)]
     for p in procs:
         assert p.wait(timeout=300) == 0
@@ -59,6 +60,23 @@ def test_two_ranks_equal_single_process(golden_dir, tmp_path, loss_name, port):
         assert torch.equal(r0[k], r1[k]), k                      # replicas stay bit-identical after the all-reduced step
         d = (r0[k] - one[k]).abs()
         assert d.max() < 2.1e-3 and (d > 5e-4).float().mean() < 0.02, (k, d.max())    # same Adam step up to bf16-noise sign flips on tiny gradients
+
+
+def test_two_ranks_with_the_gradient_overlap_switched_off(golden_dir, tmp_path):
+    """ONEPROT_GRAD_OVERLAP=0: no all-reduce is issued from inside the backward (nothing co-resident with its persistent kernels); the arena gradients
+    are reduced in buckets afterwards -- the same numbers as the overlapped form."""
+    golden = os.path.join(golden_dir, "esm_pair_hd16.pt")
+    out_on, out_off = str(tmp_path / "on"), str(tmp_path / "off")
+    os.makedirs(out_on); os.makedirs(out_off)
+    _run(2, out_on, golden, 29781)
+    _run(2, out_off, golden, 29783, env={"ONEPROT_GRAD_OVERLAP": "0"})
+    on = [torch.load(os.path.join(out_on, f"CLIP_w2_rank{r}.pt"), weights_only=False) for r in range(2)]
+    off = [torch.load(os.path.join(out_off, f"CLIP_w2_rank{r}.pt"), weights_only=False) for r in range(2)]
+    assert all(r["overlap_calls"] >= 2 for r in on) and all(r["overlap_calls"] == 0 for r in off)
+    for a, b in zip(on, off):
+        assert a["loss"] == b["loss"] and abs(a["gnorm"] - b["gnorm"]) <= 1e-6 * a["gnorm"]
+        assert torch.equal(a["w"], b["w"]) and torch.equal(a["emb"], b["emb"])          # the same mean of the same two gradients
+    assert torch.equal(off[0]["w"], off[1]["w"])
 
 
 @pytest.mark.parametrize("loss_name,port", [("CLIP", 29771), ("SIGLIP", 29775)])

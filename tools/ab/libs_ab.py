@@ -1,0 +1,156 @@
+#!/usr/bin/env python3
+"""Development tool (GPU): SEVERAL builds of liboneprot_hip.so against each other in ONE process (boxes differ by +-4 %, builds are only ever
+compared inside one process): interleaved rounds, medians, outputs checked against the first library's.
+usage: libs_ab.py name=path.so [name=path.so ...]     env AB_CASES=nt,gln,attn,tn (default all)  AB_ROUNDS=5  AB_ONLY=<substring of a case name>
+       AB_FORCE_SHAPE=<oneprot_gemm_force_shape id, e.g. 40 / 41>  AB_TUNE=<first argument of oneprot_gemm_tune, e.g. 19968 = 256 * 78: main loop only>
+The first library is the reference column; `name=product` stands for oneprot_amd/liboneprot_hip.so."""
+import ctypes, os, statistics, sys
+ROOT = os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+sys.path.insert(0, ROOT)
+import torch
+from oneprot_amd import hip
+
+libs = {}
+for spec in sys.argv[1:]:
+    name, _, path = spec.partition("=")
+    path = hip.LIB_PATH if path in ("", "product") else os.path.abspath(path)
+    h = ctypes.CDLL(path)
+    for sym, (res, args) in hip._SIGS.items():
+        fn = getattr(h, sym, None)
+        if fn is not None:
+            fn.restype, fn.argtypes = res, args
+    libs[name] = h
+    if os.environ.get("AB_FORCE_SHAPE"):
+        h.oneprot_gemm_force_shape(int(os.environ["AB_FORCE_SHAPE"]))
+    if os.environ.get("AB_TUNE"):
+        h.oneprot_gemm_tune(int(os.environ["AB_TUNE"]), 0)
+if not libs:
+    sys.exit(__doc__)
+groups = os.environ.get("AB_CASES", "nt,gln,attn,tn").split(",")
+rounds = int(os.environ.get("AB_ROUNDS", "5"))
+only = os.environ.get("AB_ONLY", "")
+
+
+def call(h, sym, *args):
+    rc = getattr(h, sym)(*[hip.ptr(a) if isinstance(a, torch.Tensor) or a is None else a for a in args], hip.stream())
+    if rc != 0:
+        raise RuntimeError(f"{sym} returned {rc}")
+
+
+def timeit(fn, iters=5):
+    fn(); torch.cuda.synchronize()
+    e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    e0.record()
+    for _ in range(iters):
+        fn()
+    e1.record(); torch.cuda.synchronize()
+    return e0.elapsed_time(e1) / iters * 1e3
+
+
+B, L, H, hd = 256, 512, 20, 32
+d, f, T = 640, 2560, 256 * 512
+g = torch.Generator(device="cuda").manual_seed(0)
+rnd = lambda *s: torch.randn(*s, device="cuda", generator=g)
+cases = []      # (name, flops, make(h) -> fn, outputs: list of tensors to compare)
+
+
+def nt_case(name, N, K, epi, two=True):
+    A = rnd(T, K).to(torch.bfloat16); W = (rnd(N, K) * 0.05).to(torch.bfloat16); bias = rnd(N)
+    cos = torch.rand(L, hd // 2, device="cuda"); sin = torch.rand(L, hd // 2, device="cuda")
+    if epi == hip.EPI_QKV_ROPE:
+        o = [torch.empty(B, H, L, hd, dtype=torch.bfloat16, device="cuda") for _ in range(3)]
+        mk = lambda h: (lambda: call(h, "oneprot_gemm_bf16_nt", A, W, T, N, K, K, K, epi, bias, o[0], o[1], o[2], None, cos, sin, hd ** -0.5, L, H, hd))
+        outs = o
+    elif epi == hip.EPI_BIAS_RESID:
+        res = rnd(T, N); o0 = torch.empty_like(res)
+        mk = lambda h: (lambda: call(h, "oneprot_gemm_bf16_nt", A, W, T, N, K, K, K, epi, bias, o0, None, None, res, None, None, 1.0, 0, 0, 0))
+        outs = [o0]
+    elif epi == hip.EPI_BIAS_GELU:
+        o0 = torch.empty(T, N, dtype=torch.bfloat16, device="cuda"); o1 = torch.empty_like(o0) if two else None
+        mk = lambda h: (lambda: call(h, "oneprot_gemm_bf16_nt", A, W, T, N, K, K, K, epi, bias, o0, o1, None, None, None, None, 1.0, 0, 0, 0))
+        outs = [o0] + ([o1] if two else [])
+    elif epi == hip.EPI_GELU_BWD:
+        o0 = torch.empty(T, N, dtype=torch.bfloat16, device="cuda"); aux = rnd(T, N).to(torch.bfloat16)
+        mk = lambda h: (lambda: call(h, "oneprot_gemm_bf16_nt", A, W, T, N, K, K, K, epi, None, o0, None, None, aux, None, None, 1.0, 0, 0, 0))
+        outs = [o0]
+    else:
+        o0 = torch.empty(T, N, dtype=torch.bfloat16, device="cuda")
+        mk = lambda h: (lambda: call(h, "oneprot_gemm_bf16_nt", A, W, T, N, K, K, K, epi, None, o0, None, None, None, None, None, 1.0, 0, 0, 0))
+        outs = [o0]
+    cases.append((name, 2.0 * T * N * K, mk, outs))
+
+
+if "nt" in groups:
+    nt_case("nt qkv_fwd    N1920 K640  rope", 3 * d, d, hip.EPI_QKV_ROPE)
+    nt_case("nt ffn1_fwd   N2560 K640  gelu only", f, d, hip.EPI_BIAS_GELU, two=False)
+    nt_case("nt ffn1_fwd   N2560 K640  gelu+gelu'", f, d, hip.EPI_BIAS_GELU)
+    nt_case("nt ffn2_fwd   N640  K2560 resid", d, f, hip.EPI_BIAS_RESID)
+    nt_case("nt out_fwd    N640  K640  resid", d, d, hip.EPI_BIAS_RESID)
+    nt_case("nt plain      N2560 K640  bf16", f, d, hip.EPI_BF16)
+    nt_case("nt ffn2_dgrad N2560 K640  gelu'", f, d, hip.EPI_GELU_BWD)
+    nt_case("nt ffn1_dgrad N640  K2560 bf16", d, f, hip.EPI_BF16)
+    nt_case("nt out_dgrad  N640  K640  bf16", d, d, hip.EPI_BF16)
+    nt_case("nt qkv_dgrad  N640  K1920 bf16", d, 3 * d, hip.EPI_BF16)
+
+if "gln" in groups:
+    for nm, K in (("gln out-proj K=640", 640), ("gln FFN-2   K=2560", 2560)):
+        A = rnd(T, K).to(torch.bfloat16); W = (rnd(d, K) * 0.05).to(torch.bfloat16); bias = rnd(d); gamma = rnd(d); beta = rnd(d)
+        x = rnd(T, d); xo = torch.empty_like(x); hh = torch.empty(T, d, dtype=torch.bfloat16, device="cuda"); mean = torch.empty(T, device="cuda"); rstd = torch.empty(T, device="cuda")
+        packed = {}
+
+        def mk(h, A=A, W=W, K=K, bias=bias, gamma=gamma, beta=beta, x=x, xo=xo, hh=hh, mean=mean, rstd=rstd, packed=packed):
+            Wp = torch.empty(d * K, dtype=torch.bfloat16, device="cuda")
+            call(h, "oneprot_gemm_ln_pack_weight", W, Wp, d, K)      # every library packs for its own kernel
+            packed[id(h)] = Wp
+            return lambda: call(h, "oneprot_gemm_bf16_nt_resid_ln", A, Wp, T, d, K, K, bias, x, xo, gamma, beta, 1e-5, hh, mean, rstd)
+        cases.append((nm, 2.0 * T * d * K, mk, [xo, hh, mean, rstd]))
+
+if "attn" in groups:
+    mkq = lambda: (rnd(B, H, L, hd) * 0.7).to(torch.bfloat16)
+    q, k, v = mkq(), mkq(), mkq()
+    lens = torch.randint(L // 2, L + 1, (B,), device="cuda", generator=g)
+    ragged = torch.where(torch.arange(L, device="cuda")[None, :] < lens[:, None], 0.0, float("-inf")).float().contiguous()
+    nopad = torch.zeros_like(ragged)
+    ctx = torch.empty(B * L, H * hd, dtype=torch.bfloat16, device="cuda"); lse = torch.empty(B, H, L, device="cuda")
+    dctx = (rnd(B * L, H * hd) * 0.1).to(torch.bfloat16)
+    dqkv = torch.empty(B * L, 3 * H * hd, dtype=torch.bfloat16, device="cuda")
+    cos = torch.rand(L, hd // 2, device="cuda"); sin = torch.rand(L, hd // 2, device="cuda")
+    fl = 4.0 * B * H * L * L * hd
+    for nm, kb in (("no padding", nopad), ("ragged", ragged)):
+        cases.append((f"attn fwd {nm}", fl, (lambda h, kb=kb: (lambda: call(h, "oneprot_attn_fwd", q, k, v, kb, ctx, lse, B, H, L, hd))), [ctx, lse]))
+
+        def mkb(h, kb=kb):
+            ws = torch.empty(h.oneprot_attn_bwd_workspace(B, H, L), dtype=torch.uint8, device="cuda")
+            call(h, "oneprot_attn_fwd", q, k, v, kb, ctx, lse, B, H, L, hd)
+            return lambda: call(h, "oneprot_attn_bwd", q, k, v, kb, ctx, dctx, lse, cos, sin, hd ** -0.5, dqkv, ws, B, H, L, hd)
+        cases.append((f"attn bwd {nm}", 2.5 * fl, mkb, [dqkv]))
+
+if "tn" in groups:
+    for nm, N, K in (("tn qkv  dW[1920,640]", 3 * d, d), ("tn out  dW[640,640]", d, d), ("tn ffn1 dW[2560,640]", f, d), ("tn ffn2 dW[640,2560]", d, f)):
+        dY = rnd(T, N).to(torch.bfloat16); X = rnd(T, K).to(torch.bfloat16)
+        dW, db = torch.empty(N, K, device="cuda"), torch.empty(N, device="cuda")
+
+        def mk(h, dY=dY, X=X, N=N, K=K, dW=dW, db=db):
+            ws = torch.empty(h.oneprot_gemm_bf16_tn_workspace(N, K), dtype=torch.uint8, device="cuda")
+            return lambda: call(h, "oneprot_gemm_bf16_tn", dY, X, T, N, K, N, K, dW, db, ws, ws.numel(), 0)
+        cases.append((nm, 2.0 * T * N * K, mk, [dW, db]))
+
+print(f"median us per launch over {rounds} interleaved rounds (TFLOP/s) | max abs difference of the outputs from `{next(iter(libs))}`", flush=True)
+for name, fl, mk, outs in cases:
+    if only and only not in name:
+        continue
+    fns = {n: mk(h) for n, h in libs.items()}
+    res = {n: [] for n in libs}
+    for r in range(rounds):
+        for n in (list(libs) if r % 2 == 0 else list(libs)[::-1]):
+            res[n].append(timeit(fns[n]))
+    ref, diffs = None, {}
+    for n in libs:
+        fns[n](); torch.cuda.synchronize()
+        cur = [o.float().clone() for o in outs]
+        if ref is None:
+            ref = cur
+        else:
+            diffs[n] = max(float((a - b).abs().nan_to_num(nan=1e30).max()) for a, b in zip(cur, ref))
+    row = "  ".join(f"{n}:{statistics.median(t):7.1f} ({fl / statistics.median(t) / 1e6:4.0f})" for n, t in res.items())
+    print(f"{name:36s} {row}   | " + " ".join(f"{n}:{v:.2e}" for n, v in diffs.items()), flush=True)
