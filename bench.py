@@ -319,6 +319,20 @@ def other_workloads(args, dev, steps=3):
         dt = (time.perf_counter() - t0) / steps
         res[tag] = {"value": round(batch * len(w["subs"]) / dt, 1), "unit": "protein-pairs/sec (1 GPU)", "ms_per_step": round(dt * 1e3, 2), "steps": steps,
                     "pairs_per_gpu_per_modality": batch, "sub_steps_per_step": len(w["subs"]), "loss": round(float(ls.detach()), 5), "workload": w["desc"]}
+        if "text" in mod.network:
+            # the text tower runs HF's train-mode dropout as the reference does (frozen tower included, ref text_encoder.py:56-62); the same step with it
+            # switched off (transformer.train_dropout = False: what rounds 1-4 measured) beside it
+            res[tag]["text_tower_dropout"] = "on (reference behaviour; ONEPROT_BERT_DROPOUT=0 / transformer.train_dropout = False switch it off)"
+            mod.network["text"].transformer.train_dropout = False
+            mod.training_step(bt, 0)
+            torch.cuda.synchronize()
+            t0 = time.perf_counter()
+            for _ in range(steps):
+                mod.training_step(bt, 0)
+            torch.cuda.synchronize()
+            dt0 = (time.perf_counter() - t0) / steps
+            res[tag]["value_text_dropout_off"] = round(batch * len(w["subs"]) / dt0, 1)
+            res[tag]["ms_per_step_text_dropout_off"] = round(dt0 * 1e3, 2)
         del mod, bt, w, ls
         gc.collect(); torch.cuda.empty_cache()
     return res

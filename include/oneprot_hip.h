@@ -73,10 +73,10 @@ int oneprot_attnpool_bwd(const float* x, const float* attn, const float* w, cons
 enum {
   ONEPROT_EPI_BF16 = 0,        /* out0 bf16 [M,N] = acc (+bias)                                                   */
   ONEPROT_EPI_F32 = 1,         /* out0 fp32 [M,N] = acc (+bias)                                                   */
-  ONEPROT_EPI_BIAS_GELU = 2,   /* z = acc+bias; out0 bf16 = gelu_erf(z); out1 bf16 = gelu_erf'(z) (optional, for bwd) */
+  ONEPROT_EPI_BIAS_GELU = 2,   /* z = acc+bias; out0 bf16 = gelu_erf(z); out1 u8 [M,N] = gelu_erf'(z) as the code rint(192 g' + 25) (optional, for bwd) */
   ONEPROT_EPI_BIAS_RESID = 3,  /* out0 fp32 = acc + bias + resid fp32 (out0 may alias resid); out1 bf16 copy opt. */
   ONEPROT_EPI_QKV_ROPE = 4,    /* N = 3*H*hd: q=(acc+b)*q_scale -> rope -> out0 [B,H,L,hd]; k -> rope -> out1; v -> out2 */
-  ONEPROT_EPI_GELU_BWD = 5     /* out0 bf16 = acc * aux, aux bf16 [M,N] = gelu_erf'(z) saved by ONEPROT_EPI_BIAS_GELU  */
+  ONEPROT_EPI_GELU_BWD = 5     /* out0 bf16 = acc * g', g' = (aux - 25) / 192, aux u8 [M,N] = the codes saved by ONEPROT_EPI_BIAS_GELU  */
 };
 /* C[M,N] = A[M,K] * B[N,K]^T, A and B bf16 row-major with leading dims lda/ldb (elements), fp32 accumulation. */
 int oneprot_gemm_bf16_nt(const void* A, const void* Bw, int64_t M, int N, int K, int lda, int ldb, int epilogue, const float* bias,
@@ -89,6 +89,9 @@ int oneprot_gemm_bf16_nt(const void* A, const void* Bw, int64_t M, int N, int K,
 int oneprot_gemm_ln_pack_weight(const void* W_bf16 /* [N,K] row-major */, void* Wp, int N, int K, void* stream);
 int oneprot_gemm_bf16_nt_resid_ln(const void* A, const void* Wp, int64_t M, int N, int K, int lda, const float* bias, const float* resid, float* x_out,
                                   const float* gamma, const float* beta, float eps, void* h_out, float* mean, float* rstd, void* stream);
+/* test / tuning hook: kernel form of oneprot_gemm_bf16_nt_resid_ln -- 1 (default): four-wave work-groups on 64-row tiles, two per CU (one's K loop
+   under the other's HBM-bound epilogue); 0: eight-wave work-groups on 128-row tiles, one per CU.  Bit-identical results. */
+void oneprot_gemm_ln_form(int form);
 /* test / tuning hook: force the block shape of oneprot_gemm_bf16_nt (0..5, see csrc/gemm_nt.hip; -1 = heuristic). */
 void oneprot_gemm_force_shape(int shape);
 /* test / tuning hook: L2 super-tile of the per-tile kernels (sup_m row panels x sup_n column tiles per XCD at a time; <= 0 keeps a value). */

@@ -1,9 +1,10 @@
 """BERT text tower on the HIP kernels -- what the reference obtains from `AutoModel.from_pretrained` in TextEncoder
 (ref text_encoder.py:33) i.e. transformers' BertModel (hf modeling_bert.py:53-108 embeddings, 139-204 attention, 354-417 layer;
 post-LN, 1/sqrt(hd) inside attention, erf-GELU).  State-dict keys are BertModel's.  Forward and hand-written backward
-(`frozen=False`, the TextEncoder signature default); dropout runs at p = 0 by default (the reference keeps HF's 0.1 active in train mode even
-for the frozen tower, which makes its outputs non-deterministic -- SURVEY.md section 8 a7; parity is defined against eval mode).  HF's four
-train-mode dropouts are available as an option (`train_dropout` / ONEPROT_BERT_DROPOUT=1, see _train_dropout below)."""
+(`frozen=False`, the TextEncoder signature default).  Dropout follows the reference: HF's four train-mode dropouts (p = 0.1) are active whenever the
+module is in train mode, also for the frozen tower (ref text_encoder.py:56-62 never switches it to eval -- SURVEY.md section 8 a7); `.eval()`,
+`transformer.train_dropout = False` or ONEPROT_BERT_DROPOUT=0 run p = 0, which is what parity against the eval-mode reference is defined on
+(see _train_dropout below)."""
 import os
 import warnings
 
@@ -94,15 +95,15 @@ class BertTransformer(ArenaModule):
             self._transpose_layer_weights("w2", "encoder.layer.{i}.output.dense.weight", d, f)
 
     # ---- hf's train-mode dropout (hidden_dropout_prob / attention_probs_dropout_prob, 0.1 in bert-base).  The reference never switches its text tower
-    # to eval mode (text_encoder.py:59), so even the frozen tower of the shipped configuration is stochastic there.  Here it is an OPTION, off by
-    # default (parity is defined against eval mode, INTEGRATION.md "Deviations"): ONEPROT_BERT_DROPOUT=1 or `transformer.train_dropout = True`
-    # applies all four dropouts in train mode, to a frozen tower (forward only) and to a trainable one (the backward regenerates every mask: the dense
+    # to eval mode (text_encoder.py:59), so even the frozen tower of the shipped configuration is stochastic there -- and so it is here since round 5:
+    # ON by default in train mode (ONEPROT_BERT_DROPOUT=0 or `transformer.train_dropout = False` switch it off: the parity tests against the
+    # eval-mode reference do).  All four dropouts, for a frozen tower (forward only) and a trainable one (the backward regenerates every mask: the dense
     # outputs' gradients pass through the same hidden masks, the attention backward runs its masked form, oneprot_attn_bwd_dropout).  Hidden masks come
     # from the counter-based generator of the LoRA dropout (Philox4x32-10 of seed, call, layer, site, element), the attention masks from a per-element hash.
     train_dropout = None
 
     def _train_dropout(self):
-        on = self.train_dropout if self.train_dropout is not None else os.environ.get("ONEPROT_BERT_DROPOUT", "0") == "1"
+        on = self.train_dropout if self.train_dropout is not None else os.environ.get("ONEPROT_BERT_DROPOUT", "1") != "0"
         cfg = self.config
         if not (on and self.training):
             return False
@@ -163,7 +164,7 @@ class BertTransformer(ArenaModule):
             p = f"encoder.layer.{i}."
             if save:     # per layer: input (bf16), attention operands, the two pre-LN sums with their statistics, FFN intermediates
                 st = dict(x16=h, q=b16(B, H, L, hd), k=b16(B, H, L, hd), v=b16(B, H, L, hd), ctx=b16(T, d), lse=f32(B, H, L), s1=f32(T, d), mean1=f32(T), rstd1=f32(T),
-                          y1=f32(T, d), y16=b16(T, d), z=b16(T, f), u=b16(T, f), s2=f32(T, d), mean2=f32(T), rstd2=f32(T))
+                          y1=f32(T, d), y16=b16(T, d), z=torch.empty(T, f, dtype=torch.uint8, device=dev), u=b16(T, f), s2=f32(T, d), mean2=f32(T), rstd2=f32(T))
                 q, k, v, ctx, u, z, lse = st["q"], st["k"], st["v"], st["ctx"], st["u"], st["z"], st["lse"]
                 s1, s2, y1, y16, x_out, h_out = st["s1"], st["s2"], st["y1"], st["y16"], f32(T, d), b16(T, d)
                 m1, r1, m2, r2 = st["mean1"], st["rstd1"], st["mean2"], st["rstd2"]

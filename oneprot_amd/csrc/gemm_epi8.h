@@ -39,6 +39,15 @@ template <int IMM> __device__ __forceinline__ void gst16_s(const void* sbase, un
   // (s_nop 1: a store of more than 8 bytes reads its data registers late; hipcc pads its own stores against the next writer of those registers, not an asm one)
   asm volatile("global_store_dwordx4 %0, %1, %2 offset:%3\n\ts_nop 1" ::"v"(voff), "v"(v), "s"(sbase), "n"(IMM) : "memory");
 }
+template <int IMM> __device__ __forceinline__ void gst8_s(const void* sbase, unsigned voff, const u32x2& v) {
+  asm volatile("global_store_dwordx2 %0, %1, %2 offset:%3" ::"v"(voff), "v"(v), "s"(sbase), "n"(IMM) : "memory");
+}
+// 8-byte load into the low half of a 16-byte register group (the one-byte gelu' codes of GELU_BWD: 8 elements per lane)
+template <int IMM> __device__ __forceinline__ void gload8_s(u32x4& d, const void* sbase, unsigned voff) {
+  u32x2 t;
+  asm volatile("global_load_dwordx2 %0, %1, %2 offset:%3" : "=v"(t) : "v"(voff), "s"(sbase), "n"(IMM) : "memory");
+  d.x = t.x; d.y = t.y;
+}
 // wait until at most N vector-memory operations are in flight; the loaded registers are defined from here on
 template <int N, int G> __device__ __forceinline__ void wait_vm_pin(u32x4 (&r)[G]) {
   asm volatile("s_waitcnt vmcnt(%1)" : "+v"(r[0]) : "n"(N) : "memory");
@@ -53,6 +62,12 @@ __device__ __forceinline__ u32x4 lane_perm(int addr, u32x4 v) {
   u32x4 r;
   r.x = (unsigned)__builtin_amdgcn_ds_bpermute(addr, (int)v.x); r.y = (unsigned)__builtin_amdgcn_ds_bpermute(addr, (int)v.y);
   r.z = (unsigned)__builtin_amdgcn_ds_bpermute(addr, (int)v.z); r.w = (unsigned)__builtin_amdgcn_ds_bpermute(addr, (int)v.w);
+  return r;
+}
+
+__device__ __forceinline__ u32x2 lane_perm2(int addr, u32x2 v) {
+  u32x2 r;
+  r.x = (unsigned)__builtin_amdgcn_ds_bpermute(addr, (int)v.x); r.y = (unsigned)__builtin_amdgcn_ds_bpermute(addr, (int)v.y);
   return r;
 }
 
@@ -76,6 +91,22 @@ __device__ __forceinline__ void run_groups(LoadF&& load, FinF&& finish) {
       if constexpr (g + 2 < NG) load(std::integral_constant<int, g + 2>{}, r[g & 1]);
     }, std::make_integer_sequence<int, NG>{});
   }
+}
+
+// The same with per-group operation counts: Cnt::gl(g) loads and Cnt::gs(g) stores in group g (the one-byte gelu' tensor is moved in 16-byte pieces
+// where two column units of a row block pair up and in 8-byte pieces for the lone half line of a 160-column wave block).
+template <int NG, int MAXGL, class Cnt, class LoadF, class FinF>
+__device__ __forceinline__ void run_groups_v(LoadF&& load, FinF&& finish) {
+  u32x4 r[2][MAXGL > 0 ? MAXGL : 1];
+  if constexpr (Cnt::gl(0) > 0) load(std::integral_constant<int, 0>{}, r[0]);
+  if constexpr (NG > 1) { if constexpr (Cnt::gl(1) > 0) load(std::integral_constant<int, 1>{}, r[1]); }
+  static_for([&](auto gc) {
+    constexpr int g = decltype(gc)::value;
+    constexpr int younger = (g >= 1 ? Cnt::gs(g - 1) : 0) + (g + 1 < NG ? Cnt::gl(g + 1) : 0);
+    if constexpr (Cnt::gl(g) > 0) wait_vm_pin<(younger > 63 ? 63 : younger)>(r[g & 1]);
+    finish(gc, r[g & 1]);
+    if constexpr (g + 2 < NG) { if constexpr (Cnt::gl(g + 2) > 0) load(std::integral_constant<int, g + 2>{}, r[g & 1]); }
+  }, std::make_integer_sequence<int, NG>{});
 }
 
 // ---- store order.  One store instruction of the row layout covers 16 rows x 64 bytes: half of a 128-byte line per row.  When the other half
@@ -106,7 +137,15 @@ __device__ __forceinline__ void epilogue_pair_body(const GemmArgs& p, f32x4 (&ac
 #endif
   constexpr bool HOLD = !DUAL || G8_HOLD_DUAL;
   using Plan = LinePlan<MT, NT / 2, ODD>;
-  constexpr int NG = Plan::NG, GL = (HB ? 4 : 0) + (AUX ? 4 : 0), GS = 4 * (DUAL ? 2 : 1);
+  constexpr int NG = Plan::NG, GL = (HB ? 4 : 0) + (AUX ? 4 : 0);
+  // the one-byte gelu' tensor (out1 of DUAL, aux of GELU_BWD): a lane owns 8 bytes of a unit; in the groups made of two neighbouring column units x two
+  // row blocks the lanes of a pair swap halves so that every lane moves 16 contiguous bytes (even lane: unit pp, odd lane: unit pp + 1) -- 8-byte
+  // pieces ran the two-output FFN-1 launch 4 % slower than the bf16 tensor had; the lone-half-line groups (one column unit x four row blocks) keep them
+  struct Cnt {
+    static constexpr bool lone(int g) { return g < Plan::NSG; }
+    static constexpr int gl(int g) { return (HB ? 4 : 0) + (AUX ? (lone(g) ? 4 : 2) : 0); }
+    static constexpr int gs(int g) { return 4 + (DUAL ? (lone(g) ? 4 : 2) : 0); }
+  };
   const int q = lane >> 4;                                  // accumulator layout: lane (c, q) owns columns q*8 .. q*8+7 of the pair, row c
   const int sr = lane >> 2, sq = lane & 3;                  // row layout (stores, GELU' loads): lane owns row sr, columns sq*8 .. sq*8+7
   const int pa = to_rows_addr(lane), pb = to_acc_addr(lane);
@@ -117,9 +156,14 @@ __device__ __forceinline__ void epilogue_pair_body(const GemmArgs& p, f32x4 (&ac
   const size_t rstep = (size_t)16 * p.N;
   const float* bbase = HB ? p.bias + n0 + wc * (NT * 16) : nullptr;     // accumulator layout: lane (c, q) owns columns q*8 .. q*8+7 of the pair
   const unsigned boff = (unsigned)q * 32u;
-  const bf16_t* aux0 = AUX ? (const bf16_t*)p.aux + t0 : nullptr;
+  // gelu' travels as one byte per element (gemm_epi.h: gelu_grad_encode8): out1 of the two-output GELU and aux of GELU_BWD are byte tensors, the
+  // same lane owns the same 8 columns -- 8 bytes -- and `voff8` is its byte offset there
+  const unsigned char* aux0 = AUX ? (const unsigned char*)p.aux + t0 : nullptr;
   const bf16_t* out0 = (const bf16_t*)p.out0 + t0;
-  const bf16_t* out1 = DUAL ? (const bf16_t*)p.out1 + t0 : nullptr;
+  const unsigned char* out1 = DUAL ? (const unsigned char*)p.out1 + t0 : nullptr;
+  const unsigned voff8 = (unsigned)(sr * p.N + sq * 8);
+  const bool odd = (sq & 1) != 0;
+  const unsigned voff16 = (unsigned)(sr * p.N + (odd ? 32 + (sq - 1) * 8 : sq * 8));      // relative to the EVEN unit of the pair
   auto load = [&](auto gc, u32x4 (&r)[GL > 0 ? GL : 1]) {
     constexpr int g = decltype(gc)::value;
     if constexpr (HB) {                                     // (a lone-half group fetches its bias twice: the count per group stays uniform)
@@ -127,15 +171,21 @@ __device__ __forceinline__ void epilogue_pair_body(const GemmArgs& p, f32x4 (&ac
       gload16_s<Plan::col(g, 1) * 128>(r[2], bbase, boff); gload16_s<Plan::col(g, 1) * 128 + 16>(r[3], bbase, boff);
     }
     if constexpr (AUX) {
-      static_for([&](auto uc) {
-        constexpr int u = decltype(uc)::value;
-        gload16_s<Plan::col(g, u) * 64>(r[(HB ? 4 : 0) + u], aux0 + Plan::row(g, u) * rstep, voff);
-      }, std::make_integer_sequence<int, 4>{});
+      if constexpr (Cnt::lone(g)) {
+        static_for([&](auto uc) {
+          constexpr int u = decltype(uc)::value;
+          gload8_s<Plan::col(g, u) * 32>(r[(HB ? 4 : 0) + u], aux0 + Plan::row(g, u) * rstep, voff8);
+        }, std::make_integer_sequence<int, 4>{});
+      } else {                                              // units (0, 1) and (2, 3): neighbouring column units of one row block
+        gload16_s<Plan::col(g, 0) * 32>(r[(HB ? 4 : 0) + 0], aux0 + Plan::row(g, 0) * rstep, voff16);
+        gload16_s<Plan::col(g, 2) * 32>(r[(HB ? 4 : 0) + 1], aux0 + Plan::row(g, 2) * rstep, voff16);
+      }
     }
   };
   auto finish = [&](auto gc, const u32x4 (&r)[GL > 0 ? GL : 1]) {
     constexpr int g = decltype(gc)::value;
-    u32x4 hw, hz;                                           // HOLD: unit 2k waits, packed, for unit 2k+1
+    u32x4 hw; u32x2 hz;                                     // HOLD: unit 2k waits, packed, for unit 2k+1
+    u32x2 cnext;                                            // GELU_BWD, paired groups: the codes of unit 2k+1, separated when unit 2k was
     static_for([&](auto uc) {
       constexpr int u = decltype(uc)::value, pp = Plan::col(g, u), i = Plan::row(g, u), bs = 2 * (u & 1);
       float v[8];
@@ -147,26 +197,33 @@ __device__ __forceinline__ void epilogue_pair_body(const GemmArgs& p, f32x4 (&ac
       }
       if constexpr (EPI == ONEPROT_EPI_BIAS_GELU) {
         if constexpr (DUAL) {
-          float dg[8];
-#pragma unroll
-          for (int e = 0; e < 8; ++e) gelu_fwd_and_grad(v[e], v[e], dg[e]);
-          u32x4 z; z.x = pack2bf(dg[0], dg[1]); z.y = pack2bf(dg[2], dg[3]); z.z = pack2bf(dg[4], dg[5]); z.w = pack2bf(dg[6], dg[7]);
-          z = lane_perm(pa, z);
-          if constexpr (!HOLD) gst16_s<pp * 64>(out1 + i * rstep, voff, z);
+          const u32x2 z = lane_perm2(pa, gelu_fwd_and_code8(v));
+          if constexpr (Cnt::lone(g)) gst8_s<pp * 32>(out1 + i * rstep, voff8, z);
           else if constexpr ((u & 1) == 0) hz = z;
-          else {
-            __builtin_amdgcn_sched_barrier(0);
-            gst16_s<Plan::col(g, u - 1) * 64>(out1 + Plan::row(g, u - 1) * rstep, voff, hz);
-            gst16_s<pp * 64>(out1 + i * rstep, voff, z);
-            __builtin_amdgcn_sched_barrier(0);
+          else {                                            // hz = unit pp - 1, z = unit pp of the same rows: swap halves, one 16-byte store per lane
+            const unsigned sx = odd ? hz.x : z.x, sy = odd ? hz.y : z.y;
+            const unsigned rx = (unsigned)__builtin_amdgcn_update_dpp(0, (int)sx, 0xB1, 0xF, 0xF, false);      // quad_perm [1, 0, 3, 2]
+            const unsigned ry = (unsigned)__builtin_amdgcn_update_dpp(0, (int)sy, 0xB1, 0xF, 0xF, false);
+            u32x4 o;
+            o.x = odd ? rx : hz.x; o.y = odd ? ry : hz.y; o.z = odd ? z.x : rx; o.w = odd ? z.y : ry;
+            gst16_s<Plan::col(g, u - 1) * 32>(out1 + i * rstep, voff16, o);
           }
         } else {
           gelu_fwd_only8(v);
         }
       } else if constexpr (AUX) {
-        const u32x4 t = lane_perm(pb, r[(HB ? 4 : 0) + u]);
-        v[0] *= bflo(t.x); v[1] *= bfhi(t.x); v[2] *= bflo(t.y); v[3] *= bfhi(t.y);
-        v[4] *= bflo(t.z); v[5] *= bfhi(t.z); v[6] *= bflo(t.w); v[7] *= bfhi(t.w);
+        u32x2 code;
+        if constexpr (Cnt::lone(g)) { const u32x4& ra = r[(HB ? 4 : 0) + u]; code = (u32x2){ra.x, ra.y}; }
+        else if constexpr ((u & 1) == 0) {                  // 16 bytes = this lane's half of units u and u + 1 and its neighbour's: swap back
+          const u32x4& ra = r[(HB ? 4 : 0) + (u >> 1)];
+          const unsigned sx = odd ? ra.x : ra.z, sy = odd ? ra.y : ra.w;
+          const unsigned rx = (unsigned)__builtin_amdgcn_update_dpp(0, (int)sx, 0xB1, 0xF, 0xF, false);
+          const unsigned ry = (unsigned)__builtin_amdgcn_update_dpp(0, (int)sy, 0xB1, 0xF, 0xF, false);
+          code = odd ? (u32x2){rx, ry} : (u32x2){ra.x, ra.y};
+          cnext = odd ? (u32x2){ra.z, ra.w} : (u32x2){rx, ry};
+        } else code = cnext;
+        const u32x2 t = lane_perm2(pb, code);
+        gelu_grad_apply8(v, t.x, t.y);
       }
       u32x4 w; w.x = pack2bf(v[0], v[1]); w.y = pack2bf(v[2], v[3]); w.z = pack2bf(v[4], v[5]); w.w = pack2bf(v[6], v[7]);
       w = lane_perm(pa, w);
@@ -183,7 +240,7 @@ __device__ __forceinline__ void epilogue_pair_body(const GemmArgs& p, f32x4 (&ac
     G8_ESTAMP(g + 1);
   };
   G8_ESTAMP(0);
-  run_groups<NG, GL, GS>(load, finish);
+  run_groups_v<NG, GL, Cnt>(load, finish);
 }
 template <int EPI, bool HB, bool DUAL, int MT, int NT>
 __device__ __forceinline__ void epilogue_pair(const GemmArgs& p, f32x4 (&acc)[MT][NT], int m0, int n0, int wr, int wc, int lane) {
@@ -326,7 +383,11 @@ __device__ __forceinline__ void epilogue_rope32(const GemmArgs& p, f32x4 (&acc)[
 
 // vector-memory stores one wave issues per tile (for the store-tolerant wait that follows the epilogue)
 template <int EPI, bool DUAL, int MT, int NT> constexpr int epilogue_stores() {
-  if (EPI == ONEPROT_EPI_BF16 || EPI == ONEPROT_EPI_GELU_BWD || EPI == ONEPROT_EPI_BIAS_GELU) return MT * NT / 2 * (DUAL ? 2 : 1);
+  if (EPI == ONEPROT_EPI_BIAS_GELU && DUAL) {               // out0 in 16-byte pieces; the one-byte out1 in 16-byte pieces for paired units, 8-byte for the lone half line
+    const int lone_units = (((NT / 2) & 1) != 0) ? MT : 0;
+    return MT * NT / 2 + lone_units + (MT * NT / 2 - lone_units) / 2;
+  }
+  if (EPI == ONEPROT_EPI_BF16 || EPI == ONEPROT_EPI_GELU_BWD || EPI == ONEPROT_EPI_BIAS_GELU) return MT * NT / 2;
   if (EPI == ONEPROT_EPI_QKV_ROPE) return MT * NT / 2;      // head_dim 32: one 16-byte store per head and row block (head_dim 64 issues twice as many: the smaller count is the safe one)
   return MT * NT * (DUAL ? 2 : 1);      // F32, BIAS_RESID (fp32 + optional bf16 copy)
 }

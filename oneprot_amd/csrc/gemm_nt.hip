@@ -135,13 +135,9 @@ __device__ __forceinline__ void gemm_epilogue(const GemmArgs& p, f32x4 (&acc)[MT
       gst(c, v[0], v[1], v[2], v[3], p.nt_store);
       gst(c + 4, v[4], v[5], v[6], v[7], p.nt_store);
     } else if (EPI == ONEPROT_EPI_BIAS_GELU) {
-      float dg[8];
-#pragma unroll
-      for (int e = 0; e < 8; ++e) gelu_fwd_and_grad(v[e], v[e], dg[e]);
-      if (p.out1) {          // gelu'(z), consumed by the GELU_BWD epilogue of the dgrad GEMM
-        u32x4 z; z.x = pack2bf(dg[0], dg[1]); z.y = pack2bf(dg[2], dg[3]); z.z = pack2bf(dg[4], dg[5]); z.w = pack2bf(dg[6], dg[7]);
-        gst(reinterpret_cast<u32x4*>((bf16_t*)p.out1 + o), z, p.nt_store);
-      }
+      if (p.out1) {          // gelu'(z) codes, consumed by the GELU_BWD epilogue of the dgrad GEMM
+        gst(reinterpret_cast<u32x2*>((unsigned char*)p.out1 + o), gelu_fwd_and_code8(v), p.nt_store);
+      } else gelu_fwd_only8(v);
       u32x4 w; w.x = pack2bf(v[0], v[1]); w.y = pack2bf(v[2], v[3]); w.z = pack2bf(v[4], v[5]); w.w = pack2bf(v[6], v[7]);
       gst(reinterpret_cast<u32x4*>((bf16_t*)p.out0 + o), w, p.nt_store);
     } else if (EPI == ONEPROT_EPI_BIAS_RESID) {
@@ -156,9 +152,8 @@ __device__ __forceinline__ void gemm_epilogue(const GemmArgs& p, f32x4 (&acc)[MT
         gst(reinterpret_cast<u32x4*>((bf16_t*)p.out1 + o), w, p.nt_store);
       }
     } else if (EPI == ONEPROT_EPI_GELU_BWD) {
-      const u32x4 z = *reinterpret_cast<const u32x4*>((const bf16_t*)p.aux + o);     // aux = gelu'(z) saved by the forward epilogue
-      v[0] *= bflo(z.x); v[1] *= bfhi(z.x); v[2] *= bflo(z.y); v[3] *= bfhi(z.y);
-      v[4] *= bflo(z.z); v[5] *= bfhi(z.z); v[6] *= bflo(z.w); v[7] *= bfhi(z.w);
+      const u32x2 z = *reinterpret_cast<const u32x2*>((const unsigned char*)p.aux + o);     // aux = gelu'(z) codes saved by the forward epilogue (gemm_epi.h)
+      gelu_grad_apply8(v, z.x, z.y);
       u32x4 w; w.x = pack2bf(v[0], v[1]); w.y = pack2bf(v[2], v[3]); w.z = pack2bf(v[4], v[5]); w.w = pack2bf(v[6], v[7]);
       gst(reinterpret_cast<u32x4*>((bf16_t*)p.out0 + o), w, p.nt_store);
     } else if (EPI == ONEPROT_EPI_QKV_ROPE) {
@@ -662,17 +657,12 @@ __device__ __forceinline__ void pp_chunk(const GemmArgs& p, f32x4 (&acc)[MT][NTW
     for (int r = 0; r < 4; ++r) { v[r] = acc[i][2 * pp][r]; v[4 + r] = acc[i][2 * pp + 1][r]; }
     if (EPI == ONEPROT_EPI_BIAS_GELU) {
       if (p.out1 != nullptr) {
-        float dg[8];
-#pragma unroll
-        for (int e = 0; e < 8; ++e) gelu_fwd_and_grad(v[e], v[e], dg[e]);
-        u32x4 z; z.x = pack2bf(dg[0], dg[1]); z.y = pack2bf(dg[2], dg[3]); z.z = pack2bf(dg[4], dg[5]); z.w = pack2bf(dg[6], dg[7]);
-        *reinterpret_cast<u32x4*>(reinterpret_cast<unsigned char*>((bf16_t*)p.out1 + uo) + lane_off) = z;
+        *reinterpret_cast<u32x2*>((unsigned char*)p.out1 + uo + (lane_off >> 1)) = gelu_fwd_and_code8(v);      // one byte per element: half the bf16 lane offset
       } else {
         gelu_fwd_only8(v);
       }
     } else if (EPI == ONEPROT_EPI_GELU_BWD) {
-      v[0] *= bflo(aux16.x); v[1] *= bfhi(aux16.x); v[2] *= bflo(aux16.y); v[3] *= bfhi(aux16.y);
-      v[4] *= bflo(aux16.z); v[5] *= bfhi(aux16.z); v[6] *= bflo(aux16.w); v[7] *= bfhi(aux16.w);
+      gelu_grad_apply8(v, aux16.x, aux16.y);
     }
     u32x4 w; w.x = pack2bf(v[0], v[1]); w.y = pack2bf(v[2], v[3]); w.z = pack2bf(v[4], v[5]); w.w = pack2bf(v[6], v[7]);
     *reinterpret_cast<u32x4*>(reinterpret_cast<unsigned char*>((bf16_t*)p.out0 + uo) + lane_off) = w;

@@ -40,6 +40,7 @@ struct LnArgs {
   const float* gamma; const float* beta; float eps;
   bf16_t* h_out; float* mean; float* rstd;
   int tiles;
+  int late_ticks;
 };
 
 __device__ __forceinline__ void bar() { asm volatile("s_barrier" ::: "memory"); }
@@ -319,6 +320,267 @@ __global__ void __launch_bounds__(512, 2) k_gemm_ln(const LnArgs p) {
   }
 }
 
+
+// ------------------------------------------------------------------------------------------------------------------------------------------
+// FOUR-WAVE form, two work-groups per CU (round 5).  The launch is an HBM kernel (1.01 GB against 107 GFLOP at K = 640): the eight-wave kernel above
+// spends 70 us in its K loops with the HBM idle and 183 us in its epilogues with the matrix pipe idle, and every CU reaches both together.  Here a
+// work-group is ONE wave group (4 waves, one per SIMD, the same 64 x 160 wave tile) on a 64 x 640 tile with half the LDS (76 KB: three weight
+// units + two activation tiles), so two independent work-groups share a CU and one's K loop runs under the other's epilogue -- they drift apart
+// by themselves (a work-group waiting on its stores does not hold the other back), and chip-wide 512 work-groups keep the memory system busy.
+// The K loop is not software-pipelined (read -> wait -> 20 MFMAs -> counted vmcnt -> barrier): it has the partner work-group's wave to fill the SIMD
+// and only a quarter of the launch's time to account for.  Same packed weight, same epilogue arithmetic (bit-identical results).
+namespace g1 {
+constexpr int BM = 64, NWU = 3;
+constexpr int A_UNIT = BM * 128;                                                           // 8 KB: 8 pieces, 2 per wave
+constexpr int OFF_W = NA * A_UNIT, OFF_S = OFF_W + NWU * W_UNIT, LDS = OFF_S + 2048;       // 16 + 60 + 2 KB
+static_assert(2 * LDS <= 160 * 1024, "two work-groups per CU");
+}
+
+__global__ void __launch_bounds__(256, 2) k_gemm_ln4(const LnArgs p) {
+  extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+  const int tid = threadIdx.x, lane = tid & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int wc = wave;                                      // wave tile: all 64 rows, columns 160 wc .. +159
+  const int nk = p.K >> 6;
+  const int PH = 4 * nk;                                    // phases (= weight units) per output tile
+  const int G = gridDim.x;
+  const int Q = p.tiles > (int)blockIdx.x ? (p.tiles - (int)blockIdx.x + G - 1) / G : 0;
+  if (Q == 0) return;
+  const unsigned lds0 = (unsigned)(uintptr_t)LDS_PTR(smem);
+  // de-phasing: the work-groups of the grid's second half (the second work-group of every CU under in-order dispatch) start `late_ticks` of the
+  // 100 MHz wall clock late, so that their epilogues fall on the first half's K loops
+  if (p.late_ticks > 0 && (int)blockIdx.x >= (G >> 1)) {
+    const long long t0 = (long long)__builtin_amdgcn_s_memrealtime();
+    while ((long long)__builtin_amdgcn_s_memrealtime() - t0 < p.late_ticks) __builtin_amdgcn_s_sleep(16);
+  }
+
+  const int sr = lane >> 3, sc = lane & 7;
+  unsigned a_voff[2];
+#pragma unroll
+  for (int i = 0; i < 2; ++i) {
+    const int row = (i * 4 + wave) * 8 + sr;                // piece i * 4 + wave covers rows 8 piece .. + 7 of the 64-row tile
+    a_voff[i] = (unsigned)row * (unsigned)p.lda * 2u + (unsigned)(sc ^ ((row >> 1) & 7)) * 16u;
+  }
+  const unsigned w_voff = (unsigned)lane * 16u;
+  auto issue_a = [&](const unsigned char* abase, int slot) {
+#pragma unroll
+    for (int i = 0; i < 2; ++i) glds16(a_voff[i], abase, lds0 + slot * g1::A_UNIT + (i * 4 + wave) * 1024);
+  };
+  auto issue_w = [&](const unsigned char* wbase, int slot) {
+#pragma unroll
+    for (int i = 0; i < 5; ++i) glds16(w_voff, wbase + (i * 4 + wave) * 1024, lds0 + g1::OFF_W + slot * W_UNIT + (i * 4 + wave) * 1024);
+  };
+  int wq = 0, wu = 0, wslot = 0;
+  int aq = 0, as = 0, aslot = 0;
+  auto a_ptr = [&](int q, int s) { return reinterpret_cast<const unsigned char*>(p.A + (size_t)(((int)blockIdx.x + q * G) * g1::BM) * p.lda) + (size_t)s * 128; };
+  auto next_w = [&]() { if (wq < Q) issue_w(p.Wp + (size_t)wu * W_UNIT, wslot); if (++wu == PH) { wu = 0; ++wq; } wslot = wslot + 1 == g1::NWU ? 0 : wslot + 1; };
+  auto next_a = [&]() { if (aq < Q) issue_a(a_ptr(aq, as), aslot); if (++as == nk) { as = 0; ++aq; } aslot ^= 1; };
+
+  const int fr = lane & 15, fq = lane >> 4;
+  const unsigned a_rd = (unsigned)fr * 128u + (unsigned)((fq ^ (fr >> 1)) << 4);
+  const unsigned w_rd = g1::OFF_W + (unsigned)(wc * 80 + fr) * 64u + (unsigned)((fq ^ ((fr >> 1) & 3)) << 4);
+
+  f32x4 acc[MT][NT];
+  auto zero_acc = [&]() {
+    float z = 0.f;
+    asm volatile("" : "+v"(z));
+#pragma unroll
+    for (int i = 0; i < MT; ++i)
+#pragma unroll
+      for (int j = 0; j < NT; ++j) acc[i][j] = (f32x4){z, z, z, z};
+  };
+  zero_acc();
+  bf8_t fa[MT], fb[NH];
+
+  // One phase = (K-slab KK of the activation tile, column half HALF) = one weight unit.  Entered behind a barrier that every wave passed after it
+  // had (i) waited for its share of this phase's operands and (ii) retired its reads of the previous phase: the unit two phases ahead goes into the
+  // slot read in the previous phase.  `tail`: 0 counted wait (the next unit was requested one phase ago: only this phase's requests are younger),
+  // 1 the next unit was requested BEFORE the epilogue (its >= 63 younger stores and loads: any count <= 63 covers it), 2 drain.
+  int rslot = 0;
+  bool skip_w = false;                                      // the unit this phase would request went out ahead of the last epilogue
+  auto phase = [&](auto kkc, auto halfc, int abuf, const int tail, const bool a_too) {
+    constexpr int KK = decltype(kkc)::value, HALF = decltype(halfc)::value;
+    if constexpr (HALF == 0) {
+      const unsigned char* ab = smem + abuf * g1::A_UNIT;
+#pragma unroll
+      for (int mt = 0; mt < MT; ++mt) fa[mt] = *reinterpret_cast<const bf8_t*>(ab + ((a_rd + mt * 2048) ^ (KK << 6)));
+    }
+    const unsigned char* wb = smem + rslot * W_UNIT;
+#pragma unroll
+    for (int nt = 0; nt < NH; ++nt) fb[nt] = *reinterpret_cast<const bf8_t*>(wb + w_rd + nt * 1024);
+    __builtin_amdgcn_sched_barrier(0);
+    if (!skip_w) next_w();                                  // two phases ahead, into the slot read one phase ago
+    skip_w = false;
+    if (a_too) next_a();                                    // (KK, HALF) == (1, 1): the activation tile two K-tiles ahead, into the buffer whose last read was one phase ago
+    wait_lgkm<0>();
+    __builtin_amdgcn_sched_barrier(0);
+    __builtin_amdgcn_s_setprio(1);
+#pragma unroll
+    for (int mt = 0; mt < MT; ++mt)
+#pragma unroll
+      for (int nt = 0; nt < NH; ++nt)
+        acc[mt][HALF * NH + nt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(fb[nt], fa[mt], acc[mt][HALF * NH + nt], 0, 0, 0);
+    __builtin_amdgcn_s_setprio(0);
+    __builtin_amdgcn_sched_barrier(0);
+    // younger than the next phase's unit: this phase's weight request (5 pieces per wave) and, in the phases (1, 1) / (0, 0), the activation tile
+    // requested in / one phase before this one (2 pieces; it is read four / three phases from now)
+    if (tail == 2) wait_vmcnt<0>();
+    else if (tail == 1) wait_vmcnt<63>();
+    else if (KK == HALF) wait_vmcnt<5 + 2>(); else wait_vmcnt<5>();
+    bar();
+    rslot = rslot + 1 == g1::NWU ? 0 : rslot + 1;
+  };
+
+  // ---- prologue: A(0), W(0), W(1), A(1) requested; A(0), W(0) landed
+  next_a(); next_w(); next_w(); next_a();
+  if (Q * nk < 2) wait_vmcnt<0>(); else wait_vmcnt<5 + 2>();
+  bar();
+
+  const int c = lane & 15, q4 = lane >> 4;
+  const int rsr = lane >> 2, rsq = lane & 3;
+  const int pa = to_rows_addr(lane);
+  float* scratch = reinterpret_cast<float*>(smem + g1::OFF_S);      // [64 rows][4 column waves][2]
+  int abuf = 0;
+  long done = 0;
+  const long total = (long)Q * PH;
+  int behind = 0;                                           // phases whose NEXT unit was requested before the last epilogue
+#pragma clang loop unroll(disable)
+  for (int q = 0; q < Q; ++q) {
+#pragma clang loop unroll(disable)
+    for (int s = 0; s < nk; ++s) {
+      // tail of phase d: the unit of phase d + 1 must have landed; nothing is requested beyond the stream's end
+      // (the counted waits assume that every request of the steady state was really issued: over the stream's last two K-tiles, where the activation
+      // and then the weight requests run out, the waits drain instead)
+      auto tl = [&]() { const int t = done + 8 > total ? 2 : (behind > 0 ? 1 : 0); if (behind > 0) --behind; ++done; return t; };
+      { const int t = tl(); phase(std::integral_constant<int, 0>{}, std::integral_constant<int, 0>{}, abuf, t, false); }
+      { const int t = tl(); phase(std::integral_constant<int, 0>{}, std::integral_constant<int, 1>{}, abuf, t, false); }
+      { const int t = tl(); phase(std::integral_constant<int, 1>{}, std::integral_constant<int, 0>{}, abuf, t, false); }
+      { const int t = tl(); phase(std::integral_constant<int, 1>{}, std::integral_constant<int, 1>{}, abuf, t, true); }
+      abuf ^= 1;
+    }
+    // the slot of the tile's last unit is free (its reads retired before the closing barrier): the third unit of the next tile is requested ahead of the
+    // epilogue, so that the first two phases of the next tile wait for nothing issued behind the stores
+    if (q + 1 < Q) { next_w(); skip_w = true; behind = 2; }
+
+    // =========================== epilogue: x = acc + bias + resid ; h = LayerNorm(x) (the arithmetic of k_gemm_ln) ===========================
+    const int m0 = ((int)blockIdx.x + q * G) * g1::BM;
+    const size_t o0 = (size_t)(m0 + rsr) * BN + wc * 160 + rsq * 4;
+    const size_t rstep = (size_t)16 * BN;
+    const unsigned bias_off = (unsigned)(wc * 160 + q4 * 4) * 4u;
+    const unsigned row_off = (unsigned)(rsr * BN + wc * 160 + rsq * 4) * 4u;
+    const float* res_t = p.resid + (size_t)m0 * BN;
+    float* xo = p.x_out + o0;
+    float s1[MT] = {0.f, 0.f, 0.f, 0.f};
+    {
+      constexpr int GL = 2 + 4, GS = 4, NG = (NT / 2) * (MT / 2);
+      auto load = [&](auto gc, u32x4 (&r)[GL]) {
+        constexpr int g = decltype(gc)::value, a2 = 2 * (g / (MT / 2)), i2 = 2 * (g % (MT / 2));
+        gload16s<a2 * 64>(r[0], bias_off, p.bias);
+        gload16s<(a2 + 1) * 64>(r[1], bias_off, p.bias);
+        gload16s<a2 * 64>(r[2], row_off, res_t + i2 * rstep);
+        gload16s<(a2 + 1) * 64>(r[3], row_off, res_t + i2 * rstep);
+        gload16s<a2 * 64>(r[4], row_off, res_t + (i2 + 1) * rstep);
+        gload16s<(a2 + 1) * 64>(r[5], row_off, res_t + (i2 + 1) * rstep);
+      };
+      auto finish = [&](auto gc, const u32x4 (&r)[GL]) {
+        constexpr int g = decltype(gc)::value, a2 = 2 * (g / (MT / 2)), i2 = 2 * (g % (MT / 2));
+        float h0, h1, h2, h3;
+        g8::static_for([&](auto uc) {
+          constexpr int u = decltype(uc)::value, j = a2 + (u & 1), i = i2 + (u >> 1);
+          u32x4 a;
+          a.x = __builtin_bit_cast(unsigned, acc[i][j][0] + as_f(r[u & 1].x)); a.y = __builtin_bit_cast(unsigned, acc[i][j][1] + as_f(r[u & 1].y));
+          a.z = __builtin_bit_cast(unsigned, acc[i][j][2] + as_f(r[u & 1].z)); a.w = __builtin_bit_cast(unsigned, acc[i][j][3] + as_f(r[u & 1].w));
+          a = lane_perm(pa, a);
+          const u32x4 t = r[2 + u];
+          const float x0 = as_f(a.x) + as_f(t.x), x1 = as_f(a.y) + as_f(t.y), x2 = as_f(a.z) + as_f(t.z), x3 = as_f(a.w) + as_f(t.w);
+          acc[i][j] = (f32x4){x0, x1, x2, x3};
+          s1[i] += (x0 + x1) + (x2 + x3);
+          if constexpr ((u & 1) == 0) { h0 = x0; h1 = x1; h2 = x2; h3 = x3; }
+          else {
+            __builtin_amdgcn_sched_barrier(0);
+            gst(xo + i * rstep + (j - 1) * 16, h0, h1, h2, h3, 0);
+            gst(xo + i * rstep + j * 16, x0, x1, x2, x3, 0);
+            __builtin_amdgcn_sched_barrier(0);
+          }
+        }, std::make_integer_sequence<int, 4>{});
+      };
+      run_groups<NG, GL, GS>(load, finish);
+    }
+    float mw[MT], m2[MT];
+#pragma unroll
+    for (int i = 0; i < MT; ++i) {
+      float s = s1[i];
+      s += __shfl_xor(s, 1, 64); s += __shfl_xor(s, 2, 64);
+      mw[i] = s * (1.0f / 160.0f);
+      float qv = 0.f;
+#pragma unroll
+      for (int j = 0; j < NT; ++j) {
+        const float a = acc[i][j][0] - mw[i], b = acc[i][j][1] - mw[i], cc = acc[i][j][2] - mw[i], d = acc[i][j][3] - mw[i];
+        qv += (a * a + b * b) + (cc * cc + d * d);
+      }
+      qv += __shfl_xor(qv, 1, 64); qv += __shfl_xor(qv, 2, 64);
+      m2[i] = qv;
+      if (rsq == 0) *reinterpret_cast<float2*>(scratch + ((i * 16 + rsr) * 4 + wc) * 2) = make_float2(mw[i], qv);
+    }
+    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+    bar();
+    float mean[MT], rstd[MT];
+#pragma unroll
+    for (int i = 0; i < MT; ++i) {
+      const float4 p01 = *reinterpret_cast<const float4*>(scratch + (i * 16 + rsr) * 8);
+      const float4 p23 = *reinterpret_cast<const float4*>(scratch + (i * 16 + rsr) * 8 + 4);
+      const float mu = ((p01.x + p01.z) + (p23.x + p23.z)) * 0.25f;
+      const float d0 = p01.x - mu, d1 = p01.z - mu, d2 = p23.x - mu, d3 = p23.z - mu;
+      const float M2 = ((p01.y + p01.w) + (p23.y + p23.w)) + 160.0f * ((d0 * d0 + d1 * d1) + (d2 * d2 + d3 * d3));
+      mean[i] = mu;
+      rstd[i] = rsqrtf(M2 * (1.0f / 640.0f) + p.eps);
+      if (wc == 0 && rsq == 0) {
+        if (p.mean) p.mean[m0 + i * 16 + rsr] = mu;
+        if (p.rstd) p.rstd[m0 + i * 16 + rsr] = rstd[i];
+      }
+    }
+    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+    bar();
+    {
+      constexpr int GL = 4, GS = MT, NG = NT / 2;
+      const unsigned gb_off = (unsigned)(wc * 160 + rsq * 4) * 4u;
+      bf16_t* ho = p.h_out + (size_t)(m0 + rsr) * BN + wc * 160 + (rsq & 1) * 16 + (rsq >> 1) * 8;
+      const bool odd = (rsq & 1) != 0;
+      auto pass2 = [&](auto oddc) {
+        constexpr bool ODDW = decltype(oddc)::value;
+        auto load = [&](auto gc, u32x4 (&r)[GL]) {
+          constexpr int g = decltype(gc)::value, j = 2 * (ODDW ? g : (g + NG - 1) % NG);
+          gload16s<j * 64>(r[0], gb_off, p.gamma); gload16s<j * 64>(r[1], gb_off, p.beta);
+          gload16s<(j + 1) * 64>(r[2], gb_off, p.gamma); gload16s<(j + 1) * 64>(r[3], gb_off, p.beta);
+        };
+        auto finish = [&](auto gc, const u32x4 (&r)[GL]) {
+          constexpr int g = decltype(gc)::value, a = ODDW ? g : (g + NG - 1) % NG, j = 2 * a;
+#pragma unroll
+          for (int i = 0; i < MT; ++i) {
+            u32x2 w[2];
+#pragma unroll
+            for (int t = 0; t < 2; ++t) {
+              const u32x4 ga = r[2 * t], be = r[2 * t + 1];
+              const float h0 = (acc[i][j + t][0] - mean[i]) * rstd[i] * as_f(ga.x) + as_f(be.x), h1 = (acc[i][j + t][1] - mean[i]) * rstd[i] * as_f(ga.y) + as_f(be.y);
+              const float h2 = (acc[i][j + t][2] - mean[i]) * rstd[i] * as_f(ga.z) + as_f(be.z), h3 = (acc[i][j + t][3] - mean[i]) * rstd[i] * as_f(ga.w) + as_f(be.w);
+              w[t].x = pack2bf(h0, h1); w[t].y = pack2bf(h2, h3);
+            }
+            const unsigned sx = odd ? w[0].x : w[1].x, sy = odd ? w[0].y : w[1].y;
+            const unsigned rx = (unsigned)__builtin_amdgcn_update_dpp(0, (int)sx, 0xB1, 0xF, 0xF, false);
+            const unsigned ry = (unsigned)__builtin_amdgcn_update_dpp(0, (int)sy, 0xB1, 0xF, 0xF, false);
+            u32x4 o;
+            o.x = odd ? rx : w[0].x; o.y = odd ? ry : w[0].y; o.z = odd ? w[1].x : rx; o.w = odd ? w[1].y : ry;
+            gst(reinterpret_cast<u32x4*>(ho + i * rstep + a * 32), o, 0);
+          }
+        };
+        run_groups<NG, GL, GS>(load, finish);
+      };
+      if (wc & 1) pass2(std::true_type{}); else pass2(std::false_type{});
+    }
+    zero_acc();
+  }
+}
+
 }  // namespace gln
 
 // W bf16 [640, K] -> packed units for oneprot_gemm_bf16_nt_resid_ln (K * 640 * 2 bytes)
@@ -330,6 +592,10 @@ extern "C" int oneprot_gemm_ln_pack_weight(const void* W, void* Wp, int N, int K
   return launch_status();
 }
 
+// test / experiment hook: 0 = eight-wave kernel (128-row tiles, one work-group per CU; default), 1 = four-wave kernel (64-row tiles, two per CU)
+static int g_gln_form = 0;
+extern "C" void oneprot_gemm_ln_form(int form) { g_gln_form = form; }
+
 extern "C" int oneprot_gemm_bf16_nt_resid_ln(const void* A, const void* Wp, int64_t M, int N, int K, int lda, const float* bias, const float* resid, float* x_out,
                                              const float* gamma, const float* beta, float eps, void* h_out, float* mean, float* rstd, void* stream) {
   if (!A || !Wp || !bias || !resid || !x_out || !gamma || !beta || !h_out || M <= 0 || M > 0x7fffffff) return OP_EINVAL;
@@ -339,6 +605,7 @@ extern "C" int oneprot_gemm_bf16_nt_resid_ln(const void* A, const void* Wp, int6
   static int n_cu = 0;
   if (!configured) {
     if (hipFuncSetAttribute((const void*)gln::k_gemm_ln, hipFuncAttributeMaxDynamicSharedMemorySize, gln::LDS) != hipSuccess) return OP_ELAUNCH;
+    if (hipFuncSetAttribute((const void*)gln::k_gemm_ln4, hipFuncAttributeMaxDynamicSharedMemorySize, gln::g1::LDS) != hipSuccess) return OP_ELAUNCH;
     int dev = 0; hipDeviceProp_t prop;
     if (hipGetDevice(&dev) != hipSuccess || hipGetDeviceProperties(&prop, dev) != hipSuccess) return OP_ELAUNCH;
     n_cu = prop.multiProcessorCount;
@@ -346,8 +613,16 @@ extern "C" int oneprot_gemm_bf16_nt_resid_ln(const void* A, const void* Wp, int6
   }
   gln::LnArgs a;
   a.A = (const bf16_t*)A; a.Wp = (const unsigned char*)Wp; a.M = (int)M; a.K = K; a.lda = lda; a.bias = bias; a.resid = resid; a.x_out = x_out;
-  a.gamma = gamma; a.beta = beta; a.eps = eps; a.h_out = (bf16_t*)h_out; a.mean = mean; a.rstd = rstd; a.tiles = (int)(M / gln::BM);
-  const int grid = a.tiles < n_cu ? a.tiles : n_cu;
-  hipLaunchKernelGGL(gln::k_gemm_ln, dim3(grid), dim3(512), gln::LDS, (hipStream_t)stream, a);
+  a.gamma = gamma; a.beta = beta; a.eps = eps; a.h_out = (bf16_t*)h_out; a.mean = mean; a.rstd = rstd;
+  a.late_ticks = (g_gln_form >> 8) * 100;                       // (experiment: form | delay in microseconds << 8)
+  if ((g_gln_form & 255) == 1) {
+    a.tiles = (int)(M / gln::g1::BM);
+    const int grid = a.tiles < 2 * n_cu ? a.tiles : 2 * n_cu;
+    hipLaunchKernelGGL(gln::k_gemm_ln4, dim3(grid), dim3(256), gln::g1::LDS, (hipStream_t)stream, a);
+  } else {
+    a.tiles = (int)(M / gln::BM);
+    const int grid = a.tiles < n_cu ? a.tiles : n_cu;
+    hipLaunchKernelGGL(gln::k_gemm_ln, dim3(grid), dim3(512), gln::LDS, (hipStream_t)stream, a);
+  }
   return launch_status();
 }

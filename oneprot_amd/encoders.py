@@ -620,7 +620,7 @@ class StructEncoder(BaseEncoder):
 
 class TextEncoder(BaseEncoder):
     """ref text_encoder.py:8-62: BERT text tower (frozen in every shipped config, text.yaml:12; `frozen=False` -- the signature default --
-    trains it through the hand-written BERT backward of oneprot_amd/bert.py).  Dropout runs at p = 0 unless `transformer.train_dropout` / ONEPROT_BERT_DROPOUT=1 asks for HF's train-mode dropout (see bert.py)."""
+    trains it through the hand-written BERT backward of oneprot_amd/bert.py).  HF's train-mode dropout is active in train mode, as in the reference (frozen tower included); `transformer.train_dropout = False` / ONEPROT_BERT_DROPOUT=0 / `.eval()` run p = 0 (see bert.py)."""
 
     def __init__(self, model_name_or_path: str, output_dim: int, pooling_type: str = "mean", proj_type: str = "linear", use_logit_scale: bool = False,
                  learnable_logit_scale: bool = False, frozen: bool = False, use_lora: bool = False, lora_r: int = 8, lora_alpha: int = 16,

@@ -696,7 +696,7 @@ class EsmTransformer(ArenaModule):
             p = f"encoder.layer.{i}."
             if save:
                 st = dict(x_in=x, mean1=f32(T), rstd1=f32(T), mean2=f32(T), rstd2=f32(T), h1=b16(T, d), q=b16(B, H, L, hd), k=b16(B, H, L, hd),
-                          v=b16(B, H, L, hd), ctx=b16(T, dp), lse=f32(B, H, L), h2=b16(T, d), z=b16(T, f), u=b16(T, f))
+                          v=b16(B, H, L, hd), ctx=b16(T, dp), lse=f32(B, H, L), h2=b16(T, d), z=torch.empty(T, f, dtype=torch.uint8, device=dev), u=b16(T, f))
                 h1, q, k, v, ctx_, h2, u, z = st["h1"], st["q"], st["k"], st["v"], st["ctx"], st["h2"], st["u"], st["z"]
                 m1, r1, m2, r2, lse = st["mean1"], st["rstd1"], st["mean2"], st["rstd2"], st["lse"]
             else:

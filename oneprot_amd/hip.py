@@ -49,6 +49,7 @@ _SIGS = {
     "oneprot_gemm_bf16_nt": (I, [P, P, L64, I, I, I, I, I, P, P, P, P, P, P, P, F, I, I, I, P]),
     "oneprot_gemm_ln_pack_weight": (I, [P, P, I, I, P]),
     "oneprot_gemm_bf16_nt_resid_ln": (I, [P, P, L64, I, I, I, P, P, P, P, P, F, P, P, P, P]),
+    "oneprot_gemm_ln_form": (None, [I]),
     "oneprot_gemm_force_shape": (None, [I]),
     "oneprot_gemm_tune": (None, [I, I]),
     "oneprot_gemm_bf16_tn_workspace": (SZ, [I, I]),

@@ -172,13 +172,19 @@ def test_gemm_nt_epilogues(M, N, K, gemm_shape):
     assert_close(outf, ref, 1e-4, 1e-3 * math.sqrt(K / 64), "EPI_F32")
     # bias + gelu (+z)
     u = torch.empty(M, N, dtype=torch.bfloat16, device=DEV)
-    z = torch.empty(M, N, dtype=torch.bfloat16, device=DEV)
+    z = torch.empty(M, N, dtype=torch.uint8, device=DEV)                 # gelu'(z) as one-byte codes c = rint(192 g' + 25) (include/oneprot_hip.h)
     hip.call("oneprot_gemm_bf16_nt", A, W, M, N, K, K, K, hip.EPI_BIAS_GELU, bias, u, z, None, None, None, None, 1.0, 0, 0, 0)
     zr = (ref + bias).requires_grad_(True)
     gz = torch.nn.functional.gelu(zr)
     gz.sum().backward()
     assert_close(u, gz.detach(), 2 ** -7, 2e-2, "gelu(z)")
-    assert_close(z, zr.grad, 2 ** -7, 1e-2, "gelu'(z)")
+    zdec = (z.float() - 25.0) / 192.0
+    # half a code step (1/384) + the slope of gelu' (<= 0.8) times the bf16-operand error of z itself; exact at the saturated ends
+    assert float((zdec - zr.grad).abs().max()) < 1 / 384 + 2e-3, "gelu'(z) codes"
+    assert float((zdec - zr.grad).abs().mean()) < 1.6e-3
+    sat = zr.detach().abs() > 6.0
+    if bool(sat.any()):
+        assert torch.equal(zdec[sat], (zr.detach()[sat] > 0).float())
     u2 = torch.empty(M, N, dtype=torch.bfloat16, device=DEV)            # forward-only form (frozen tower): no derivative output
     hip.call("oneprot_gemm_bf16_nt", A, W, M, N, K, K, K, hip.EPI_BIAS_GELU, bias, u2, None, None, None, None, None, 1.0, 0, 0, 0)
     assert_close(u2, gz.detach(), 2 ** -7, 2e-2, "gelu(z), no derivative")
@@ -195,14 +201,46 @@ def test_gemm_nt_epilogues(M, N, K, gemm_shape):
     # gelu backward epilogue
     dz = torch.empty(M, N, dtype=torch.bfloat16, device=DEV)
     hip.call("oneprot_gemm_bf16_nt", A, W, M, N, K, K, K, hip.EPI_GELU_BWD, None, dz, None, None, z, None, None, 1.0, 0, 0, 0)
-    assert_close(dz, ref * z.float(), 2 ** -6, 3e-2, "gelu bwd")
+    assert_close(dz, ref * zdec, 2 ** -6, 3e-2, "gelu bwd")
 
 
-@pytest.mark.parametrize("M,K,inplace", [(128, 64, False), (256, 640, True), (1024, 2560, False), (33280, 640, True), (65536 + 128, 128, False)])
-def test_gemm_resid_layernorm_fused(M, K, inplace):
+@pytest.mark.parametrize("form", [1, 0])
+@pytest.mark.parametrize("M,K,inplace", [(128, 64, False), (256, 640, True), (1024, 2560, False), (33280, 640, True), (65536 + 128, 128, False), (98304 + 384, 192, True)])
+def test_gemm_resid_layernorm_fused(M, K, inplace, form):
     """Full-row N = 640 GEMM with bias + residual AND the following LayerNorm in the epilogue (oneprot_gemm_bf16_nt_resid_ln) against fp32 torch:
-    x (fp32), h = LN(x) (bf16), mean, rstd.  33280 rows = 260 tiles (work-groups with one and with two tiles: the operand stream crosses a tile
-    boundary behind an epilogue), 65664 rows = 513 tiles (two and three), K = 64 is a single K-tile, in-place residual as the frozen tower runs it."""
+    x (fp32), h = LN(x) (bf16), mean, rstd, both kernel forms (1: four waves on 64-row tiles, two work-groups per CU -- the default; 0: eight waves on
+    128-row tiles).  33280 rows = 260 / 520 tiles (work-groups with one and with two tiles: the operand stream crosses a tile boundary behind an
+    epilogue), 65664 rows = 513 / 1026 tiles (two and three), 98688 rows = 771 / 1542 (three and four), K = 64 is a single K-tile, K = 128 / 192 streams
+    of a few weight units only (requests run out inside the first tiles), in-place residual as the frozen tower runs it."""
+    hip.query("oneprot_gemm_ln_form", form)
+    try:
+        _gemm_resid_layernorm_fused(M, K, inplace)
+    finally:
+        hip.query("oneprot_gemm_ln_form", 1)
+
+
+def test_gemm_resid_layernorm_forms_bit_identical():
+    """the two kernel forms run the same arithmetic in the same order: equal bits"""
+    M, K, N = 4096, 640, 640
+    g = torch.Generator().manual_seed(12)
+    A = bf(torch.randn(M, K, generator=g)).to(DEV); W = bf(torch.randn(N, K, generator=g) * 0.1).to(DEV)
+    bias, gamma, beta = torch.randn(N, generator=g).to(DEV), torch.randn(N, generator=g).to(DEV), torch.randn(N, generator=g).to(DEV)
+    resid = torch.randn(M, N, generator=g).to(DEV)
+    Wp = torch.empty(N * K, dtype=torch.bfloat16, device=DEV)
+    hip.call("oneprot_gemm_ln_pack_weight", W, Wp, N, K)
+    outs = []
+    for form in (0, 1):
+        hip.query("oneprot_gemm_ln_form", form)
+        x, h = torch.empty(M, N, device=DEV), torch.empty(M, N, dtype=torch.bfloat16, device=DEV)
+        mean, rstd = torch.empty(M, device=DEV), torch.empty(M, device=DEV)
+        hip.call("oneprot_gemm_bf16_nt_resid_ln", A, Wp, M, N, K, K, bias, resid, x, gamma, beta, 1e-5, h, mean, rstd)
+        outs.append((x, h, mean, rstd))
+    hip.query("oneprot_gemm_ln_form", 1)
+    for a, b in zip(*outs):
+        assert torch.equal(a, b)
+
+
+def _gemm_resid_layernorm_fused(M, K, inplace):
     N = 640
     g = torch.Generator().manual_seed(11)
     A = bf(torch.randn(M, K, generator=g)).to(DEV)

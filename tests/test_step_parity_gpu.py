@@ -238,6 +238,7 @@ def test_text_encoder_vs_reference(golden_dir, tmp_path):
                        intermediate_size=cfg["ffn"], max_position_embeddings=cfg["max_pos"], pad_token_id=cfg["pad"], layer_norm_eps=cfg["eps"]), f)
     enc = TextEncoder(path, output_dim=cfg["output_dim"], pooling_type="cls", proj_type="mlp", use_logit_scale=True, learnable_logit_scale=False, frozen=True,
                       use_lora=False)
+    enc.transformer.train_dropout = False      # held against the eval-mode reference / oracle (the default follows the reference: HF's train-mode dropout)
     enc.load_state_dict(g["sd"], strict=True)
     enc = enc.to(DEV).eval()
     with torch.no_grad():
@@ -275,8 +276,8 @@ def _bert_keep_masks(tr, call, B, T):
 
 def test_text_encoder_train_mode_dropout_vs_oracle(golden_dir, tmp_path):
     """hf's train-mode dropout of the frozen BERT tower (embeddings, attention probabilities, the two dense outputs per layer; the reference leaves it
-    on in train mode: text_encoder.py:59), behind `transformer.train_dropout = True`: last hidden state and features against the oracle handed the masks
-    the HIP path drew; off by default; eval mode untouched; a second call draws new masks."""
+    on in train mode: text_encoder.py:59), ON by default in train mode since round 5: last hidden state and features against the oracle handed the masks
+    the HIP path drew; `transformer.train_dropout = False` switches it off; eval mode untouched; a second call draws new masks."""
     os.environ.update(RANK="0", WORLD_SIZE="1", ONEPROT_ALLOW_RANDOM_INIT="1")
     from oneprot_amd import hip
     from src.models.components.text_encoder import TextEncoder
@@ -295,10 +296,11 @@ def test_text_encoder_train_mode_dropout_vs_oracle(golden_dir, tmp_path):
     tr = enc.transformer
     ids = g["ids"]
     B, T = ids.shape
+    tr.train_dropout = False
     with torch.no_grad():
-        plain = enc(ids.to(DEV)).cpu()                                   # the option is off by default: train mode == eval mode
+        plain = enc(ids.to(DEV)).cpu()                                   # switched off: train mode == eval mode
     assert torch.nn.functional.cosine_similarity(plain, g["features"], dim=-1).min() > 0.999
-    tr.train_dropout = True
+    tr.train_dropout = None                                              # the default: follows the module's train / eval mode, as the reference's tower does
     assert (float(tr.config.hidden_dropout_prob), float(tr.config.attention_probs_dropout_prob)) == (0.1, 0.1)
     with torch.no_grad():
         feats = enc(ids.to(DEV)).cpu()
@@ -333,6 +335,7 @@ def test_trainable_text_encoder_gradients_vs_reference(golden_dir, tmp_path):
                        intermediate_size=cfg["ffn"], max_position_embeddings=cfg["max_pos"], pad_token_id=cfg["pad"], layer_norm_eps=cfg["eps"]), f)
     enc = TextEncoder(path, output_dim=cfg["output_dim"], pooling_type="mean", proj_type="linear", use_logit_scale=True, learnable_logit_scale=False, frozen=False,
                       use_lora=False)
+    enc.transformer.train_dropout = False      # held against the eval-mode reference / oracle (the default follows the reference: HF's train-mode dropout)
     enc.load_state_dict(g["sd"], strict=True)
     enc = enc.to(DEV)
     feats = enc(g["ids"].to(DEV))
@@ -425,6 +428,7 @@ def test_bert_base_shape_trainable_substep_vs_oracle():
     seq = SequenceEncoder("facebook/esm2_t6_8M_UR50D", output_dim=1024, pooling_type="mean", proj_type="mlp", use_lora=False, frozen=False)
     tx = TextEncoder("bert-base-uncased", output_dim=1024, pooling_type="cls", proj_type="mlp", use_logit_scale=True, learnable_logit_scale=False, frozen=False,
                      use_lora=False)
+    tx.transformer.train_dropout = False      # held against the eval-mode reference / oracle (the default follows the reference: HF's train-mode dropout)
     with torch.no_grad():
         for k, v in tx.transformer.named_views().items():
             if k.endswith(".bias"):
@@ -768,6 +772,7 @@ def test_lora_text_encoder_vs_oracle(golden_dir, tmp_path, lora_dropout):
                        intermediate_size=cfg["ffn"], max_position_embeddings=cfg["max_pos"], pad_token_id=cfg["pad"], layer_norm_eps=cfg["eps"]), f)
     enc = TextEncoder(path, output_dim=cfg["output_dim"], pooling_type="mean", proj_type="linear", use_logit_scale=True, frozen=True, use_lora=True, lora_r=4,
                       lora_alpha=16, lora_dropout=lora_dropout)
+    enc.transformer.train_dropout = False      # held against the eval-mode reference / oracle (the default follows the reference: HF's train-mode dropout)
     enc.load_state_dict(g["sd"], strict=False)           # base weights from the (adapter-free) fixture; adapters stay at their init
     with torch.no_grad():
         enc.transformer.lora_B.normal_(0, 0.05)
@@ -844,6 +849,7 @@ def test_mixed_batch_round_robin(golden_dir, tmp_path):
     seq = SequenceEncoder(p, output_dim=48, pooling_type="mean", proj_type="mlp", use_lora=False, frozen=True)
     st = StructTokenEncoder(p, output_dim=48, pooling_type="mean", proj_type="linear", use_logit_scale=True)
     tx = TextEncoder(pb, output_dim=48, pooling_type="cls", proj_type="mlp", use_logit_scale=True, frozen=True, use_lora=False)
+    tx.transformer.train_dropout = False      # held against the eval-mode reference / oracle (the default follows the reference: HF's train-mode dropout)
     seq.load_state_dict(g["sd_seq"]); st.load_state_dict(g["sd_st"]); tx.load_state_dict(tb["sd"])
     module = OneProtLitModule(components={"sequence": seq, "struct_token": st, "text": tx}, optimizer=functools.partial(FusedAdam, lr=1e-3), loss_fn="CLIP",
                               use_l1_regularization=True, train_on_all_modalities_after_step=1).to(DEV)

@@ -24,6 +24,8 @@ for spec in sys.argv[1:]:
         h.oneprot_gemm_force_shape(int(os.environ["AB_FORCE_SHAPE"]))
     if os.environ.get("AB_TUNE"):
         h.oneprot_gemm_tune(int(os.environ["AB_TUNE"]), 0)
+    if "@gln" in name and hasattr(h, "oneprot_gemm_ln_form"):      # e.g. old@gln0=product: the same library with the eight-wave fused GEMM + LN kernel
+        h.oneprot_gemm_ln_form(int(name.split("@gln")[1]))          # (form | start delay of the second half of the grid in us << 8)
 if not libs:
     sys.exit(__doc__)
 groups = os.environ.get("AB_CASES", "nt,gln,attn,tn").split(",")
