@@ -38,7 +38,7 @@ def ws(nbytes):
 
 # ------------------------------------------------------------------------------------------------------
 def test_library_loads():
-    assert hip.query("oneprot_abi_version") == 4
+    assert hip.query("oneprot_abi_version") == 5
 
 
 @pytest.mark.parametrize("B,L,d,vocab", [(3, 17, 64, 33), (4, 130, 640, 54)])
