@@ -182,6 +182,9 @@ int oneprot_key_padding_bias(const int64_t* ids, float* bias, int64_t n, int pad
 int oneprot_dropout_bf16(const void* x, void* y, int64_t n, float p, uint64_t seed, uint64_t stream_id, void* stream);
 /* the same on fp32 (hidden-state dropout of the BERT tower: hf modeling_bert.py BertEmbeddings / BertSelfOutput / BertOutput); y may alias x. */
 int oneprot_dropout_f32(const float* x, float* y, int64_t n, float p, uint64_t seed, uint64_t stream_id, void* stream);
+/* y = resid + dropout(x): the dense output's dropout and the residual add that follows it in BertSelfOutput / BertOutput (hf modeling_bert.py) in one pass;
+   the same mask as oneprot_dropout_f32 for the same (seed, stream_id); y may alias x or resid. */
+int oneprot_dropout_add_f32(const float* x, const float* resid, float* y, int64_t n, float p, uint64_t seed, uint64_t stream_id, void* stream);
 /* dx += mask(seed, stream_id) * dy / keep: the backward of the call above with the same (p, seed, stream_id), added into an existing bf16 gradient. */
 int oneprot_dropout_bwd_add_bf16(const void* dy, void* dx, int64_t n, float p, uint64_t seed, uint64_t stream_id, void* stream);
 /* the same into an fp32 gradient (the post-LN BERT tower keeps the layer-input gradient in fp32; ref text_encoder.py:39-52). */

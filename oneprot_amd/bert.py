@@ -190,8 +190,7 @@ class BertTransformer(ArenaModule):
                 # s1 = x + dropout(ctx Wo^T + bo): the residual add leaves the GEMM epilogue so that the mask can sit between the two
                 hip.call("oneprot_gemm_bf16_nt", ctx, self._w16(p + "attention.output.dense.weight"), T, d, d, d, d, hip.EPI_F32,
                          self.view(p + "attention.output.dense.bias"), y_drop, None, None, None, None, None, 1.0, 0, 0, 0)
-                hip.call("oneprot_dropout_f32", y_drop, y_drop, T * d, p_h, self._drop_seed, self._drop_stream(drop_call, i, 1))
-                torch.add(x, y_drop, out=s1)
+                hip.call("oneprot_dropout_add_f32", y_drop, x, s1, T * d, p_h, self._drop_seed, self._drop_stream(drop_call, i, 1))
             else:
                 hip.call("oneprot_attn_fwd", q, k, v, key_bias, ctx, lse, B, H, L, hd)
                 hip.call("oneprot_gemm_bf16_nt", ctx, self._w16(p + "attention.output.dense.weight"), T, d, d, d, d, hip.EPI_BIAS_RESID,
@@ -203,8 +202,7 @@ class BertTransformer(ArenaModule):
             if drop:
                 hip.call("oneprot_gemm_bf16_nt", u, self._w16(p + "output.dense.weight"), T, d, f, f, f, hip.EPI_F32, self.view(p + "output.dense.bias"),
                          y_drop, None, None, None, None, None, 1.0, 0, 0, 0)
-                hip.call("oneprot_dropout_f32", y_drop, y_drop, T * d, p_h, self._drop_seed, self._drop_stream(drop_call, i, 2))
-                torch.add(y1, y_drop, out=s2)
+                hip.call("oneprot_dropout_add_f32", y_drop, y1, s2, T * d, p_h, self._drop_seed, self._drop_stream(drop_call, i, 2))
             else:
                 hip.call("oneprot_gemm_bf16_nt", u, self._w16(p + "output.dense.weight"), T, d, f, f, f, hip.EPI_BIAS_RESID, self.view(p + "output.dense.bias"),
                          s2, None, None, y1, None, None, 1.0, 0, 0, 0)

@@ -283,9 +283,10 @@ __global__ void __launch_bounds__(256) k_dropout_bwd_add_f32(const u32x4* __rest
     dx[2 * i] = a; dx[2 * i + 1] = b;
   }
 }
-// y = dropout(x) on fp32 (hidden-state dropout of the BERT tower: hf modeling_bert.py BertEmbeddings / BertSelfOutput / BertOutput), in place allowed
-__global__ void __launch_bounds__(256) k_dropout_f32(const float4* __restrict__ x, float4* __restrict__ y, size_t n8, unsigned thr, float scale, unsigned long long seed,
-                                                     unsigned long long stream_id) {
+// y = dropout(x) [+ resid] on fp32 (hidden-state dropout of the BERT tower: hf modeling_bert.py BertEmbeddings / BertSelfOutput / BertOutput -- the two
+// dense outputs are added to the residual stream right after their dropout), in place allowed
+__global__ void __launch_bounds__(256) k_dropout_f32(const float4* __restrict__ x, const float4* __restrict__ resid, float4* __restrict__ y, size_t n8, unsigned thr, float scale,
+                                                     unsigned long long seed, unsigned long long stream_id) {
   for (size_t i = (size_t)blockIdx.x * 256 + threadIdx.x; i < n8; i += (size_t)gridDim.x * 256) {
     unsigned rnd[4];
     philox4x32_10((unsigned)i, (unsigned)(i >> 32), (unsigned)stream_id, (unsigned)(stream_id >> 32), (unsigned)seed, (unsigned)(seed >> 32), rnd);
@@ -296,17 +297,21 @@ __global__ void __launch_bounds__(256) k_dropout_f32(const float4* __restrict__ 
       *o[2 * j] = ((rnd[j] & 0xffffu) >= thr) ? *o[2 * j] * scale : 0.f;
       *o[2 * j + 1] = ((rnd[j] >> 16) >= thr) ? *o[2 * j + 1] * scale : 0.f;
     }
+    if (resid) {
+      const float4 ra = resid[2 * i], rb = resid[2 * i + 1];
+      a.x += ra.x; a.y += ra.y; a.z += ra.z; a.w += ra.w; b.x += rb.x; b.y += rb.y; b.z += rb.z; b.w += rb.w;
+    }
     y[2 * i] = a; y[2 * i + 1] = b;
   }
 }
-static int launch_dropout(int mode, const void* x, void* y, int64_t n, float p, uint64_t seed, uint64_t stream_id, void* stream) {
+static int launch_dropout(int mode, const void* x, void* y, int64_t n, float p, uint64_t seed, uint64_t stream_id, void* stream, const void* resid = nullptr) {
   if (!x || !y || n <= 0 || (n & 7) || !(p >= 0.f) || !(p < 1.f)) return OP_EINVAL;
-  if (((uintptr_t)x | (uintptr_t)y) & 15) return OP_EINVAL;
+  if (((uintptr_t)x | (uintptr_t)y | (uintptr_t)resid) & 15) return OP_EINVAL;
   const unsigned thr = (unsigned)(p * 65536.f + 0.5f);
   if (thr >= 65536u) return OP_EINVAL;
   const float scale = 65536.f / (float)(65536u - thr);
   const size_t n8 = (size_t)n >> 3;
-  if (mode == 3) hipLaunchKernelGGL(k_dropout_f32, dim3(ew_grid(n8)), dim3(256), 0, (hipStream_t)stream, (const float4*)x, (float4*)y, n8, thr, scale, (unsigned long long)seed, (unsigned long long)stream_id);
+  if (mode == 3) hipLaunchKernelGGL(k_dropout_f32, dim3(ew_grid(n8)), dim3(256), 0, (hipStream_t)stream, (const float4*)x, (const float4*)resid, (float4*)y, n8, thr, scale, (unsigned long long)seed, (unsigned long long)stream_id);
   else if (mode == 2) hipLaunchKernelGGL(k_dropout_bwd_add_f32, dim3(ew_grid(n8)), dim3(256), 0, (hipStream_t)stream, (const u32x4*)x, (float4*)y, n8, thr, scale, (unsigned long long)seed, (unsigned long long)stream_id);
   else if (mode == 0) hipLaunchKernelGGL(k_dropout_bf16<0>, dim3(ew_grid(n8)), dim3(256), 0, (hipStream_t)stream, (const u32x4*)x, (u32x4*)y, n8, thr, scale, (unsigned long long)seed, (unsigned long long)stream_id);
   else hipLaunchKernelGGL(k_dropout_bf16<1>, dim3(ew_grid(n8)), dim3(256), 0, (hipStream_t)stream, (const u32x4*)x, (u32x4*)y, n8, thr, scale, (unsigned long long)seed, (unsigned long long)stream_id);
@@ -320,6 +325,10 @@ extern "C" int oneprot_dropout_bwd_add_bf16(const void* dy, void* dx, int64_t n,
 }
 extern "C" int oneprot_dropout_f32(const float* x, float* y, int64_t n, float p, uint64_t seed, uint64_t stream_id, void* stream) {
   return launch_dropout(3, x, y, n, p, seed, stream_id, stream);
+}
+extern "C" int oneprot_dropout_add_f32(const float* x, const float* resid, float* y, int64_t n, float p, uint64_t seed, uint64_t stream_id, void* stream) {
+  if (!resid) return OP_EINVAL;
+  return launch_dropout(3, x, y, n, p, seed, stream_id, stream, resid);
 }
 extern "C" int oneprot_dropout_bwd_add_f32(const void* dy, float* dx, int64_t n, float p, uint64_t seed, uint64_t stream_id, void* stream) {
   return launch_dropout(2, dy, dx, n, p, seed, stream_id, stream);
@@ -380,4 +389,4 @@ extern "C" int oneprot_diag_rank(const float* logits, int* rank_row, int* rank_c
   return launch_status();
 }
 
-extern "C" int oneprot_abi_version(void) { return 5; }      // 5: gelu' travels as one-byte codes (out1 of ONEPROT_EPI_BIAS_GELU / aux of ONEPROT_EPI_GELU_BWD are u8 tensors), oneprot_gemm_ln_form; 2: oneprot_gemm_bf16_tn takes workspace_bytes; 3: fused GEMM + LayerNorm entry points, oneprot_dot_f32; 4: oneprot_siglip_fwd_bwd_dev, oneprot_attn_force_fwd_path, oneprot_transpose_cast_f32_to_bf16_batched, oneprot_dropout_bf16 / _bwd_add_bf16 / _bwd_add_f32
+extern "C" int oneprot_abi_version(void) { return 5; }      // 5: gelu' travels as one-byte codes (out1 of ONEPROT_EPI_BIAS_GELU / aux of ONEPROT_EPI_GELU_BWD are u8 tensors), oneprot_gemm_ln_form, oneprot_dropout_add_f32; 2: oneprot_gemm_bf16_tn takes workspace_bytes; 3: fused GEMM + LayerNorm entry points, oneprot_dot_f32; 4: oneprot_siglip_fwd_bwd_dev, oneprot_attn_force_fwd_path, oneprot_transpose_cast_f32_to_bf16_batched, oneprot_dropout_bf16 / _bwd_add_bf16 / _bwd_add_f32

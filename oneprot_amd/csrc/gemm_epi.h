@@ -43,78 +43,54 @@ template <bool PAIR> __device__ __forceinline__ constexpr int direct_nmap(int j,
 }
 
 // erf-GELU with ONE output (frozen towers, validation): gelu(x) = x Phi(x) = max(x, 0) - |x| h(|x|), h(a) = 0.5 erfc(a / sqrt2) = Phi(-a).
-// log2 h is smooth (-a^2/2 log2 e plus a slowly varying term), so h = 2^q(a) with q a degree-7 polynomial (weighted minimax fit on [0, 6];
-// relative error of h <= 3.3e-6 for a < 3 and <= 9.2e-5 up to 6, |gelu error| <= 3.0e-7 everywhere -- the level of the Abramowitz-Stegun form
-// of gelu_fwd_and_grad, far below the bf16 rounding of the stored value; beyond 6 q keeps falling (negative leading coefficient), h -> 0).
-// 7 fma + 1 exp2 + max + fma per element against 12 plain + 2 transcendental instructions of the rational form: the epilogues that inline this
-// are bound by vector-instruction issue (~58 SIMD-cycles per element).  The two-output form (gelu_fwd_and_code8 below) keeps the rational
-// form, whose exponential is shared with the derivative.
+// log2 h is smooth (-a^2/2 log2 e plus a slowly varying term), so h = 2^q(a) with q a polynomial in a (weighted minimax fits on [0, 6], the weight
+// following |x| h, i.e. what the error does to the output; beyond 6 q keeps falling -- negative leading coefficient -- and h -> 0):
+//   degree 5 (shipped): relative error of h <= 1.8e-4 for a < 3, |gelu error| <= 1.3e-5 everywhere = 1/11 of the bf16 half-ulp of the stored value;
+//   degree 7: 3.3e-6 / 3.5e-7, the level of the Abramowitz-Stegun form of the two-output epilogue (-DGELU_FWD_FORM=7; 0 = that rational form).
+// One transcendental and 5 (7) fma + max + fma per element against 12 plain + 2 transcendental instructions: the epilogues that inline this are
+// bound by vector-instruction issue.  Eight values at once (one lane's 16-byte store) with the polynomial on v_pk_fma_f32: a vector
+// instruction of a wave costs the SIMD 4 cycles whether it carries one fp32 per lane or two (every plain instruction removed per element is worth
+// 9-11 us of a 335 M-element launch; the packed form of the degree-7 polynomial took FFN-1 from 465 to 434 us; hipcc packs the bias add and the
+// final fma by itself but not a Horner chain).  The two-output form (gelu_fwd_and_code8 below) keeps the rational form, whose exponential is
+// shared with the derivative.
 #ifndef GELU_FWD_FORM
-#define GELU_FWD_FORM 7
-#endif
-__device__ __forceinline__ float gelu_fwd_only(float x) {
-#if GELU_FWD_FORM == 0
-  const float t = __builtin_amdgcn_rcpf(fmaf(0.23164189f, fabsf(x), 1.0f));
-  const float e = __builtin_amdgcn_exp2f(x * x * -0.72134752f);
-  float poly = fmaf(0.5307027145f, t, -0.7265760135f);
-  poly = fmaf(poly, t, 0.7107068705f);
-  poly = fmaf(poly, t, -0.142248368f);
-  poly = fmaf(poly, t, 0.127414796f);
-  const float h = poly * t * e;
-  return x * (0.5f + copysignf(0.5f - h, x));
-#else
-  const float a = fabsf(x);
-#if GELU_FWD_FORM == 7
-  float q = fmaf(-1.3735314885e-06f, a, 5.3708949533e-05f);
-  q = fmaf(q, a, -8.7965580671e-04f);
-  q = fmaf(q, a, 8.3529787465e-03f);
-  q = fmaf(q, a, -5.3730911583e-02f);
-  q = fmaf(q, a, -4.5861420912e-01f);
-  q = fmaf(q, a, -1.1512197648e+00f);
-  q = fmaf(q, a, -9.9999524375e-01f);
-#else      // degree 5 (timing experiments only: relative error of h 1.8e-4)
-  float q = fmaf(-2.9390228453e-04f, a, 5.6289777323e-03f);
-  q = fmaf(q, a, -4.7738369713e-02f);
-  q = fmaf(q, a, -4.6464447721e-01f);
-  q = fmaf(q, a, -1.1489399185e+00f);
-  q = fmaf(q, a, -1.0001595425e+00f);
-#endif
-  const float h = __builtin_amdgcn_exp2f(q);
-  float r;
-  asm("v_max_f32 %0, 0, %1" : "=v"(r) : "v"(x));           // (plain max: fmaxf adds a canonicalising v_max of x with itself)
-  return fmaf(-a, h, r);
-#endif
-}
-
-// Eight values at once (one lane's 16-byte store), the polynomial on v_pk_fma_f32: a vector instruction of a wave costs the SIMD 4 cycles whether it
-// carries one fp32 per lane or two (measured in these epilogues: every plain instruction removed per element is worth 9-11 us of a 335 M-element
-// launch, and the packed form of this polynomial took FFN-1 from 465 to 434 us; hipcc packs the bias add and the final fma by itself but not a Horner chain).
-#ifndef GELU_FWD_PK
-#define GELU_FWD_PK 1
+#define GELU_FWD_FORM 5
 #endif
 __device__ __forceinline__ void gelu_fwd_only8(float (&v)[8]) {
-#if GELU_FWD_PK && GELU_FWD_FORM == 7
+#if GELU_FWD_FORM == 0
+#pragma unroll
+  for (int e = 0; e < 8; ++e) {
+    const float x = v[e];
+    const float t = __builtin_amdgcn_rcpf(fmaf(0.23164189f, fabsf(x), 1.0f));
+    const float ex = __builtin_amdgcn_exp2f(x * x * -0.72134752f);
+    float poly = fmaf(0.5307027145f, t, -0.7265760135f);
+    poly = fmaf(poly, t, 0.7107068705f);
+    poly = fmaf(poly, t, -0.142248368f);
+    poly = fmaf(poly, t, 0.127414796f);
+    v[e] = x * (0.5f + copysignf(0.5f - poly * t * ex, x));
+  }
+#else
+#if GELU_FWD_FORM == 7
+  constexpr int DEG = 7;
+  constexpr float C[8] = {-1.3735314885e-06f, 5.3708949533e-05f, -8.7965580671e-04f, 8.3529787465e-03f, -5.3730911583e-02f, -4.5861420912e-01f, -1.1512197648e+00f, -9.9999524375e-01f};
+#else
+  constexpr int DEG = 5;
+  constexpr float C[6] = {-2.9390228453e-04f, 5.6289777323e-03f, -4.7738369713e-02f, -4.6464447721e-01f, -1.1489399185e+00f, -1.0001595425e+00f};
+#endif
 #pragma unroll
   for (int e = 0; e < 8; e += 2) {
     const f32x2_t x = {v[e], v[e + 1]};
     const f32x2_t a = {fabsf(v[e]), fabsf(v[e + 1])};
-    f32x2_t q = __builtin_elementwise_fma((f32x2_t){-1.3735314885e-06f, -1.3735314885e-06f}, a, (f32x2_t){5.3708949533e-05f, 5.3708949533e-05f});
-    q = __builtin_elementwise_fma(q, a, (f32x2_t){-8.7965580671e-04f, -8.7965580671e-04f});
-    q = __builtin_elementwise_fma(q, a, (f32x2_t){8.3529787465e-03f, 8.3529787465e-03f});
-    q = __builtin_elementwise_fma(q, a, (f32x2_t){-5.3730911583e-02f, -5.3730911583e-02f});
-    q = __builtin_elementwise_fma(q, a, (f32x2_t){-4.5861420912e-01f, -4.5861420912e-01f});
-    q = __builtin_elementwise_fma(q, a, (f32x2_t){-1.1512197648e+00f, -1.1512197648e+00f});
-    q = __builtin_elementwise_fma(q, a, (f32x2_t){-9.9999524375e-01f, -9.9999524375e-01f});
+    f32x2_t q = __builtin_elementwise_fma((f32x2_t){C[0], C[0]}, a, (f32x2_t){C[1], C[1]});
+#pragma unroll
+    for (int k = 2; k <= DEG; ++k) q = __builtin_elementwise_fma(q, a, (f32x2_t){C[k], C[k]});
     const f32x2_t h = {__builtin_amdgcn_exp2f(q.x), __builtin_amdgcn_exp2f(q.y)};
     float r0, r1;
-    asm("v_max_f32 %0, 0, %1" : "=v"(r0) : "v"(x.x));
+    asm("v_max_f32 %0, 0, %1" : "=v"(r0) : "v"(x.x));       // (plain max: fmaxf adds a canonicalising v_max of x with itself)
     asm("v_max_f32 %0, 0, %1" : "=v"(r1) : "v"(x.y));
     const f32x2_t g = __builtin_elementwise_fma(-a, h, (f32x2_t){r0, r1});
     v[e] = g.x; v[e + 1] = g.y;
   }
-#else
-#pragma unroll
-  for (int e = 0; e < 8; ++e) v[e] = gelu_fwd_only(v[e]);
 #endif
 }
 

@@ -381,6 +381,86 @@ __device__ __forceinline__ void epilogue_rope32(const GemmArgs& p, f32x4 (&acc)[
   run_groups<NG, GL, GS>(load, finish);
 }
 
+// QKV / RoPE, head_dim 64 (BERT-base, ESM-2-650M; natural map, wave column block = whole heads of four tiles: tiles 4h, 4h+1 hold the first half of
+// the head, 4h+2, 4h+3 the second, the rotation partner of a column is the same register of tile j ^ 2).  Round 5: this shape used to run the
+// generic tail (bias into the accumulators, then rope_store_direct: per-element divisions, table loads waited for one by one, 8-byte stores) --
+// 584 us for the 650M QKV launch of the cfg-5 shape, a fifth of that step.  Group = (head, row block): bias, cos and sin pieces of the group run
+// two groups ahead of the stores; after the lane transpose neighbouring lanes swap halves, so a (token, head) row of 128 bytes leaves as
+// 2 x 4 lanes x 16 bytes.
+template <bool HB, int MT, int NT>
+__device__ __forceinline__ void epilogue_rope64(const GemmArgs& p, f32x4 (&acc)[MT][NT], int m0, int n0, int wr, int wc, int lane) {
+  static_assert(NT % 4 == 0, "whole 64-wide heads per wave column block");
+  constexpr int HD = 64, HALF = 32, NHB = NT / 4, NG = NHB * MT, GL = (HB ? 4 : 0) + 4, GS = 2;
+  const int c = lane & 15, q = lane >> 4;
+  const int mrow0 = m0 + wr * (MT * 16) + c, ncol0 = n0 + wc * (NT * 16);
+  const int dm = p.H * HD;
+  const int sec = __builtin_amdgcn_readfirstlane(ncol0 / dm);
+  const int head0 = (ncol0 - sec * dm) / HD;
+  const float sc = sec == 0 ? p.q_scale : 1.0f;
+  const bool rot = sec < 2;                                 // v: no rotation
+  const float* bbase = HB ? p.bias + ncol0 : nullptr;
+  const unsigned boff = (unsigned)q * 16u;
+  const int row0 = m0 + wr * (MT * 16);
+  const int b0 = __builtin_amdgcn_readfirstlane(row0 / p.L);
+  const bf16_t* dst = (const bf16_t*)(sec == 0 ? p.out0 : (sec == 1 ? p.out1 : p.out2)) + ((size_t)b0 * p.H + head0) * p.L * HD;
+  const int sr = lane >> 2, sq = lane & 3, pa = to_rows_addr(lane);
+  const bool odd = (sq & 1) != 0;
+  unsigned roff[MT];                                        // row layout: byte offset of the lane's 16-byte piece inside the first 32 columns of its (token, head) row
+  unsigned toff[MT];                                        // accumulator layout: byte offset of the lane's 4 table entries (row l of the cos / sin tables)
+#pragma unroll
+  for (int i = 0; i < MT; ++i) {
+    const int gs = row0 + i * 16 + sr;
+    const int bs = gs / p.L, ls = gs - bs * p.L;
+    roff[i] = (unsigned)((((bs - b0) * p.H) * p.L + ls) * HD + (odd ? 16 + (sq - 1) * 4 : sq * 4)) * 2u;
+    toff[i] = (unsigned)(((mrow0 + i * 16) % p.L) * HALF + q * 4) * 4u;
+  }
+  const size_t hstep = (size_t)p.L * HD;
+  auto load = [&](auto gc, u32x4 (&r)[GL]) {
+    constexpr int g = decltype(gc)::value, hh = g / MT, i = g % MT;
+    gload16_s<0>(r[0], p.cos, toff[i]); gload16_s<64>(r[1], p.cos, toff[i]);
+    gload16_s<0>(r[2], p.sin, toff[i]); gload16_s<64>(r[3], p.sin, toff[i]);
+    if constexpr (HB) {
+      gload16_s<hh * 256>(r[4], bbase, boff); gload16_s<hh * 256 + 64>(r[5], bbase, boff);
+      gload16_s<hh * 256 + 128>(r[6], bbase, boff); gload16_s<hh * 256 + 192>(r[7], bbase, boff);
+    }
+  };
+  auto finish = [&](auto gc, const u32x4 (&r)[GL]) {
+    constexpr int g = decltype(gc)::value, hh = g / MT, i = g % MT, j0 = 4 * hh;
+    float v[4][4];
+#pragma unroll
+    for (int t = 0; t < 4; ++t) {
+      v[t][0] = acc[i][j0 + t][0]; v[t][1] = acc[i][j0 + t][1]; v[t][2] = acc[i][j0 + t][2]; v[t][3] = acc[i][j0 + t][3];
+      if constexpr (HB) { v[t][0] += as_f(r[4 + t].x); v[t][1] += as_f(r[4 + t].y); v[t][2] += as_f(r[4 + t].z); v[t][3] += as_f(r[4 + t].w); }
+    }
+    u32x4 w[2];                                             // [half of the head]: {tile 2 half, tile 2 half + 1} packed
+#pragma unroll
+    for (int t = 0; t < 2; ++t) {                           // column tile inside a half: table entries 16 t + q * 4 ..
+      const float cv[4] = {as_f(r[t].x), as_f(r[t].y), as_f(r[t].z), as_f(r[t].w)}, sv[4] = {as_f(r[2 + t].x), as_f(r[2 + t].y), as_f(r[2 + t].z), as_f(r[2 + t].w)};
+      float ol[4], oh[4];
+#pragma unroll
+      for (int e = 0; e < 4; ++e) {
+        const float a = v[t][e] * sc, b = v[2 + t][e] * sc;
+        ol[e] = rot ? a * cv[e] - b * sv[e] : a;
+        oh[e] = rot ? b * cv[e] + a * sv[e] : b;
+      }
+      if (t == 0) { w[0].x = pack2bf(ol[0], ol[1]); w[0].y = pack2bf(ol[2], ol[3]); w[1].x = pack2bf(oh[0], oh[1]); w[1].y = pack2bf(oh[2], oh[3]); }
+      else { w[0].z = pack2bf(ol[0], ol[1]); w[0].w = pack2bf(ol[2], ol[3]); w[1].z = pack2bf(oh[0], oh[1]); w[1].w = pack2bf(oh[2], oh[3]); }
+    }
+    const bf16_t* d = dst + hh * hstep;
+#pragma unroll
+    for (int hf = 0; hf < 2; ++hf) {
+      const u32x4 t = lane_perm(pa, w[hf]);                 // row layout: lane (sr, sq) holds columns sq*4.. of tile 2 hf (x, y) and of tile 2 hf + 1 (z, w)
+      const unsigned sx = odd ? t.x : t.z, sy = odd ? t.y : t.w;
+      const unsigned rx = (unsigned)__builtin_amdgcn_update_dpp(0, (int)sx, 0xB1, 0xF, 0xF, false);      // quad_perm [1, 0, 3, 2]
+      const unsigned ry = (unsigned)__builtin_amdgcn_update_dpp(0, (int)sy, 0xB1, 0xF, 0xF, false);
+      u32x4 o;
+      o.x = odd ? rx : t.x; o.y = odd ? ry : t.y; o.z = odd ? t.z : rx; o.w = odd ? t.w : ry;
+      if (hf == 0) gst16_s<0>(d, roff[i], o); else gst16_s<HALF * 2>(d, roff[i], o);
+    }
+  };
+  run_groups<NG, GL, GS>(load, finish);
+}
+
 // vector-memory stores one wave issues per tile (for the store-tolerant wait that follows the epilogue)
 template <int EPI, bool DUAL, int MT, int NT> constexpr int epilogue_stores() {
   if (EPI == ONEPROT_EPI_BIAS_GELU && DUAL) {               // out0 in 16-byte pieces; the one-byte out1 in 16-byte pieces for paired units, 8-byte for the lone half line

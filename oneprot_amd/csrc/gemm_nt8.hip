@@ -455,17 +455,7 @@ __global__ void __launch_bounds__(512, 2) k_gemm8(const GemmArgs p, const int g8
       if constexpr (DirectMap<EPI>::PAIR) epilogue_pair<EPI, HB, DUAL, MT, NT>(p, acc, m0, n0, wr, wc, lane_e);
       else if constexpr (EPI == ONEPROT_EPI_QKV_ROPE) {
         if (p.hd == 32) epilogue_rope32<HB, MT, NT>(p, acc, m0, n0, wr, wc, lane_e);
-        else if constexpr ((NT * 16) % 64 == 0) {                            // head_dim 64: bias into the accumulators, then the generic tail
-          if constexpr (HB) {
-#pragma unroll
-            for (int j = 0; j < NT; ++j) {
-              const float4 t = *reinterpret_cast<const float4*>(p.bias + n0 + wc * (NT * 16) + j * 16 + (lane_e >> 4) * 4);
-#pragma unroll
-              for (int i = 0; i < MT; ++i) { acc[i][j][0] += t.x; acc[i][j][1] += t.y; acc[i][j][2] += t.z; acc[i][j][3] += t.w; }
-            }
-          }
-          gemm_epilogue_direct<EPI, MT, NT>(p, acc, m0, n0, wr, wc, lane_e);
-        }
+        else if constexpr ((NT * 16) % 64 == 0) epilogue_rope64<HB, MT, NT>(p, acc, m0, n0, wr, wc, lane_e);      // head_dim 64 (whole heads per wave column block)
       } else epilogue_f32<EPI, HB, DUAL, MT, NT>(p, acc, m0, n0, wr, wc, lane_e);
     }
     STAMP_E(3);

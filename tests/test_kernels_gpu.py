@@ -268,7 +268,8 @@ def _gemm_resid_layernorm_fused(M, K, inplace):
         hip.call("oneprot_gemm_bf16_nt_resid_ln", A[:100].contiguous(), Wp, 100, N, K, K, bias, resid, x, gamma, beta, 1e-5, h, mean, rstd)
 
 
-@pytest.mark.parametrize("B,L,H,hd", [(3, 24, 4, 16), (2, 37, 2, 32), (2, 130, 20, 32), (2, 50, 2, 64), (5, 512, 20, 32), (16, 512, 8, 32), (4, 128, 4, 64), (8, 96, 8, 32)])
+@pytest.mark.parametrize("B,L,H,hd", [(3, 24, 4, 16), (2, 37, 2, 32), (2, 130, 20, 32), (2, 50, 2, 64), (5, 512, 20, 32), (16, 512, 8, 32), (4, 128, 4, 64), (8, 96, 8, 32),
+                                      (16, 512, 12, 64), (24, 336, 4, 64)])      # head_dim 64 on the 8-phase 256 x 256 form (BERT-base width; rows that cross batch elements inside a wave block)
 def test_gemm_qkv_rope_epilogue(B, L, H, hd, gemm_shape):
     d = H * hd
     M, N, K = B * L, 3 * d, d
@@ -775,6 +776,30 @@ def test_dropout_streams_of_different_consumers_and_towers_are_independent():
     for a, b in ((bert_emb, lora_q0), (lora_q0, lora_q0_other)):
         agree = float((a == b).float().mean())
         assert abs(agree - (0.9 * 0.9 + 0.1 * 0.1)) < 0.01, agree
+
+
+def test_dropout_f32_and_its_residual_form():
+    """oneprot_dropout_f32 (the BERT tower's hidden dropout) and oneprot_dropout_add_f32 = resid + dropout(x) in one pass (hf BertSelfOutput / BertOutput:
+    dropout of the dense output, then the residual add): same mask for the same (seed, stream), exact values, aliasing allowed."""
+    g = torch.Generator().manual_seed(9)
+    n = 64 * 768
+    x = torch.randn(n, generator=g).to(DEV)
+    resid = torch.randn(n, generator=g).to(DEV)
+    p_, seed, stream = 0.1, 0xABCDEF, (1 << 60) | 77
+    d = torch.empty_like(x)
+    hip.call("oneprot_dropout_f32", x, d, n, p_, seed, stream)
+    keep = d != 0
+    thr = int(p_ * 65536 + 0.5)
+    assert abs(float(keep.float().mean()) - (1 - thr / 65536)) < 0.01
+    assert torch.equal(d[keep], x[keep] * (65536.0 / (65536 - thr)))
+    y = torch.empty_like(x)
+    hip.call("oneprot_dropout_add_f32", x, resid, y, n, p_, seed, stream)
+    assert torch.equal(y, resid + d)
+    y2 = resid.clone()
+    hip.call("oneprot_dropout_add_f32", x, y2, y2, n, p_, seed, stream)          # in place on the residual stream
+    assert torch.equal(y2, y)
+    with pytest.raises(hip.HipKernelError):
+        hip.call("oneprot_dropout_add_f32", x, None, y, n, p_, seed, stream)
 
 
 def test_dropout_bf16_mask_is_a_function_of_seed_stream_and_element():

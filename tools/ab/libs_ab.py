@@ -94,6 +94,15 @@ if "nt" in groups:
     nt_case("nt out_dgrad  N640  K640  bf16", d, d, hip.EPI_BF16)
     nt_case("nt qkv_dgrad  N640  K1920 bf16", d, 3 * d, hip.EPI_BF16)
 
+if "nt64" in groups:      # head_dim 64 QKV launches: BERT-base (T = 65536, d = 768) and ESM-2-650M at 128 pairs (T = 65536, d = 1280)
+    for nm, B_, L_, H_, hd_ in (("nt64 BERT-base QKV d768", 256, 256, 12, 64), ("nt64 ESM-2-650M QKV d1280", 128, 512, 20, 64)):
+        d_, T_ = H_ * hd_, B_ * L_
+        A = rnd(T_, d_).to(torch.bfloat16); W = (rnd(3 * d_, d_) * 0.05).to(torch.bfloat16); bias = rnd(3 * d_)
+        cos = torch.rand(L_, hd_ // 2, device="cuda"); sin = torch.rand(L_, hd_ // 2, device="cuda")
+        o = [torch.empty(B_, H_, L_, hd_, dtype=torch.bfloat16, device="cuda") for _ in range(3)]
+        mk = lambda h, A=A, W=W, bias=bias, cos=cos, sin=sin, o=o, T_=T_, d_=d_, L_=L_, H_=H_, hd_=hd_: (lambda: call(h, "oneprot_gemm_bf16_nt", A, W, T_, 3 * d_, d_, d_, d_, hip.EPI_QKV_ROPE, bias, o[0], o[1], o[2], None, cos, sin, hd_ ** -0.5, L_, H_, hd_))
+        cases.append((nm, 2.0 * T_ * 3 * d_ * d_, mk, o))
+
 if "gln" in groups:
     for nm, K in (("gln out-proj K=640", 640), ("gln FFN-2   K=2560", 2560)):
         A = rnd(T, K).to(torch.bfloat16); W = (rnd(d, K) * 0.05).to(torch.bfloat16); bias = rnd(d); gamma = rnd(d); beta = rnd(d)
