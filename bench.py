@@ -45,7 +45,7 @@ import time
 ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, ROOT)
 
-PROFILE_ROUND = "r04"         # committed rocprofv3 summaries this file quotes (profiles/<round>_*.json, tools/profile_round.sh)
+PROFILE_ROUND = "r05"         # committed rocprofv3 summaries this file quotes (profiles/<round>_*.json, tools/profile_round.sh)
 PEAK_BF16_TFLOPS = 2500.0
 PEAK_HBM_GBS = 8000.0
 ESM = {"8M": "facebook/esm2_t6_8M_UR50D", "35M": "facebook/esm2_t12_35M_UR50D", "150M": "facebook/esm2_t30_150M_UR50D", "650M": "facebook/esm2_t33_650M_UR50D"}
@@ -467,7 +467,7 @@ def main():
                 n1 = len(launches) - n2
                 traffic = (n2 * tj["ffn1"]["traffic_bytes_per_launch"] + n1 * tj["ffn1fwd"]["traffic_bytes_per_launch"]) / max(len(launches), 1) / 1e9
                 traffic_alg = (n2 * tj["ffn1"]["algorithmic_bytes_per_launch"] + n1 * tj["ffn1fwd"]["algorithmic_bytes_per_launch"]) / max(len(launches), 1) / 1e9
-                traffic_src = f"{PROFILE_ROUND}_pmc_traffic.json; {n2} launches with two bf16 outputs at {tj['ffn1']['traffic_bytes_per_launch'] / 1e9:.2f} GB, {n1} with one at {tj['ffn1fwd']['traffic_bytes_per_launch'] / 1e9:.2f} GB"
+                traffic_src = f"{PROFILE_ROUND}_pmc_traffic.json; {n2} launches with two outputs (bf16 gelu + one-byte gelu' codes) at {tj['ffn1']['traffic_bytes_per_launch'] / 1e9:.2f} GB, {n1} with one at {tj['ffn1fwd']['traffic_bytes_per_launch'] / 1e9:.2f} GB"
             except Exception:
                 pass
         cfg_tag = {"struct_token": "cfg-2" if world == 1 else "cfg-3-shaped", "text": "cfg-4-shaped", "roundrobin": "cfg-5-shaped"}[args.pair]

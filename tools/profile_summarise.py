@@ -25,11 +25,11 @@ def counter_per_dispatch(d, counter, pattern):
 
 
 traffic = {}
-for what, label in (("ffn1", "two bf16 outputs (gelu and gelu': trainable tower)"), ("ffn1fwd", "one bf16 output (frozen tower)")):
+for what, label in (("ffn1", "two outputs (bf16 gelu and one-byte gelu' codes: trainable tower)"), ("ffn1fwd", "one bf16 output (frozen tower)")):
     f, kn = counter_per_dispatch(f"fetch_{what}", "FETCH_SIZE", "k_gemm")
     w, _ = counter_per_dispatch(f"write_{what}", "WRITE_SIZE", "k_gemm")
     fmed, wmed = f[len(f) // 2], w[len(w) // 2]
-    alg = 131072 * 640 * 2 + 2560 * 640 * 2 + 131072 * 2560 * 2 * (2 if what == "ffn1" else 1)
+    alg = 131072 * 640 * 2 + 2560 * 640 * 2 + 131072 * 2560 * (3 if what == "ffn1" else 2)      # bf16 gelu(z) (+ the one-byte gelu' codes since round 5)
     traffic[what] = {"kernel": kn, "what": "FFN-1 [131072,640]x[2560,640]^T + bias + GELU, " + label, "FETCH_SIZE_KB_raw_median": fmed, "WRITE_SIZE_KB_raw_median": wmed,
                      "fetch_bytes": fmed * 1024 * 2, "write_bytes": wmed * 1024, "traffic_bytes_per_launch": fmed * 1024 * 2 + wmed * 1024, "algorithmic_bytes_per_launch": alg,
                      "ratio": round((fmed * 1024 * 2 + wmed * 1024) / alg, 3), "launches": len(f)}
