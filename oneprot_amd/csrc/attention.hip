@@ -18,6 +18,7 @@
 #include "common.h"
 #include "../../include/oneprot_hip.h"
 #include <float.h>
+#include <atomic>
 
 #define LOG2E 1.4426950408889634f
 #define KC 256        // keys (or queries) staged per LDS chunk
@@ -370,15 +371,49 @@ extern "C" int oneprot_attn_dropout_keep(void* keep, int B, int H, int L, float 
 // a common-mode error of ~2^-9 / sqrt(n) on every context row: the loss of the hd-32 reference fixture moved by 1.1e-3.  So the sum is taken by an
 // all-ones MFMA over the packed fragments, as in k_attn_fwd: no vector instructions, 16 accumulator registers per block; same kernel time as the
 // vector form (301 against 293 us, tools/ab/attn_ab.py).
+// Row sum of one packed fragment, two forms.  MFMA: an all-ones MFMA per fragment (no vector instructions, a 16-register accumulator tile whose
+// registers all hold the sum).  DOT2: v_dot2c_f32_bf16 against (1, 1), two ROUNDED probabilities per vector instruction, one register, no matrix-pipe
+// time; the lane then holds the sum over ITS 16 keys of every 32 (the other 16 sit in lane ^ 32) and the halves meet once, in finish_sum.  hd <= 32
+// kernels are bound by the vector pipe and keep the MFMA form (same time either way, tools/ab/libs_ab.py); the hd-64 kernels are matrix-bound and
+// short of registers and take DOT2.  (Inline asm: hipcc 7.2 compiles __builtin_amdgcn_fdot2_f32_bf16 on the four words of a fragment into four
+// instructions that all read word 0.)
+template <bool DOT2> struct RowSum;
+template <> struct RowSum<false> {
+  f32x16 lacc;
+  __device__ __forceinline__ void zero() { lacc = zero16(); }
+  __device__ __forceinline__ void add(const bf8_t& pf) {
+    const u32x4 ones = {0x3F803F80u, 0x3F803F80u, 0x3F803F80u, 0x3F803F80u};
+    lacc = MFMA32(__builtin_bit_cast(bf8_t, ones), pf, lacc);
+  }
+  __device__ __forceinline__ float take() { const float x = lacc[0]; lacc = zero16(); return x; }
+  static __device__ __forceinline__ float whole(float l) { return l; }
+};
+template <> struct RowSum<true> {
+  float lsum;
+  __device__ __forceinline__ void zero() { lsum = 0.f; }
+  __device__ __forceinline__ void add(const bf8_t& pf) {
+    const u32x4 w = __builtin_bit_cast(u32x4, pf);
+    const unsigned one = 0x3F803F80u;
+    asm("v_dot2c_f32_bf16 %0, %1, %2" : "+v"(lsum) : "s"(one), "v"(w.x));
+    asm("v_dot2c_f32_bf16 %0, %1, %2" : "+v"(lsum) : "s"(one), "v"(w.y));
+    asm("v_dot2c_f32_bf16 %0, %1, %2" : "+v"(lsum) : "s"(one), "v"(w.z));
+    asm("v_dot2c_f32_bf16 %0, %1, %2" : "+v"(lsum) : "s"(one), "v"(w.w));
+  }
+  __device__ __forceinline__ float take() { const float x = lsum; lsum = 0.f; return x; }
+  static __device__ __forceinline__ float whole(float l) { return l + __shfl_xor(l, 32, 64); }
+};
+#ifndef ROWSUM_DOT2_MIN_HD
+#define ROWSUM_DOT2_MIN_HD 64
+#endif
 template <int HD> struct RowState {
   f32x16 acc[Cfg<HD>::DBLK];
-  f32x16 lacc;                      // every register: sum over the keys so far of the lane's query (since the last scale_sum / finish_sum)
-  float m, l;
+  RowSum<(HD >= ROWSUM_DOT2_MIN_HD)> rs;      // sum over the keys so far of the lane's query since the last scale_sum / finish_sum
+  float m, l;                       // (DOT2: l is a half sum until finish_sum)
   u32x4 qe;                         // exact pass, query side of the bookkeeping k-step: bf16 [-m split in three, 1, 0, 0, 0, 0] in the lanes with h == 0
   bool first;
   __device__ __forceinline__ void reset(int h) {
     m = 0.f; l = 0.f; first = true;
-    lacc = zero16();
+    rs.zero();
 #pragma unroll
     for (int d = 0; d < Cfg<HD>::DBLK; ++d) acc[d] = zero16();
     const u32x4 z = {0u, 0u, 0u, 0u};
@@ -386,12 +421,9 @@ template <int HD> struct RowState {
     if (h == 0) qe.y = 0x3F800000u;      // -m = 0, slot 3 = 1.0 (picks up the key bias)
   }
   // accumulate the row sum of one packed fragment (8 bf16 probabilities)
-  __device__ __forceinline__ void add_frag(const bf8_t& pf) {
-    const u32x4 ones = {0x3F803F80u, 0x3F803F80u, 0x3F803F80u, 0x3F803F80u};
-    lacc = MFMA32(__builtin_bit_cast(bf8_t, ones), pf, lacc);
-  }
-  __device__ __forceinline__ void scale_sum(float alpha) { l = (l + lacc[0]) * alpha; lacc = zero16(); }
-  __device__ __forceinline__ void finish_sum() { l += lacc[0]; lacc = zero16(); }
+  __device__ __forceinline__ void add_frag(const bf8_t& pf) { rs.add(pf); }
+  __device__ __forceinline__ void scale_sum(float alpha) { l = (l + rs.take()) * alpha; }      // (alpha is the same in lane ^ 32: half sums stay half sums)
+  __device__ __forceinline__ void finish_sum() { l += rs.take(); l = rs.whole(l); }
   __device__ __forceinline__ bool sums_ok() const { return l >= FWD2_TINY && l <= FWD2_BIG; }
 };
 
@@ -451,9 +483,30 @@ template <int HD> struct FragOff {
         v[sb][db][1] = r1 * C::ROWB + (swz<C::HDP>(r1, col >> 3) << 4) + (col & 7) * 2;
       }
   }
+  __device__ __forceinline__ int koff(int st) const { return k[st]; }
   __device__ __forceinline__ bf8_t vt(const unsigned char* tile, int sb, int db) const {
     const s16x4 a = __builtin_amdgcn_ds_read_tr16_b64_v4i16((__attribute__((address_space(3))) s16x4*)(tile + v[sb][db][0]));
     const s16x4 b = __builtin_amdgcn_ds_read_tr16_b64_v4i16((__attribute__((address_space(3))) s16x4*)(tile + v[sb][db][1]));
+    s16x8 o;
+    o[0] = a[0]; o[1] = a[1]; o[2] = a[2]; o[3] = a[3]; o[4] = b[0]; o[5] = b[1]; o[6] = b[2]; o[7] = b[3];
+    return __builtin_bit_cast(bf8_t, o);
+  }
+};
+// the same offsets for 128-byte rows (hd 64) from TWO registers instead of twelve: with x(row) = (row >> 1) & 7 the row fragment of k-step st sits at
+// k0 ^ (st << 5) (chunk 2 st + h = 2 st ^ h), and the transposed fragment (sb, db, j) at (v0 + 2048 sb + 1024 j) ^ ((db ^ j) << 6) (row 16 sb + 8 j + r0:
+// x = 4 j ^ (r0 >> 1); chunk 4 db ^ (col0 >> 3)).  A few more vector instructions per tile, which this matrix-bound kernel has to spare.
+struct FragOffW {
+  int k0, v0;
+  __device__ __forceinline__ void init(int lane) {
+    const int h = lane >> 5, r = lane & 31, g = lane >> 4, i = lane & 15;
+    k0 = r * 128 + ((h ^ ((r >> 1) & 7)) << 4);
+    const int col0 = 16 * (g & 1) + 4 * (i & 3), r0 = 4 * h + (i >> 2);
+    v0 = r0 * 128 + (((col0 >> 3) ^ (r0 >> 1)) << 4) + (col0 & 7) * 2;
+  }
+  __device__ __forceinline__ int koff(int st) const { return k0 ^ (st << 5); }
+  __device__ __forceinline__ bf8_t vt(const unsigned char* tile, int sb, int db) const {
+    const s16x4 a = __builtin_amdgcn_ds_read_tr16_b64_v4i16((__attribute__((address_space(3))) s16x4*)(tile + ((v0 + 2048 * sb) ^ (db << 6))));
+    const s16x4 b = __builtin_amdgcn_ds_read_tr16_b64_v4i16((__attribute__((address_space(3))) s16x4*)(tile + ((v0 + 2048 * sb + 1024) ^ ((db ^ 1) << 6))));
     s16x8 o;
     o[0] = a[0]; o[1] = a[1]; o[2] = a[2]; o[3] = a[3]; o[4] = b[0]; o[5] = b[1]; o[6] = b[2]; o[7] = b[3];
     return __builtin_bit_cast(bf8_t, o);
@@ -464,12 +517,13 @@ template <int HD> struct FragOff {
 template <int HD> struct TileFrags {
   bf8_t k[Cfg<HD>::KSTEPS];
   bf8_t v[2][Cfg<HD>::DBLK];
-  __device__ __forceinline__ void load(const unsigned char* sK, const unsigned char* sV, int t, const FragOff<HD>& fo) {
+  template <class FO>
+  __device__ __forceinline__ void load(const unsigned char* sK, const unsigned char* sV, int t, const FO& fo) {
     typedef Cfg<HD> C;
     const unsigned char* kt = sK + t * 32 * C::ROWB;
     const unsigned char* vt = sV + t * 32 * C::ROWB;
 #pragma unroll
-    for (int st = 0; st < C::KSTEPS; ++st) k[st] = *reinterpret_cast<const bf8_t*>(kt + fo.k[st]);
+    for (int st = 0; st < C::KSTEPS; ++st) k[st] = *reinterpret_cast<const bf8_t*>(kt + fo.koff(st));
 #pragma unroll
     for (int sb = 0; sb < 2; ++sb)
 #pragma unroll
@@ -756,16 +810,11 @@ __device__ __forceinline__ void fwd2_pass(unsigned char* smem, const bf16_t* __r
 }
 
 template <int HD>
-__global__ void __launch_bounds__(512, HD <= 32 ? 4 : 2) k_attn_fwd2(const bf16_t* __restrict__ q, const bf16_t* __restrict__ k, const bf16_t* __restrict__ v,
-                                                                  const float* __restrict__ key_bias, bf16_t* __restrict__ ctx, float* __restrict__ lse_out, int B,
-                                                                  int H, int L, int nqb) {
+__device__ __forceinline__ void fwd2_body(unsigned char* smem, const bf16_t* __restrict__ q, const bf16_t* __restrict__ k, const bf16_t* __restrict__ v,
+                                          const float* __restrict__ key_bias, bf16_t* __restrict__ ctx, float* __restrict__ lse_out, int H, int L, int bh, int qb) {
   typedef Cfg<HD> C;
   typedef Fwd2<HD> F;
-  extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
   int* sFlag = reinterpret_cast<int*>(smem + F::FLAG_OFF);
-  int bh, qb;
-  decode_block(nqb, B * H, bh, qb);
-  if (bh >= B * H) return;
   const int b = bh / H, head = bh - b * H;
   const int lane = threadIdx.x & 63, wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6), h = lane >> 5, r = lane & 31;
   const int q0 = qb * 256 + wave * 32;
@@ -806,6 +855,34 @@ __global__ void __launch_bounds__(512, HD <= 32 ? 4 : 2) k_attn_fwd2(const bf16_
   asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
 #endif
   FWD2_T(7);
+}
+
+template <int HD>
+__global__ void __launch_bounds__(512, HD <= 32 ? 4 : 2) k_attn_fwd2(const bf16_t* __restrict__ q, const bf16_t* __restrict__ k, const bf16_t* __restrict__ v,
+                                                                  const float* __restrict__ key_bias, bf16_t* __restrict__ ctx, float* __restrict__ lse_out, int B,
+                                                                  int H, int L, int nqb) {
+  extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+  int bh, qb;
+  decode_block(nqb, B * H, bh, qb);
+  if (bh >= B * H) return;
+  fwd2_body<HD>(smem, q, k, v, key_bias, ctx, lse_out, H, L, bh, qb);
+}
+
+// the slabs that k_attn_fwd3w marked (sums out of range), once more through k_attn_fwd2's path (fast pass, then the work-group-wide exact pass).  Every
+// work-group first reads the launch's one word: nothing marked (the normal case) and it leaves.
+template <int HD>
+__global__ void __launch_bounds__(512, 2) k_attn_fwd2_redo(const bf16_t* __restrict__ q, const bf16_t* __restrict__ k, const bf16_t* __restrict__ v,
+                                                        const float* __restrict__ key_bias, bf16_t* __restrict__ ctx, float* __restrict__ lse_out, int B, int H, int L,
+                                                        int nqb, const unsigned* __restrict__ redo_any, const unsigned* __restrict__ redo_slab, unsigned epoch) {
+  extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+  if (*redo_any != epoch) return;
+  const int items = B * H * nqb;
+  for (int item = blockIdx.x; item < items; item += gridDim.x) {
+    const int bh = item / nqb, qb = item - bh * nqb;
+    if (redo_slab[bh] != epoch) continue;
+    fwd2_body<HD>(smem, q, k, v, key_bias, ctx, lse_out, H, L, bh, qb);
+    __syncthreads();
+  }
 }
 
 // ---- k_attn_fwd3: persistent, LDS-DMA double buffered, two query blocks per wave (hd <= 32, L <= 512) ------------------------------------
@@ -1005,6 +1082,243 @@ __global__ void __launch_bounds__(512, 2) k_attn_fwd3(const bf16_t* __restrict__
     for (int i = 0; i < NST; ++i) store1(pend, pend_bh, i);
 }
 
+// ---- k_attn_fwd3w: the persistent form for 128-byte rows (hd = 64: BERT-base, ESM-2-650M), L <= 512 ------------------------------------------
+// Same skeleton as k_attn_fwd3 -- one persistent 8-wave work-group per CU, two 32-query blocks per wave, K / V / bias by LDS-DMA into the other half
+// of the LDS while the current half is computed, one barrier per buffer -- but a buffer holds a CHUNK of 256 keys (2 x 32 KB images), so a slab of
+// L > 256 is two chunks and the stream of buffers runs across slab boundaries: [slab n chunk 0][slab n chunk 1][slab n+1 chunk 0] ...  What differs
+// from the 64-byte-row kernel, all for registers (two blocks of hd 64 hold 64 output accumulators and 32 q-fragment registers per wave):
+//   * ONE set of K / V^T tile fragments, reloaded in place (K behind the score chains, V^T behind the P.V MFMAs) instead of two sets in turn;
+//   * the q fragments of the next slab are requested at the start of the slab's LAST chunk, not a whole slab ahead;
+//   * the outputs leave at the end of the slab's last chunk (not from the next slab's tile loop: no registers to hold them);
+//   * a slab's first chunk is gone from the LDS when the row sums are checked, and an exact pass inside this kernel cost the fast path 47-88 spilled
+//     registers wherever it was put: a slab with a sum out of range is MARKED (redo_slab[bh] = epoch of this launch, one word redo_any for the launch)
+//     and k_attn_fwd2_redo, launched right behind, repeats the marked slabs with k_attn_fwd2's work-group-wide exact pass.  In the normal case that
+//     kernel is 256 work-groups that read one word and leave.  A correctness net for scores beyond +-60, not a working point (tests drive it with +-400).
+#define REDO_SLOTS 8
+#define REDO_SLABS 32768
+__device__ unsigned g_fwd3w_redo_any[REDO_SLOTS];
+__device__ unsigned g_fwd3w_redo_slab[REDO_SLOTS * REDO_SLABS];
+template <int HD> struct Fwd3W {
+  static constexpr int CK = 256;                           // keys per buffer
+  static constexpr int TILE = CK * Cfg<HD>::ROWB;          // 32 KB at hd 64
+  static constexpr int BUF = 2 * TILE + CK * 4;            // K image, V image, fp32 bias
+  static constexpr int TOTAL = 2 * BUF + 4096;             // (+ one tile: the fragment prefetch of the tile behind a chunk's last one stays inside the allocation)
+};
+
+// fast-pass tile with ONE fragment set: NEXT reloads it in place for tile t + 1
+template <int HD, int NB, bool BOOK, bool NEXT, class Side>
+__device__ __forceinline__ void fwd_tile_fast_ip(const unsigned char* sK, const unsigned char* sV, const float* sBias, bool have_bias, int nkeys, int t,
+                                                 const bf8_t (&qf)[NB][Cfg<HD>::KSTEPS], RowState<HD> (&st)[NB], int lane, const FragOffW& fo,
+                                                 TileFrags<HD>& f, Side&& side) {
+  typedef Cfg<HD> C;
+  const int h = lane >> 5;
+  f32x16 s[NB];
+  if constexpr (BOOK) {
+    const bf8_t ke = key_entry(sBias, have_bias, nkeys, t, lane);
+    u32x4 q1 = {0u, 0u, 0u, 0u};
+    if (h == 0) q1.y = 0x3F800000u;
+#pragma unroll
+    for (int b = 0; b < NB; ++b) s[b] = MFMA32(ke, __builtin_bit_cast(bf8_t, q1), zero16());
+#pragma unroll
+    for (int k = 0; k < C::KSTEPS; ++k)
+#pragma unroll
+      for (int b = 0; b < NB; ++b) s[b] = MFMA32(f.k[k], qf[b][k], s[b]);
+  } else {
+#pragma unroll
+    for (int b = 0; b < NB; ++b) s[b] = MFMA32(f.k[0], qf[b][0], zero16());
+#pragma unroll
+    for (int k = 1; k < C::KSTEPS; ++k)
+#pragma unroll
+      for (int b = 0; b < NB; ++b) s[b] = MFMA32(f.k[k], qf[b][k], s[b]);
+  }
+  if constexpr (NEXT) {
+    const unsigned char* kt = sK + (t + 1) * 32 * C::ROWB;
+#pragma unroll
+    for (int st_ = 0; st_ < C::KSTEPS; ++st_) f.k[st_] = *reinterpret_cast<const bf8_t*>(kt + fo.koff(st_));
+  }
+  __builtin_amdgcn_sched_barrier(0);
+  side();
+#pragma unroll
+  for (int b = 0; b < NB; ++b) {
+#pragma unroll
+    for (int e = 0; e < 16; ++e) s[b][e] = __builtin_amdgcn_exp2f(s[b][e]);
+#pragma unroll
+    for (int sb = 0; sb < 2; ++sb) {
+      const bf8_t pf = pack8(s[b], sb);
+      st[b].add_frag(pf);
+#pragma unroll
+      for (int d = 0; d < C::DBLK; ++d) st[b].acc[d] = MFMA32(f.v[sb][d], pf, st[b].acc[d]);
+    }
+  }
+  if constexpr (NEXT) {
+    const unsigned char* vt = sV + (t + 1) * 32 * C::ROWB;
+#pragma unroll
+    for (int sb = 0; sb < 2; ++sb)
+#pragma unroll
+      for (int d = 0; d < C::DBLK; ++d) f.v[sb][d] = fo.vt(vt, sb, d);
+  }
+}
+
+template <int HD, int NB, class Side>
+__device__ __forceinline__ void fwd_chunk_fast_ip(const unsigned char* sK, const unsigned char* sV, const float* sBias, bool have_bias, int nkeys, int nt,
+                                                  unsigned long long NZ, unsigned long long DEAD, const bf8_t (&qf)[NB][Cfg<HD>::KSTEPS], RowState<HD> (&st)[NB],
+                                                  int lane, const FragOffW& fo, Side&& side) {
+  unsigned long long special = (NZ | (NZ >> 1) | (NZ >> 2) | (NZ >> 3)) & 0x1111111111111111ull;
+  if (nt < 16) special |= ~0ull << (4 * nt);
+  int t = 0;
+  while (t < nt) {
+    const unsigned long long rest = special >> (4 * t);
+    const int run_end = rest ? t + (__builtin_ctzll(rest) >> 2) : nt;
+    if (t < run_end) {
+      TileFrags<HD> f;
+      f.load(sK, sV, t, fo);
+      for (; t + 1 < run_end; ++t) fwd_tile_fast_ip<HD, NB, false, true>(sK, sV, sBias, have_bias, nkeys, t, qf, st, lane, fo, f, side);
+      fwd_tile_fast_ip<HD, NB, false, false>(sK, sV, sBias, have_bias, nkeys, t, qf, st, lane, fo, f, side);
+      ++t;
+    }
+    if (t < nt) {
+      if (tile_class(NZ, DEAD, t) == 1) {
+        TileFrags<HD> f;
+        f.load(sK, sV, t, fo);
+        fwd_tile_fast_ip<HD, NB, true, false>(sK, sV, sBias, have_bias, nkeys, t, qf, st, lane, fo, f, side);
+      }
+      ++t;
+    }
+  }
+}
+
+template <int HD>
+__global__ void __launch_bounds__(512, 2) k_attn_fwd3w(const bf16_t* __restrict__ q, const bf16_t* __restrict__ k, const bf16_t* __restrict__ v,
+                                                    const float* __restrict__ key_bias, bf16_t* __restrict__ ctx, float* __restrict__ lse_out, int B, int H,
+                                                    int L, unsigned* __restrict__ redo_any, unsigned* __restrict__ redo_slab, unsigned epoch) {
+  typedef Cfg<HD> C;
+  typedef Fwd3W<HD> F;
+  static_assert(C::ROWB == 128, "k_attn_fwd3w stages 128-byte rows");
+  extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+  const unsigned lds0 = (unsigned)(uintptr_t)LDS_PTR(smem);
+  const int lane = threadIdx.x & 63, wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6), h = lane >> 5, r = lane & 31;
+  const int nw = blockDim.x >> 6;
+  const int nbh = B * H, per_xcd = (nbh + 7) >> 3, nslot = gridDim.x >> 3;
+  const int xcd = blockIdx.x & 7;
+  const int bh_end = min(nbh, (xcd + 1) * per_xcd);
+  int bh = xcd * per_xcd + (int)(blockIdx.x >> 3);
+  const int q0 = wave * 64;
+  const bool active = q0 < L;
+  int qidx[2], qrow[2];
+#pragma unroll
+  for (int b = 0; b < 2; ++b) { qidx[b] = q0 + 32 * b + r; qrow[b] = qidx[b] < L ? qidx[b] : L - 1; }
+  const int nrows = (L + 31) & ~31;
+  const int nch = (nrows + F::CK - 1) / F::CK;              // chunks per slab (1 or 2)
+  const int dm = H * HD;
+  const unsigned char* zero = reinterpret_cast<const unsigned char*>(g_attn_zero_page);
+  const bool have_bias = key_bias != nullptr;
+
+  // One LDS-DMA piece = 8 rows x 128 B, lane-linear: lane (j = lane >> 3, slot = lane & 7) fills row 8 p + j, slot `slot` of the swizzled image with the
+  // source chunk slot ^ ((row >> 1) & 7) = slot ^ (j >> 1) ^ 4 (p & 1): one per-lane offset, bit 6 flipped for odd pieces.
+  const unsigned kv_lane_off = (unsigned)(lane >> 3) * 128u + (unsigned)(((lane & 7) ^ ((lane >> 4) & 3)) << 4);
+  auto rows_of = [&](int c) { return min(F::CK, nrows - c * F::CK); };
+  auto n_dma_of = [&](int c) {
+    const int np = rows_of(c) >> 3;
+    const int mine = np > wave ? (np - wave + nw - 1) / nw : 0;
+    return 2 * mine + ((have_bias && 64 * wave < rows_of(c)) ? 1 : 0);
+  };
+  auto dma_piece = [&](int item, int c, int buf, int i) {      // i-th memory instruction of this wave for chunk c of slab `item`: K / V pieces alternating, then the bias
+    const int np = rows_of(c) >> 3;
+    const int mine = np > wave ? (np - wave + nw - 1) / nw : 0;
+    const unsigned dst0 = lds0 + buf * F::BUF;
+    if (i < 2 * mine) {
+      const int p = wave + nw * (i >> 1);
+      const int row0 = c * F::CK + 8 * p;
+      const unsigned char* base = reinterpret_cast<const unsigned char*>(((i & 1) ? v : k) + (size_t)item * L * HD);
+      const unsigned dst = dst0 + ((i & 1) ? F::TILE : 0) + p * 1024;
+      if (row0 + 8 <= L) glds16_s(kv_lane_off ^ ((unsigned)(p & 1) << 6), base + (size_t)row0 * (HD * 2), dst);
+      else {
+        const int row = row0 + (lane >> 3);
+        const int ch = (lane & 7) ^ ((row >> 1) & 7);
+        glds16_addr(row < L ? base + (size_t)row * (HD * 2) + ch * 16 : zero, dst);
+      }
+    } else {
+      const int k0 = c * F::CK + 64 * wave;
+      const float* br = key_bias + (size_t)(item / H) * L + k0;
+      if (k0 + 64 <= L) glds4_s((unsigned)lane * 4u, br, dst0 + 2 * F::TILE + wave * 256);
+      else glds4_addr(k0 + lane < L ? (const void*)(br + lane) : (const void*)zero, dst0 + 2 * F::TILE + wave * 256);
+    }
+  };
+  auto load_q = [&](int item, bf8_t (&dstq)[2][C::KSTEPS]) {
+#pragma unroll
+    for (int b = 0; b < 2; ++b)
+#pragma unroll
+      for (int st = 0; st < C::KSTEPS; ++st) dstq[b][st] = *reinterpret_cast<const bf8_t*>(q + ((size_t)item * L + qrow[b]) * HD + 16 * st + 8 * h);
+  };
+
+  bf8_t qf[2][C::KSTEPS], qn[2][C::KSTEPS];
+  if (bh < bh_end) {
+    const int n0 = n_dma_of(0);
+    for (int i = 0; i < n0; ++i) dma_piece(bh, 0, 0, i);
+    load_q(bh, qf);
+  }
+  FragOffW fo;
+  fo.init(lane);
+  RowState<HD> st[2];
+  int buf = 0, c = 0;
+  while (bh < bh_end) {
+    // this wave's pieces of the buffer have landed (and its q fragments, and the output stores of the slab before: a COUNTED wait that leaves exactly
+    // those stores in flight was tried -- hipcc's own wait for the q fragments, merged over the paths with and without stores, then waits for them anyway)
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    __builtin_amdgcn_s_barrier();
+    const bool last = c + 1 == nch;
+    const int nbh_ = last ? bh + nslot : bh, nc = last ? 0 : c + 1;      // the buffer after this one
+    const bool more = nbh_ < bh_end;
+    // hipcc's own wait for the q fragments goes here, where it is free -- in EVERY iteration: consumed under `c == 0` only, the other path carried
+    // "loads pending" into the tile loop and every score MFMA waited for vmcnt(8 .. 1), i.e. for the LDS-DMA pieces issued a tile earlier
+#pragma unroll
+    for (int b = 0; b < 2; ++b)
+#pragma unroll
+      for (int s_ = 0; s_ < C::KSTEPS; ++s_) asm volatile("" : "+v"(qf[b][s_]));
+    if (c == 0) { st[0].reset(h); st[1].reset(h); }
+    if (last && more) load_q(nbh_, qn);
+    const int e_all = more ? n_dma_of(nc) : 0;
+    int vm_i = 0;
+    auto vm_step = [&]() {
+      const int i = vm_i;
+      if (i >= e_all) return;
+      vm_i = i + 1;
+      dma_piece(nbh_, nc, buf ^ 1, i);
+    };
+    if (active) {
+      const unsigned char* sK = smem + buf * F::BUF;
+      const unsigned char* sV = sK + F::TILE;
+      const float* sBias = reinterpret_cast<const float*>(sK + 2 * F::TILE);
+      const int nkeys = min(F::CK, L - c * F::CK);
+      unsigned long long NZ, DEAD;
+      tile_class_masks(sBias, F::CK, nkeys, have_bias, lane, NZ, DEAD);
+      fwd_chunk_fast_ip<HD, 2>(sK, sV, sBias, have_bias, nkeys, rows_of(c) >> 5, NZ, DEAD, qf, st, lane, fo, [&] { vm_step(); vm_step(); });
+    }
+    while (vm_i < e_all) vm_step();
+    if (last) {
+      if (active) {
+        st[0].finish_sum(); st[1].finish_sum();
+        // a block whose sums are out of range: the slab is marked and k_attn_fwd2_redo (launched behind this kernel) repeats it with the running maximum
+        const bool bad = __any(!st[0].sums_ok() || !st[1].sums_ok());
+        if (bad && lane == 0) { redo_slab[bh] = epoch; *redo_any = epoch; }
+        bf16_t* dst0 = ctx + ((size_t)(bh / H) * L) * dm + (bh % H) * HD;
+        float* lse0 = lse_out ? lse_out + (size_t)bh * L : nullptr;
+#pragma unroll
+        for (int b = 0; b < 2; ++b) {
+          RowOut<HD> o;
+          o.from(st[b]);
+          if (qidx[b] < L) o.store(dst0 + (size_t)qidx[b] * dm, lse0 ? lse0 + qidx[b] : nullptr, h);
+        }
+      }
+#pragma unroll
+      for (int b = 0; b < 2; ++b)
+#pragma unroll
+        for (int s_ = 0; s_ < C::KSTEPS; ++s_) qf[b][s_] = qn[b][s_];
+    }
+    bh = nbh_; c = nc; buf ^= 1;
+  }
+}
+
 static int g_attn_fwd_path = -1;      // -1 automatic, 0 k_attn_fwd (per-tile maximum), 1 no-maximum kernels (fwd3 where eligible, else fwd2), 2 k_attn_fwd2 (A/B runs and tests)
 extern "C" void oneprot_attn_force_fwd_path(int path) { g_attn_fwd_path = path < 0 ? -1 : (path > 2 ? 1 : path); }
 
@@ -1041,9 +1355,44 @@ static int launch_fwd3(const void* q, const void* k, const void* v, const float*
 }
 
 template <int HD>
+static int launch_fwd3w(const void* q, const void* k, const void* v, const float* key_bias, void* ctx, float* lse, int B, int H, int L, hipStream_t s) {
+  static int ok = -1, n_cu = 0;
+  if (ok < 0) {
+    ok = hipFuncSetAttribute((const void*)k_attn_fwd3w<HD>, hipFuncAttributeMaxDynamicSharedMemorySize, Fwd3W<HD>::TOTAL) == hipSuccess ? 1 : 0;
+    int dev = 0; hipDeviceProp_t prop;
+    if (hipGetDevice(&dev) != hipSuccess || hipGetDeviceProperties(&prop, dev) != hipSuccess) ok = 0; else n_cu = prop.multiProcessorCount;
+  }
+  if (!ok) { (void)hipGetLastError(); return launch_fwd2<HD>(q, k, v, key_bias, ctx, lse, B, H, L, s); }
+  const int waves = (L + 63) / 64;                        // <= 8: a wave owns 64 queries
+  const int per_xcd = (B * H + 7) / 8;
+  int nslot = n_cu / 8;                                   // one persistent work-group per CU
+  if (nslot < 1) nslot = 1;
+  if (nslot > per_xcd) nslot = per_xcd;
+  // marks of this launch: a fresh epoch (no word is ever cleared) in one of REDO_SLOTS sets, so launches in flight on other streams do not share a set
+  static std::atomic<unsigned> launches{0};
+  const unsigned epoch = launches.fetch_add(1u) + 1u;
+  unsigned* any_w = nullptr; unsigned* slab_w = nullptr;
+  if (hipGetSymbolAddress((void**)&any_w, HIP_SYMBOL(g_fwd3w_redo_any)) != hipSuccess || hipGetSymbolAddress((void**)&slab_w, HIP_SYMBOL(g_fwd3w_redo_slab)) != hipSuccess)
+    return OP_ELAUNCH;
+  any_w += epoch % REDO_SLOTS; slab_w += (size_t)(epoch % REDO_SLOTS) * REDO_SLABS;
+  hipLaunchKernelGGL(k_attn_fwd3w<HD>, dim3(8 * nslot), dim3(64 * waves), Fwd3W<HD>::TOTAL, s, (const bf16_t*)q, (const bf16_t*)k, (const bf16_t*)v, key_bias,
+                     (bf16_t*)ctx, lse, B, H, L, any_w, slab_w, epoch);
+  if (launch_status() != OP_OK) return OP_ELAUNCH;
+  static int ok2 = -1;
+  if (ok2 < 0) ok2 = hipFuncSetAttribute((const void*)k_attn_fwd2_redo<HD>, hipFuncAttributeMaxDynamicSharedMemorySize, Fwd2<HD>::TOTAL) == hipSuccess ? 1 : 0;
+  if (!ok2) return OP_ELAUNCH;
+  const int nqb = (L + 255) / 256;
+  hipLaunchKernelGGL(k_attn_fwd2_redo<HD>, dim3(n_cu), dim3(512), Fwd2<HD>::TOTAL, s, (const bf16_t*)q, (const bf16_t*)k, (const bf16_t*)v, key_bias, (bf16_t*)ctx, lse,
+                     B, H, L, nqb, (const unsigned*)any_w, (const unsigned*)slab_w, epoch);
+  return launch_status();
+}
+
+template <int HD>
 static int launch_fwd_nomax(const void* q, const void* k, const void* v, const float* key_bias, void* ctx, float* lse, int B, int H, int L, hipStream_t s) {
   if constexpr (HD <= 32) {
     if (L <= Fwd3::ROWS && g_attn_fwd_path != 2) return launch_fwd3<HD>(q, k, v, key_bias, ctx, lse, B, H, L, s);
+  } else {
+    if (L <= 512 && (long)B * H <= REDO_SLABS && g_attn_fwd_path != 2) return launch_fwd3w<HD>(q, k, v, key_bias, ctx, lse, B, H, L, s);
   }
   return launch_fwd2<HD>(q, k, v, key_bias, ctx, lse, B, H, L, s);
 }

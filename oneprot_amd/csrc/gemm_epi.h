@@ -15,6 +15,7 @@ struct GemmArgs {
   float q_scale;
   int L, H, hd;
   int tiles_m, tiles_n;
+  int csplit;                   // 8-phase kernels: XCDs that share a set of row panels and divide its column tiles between them (1, 2 or 4)
   int sup_m, sup_n;             // L2 super-tile of the per-tile kernels: sup_m row panels x sup_n column tiles per XCD at a time
   int nt_store;                 // output stores non-temporal (streamed past the L2 instead of displacing the operand panels and W)
 };

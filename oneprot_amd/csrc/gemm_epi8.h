@@ -30,17 +30,28 @@ namespace g8 {
 __device__ __forceinline__ void gload16(u32x4& d, const void* ptr) { asm volatile("global_load_dwordx4 %0, %1, off" : "=v"(d) : "v"(ptr) : "memory"); }
 // saddr forms: wave-uniform 64-bit base in SGPRs + one 32-bit per-lane byte offset + an immediate.  The per-lane 64-bit pointers of the plain forms
 // (one VGPR pair per output / operand tensor and per row block) were what the two-output GELU and the QKV + RoPE epilogues spilled next to 160
-// accumulators -- and a spill reload is a vector-memory load that retires behind the epilogue's own stores.  (No cache-policy variant: the
-// non-temporal store policy of oneprot_gemm_tune never paid on these launches, DESIGN 6b, and is not offered here.)
+// accumulators -- and a spill reload is a vector-memory load that retires behind the epilogue's own stores.  (The cache policy of the
+// stores is a compile-time property of the epilogue kind, see gst16_s.)
 template <int IMM> __device__ __forceinline__ void gload16_s(u32x4& d, const void* sbase, unsigned voff) {
   asm volatile("global_load_dwordx4 %0, %1, %2 offset:%3" : "=v"(d) : "v"(voff), "s"(sbase), "n"(IMM) : "memory");
 }
-template <int IMM> __device__ __forceinline__ void gst16_s(const void* sbase, unsigned voff, const u32x4& v) {
+// NTS: non-temporal (`nt`) -- the output is streamed past the L2 instead of displacing W and the activation panels.  Measured in one process
+// (tools/ab/libs_ab.py, profiles/r05_libs_ab.txt (8)): -4 .. -7 % on the launches with many column tiles and a short K (QKV + RoPE 303 -> 285 us, FFN-1 428 ->
+// 404, two outputs 530 -> 505, BERT / 650M QKV -4 / -2 %), +3 .. +4 % on the N = 640 data gradients with K = 1920 / 2560, nothing on the fp32 outputs:
+// it is a property of the epilogue kind (QKV_ROPE, BIAS_GELU, GELU_BWD: always many column tiles over a short K), not a run-time switch.
+#ifdef G8_NO_NT      // A/B builds: every store with the default policy
+constexpr bool G8_NT = false;
+#else
+constexpr bool G8_NT = true;
+#endif
+template <int IMM, bool NTS = false> __device__ __forceinline__ void gst16_s(const void* sbase, unsigned voff, const u32x4& v) {
   // (s_nop 1: a store of more than 8 bytes reads its data registers late; hipcc pads its own stores against the next writer of those registers, not an asm one)
-  asm volatile("global_store_dwordx4 %0, %1, %2 offset:%3\n\ts_nop 1" ::"v"(voff), "v"(v), "s"(sbase), "n"(IMM) : "memory");
+  if constexpr (NTS && G8_NT) asm volatile("global_store_dwordx4 %0, %1, %2 offset:%3 nt\n\ts_nop 1" ::"v"(voff), "v"(v), "s"(sbase), "n"(IMM) : "memory");
+  else asm volatile("global_store_dwordx4 %0, %1, %2 offset:%3\n\ts_nop 1" ::"v"(voff), "v"(v), "s"(sbase), "n"(IMM) : "memory");
 }
-template <int IMM> __device__ __forceinline__ void gst8_s(const void* sbase, unsigned voff, const u32x2& v) {
-  asm volatile("global_store_dwordx2 %0, %1, %2 offset:%3" ::"v"(voff), "v"(v), "s"(sbase), "n"(IMM) : "memory");
+template <int IMM, bool NTS = false> __device__ __forceinline__ void gst8_s(const void* sbase, unsigned voff, const u32x2& v) {
+  if constexpr (NTS && G8_NT) asm volatile("global_store_dwordx2 %0, %1, %2 offset:%3 nt" ::"v"(voff), "v"(v), "s"(sbase), "n"(IMM) : "memory");
+  else asm volatile("global_store_dwordx2 %0, %1, %2 offset:%3" ::"v"(voff), "v"(v), "s"(sbase), "n"(IMM) : "memory");
 }
 // 8-byte load into the low half of a 16-byte register group (the one-byte gelu' codes of GELU_BWD: 8 elements per lane)
 template <int IMM> __device__ __forceinline__ void gload8_s(u32x4& d, const void* sbase, unsigned voff) {
@@ -132,6 +143,7 @@ template <int MT, int NP, bool ODD> struct LinePlan {      // NP column units of
 template <int EPI, bool HB, bool DUAL, int MT, int NT, bool ODD>
 __device__ __forceinline__ void epilogue_pair_body(const GemmArgs& p, f32x4 (&acc)[MT][NT], int m0, int n0, int wr, int wc, int lane) {
   constexpr bool AUX = EPI == ONEPROT_EPI_GELU_BWD;
+  constexpr bool NTS = EPI != ONEPROT_EPI_BF16;            // non-temporal output stores (gst16_s)
 #ifndef G8_HOLD_DUAL
 #define G8_HOLD_DUAL 1
 #endif
@@ -198,7 +210,7 @@ __device__ __forceinline__ void epilogue_pair_body(const GemmArgs& p, f32x4 (&ac
       if constexpr (EPI == ONEPROT_EPI_BIAS_GELU) {
         if constexpr (DUAL) {
           const u32x2 z = lane_perm2(pa, gelu_fwd_and_code8(v));
-          if constexpr (Cnt::lone(g)) gst8_s<pp * 32>(out1 + i * rstep, voff8, z);
+          if constexpr (Cnt::lone(g)) gst8_s<pp * 32, NTS>(out1 + i * rstep, voff8, z);
           else if constexpr ((u & 1) == 0) hz = z;
           else {                                            // hz = unit pp - 1, z = unit pp of the same rows: swap halves, one 16-byte store per lane
             const unsigned sx = odd ? hz.x : z.x, sy = odd ? hz.y : z.y;
@@ -206,7 +218,7 @@ __device__ __forceinline__ void epilogue_pair_body(const GemmArgs& p, f32x4 (&ac
             const unsigned ry = (unsigned)__builtin_amdgcn_update_dpp(0, (int)sy, 0xB1, 0xF, 0xF, false);
             u32x4 o;
             o.x = odd ? rx : hz.x; o.y = odd ? ry : hz.y; o.z = odd ? z.x : rx; o.w = odd ? z.y : ry;
-            gst16_s<Plan::col(g, u - 1) * 32>(out1 + i * rstep, voff16, o);
+            gst16_s<Plan::col(g, u - 1) * 32, NTS>(out1 + i * rstep, voff16, o);
           }
         } else {
           gelu_fwd_only8(v);
@@ -227,13 +239,13 @@ __device__ __forceinline__ void epilogue_pair_body(const GemmArgs& p, f32x4 (&ac
       }
       u32x4 w; w.x = pack2bf(v[0], v[1]); w.y = pack2bf(v[2], v[3]); w.z = pack2bf(v[4], v[5]); w.w = pack2bf(v[6], v[7]);
       w = lane_perm(pa, w);
-      if constexpr (!HOLD) gst16_s<pp * 64>(out0 + i * rstep, voff, w);
+      if constexpr (!HOLD) gst16_s<pp * 64, NTS>(out0 + i * rstep, voff, w);
       else if constexpr ((u & 1) == 0) hw = w;
       else {
         constexpr int pp0 = Plan::col(g, u - 1), i0 = Plan::row(g, u - 1);
         __builtin_amdgcn_sched_barrier(0);
-        gst16_s<pp0 * 64>(out0 + i0 * rstep, voff, hw);
-        gst16_s<pp * 64>(out0 + i * rstep, voff, w);
+        gst16_s<pp0 * 64, NTS>(out0 + i0 * rstep, voff, hw);
+        gst16_s<pp * 64, NTS>(out0 + i * rstep, voff, w);
         __builtin_amdgcn_sched_barrier(0);
       }
     }, std::make_integer_sequence<int, 4>{});
@@ -375,7 +387,7 @@ __device__ __forceinline__ void epilogue_rope32(const GemmArgs& p, f32x4 (&acc)[
       const unsigned ry = (unsigned)__builtin_amdgcn_update_dpp(0, (int)sy, 0xB1, 0xF, 0xF, false);
       u32x4 o;
       o.x = odd ? rx : w.x; o.y = odd ? ry : w.y; o.z = odd ? w.z : rx; o.w = odd ? w.w : ry;
-      gst16_s<0>(d, roff[i], o);
+      gst16_s<0, true>(d, roff[i], o);
     }
   };
   run_groups<NG, GL, GS>(load, finish);
@@ -455,7 +467,7 @@ __device__ __forceinline__ void epilogue_rope64(const GemmArgs& p, f32x4 (&acc)[
       const unsigned ry = (unsigned)__builtin_amdgcn_update_dpp(0, (int)sy, 0xB1, 0xF, 0xF, false);
       u32x4 o;
       o.x = odd ? rx : t.x; o.y = odd ? ry : t.y; o.z = odd ? t.z : rx; o.w = odd ? t.w : ry;
-      if (hf == 0) gst16_s<0>(d, roff[i], o); else gst16_s<HALF * 2>(d, roff[i], o);
+      if (hf == 0) gst16_s<0, true>(d, roff[i], o); else gst16_s<HALF * 2, true>(d, roff[i], o);
     }
   };
   run_groups<NG, GL, GS>(load, finish);

@@ -103,16 +103,20 @@ __global__ void __launch_bounds__(512, 2) k_gemm8(const GemmArgs p, const int g8
   const int wr = wave / C::WN, wc = wave % C::WN;
   const int nk = p.K >> 6;
 
-  // ---- this work-group's tiles: XCD x (= blockIdx & 7 under round-robin dispatch; speed only) walks row panels x, x+8, ... with n fastest
+  // ---- this work-group's tiles: XCD x (= blockIdx & 7 under round-robin dispatch; speed only).  csplit = 1: XCD x walks row panels x, x+8, ... with n
+  // fastest.  csplit = c: the XCDs form 8 / c sets; set xg walks row panels xg, xg + 8/c, ... and each of its c XCDs takes 1/c of the column tiles, so an XCD
+  // keeps 1/c of W in its L2 for the whole launch (N = 2560, K = 640: 3.3 MB of W next to four activation panels do not fit 4 MB) and reads every
+  // activation panel c times less often than W used to be re-read.
   const int x = blockIdx.x & 7, w = blockIdx.x >> 3;
-  const int panels_x = p.tiles_m > x ? (p.tiles_m - x + 7) >> 3 : 0;
-  const int Tx = panels_x * p.tiles_n;
+  const int cs = p.csplit, ng = 8 / cs, xg = x / cs, cg = x - xg * cs, tn_x = p.tiles_n / cs;
+  const int panels_x = p.tiles_m > xg ? (p.tiles_m - xg + ng - 1) / ng : 0;
+  const int Tx = panels_x * tn_x;
   const int Q = Tx > w ? (Tx - w + g8n - 1) / g8n : 0;
   if (Q == 0) return;
   auto tile_origin = [&](int qi, int& m0, int& n0) {
     const int u = qi * g8n + w;
-    const int pl = u / p.tiles_n, tn = u - pl * p.tiles_n;
-    m0 = (pl * 8 + x) * C::BM; n0 = tn * C::BN;
+    const int pl = u / tn_x, tn = u - pl * tn_x;
+    m0 = (pl * ng + xg) * C::BM; n0 = (cg * tn_x + tn) * C::BN;
   };
   const int S = Q * nk;                                    // K-tiles in this work-group's stream
   // ---- de-phasing.  Every work-group runs the same number of equally long tiles, so without it all 256 CUs reach their epilogues together and
@@ -469,6 +473,10 @@ __global__ void __launch_bounds__(512, 2) k_gemm8(const GemmArgs p, const int g8
 }
 
 static int g_dph_groups = 1, g_dph_sleeps = 0, g_g8n_cap = 0;
+#ifndef G8_CSPLIT
+#define G8_CSPLIT 0
+#endif
+static int g_csplit = G8_CSPLIT;      // 0 automatic; 1 / 2 / 4 forced (A/B builds)
 template <class C, int EPI, bool HB, bool DUAL>
 static int launch_cfg(GemmArgs a, hipStream_t s) {
   static bool configured = false;
@@ -481,9 +489,14 @@ static int launch_cfg(GemmArgs a, hipStream_t s) {
     configured = true;
   }
   a.tiles_m = a.M / C::BM; a.tiles_n = a.N / C::BN;
-  const long tiles = (long)a.tiles_m * a.tiles_n;
+  // column split: when W (N x K bf16) next to one round of activation panels overflows an XCD's 4 MB L2 and the activation panels are short (K small), halve W per XCD
+  int cs = 1;
+  if (g_csplit > 0) cs = g_csplit;
+  else if ((size_t)a.N * a.K * 2 > (size_t)(5 << 19) && a.K <= 1024) cs = 2;
+  while (cs > 1 && (a.tiles_n % cs || a.tiles_m < 8 / cs)) cs >>= 1;
+  a.csplit = cs;
+  const long per_xcd = (long)((a.tiles_m + 8 / cs - 1) / (8 / cs)) * (a.tiles_n / cs);
   int g8n = n_cu / 8;
-  const long per_xcd = (tiles + 7) / 8;
   if (g8n > per_xcd) g8n = (int)per_xcd;
   if (g8n < 1) g8n = 1;
   if (g_g8n_cap > 0 && g8n > g_g8n_cap) g8n = g_g8n_cap;      // experiment hook: fewer work-groups per XCD

@@ -10,7 +10,8 @@ from ctypes import c_float, c_int, c_int64, c_size_t, c_void_p
 import torch
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(_HERE, "liboneprot_hip.so")
+# ONEPROT_HIP_LIB: another build of the same ABI (development: step-level A/B of a variant library, tools/ab/build_lib.sh)
+LIB_PATH = os.environ.get("ONEPROT_HIP_LIB") or os.path.join(_HERE, "liboneprot_hip.so")
 
 ABI_VERSION = 5
 EPI_BF16, EPI_F32, EPI_BIAS_GELU, EPI_BIAS_RESID, EPI_QKV_ROPE, EPI_GELU_BWD = range(6)

@@ -1,7 +1,7 @@
 #!/usr/bin/env python3
 """Development tool (GPU): SEVERAL builds of liboneprot_hip.so against each other in ONE process (boxes differ by +-4 %, builds are only ever
 compared inside one process): interleaved rounds, medians, outputs checked against the first library's.
-usage: libs_ab.py name=path.so [name=path.so ...]     env AB_CASES=nt,gln,attn,tn (default all)  AB_ROUNDS=5  AB_ONLY=<substring of a case name>
+usage: libs_ab.py name=path.so [name=path.so ...]     env AB_CASES=nt,nt64,gln,attn,attn64,tn (default nt,gln,attn,tn)  AB_ROUNDS=5  AB_ONLY=<substring of a case name>
        AB_FORCE_SHAPE=<oneprot_gemm_force_shape id, e.g. 40 / 41>  AB_TUNE=<first argument of oneprot_gemm_tune, e.g. 19968 = 256 * 78: main loop only>
 The first library is the reference column; `name=product` stands for oneprot_amd/liboneprot_hip.so."""
 import ctypes, os, statistics, sys
@@ -26,6 +26,8 @@ for spec in sys.argv[1:]:
         h.oneprot_gemm_tune(int(os.environ["AB_TUNE"]), 0)
     if "@gln" in name and hasattr(h, "oneprot_gemm_ln_form"):      # e.g. old@gln0=product: the same library with the eight-wave fused GEMM + LN kernel
         h.oneprot_gemm_ln_form(int(name.split("@gln")[1]))          # (form | start delay of the second half of the grid in us << 8)
+    if "@fwd" in name:                                             # e.g. chunked@fwd2=product: the same library with the attention forward path forced
+        h.oneprot_attn_force_fwd_path(int(name.split("@fwd")[1]))
 if not libs:
     sys.exit(__doc__)
 groups = os.environ.get("AB_CASES", "nt,gln,attn,tn").split(",")
@@ -68,11 +70,11 @@ def nt_case(name, N, K, epi, two=True):
         mk = lambda h: (lambda: call(h, "oneprot_gemm_bf16_nt", A, W, T, N, K, K, K, epi, bias, o0, None, None, res, None, None, 1.0, 0, 0, 0))
         outs = [o0]
     elif epi == hip.EPI_BIAS_GELU:
-        o0 = torch.empty(T, N, dtype=torch.bfloat16, device="cuda"); o1 = torch.empty_like(o0) if two else None
+        o0 = torch.empty(T, N, dtype=torch.bfloat16, device="cuda"); o1 = torch.empty(T, N, dtype=torch.uint8, device="cuda") if two else None
         mk = lambda h: (lambda: call(h, "oneprot_gemm_bf16_nt", A, W, T, N, K, K, K, epi, bias, o0, o1, None, None, None, None, 1.0, 0, 0, 0))
         outs = [o0] + ([o1] if two else [])
     elif epi == hip.EPI_GELU_BWD:
-        o0 = torch.empty(T, N, dtype=torch.bfloat16, device="cuda"); aux = rnd(T, N).to(torch.bfloat16)
+        o0 = torch.empty(T, N, dtype=torch.bfloat16, device="cuda"); aux = torch.randint(0, 256, (T, N), dtype=torch.uint8, device="cuda", generator=g)
         mk = lambda h: (lambda: call(h, "oneprot_gemm_bf16_nt", A, W, T, N, K, K, K, epi, None, o0, None, None, aux, None, None, 1.0, 0, 0, 0))
         outs = [o0]
     else:
@@ -135,6 +137,17 @@ if "attn" in groups:
             call(h, "oneprot_attn_fwd", q, k, v, kb, ctx, lse, B, H, L, hd)
             return lambda: call(h, "oneprot_attn_bwd", q, k, v, kb, ctx, dctx, lse, cos, sin, hd ** -0.5, dqkv, ws, B, H, L, hd)
         cases.append((f"attn bwd {nm}", 2.5 * fl, mkb, [dqkv]))
+
+if "attn64" in groups:      # head_dim 64 forwards: ESM-2-650M at 128 pairs (L = 512) and BERT-base (L = 256)
+    for nm, B_, H_, L_ in (("attn64 fwd 650M  B128 H20 L512", 128, 20, 512), ("attn64 fwd BERT  B256 H12 L256", 256, 12, 256), ("attn64 fwd BERT  B256 H12 L512", 256, 12, 512)):
+        q6, k6, v6 = [(rnd(B_, H_, L_, 64) * 0.7).to(torch.bfloat16) for _ in range(3)]
+        lens6 = torch.randint(L_ // 2, L_ + 1, (B_,), device="cuda", generator=g)
+        kb6 = torch.where(torch.arange(L_, device="cuda")[None, :] < lens6[:, None], 0.0, float("-inf")).float().contiguous()
+        ctx6 = torch.empty(B_ * L_, H_ * 64, dtype=torch.bfloat16, device="cuda"); lse6 = torch.empty(B_, H_, L_, device="cuda")
+        for tag, kbx in (("no padding", torch.zeros_like(kb6)), ("ragged", kb6)):
+            cases.append((f"{nm} {tag}", 4.0 * B_ * H_ * L_ * L_ * 64,
+                          (lambda h, q6=q6, k6=k6, v6=v6, kbx=kbx, ctx6=ctx6, lse6=lse6, B_=B_, H_=H_, L_=L_: (lambda: call(h, "oneprot_attn_fwd", q6, k6, v6, kbx, ctx6, lse6, B_, H_, L_, 64))),
+                          [ctx6, lse6]))
 
 if "tn" in groups:
     for nm, N, K in (("tn qkv  dW[1920,640]", 3 * d, d), ("tn out  dW[640,640]", d, d), ("tn ffn1 dW[2560,640]", f, d), ("tn ffn2 dW[640,2560]", d, f)):
