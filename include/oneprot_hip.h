@@ -185,6 +185,12 @@ int oneprot_dropout_f32(const float* x, float* y, int64_t n, float p, uint64_t s
 /* y = resid + dropout(x): the dense output's dropout and the residual add that follows it in BertSelfOutput / BertOutput (hf modeling_bert.py) in one pass;
    the same mask as oneprot_dropout_f32 for the same (seed, stream_id); y may alias x or resid. */
 int oneprot_dropout_add_f32(const float* x, const float* resid, float* y, int64_t n, float p, uint64_t seed, uint64_t stream_id, void* stream);
+/* s = resid + dropout(x), then LayerNorm(s), one pass (hf modeling_bert.py:BertSelfOutput / BertOutput.forward: dense -> dropout -> LayerNorm(. + input);
+ * the reference runs them whenever the text tower is in train mode, src/models/components/text_encoder.py:56-62).  Same mask as oneprot_dropout_add_f32 for
+ * the same (seed, stream_id).  s_out (fp32 [T,d], the sum the LayerNorm backward needs) may be NULL; y_bf16 / y_f32 / mean / rstd as oneprot_layernorm_fwd;
+ * d a multiple of 8, d <= 2048. */
+int oneprot_dropout_add_layernorm_fwd(const float* x, const float* resid, float* s_out, const float* gamma, const float* beta, void* y_bf16, float* y_f32,
+                                      float* mean, float* rstd, int64_t T, int d, float eps, float p, uint64_t seed, uint64_t stream_id, void* stream);
 /* dx += mask(seed, stream_id) * dy / keep: the backward of the call above with the same (p, seed, stream_id), added into an existing bf16 gradient. */
 int oneprot_dropout_bwd_add_bf16(const void* dy, void* dx, int64_t n, float p, uint64_t seed, uint64_t stream_id, void* stream);
 /* the same into an fp32 gradient (the post-LN BERT tower keeps the layer-input gradient in fp32; ref text_encoder.py:39-52). */

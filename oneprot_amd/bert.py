@@ -190,23 +190,26 @@ class BertTransformer(ArenaModule):
                 # s1 = x + dropout(ctx Wo^T + bo): the residual add leaves the GEMM epilogue so that the mask can sit between the two
                 hip.call("oneprot_gemm_bf16_nt", ctx, self._w16(p + "attention.output.dense.weight"), T, d, d, d, d, hip.EPI_F32,
                          self.view(p + "attention.output.dense.bias"), y_drop, None, None, None, None, None, 1.0, 0, 0, 0)
-                hip.call("oneprot_dropout_add_f32", y_drop, x, s1, T * d, p_h, self._drop_seed, self._drop_stream(drop_call, i, 1))
+                # ... and the LayerNorm that follows reads the sum where it is formed (one kernel; a frozen tower never writes the sum)
+                hip.call("oneprot_dropout_add_layernorm_fwd", y_drop, x, s1 if save else None, self.view(p + "attention.output.LayerNorm.weight"),
+                         self.view(p + "attention.output.LayerNorm.bias"), y16, y1, m1, r1, T, d, eps, p_h, self._drop_seed, self._drop_stream(drop_call, i, 1))
             else:
                 hip.call("oneprot_attn_fwd", q, k, v, key_bias, ctx, lse, B, H, L, hd)
                 hip.call("oneprot_gemm_bf16_nt", ctx, self._w16(p + "attention.output.dense.weight"), T, d, d, d, d, hip.EPI_BIAS_RESID,
                          self.view(p + "attention.output.dense.bias"), s1, None, None, x, None, None, 1.0, 0, 0, 0)
-            hip.call("oneprot_layernorm_fwd", s1, 0, self.view(p + "attention.output.LayerNorm.weight"), self.view(p + "attention.output.LayerNorm.bias"), y16, y1,
-                     m1, r1, T, d, eps)
+                hip.call("oneprot_layernorm_fwd", s1, 0, self.view(p + "attention.output.LayerNorm.weight"), self.view(p + "attention.output.LayerNorm.bias"), y16, y1,
+                         m1, r1, T, d, eps)
             hip.call("oneprot_gemm_bf16_nt", y16, self._w16(p + "intermediate.dense.weight"), T, f, d, d, d, hip.EPI_BIAS_GELU,
                      self.view(p + "intermediate.dense.bias"), u, z, None, None, None, None, 1.0, 0, 0, 0)
             if drop:
                 hip.call("oneprot_gemm_bf16_nt", u, self._w16(p + "output.dense.weight"), T, d, f, f, f, hip.EPI_F32, self.view(p + "output.dense.bias"),
                          y_drop, None, None, None, None, None, 1.0, 0, 0, 0)
-                hip.call("oneprot_dropout_add_f32", y_drop, y1, s2, T * d, p_h, self._drop_seed, self._drop_stream(drop_call, i, 2))
+                hip.call("oneprot_dropout_add_layernorm_fwd", y_drop, y1, s2 if save else None, self.view(p + "output.LayerNorm.weight"),
+                         self.view(p + "output.LayerNorm.bias"), h_out, x_out, m2, r2, T, d, eps, p_h, self._drop_seed, self._drop_stream(drop_call, i, 2))
             else:
                 hip.call("oneprot_gemm_bf16_nt", u, self._w16(p + "output.dense.weight"), T, d, f, f, f, hip.EPI_BIAS_RESID, self.view(p + "output.dense.bias"),
                          s2, None, None, y1, None, None, 1.0, 0, 0, 0)
-            hip.call("oneprot_layernorm_fwd", s2, 0, self.view(p + "output.LayerNorm.weight"), self.view(p + "output.LayerNorm.bias"), h_out, x_out, m2, r2, T, d, eps)
+                hip.call("oneprot_layernorm_fwd", s2, 0, self.view(p + "output.LayerNorm.weight"), self.view(p + "output.LayerNorm.bias"), h_out, x_out, m2, r2, T, d, eps)
             if save:
                 saved["layers"].append(st)
             x, h = x_out, h_out

@@ -334,6 +334,96 @@ extern "C" int oneprot_dropout_bwd_add_f32(const void* dy, float* dx, int64_t n,
   return launch_dropout(2, dy, dx, n, p, seed, stream_id, stream);
 }
 
+// s = resid + dropout(x); LayerNorm(s) in ONE pass over the rows (hf modeling_bert.py BertSelfOutput / BertOutput: dense -> dropout -> LayerNorm(. + input)):
+// the separate kernels moved the sum through HBM twice (written by the dropout + add, read again by the LayerNorm).  Same mask as oneprot_dropout_f32 /
+// oneprot_dropout_add_f32 (a lane owns the 8 consecutive elements of one Philox call), same LayerNorm arithmetic as k_layernorm_fwd with eight
+// elements per lane and step instead of four.  s_out (the pre-LayerNorm sum the backward needs) is optional: a frozen tower does not write it.
+template <int NV>
+__global__ void __launch_bounds__(256) k_dropout_add_ln_fwd(const float* __restrict__ x, const float* resid, float* s_out,      // (y_f32 / s_out may alias resid: a lane reads what it writes, first)
+                                                            const float* __restrict__ gamma, const float* __restrict__ beta, bf16_t* __restrict__ y_bf16,
+                                                            float* y_f32, float* __restrict__ mean_out, float* __restrict__ rstd_out, int T, int d, float eps,
+                                                            unsigned thr, float scale, unsigned long long seed, unsigned long long stream_id) {
+  const int lane = threadIdx.x & 63;
+  const int nv8 = d >> 3;
+  const float inv_d = 1.0f / (float)d;
+  for (int row = blockIdx.x * 4 + (threadIdx.x >> 6); row < T; row += gridDim.x * 4) {
+    float v[NV][8];
+    float sum = 0.f;
+    const size_t row8 = (size_t)row * nv8;
+#pragma unroll
+    for (int i = 0; i < NV; ++i) {
+      const int c = lane + 64 * i;
+      if (c < nv8) {
+        const size_t e8 = row8 + c;
+        unsigned rnd[4];
+        philox4x32_10((unsigned)e8, (unsigned)(e8 >> 32), (unsigned)stream_id, (unsigned)(stream_id >> 32), (unsigned)seed, (unsigned)(seed >> 32), rnd);
+        const float4 a = reinterpret_cast<const float4*>(x)[2 * e8], b = reinterpret_cast<const float4*>(x)[2 * e8 + 1];
+        const float4 ra = reinterpret_cast<const float4*>(resid)[2 * e8], rb = reinterpret_cast<const float4*>(resid)[2 * e8 + 1];
+        const float xin[8] = {a.x, a.y, a.z, a.w, b.x, b.y, b.z, b.w};
+        const float rin[8] = {ra.x, ra.y, ra.z, ra.w, rb.x, rb.y, rb.z, rb.w};
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+          v[i][2 * j] = (((rnd[j] & 0xffffu) >= thr) ? xin[2 * j] * scale : 0.f) + rin[2 * j];
+          v[i][2 * j + 1] = (((rnd[j] >> 16) >= thr) ? xin[2 * j + 1] * scale : 0.f) + rin[2 * j + 1];
+        }
+        if (s_out) {
+          reinterpret_cast<float4*>(s_out)[2 * e8] = make_float4(v[i][0], v[i][1], v[i][2], v[i][3]);
+          reinterpret_cast<float4*>(s_out)[2 * e8 + 1] = make_float4(v[i][4], v[i][5], v[i][6], v[i][7]);
+        }
+        sum += ((v[i][0] + v[i][1]) + (v[i][2] + v[i][3])) + ((v[i][4] + v[i][5]) + (v[i][6] + v[i][7]));
+      }
+    }
+    const float mean = wave_sum(sum) * inv_d;
+    float q = 0.f;
+#pragma unroll
+    for (int i = 0; i < NV; ++i)
+      if (lane + 64 * i < nv8) {
+#pragma unroll
+        for (int j = 0; j < 8; ++j) { const float t = v[i][j] - mean; q += t * t; }
+      }
+    const float rstd = rsqrtf(wave_sum(q) * inv_d + eps);
+    if (lane == 0) {
+      if (mean_out) mean_out[row] = mean;
+      if (rstd_out) rstd_out[row] = rstd;
+    }
+#pragma unroll
+    for (int i = 0; i < NV; ++i) {
+      const int c = lane + 64 * i;
+      if (c < nv8) {
+        const float4 g0 = reinterpret_cast<const float4*>(gamma)[2 * c], g1 = reinterpret_cast<const float4*>(gamma)[2 * c + 1];
+        const float4 b0 = reinterpret_cast<const float4*>(beta)[2 * c], b1 = reinterpret_cast<const float4*>(beta)[2 * c + 1];
+        const float gg[8] = {g0.x, g0.y, g0.z, g0.w, g1.x, g1.y, g1.z, g1.w}, bb[8] = {b0.x, b0.y, b0.z, b0.w, b1.x, b1.y, b1.z, b1.w};
+        float o[8];
+#pragma unroll
+        for (int j = 0; j < 8; ++j) o[j] = (v[i][j] - mean) * rstd * gg[j] + bb[j];
+        const size_t e8 = row8 + c;
+        if (y_f32) {
+          reinterpret_cast<float4*>(y_f32)[2 * e8] = make_float4(o[0], o[1], o[2], o[3]);
+          reinterpret_cast<float4*>(y_f32)[2 * e8 + 1] = make_float4(o[4], o[5], o[6], o[7]);
+        }
+        if (y_bf16) {
+          u32x4 w; w.x = pack2bf(o[0], o[1]); w.y = pack2bf(o[2], o[3]); w.z = pack2bf(o[4], o[5]); w.w = pack2bf(o[6], o[7]);
+          reinterpret_cast<u32x4*>(y_bf16)[e8] = w;
+        }
+      }
+    }
+  }
+}
+extern "C" int oneprot_dropout_add_layernorm_fwd(const float* x, const float* resid, float* s_out, const float* gamma, const float* beta, void* y_bf16, float* y_f32,
+                                                 float* mean, float* rstd, int64_t T, int d, float eps, float p, uint64_t seed, uint64_t stream_id, void* stream) {
+  if (!x || !resid || !gamma || !beta || (!y_bf16 && !y_f32) || T <= 0 || d <= 0 || (d & 7) || d > 4 * 512 || !(p >= 0.f) || !(p < 1.f)) return OP_EINVAL;
+  if (((uintptr_t)x | (uintptr_t)resid | (uintptr_t)s_out | (uintptr_t)y_bf16 | (uintptr_t)y_f32 | (uintptr_t)gamma | (uintptr_t)beta) & 15) return OP_EINVAL;
+  const unsigned thr = (unsigned)(p * 65536.f + 0.5f);
+  if (thr >= 65536u) return OP_EINVAL;
+  const float scale = 65536.f / (float)(65536u - thr);
+  const int nv = (d / 8 + 63) / 64;
+  const int blocks = (int)((T + 3) / 4 < 4096 ? (T + 3) / 4 : 4096);
+#define DLN(N) hipLaunchKernelGGL((k_dropout_add_ln_fwd<N>), dim3(blocks), dim3(256), 0, (hipStream_t)stream, x, resid, s_out, gamma, beta, (bf16_t*)y_bf16, y_f32, mean, rstd, (int)T, d, eps, thr, scale, (unsigned long long)seed, (unsigned long long)stream_id)
+  if (nv <= 1) DLN(1); else if (nv == 2) DLN(2); else if (nv == 3) DLN(3); else DLN(4);
+#undef DLN
+  return launch_status();
+}
+
 // SigLIP block (ref loss.py:229-255): logits [B,B] (already scale*m@s^T) -> loss_sum += -sum logsigmoid(label*(logit+bias)) * inv_b,
 // logits <- dloss/dlogit = -label * sigmoid(-label*(logit+bias)) * inv_b;  label = +1 on the diagonal (unless negative_only), else -1.
 __global__ void __launch_bounds__(256) k_siglip_fwd_bwd(float* __restrict__ logits, float* __restrict__ row_loss, int B, float bias, const float* __restrict__ bias_dev,
@@ -389,4 +479,4 @@ extern "C" int oneprot_diag_rank(const float* logits, int* rank_row, int* rank_c
   return launch_status();
 }
 
-extern "C" int oneprot_abi_version(void) { return 5; }      // 5: gelu' travels as one-byte codes (out1 of ONEPROT_EPI_BIAS_GELU / aux of ONEPROT_EPI_GELU_BWD are u8 tensors), oneprot_gemm_ln_form, oneprot_dropout_add_f32; 2: oneprot_gemm_bf16_tn takes workspace_bytes; 3: fused GEMM + LayerNorm entry points, oneprot_dot_f32; 4: oneprot_siglip_fwd_bwd_dev, oneprot_attn_force_fwd_path, oneprot_transpose_cast_f32_to_bf16_batched, oneprot_dropout_bf16 / _bwd_add_bf16 / _bwd_add_f32
+extern "C" int oneprot_abi_version(void) { return 6; }      // 6: oneprot_dropout_add_layernorm_fwd; 5: gelu' travels as one-byte codes (out1 of ONEPROT_EPI_BIAS_GELU / aux of ONEPROT_EPI_GELU_BWD are u8 tensors), oneprot_gemm_ln_form, oneprot_dropout_add_f32; 2: oneprot_gemm_bf16_tn takes workspace_bytes; 3: fused GEMM + LayerNorm entry points, oneprot_dot_f32; 4: oneprot_siglip_fwd_bwd_dev, oneprot_attn_force_fwd_path, oneprot_transpose_cast_f32_to_bf16_batched, oneprot_dropout_bf16 / _bwd_add_bf16 / _bwd_add_f32

@@ -13,7 +13,7 @@ _HERE = os.path.dirname(os.path.abspath(__file__))
 # ONEPROT_HIP_LIB: another build of the same ABI (development: step-level A/B of a variant library, tools/ab/build_lib.sh)
 LIB_PATH = os.environ.get("ONEPROT_HIP_LIB") or os.path.join(_HERE, "liboneprot_hip.so")
 
-ABI_VERSION = 5
+ABI_VERSION = 6
 EPI_BF16, EPI_F32, EPI_BIAS_GELU, EPI_BIAS_RESID, EPI_QKV_ROPE, EPI_GELU_BWD = range(6)
 LOG2E = 1.4426950408889634      # the attention kernels take q pre-multiplied by hd^-1/2 * log2(e) (include/oneprot_hip.h)
 
@@ -82,6 +82,7 @@ _SIGS = {
     "oneprot_dropout_bwd_add_f32": (I, [P, P, L64, F, U64, U64, P]),
     "oneprot_dropout_f32": (I, [P, P, L64, F, U64, U64, P]),
     "oneprot_dropout_add_f32": (I, [P, P, P, L64, F, U64, U64, P]),
+    "oneprot_dropout_add_layernorm_fwd": (I, [P, P, P, P, P, P, P, P, P, L64, I, F, F, U64, U64, P]),
     "oneprot_key_padding_bias": (I, [P, P, L64, I, P]),
     "oneprot_sumsq_workspace": (SZ, []),
     "oneprot_sumsq": (I, [P, L64, P, P, P]),
@@ -104,7 +105,7 @@ _PTR_DTYPES = {
     "oneprot_gemm_bf16_nt": "hhf**h*ff", "oneprot_gemm_ln_pack_weight": "hh", "oneprot_gemm_bf16_nt_resid_ln": "hhfffffhff", "oneprot_gemm_bf16_tn": "hhffb", "oneprot_sgemm": "fff", "oneprot_attn_fwd": "hhhfhf",
     "oneprot_attn_bwd": "hhhfhhfffhb", "oneprot_attn_bwd_dropout": "hhhfhhfffhb", "oneprot_gelu_f32": "ff", "oneprot_gelu_bwd_f32": "fff", "oneprot_l2norm_fwd": "fff", "oneprot_l2norm_bwd": "ffff",
     "oneprot_ce_fwd_bwd": "fff", "oneprot_siglip_fwd_bwd": "fff", "oneprot_siglip_fwd_bwd_dev": "ffff", "oneprot_diag_rank": "fii", "oneprot_abs_sum": "ffb", "oneprot_dot_f32": "fffb", "oneprot_l1_bwd": "fff",
-    "oneprot_scale_by_device_scalar": "ff", "oneprot_key_padding_bias": "lf", "oneprot_dropout_bf16": "hh", "oneprot_dropout_bwd_add_bf16": "hh", "oneprot_dropout_bwd_add_f32": "hf", "oneprot_dropout_f32": "ff", "oneprot_dropout_add_f32": "fff", "oneprot_attn_fwd_dropout": "hhhfhf", "oneprot_attn_dropout_keep": "b", "oneprot_sumsq": "ffb", "oneprot_clip_coef": "fff", "oneprot_adam_step": "fffff",
+    "oneprot_scale_by_device_scalar": "ff", "oneprot_key_padding_bias": "lf", "oneprot_dropout_bf16": "hh", "oneprot_dropout_bwd_add_bf16": "hh", "oneprot_dropout_bwd_add_f32": "hf", "oneprot_dropout_f32": "ff", "oneprot_dropout_add_f32": "fff", "oneprot_dropout_add_layernorm_fwd": "fffffhfff", "oneprot_attn_fwd_dropout": "hhhfhf", "oneprot_attn_dropout_keep": "b", "oneprot_sumsq": "ffb", "oneprot_clip_coef": "fff", "oneprot_adam_step": "fffff",
     "oneprot_cast_f32_to_bf16": "fh", "oneprot_transpose_cast_f32_to_bf16": "fh", "oneprot_transpose_cast_f32_to_bf16_batched": "fh", "oneprot_colsum_bf16": "hfb",
 }
 _DT = {"f": torch.float32, "h": torch.bfloat16, "l": torch.int64, "i": torch.int32, "b": torch.uint8}

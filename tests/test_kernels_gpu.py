@@ -38,7 +38,7 @@ def ws(nbytes):
 
 # ------------------------------------------------------------------------------------------------------
 def test_library_loads():
-    assert hip.query("oneprot_abi_version") == 5
+    assert hip.query("oneprot_abi_version") == 6
 
 
 @pytest.mark.parametrize("B,L,d,vocab", [(3, 17, 64, 33), (4, 130, 640, 54)])
@@ -800,6 +800,36 @@ def test_dropout_f32_and_its_residual_form():
     assert torch.equal(y2, y)
     with pytest.raises(hip.HipKernelError):
         hip.call("oneprot_dropout_add_f32", x, None, y, n, p_, seed, stream)
+
+
+@pytest.mark.parametrize("T,d", [(67, 768), (9, 1024), (130, 264), (5, 2048)])
+def test_dropout_add_layernorm_fused_equals_the_two_kernels(T, d):
+    """oneprot_dropout_add_layernorm_fwd (hf BertSelfOutput / BertOutput: dense -> dropout -> LayerNorm(. + input) in one pass over the rows) against
+    oneprot_dropout_add_f32 followed by oneprot_layernorm_fwd: the sum bit for bit (same mask, same arithmetic), the LayerNorm outputs to the
+    rounding of a different summation order (eight elements per lane and step instead of four); without the optional sum; in place on the residual."""
+    g = torch.Generator().manual_seed(31 + d)
+    x = torch.randn(T, d, generator=g).to(DEV)
+    resid = torch.randn(T, d, generator=g).to(DEV)
+    gamma, beta = (1 + 0.1 * torch.randn(d, generator=g)).to(DEV), (0.1 * torch.randn(d, generator=g)).to(DEV)
+    p_, seed, stream = 0.1, 0x5EED, (1 << 60) | (3 << 44) | 9
+    s_ref = torch.empty_like(x)
+    hip.call("oneprot_dropout_add_f32", x, resid, s_ref, T * d, p_, seed, stream)
+    y16_ref, y_ref = torch.empty(T, d, dtype=torch.bfloat16, device=DEV), torch.empty_like(x)
+    m_ref, r_ref = torch.empty(T, device=DEV), torch.empty(T, device=DEV)
+    hip.call("oneprot_layernorm_fwd", s_ref, 0, gamma, beta, y16_ref, y_ref, m_ref, r_ref, T, d, 1e-12)
+    s, y16, y, m, r = torch.empty_like(x), torch.empty_like(y16_ref), torch.empty_like(x), torch.empty(T, device=DEV), torch.empty(T, device=DEV)
+    hip.call("oneprot_dropout_add_layernorm_fwd", x, resid, s, gamma, beta, y16, y, m, r, T, d, 1e-12, p_, seed, stream)
+    assert torch.equal(s, s_ref)
+    assert_close(m, m_ref, 1e-6, 1e-6, "mean")
+    assert_close(r, r_ref, 1e-5, 0.0, "rstd")
+    assert_close(y, y_ref, 1e-5, 2e-5, "LayerNorm fp32")
+    assert_close(y16.float(), y16_ref.float(), 2 ** -7, 1e-5, "LayerNorm bf16")
+    # a frozen tower: no sum, fp32 output in place on the residual stream
+    r2, y16b = resid.clone(), torch.empty_like(y16_ref)
+    hip.call("oneprot_dropout_add_layernorm_fwd", x, r2, None, gamma, beta, y16b, r2, None, None, T, d, 1e-12, p_, seed, stream)
+    assert torch.equal(r2, y) and torch.equal(y16b, y16)
+    with pytest.raises(hip.HipKernelError):
+        hip.call("oneprot_dropout_add_layernorm_fwd", x, resid, None, gamma, beta, y16, y, None, None, T, 12, 1e-12, p_, seed, stream)
 
 
 def test_dropout_bf16_mask_is_a_function_of_seed_stream_and_element():
