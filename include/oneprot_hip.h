@@ -89,6 +89,17 @@ int oneprot_gemm_bf16_nt(const void* A, const void* Bw, int64_t M, int N, int K,
 int oneprot_gemm_ln_pack_weight(const void* W_bf16 /* [N,K] row-major */, void* Wp, int N, int K, void* stream);
 int oneprot_gemm_bf16_nt_resid_ln(const void* A, const void* Wp, int64_t M, int N, int K, int lda, const float* bias, const float* resid, float* x_out,
                                   const float* gamma, const float* beta, float eps, void* h_out, float* mean, float* rstd, void* stream);
+/* The same product with the row statistics completed ACROSS work-groups, for the launches whose K loop the full-row kernel above runs too slowly
+ * (FFN-2, K = 4 d): x_out = resid + A W^T + bias (fp32; may alias resid) and h = LayerNorm(x_out) (bf16), by the 8-phase GEMM on 256 x 320 tiles; the
+ * column tiles of a row panel exchange (mean, M2) partials through device memory (hf modeling_esm.py:442-463 followed by :429 of the next layer or by
+ * emb_layer_norm_after, sequence_encoder.py:76-81).  W as for oneprot_gemm_bf16_nt (not packed).  stats: fp32 [2][M] = mean | rstd, or NULL.
+ * oneprot_gemm_resid_ln8_eligible: 1 when (M, N, K) is made of whole tiles this form serves (M % 256 == 0, N in {320, 640, 1280}, K % 128 == 0, >= 192 tiles),
+ * else the caller runs oneprot_gemm_bf16_nt (ONEPROT_EPI_BIAS_RESID) + oneprot_layernorm_fwd.  oneprot_gemm_resid_ln8_error: 1 after a launch in which a
+ * bounded wait for a neighbouring column tile ran out (host-synchronous query; never seen, the waits are short by construction). */
+int oneprot_gemm_resid_ln8_eligible(int64_t M, int N, int K);
+int oneprot_gemm_resid_ln8_error(void);
+int oneprot_gemm_bf16_nt_resid_ln8(const void* A, const void* W, int64_t M, int N, int K, int lda, int ldb, const float* bias, const float* resid,
+                                   float* x_out, const float* gamma, const float* beta, float eps, void* h_bf16, float* stats, void* stream);
 /* test / tuning hook: kernel form of oneprot_gemm_bf16_nt_resid_ln -- 1 (default): four-wave work-groups on 64-row tiles, two per CU (one's K loop
    under the other's HBM-bound epilogue); 0: eight-wave work-groups on 128-row tiles, one per CU.  Bit-identical results. */
 void oneprot_gemm_ln_form(int form);

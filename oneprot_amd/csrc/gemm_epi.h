@@ -18,7 +18,14 @@ struct GemmArgs {
   int csplit;                   // 8-phase kernels: XCDs that share a set of row panels and divide its column tiles between them (1, 2 or 4)
   int sup_m, sup_n;             // L2 super-tile of the per-tile kernels: sup_m row panels x sup_n column tiles per XCD at a time
   int nt_store;                 // output stores non-temporal (streamed past the L2 instead of displacing the operand panels and W)
+  // G8_EPI_RESID_LN (8-phase kernels only): out0 = x_out fp32 = acc + bias + aux; out1 = bf16 LayerNorm(x_out) with gamma = cos, beta = sin, eps = q_scale;
+  // out2 = fp32 [2][M]: mean | rstd (or null).  A row's statistics are completed across the column tiles through ln_part / ln_flag (gemm_epi8.h).
+  float* ln_part;               // [M][8] x (mean, M2): per row, one partial per wave column of every column tile
+  unsigned* ln_flag;            // [M / 64]: arrivals per 64-row wave block (zeroed before the launch)
+  unsigned* ln_err;             // sticky: a wait for the other column tiles ran out
+  int ln_slots;                 // partials per row = column tiles x wave columns
 };
+#define G8_EPI_RESID_LN 6      // internal to gemm_nt8.hip / gemm_epi8.h (entry point oneprot_gemm_bf16_nt_resid_ln8), not part of the public epilogue enum
 // 16- / 8-byte output stores with the launch's cache policy (wave-uniform branch)
 __device__ __forceinline__ void gst(u32x4* p, u32x4 v, int nt) { if (nt) __builtin_nontemporal_store(v, p); else *p = v; }
 __device__ __forceinline__ void gst(u32x2* p, u32x2 v, int nt) { if (nt) __builtin_nontemporal_store(v, p); else *p = v; }
@@ -276,3 +283,6 @@ __device__ __forceinline__ void gemm_epilogue_direct(const GemmArgs& p, f32x4 (&
 // 8-phase form (gemm_nt8.hip).  cfg 0: 256 x 256 tiles, cfg 1: 256 x 320 tiles; G8_NOT_ELIGIBLE when the problem is not made of whole tiles.
 #define G8_NOT_ELIGIBLE (-100)
 int launch_gemm8(int epi, const GemmArgs& a, int cfg, long min_tiles, hipStream_t s);
+bool gemm8_ln_eligible(long M, int N, int K);
+int launch_gemm8_ln(GemmArgs a, hipStream_t s);      // G8_EPI_RESID_LN on 256 x 320 tiles
+int gemm8_ln_error();

@@ -319,6 +319,201 @@ __device__ __forceinline__ void epilogue_f32(const GemmArgs& p, f32x4 (&acc)[MT]
   run_groups<NG, GL, GS>(load, finish);
 }
 
+// G8_EPI_RESID_LN: x_out = acc + bias + residual (fp32, as BIAS_RESID) AND h = LayerNorm(x_out) in bf16 -- the LayerNorm that follows the FFN-2 GEMM of a
+// pre-LN layer (hf modeling_esm.py:482-521 -> the next layer's :429, or emb_layer_norm_after), which used to be a kernel of its own reading x_out back (335 MB per launch at
+// the cfg-2 shape, 92 us, no matrix work).  A row of N columns is spread over N / 320 work-groups x 2 wave columns; nobody holds it whole.  So:
+//   A  the BIAS_RESID epilogue as it stands (loads two groups ahead, 16-byte fp32 stores), with the finished sums written BACK into the accumulator registers
+//      (row layout) and a running row sum per row block;
+//   B  per lane: mean and M2 = sum (s - mean)^2 over its 40 values of each of its 4 rows, in registers; the four lanes of a row (a quad) combine theirs by
+//      Chan's rule (DPP quad_perm): every lane then holds (mean, M2) of its wave block's 160 columns;
+//   C  lanes sq == 0 publish them -- ln_part[row][slot], slot = column tile x 2 + wave column, in UNCACHED device memory -- wait until the stores have
+//      landed and count the wave in on ln_flag[64-row block] (a relaxed atomic: no cache maintenance anywhere);
+//   D  the wave waits until all `ln_slots` wave blocks of its rows have arrived (they run the same tile at the same time: the work-groups of one row panel are
+//      neighbours in the launch and every work-group walks its tiles in step), bounded: a wait that runs out sets ln_err and goes on;
+//   E  lane sq reads partial sq (and sq + 4), the quad combines again: every lane has the row's statistics over all N columns;
+//   F  h = (s - mean) rstd gamma + beta from the registers, two column tiles at a time (gamma / beta two groups ahead like every epilogue operand),
+//      lane pairs swapping halves so that a lane stores 16 contiguous bytes; mean / rstd leave from slot 0.
+// The statistics are exact two-pass ones per wave block (the values are in registers) and Chan's combination is exact in exact arithmetic: the result
+// agrees with k_layernorm_fwd's two-pass form to fp32 rounding.  Deadlock: a wave only waits for waves of work-groups that were launched (the grid is one
+// work-group per CU, and a work-group that has to wait for a CU starts when the others finish: they never wait for IT twice).
+// 8-byte load that misses every cache on its way (system scope): the partial statistics of the other wave blocks
+template <int OFF> __device__ __forceinline__ void gload8_uc(u32x2& d, const void* ptr) {
+  asm volatile("global_load_dwordx2 %0, %1, off offset:%2 sc0 sc1" : "=v"(d) : "v"(ptr), "n"(OFF) : "memory");
+}
+__device__ __forceinline__ float dpp_quad_xor1(float v) { return __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), 0xB1, 0xF, 0xF, false)); }
+__device__ __forceinline__ float dpp_quad_xor2(float v) { return __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), 0x4E, 0xF, 0xF, false)); }
+// (mean, M2) of two equally large sets of n values each -> of their union
+__device__ __forceinline__ void chan_merge(float& mean, float& m2, float mo, float m2o, float n) {
+  const float d = mo - mean;
+  mean = 0.5f * (mean + mo);
+  m2 = m2 + m2o + d * d * (0.5f * n);
+}
+template <bool HB, int MT, int NT>
+__device__ __forceinline__ void epilogue_resid_ln(const GemmArgs& p, f32x4 (&acc)[MT][NT], int m0, int n0, int wr, int wc, int lane) {
+  static_assert(NT % 2 == 0, "whole lines per wave block");
+  using Plan = LinePlan<MT, NT, false>;
+  static_assert(!Plan::LONE);
+  constexpr int NG = Plan::NG, GL = (HB ? 2 : 0) + 4, GS = 4;
+  const int q = lane >> 4;
+  const int sr = lane >> 2, sq = lane & 3;
+  const int pa = to_rows_addr(lane);
+  const int row_w = m0 + wr * (MT * 16);                    // first row of the wave block
+  const int col_w = n0 + wc * (NT * 16);                    // first column
+  const size_t o0 = (size_t)(row_w + sr) * p.N + col_w + sq * 4;
+  const size_t rstep = (size_t)16 * p.N;
+  const float* bcol = HB ? p.bias + col_w + q * 4 : nullptr;
+  const float* res = (const float*)p.aux + o0;
+  float* out0 = (float*)p.out0 + o0;
+  float rsum[MT];
+#pragma unroll
+  for (int i = 0; i < MT; ++i) rsum[i] = 0.f;
+  // ---- A
+  {
+    auto load = [&](auto gc, u32x4 (&r)[GL]) {
+      constexpr int g = decltype(gc)::value;
+      if constexpr (HB) { gload16(r[0], bcol + Plan::col(g, 0) * 16); gload16(r[1], bcol + Plan::col(g, 1) * 16); }
+      static_for([&](auto uc) {
+        constexpr int u = decltype(uc)::value;
+        gload16(r[(HB ? 2 : 0) + u], res + Plan::row(g, u) * rstep + Plan::col(g, u) * 16);
+      }, std::make_integer_sequence<int, 4>{});
+    };
+    auto finish = [&](auto gc, const u32x4 (&r)[GL]) {
+      constexpr int g = decltype(gc)::value;
+      float h0, h1, h2, h3;
+      static_for([&](auto uc) {
+        constexpr int u = decltype(uc)::value, j = Plan::col(g, u), i = Plan::row(g, u);
+        float x0 = acc[i][j][0], x1 = acc[i][j][1], x2 = acc[i][j][2], x3 = acc[i][j][3];
+        if constexpr (HB) { const u32x4 t = r[u & 1]; x0 += as_f(t.x); x1 += as_f(t.y); x2 += as_f(t.z); x3 += as_f(t.w); }
+        u32x4 a; a.x = __builtin_bit_cast(unsigned, x0); a.y = __builtin_bit_cast(unsigned, x1); a.z = __builtin_bit_cast(unsigned, x2); a.w = __builtin_bit_cast(unsigned, x3);
+        a = lane_perm(pa, a);
+        x0 = as_f(a.x); x1 = as_f(a.y); x2 = as_f(a.z); x3 = as_f(a.w);
+        { const u32x4 t = r[(HB ? 2 : 0) + u]; x0 += as_f(t.x); x1 += as_f(t.y); x2 += as_f(t.z); x3 += as_f(t.w); }
+        acc[i][j][0] = x0; acc[i][j][1] = x1; acc[i][j][2] = x2; acc[i][j][3] = x3;      // row layout from here on: row sr of block i, columns j*16 + sq*4 ..
+        rsum[i] += (x0 + x1) + (x2 + x3);
+        if constexpr ((u & 1) == 0) { h0 = x0; h1 = x1; h2 = x2; h3 = x3; }
+        else {
+          constexpr int j0 = Plan::col(g, u - 1), i0 = Plan::row(g, u - 1);
+          __builtin_amdgcn_sched_barrier(0);
+          gst(out0 + i0 * rstep + j0 * 16, h0, h1, h2, h3, 0);
+          gst(out0 + i * rstep + j * 16, x0, x1, x2, x3, 0);
+          __builtin_amdgcn_sched_barrier(0);
+        }
+      }, std::make_integer_sequence<int, 4>{});
+    };
+    run_groups<NG, GL, GS>(load, finish);
+  }
+  // ---- B
+  constexpr float NL = (float)(NT * 4);                     // values per lane and row
+  float mean[MT], m2[MT];
+#pragma unroll
+  for (int i = 0; i < MT; ++i) {
+    mean[i] = rsum[i] * (1.0f / NL);
+    float s2 = 0.f;
+#pragma unroll
+    for (int j = 0; j < NT; ++j)
+#pragma unroll
+      for (int e = 0; e < 4; ++e) { const float t = acc[i][j][e] - mean[i]; s2 += t * t; }
+    m2[i] = s2;
+    chan_merge(mean[i], m2[i], dpp_quad_xor1(mean[i]), dpp_quad_xor1(m2[i]), NL);
+    chan_merge(mean[i], m2[i], dpp_quad_xor2(mean[i]), dpp_quad_xor2(m2[i]), 2.0f * NL);
+  }
+  // ---- C  (ln_part / ln_flag are UNCACHED device memory, gemm_nt8.hip: plain stores and loads reach it, coherent across the XCDs' L2s; an agent-scope
+  // release / acquire on ordinary memory writes back and invalidates a whole L2 per fence on this part -- measured: the launch 360 us longer)
+  const int slot = (n0 / (2 * NT * 16)) * 2 + wc;          // column tile x 2 + wave column (a tile is two wave columns wide)
+  volatile float2* part = reinterpret_cast<volatile float2*>(p.ln_part) + (size_t)(row_w + sr) * 8;
+  if (sq == 0) {
+#pragma unroll
+    for (int i = 0; i < MT; ++i) { float2 v2; v2.x = mean[i]; v2.y = m2[i]; const_cast<float2&>(part[(size_t)i * 16 * 8 + slot]) = v2; }
+  }
+  unsigned* flag = p.ln_flag + (row_w >> 6);
+  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");         // the partials (and everything older) have landed
+  if (lane == 0) __hip_atomic_fetch_add(flag, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+  // ---- D
+  {
+    const unsigned want = (unsigned)p.ln_slots;
+    int spins = 0;
+    while (__hip_atomic_load(flag, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) < want) {
+      __builtin_amdgcn_s_sleep(2);
+      if (++spins > (1 << 22)) { if (lane == 0) __hip_atomic_store(p.ln_err, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); break; }
+    }
+    asm volatile("" ::: "memory");
+  }
+  // ---- E  (all partial loads in flight together: uncached memory answers in a microsecond or two, one after the other they cost a tile 10 %)
+  const float nw = 4.0f * NL;                               // columns of a wave block
+  float rstd[MT];
+  {
+    const int s0 = p.ln_slots >= 4 ? sq : (sq & 1);
+    const float2* pl = reinterpret_cast<const float2*>(p.ln_part) + (size_t)(row_w + sr) * 8 + s0;
+    u32x2 pa0[MT];
+    static_for([&](auto ic) {                                 // (row block i: + 16 rows x 8 slots x 8 bytes as an immediate)
+      constexpr int i = decltype(ic)::value;
+      gload8_uc<i * 1024>(pa0[i], pl);
+    }, std::make_integer_sequence<int, MT>{});
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    float cnt = nw;
+#pragma unroll
+    for (int i = 0; i < MT; ++i) { asm volatile("" : "+v"(pa0[i])); mean[i] = as_f(pa0[i].x); m2[i] = as_f(pa0[i].y); }
+    if (p.ln_slots == 8) {                                    // four column tiles: slots sq and sq + 4
+      static_for([&](auto ic) {
+        constexpr int i = decltype(ic)::value;
+        gload8_uc<i * 1024 + 32>(pa0[i], pl);
+      }, std::make_integer_sequence<int, MT>{});
+      asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+#pragma unroll
+      for (int i = 0; i < MT; ++i) { asm volatile("" : "+v"(pa0[i])); chan_merge(mean[i], m2[i], as_f(pa0[i].x), as_f(pa0[i].y), cnt); }
+      cnt *= 2.0f;
+    }
+#pragma unroll
+    for (int i = 0; i < MT; ++i) {
+      float mu = mean[i], mm = m2[i], c = cnt;
+      chan_merge(mu, mm, dpp_quad_xor1(mu), dpp_quad_xor1(mm), c); c *= 2.0f;
+      if (p.ln_slots >= 4) { chan_merge(mu, mm, dpp_quad_xor2(mu), dpp_quad_xor2(mm), c); c *= 2.0f; }
+      mean[i] = mu;
+      rstd[i] = rsqrtf(mm / (float)p.N + p.q_scale);
+    }
+  }
+  if (slot == 0 && sq == 0 && p.out2) {
+    float* st = (float*)p.out2 + row_w + sr;
+#pragma unroll
+    for (int i = 0; i < MT; ++i) { st[i * 16] = mean[i]; st[(size_t)p.M + i * 16] = rstd[i]; }
+  }
+  // ---- F
+  {
+    constexpr int NP = NT / 2, GLF = 4, GSF = MT;
+    const float* gcol = p.cos + col_w + sq * 4;
+    const float* bcolf = p.sin + col_w + sq * 4;
+    const bool odd = (sq & 1) != 0;
+    const bf16_t* hbase = (const bf16_t*)p.out1 + (size_t)row_w * p.N + col_w;
+    const unsigned voffh = (unsigned)(sr * p.N + (odd ? 16 + (sq - 1) * 4 : sq * 4)) * 2u;
+    auto load = [&](auto gc, u32x4 (&r)[GLF]) {
+      constexpr int jp = decltype(gc)::value;
+      gload16(r[0], gcol + (2 * jp) * 16); gload16(r[1], gcol + (2 * jp + 1) * 16);
+      gload16(r[2], bcolf + (2 * jp) * 16); gload16(r[3], bcolf + (2 * jp + 1) * 16);
+    };
+    auto finish = [&](auto gc, const u32x4 (&r)[GLF]) {
+      constexpr int jp = decltype(gc)::value;
+      static_for([&](auto ic) {
+        constexpr int i = decltype(ic)::value;
+        const float mu = mean[i], rs = rstd[i];
+        const f32x4 sa = acc[i][2 * jp], sb = acc[i][2 * jp + 1];
+        const float a0 = (sa[0] - mu) * rs * as_f(r[0].x) + as_f(r[2].x), a1 = (sa[1] - mu) * rs * as_f(r[0].y) + as_f(r[2].y);
+        const float a2 = (sa[2] - mu) * rs * as_f(r[0].z) + as_f(r[2].z), a3 = (sa[3] - mu) * rs * as_f(r[0].w) + as_f(r[2].w);
+        const float b0 = (sb[0] - mu) * rs * as_f(r[1].x) + as_f(r[3].x), b1 = (sb[1] - mu) * rs * as_f(r[1].y) + as_f(r[3].y);
+        const float b2 = (sb[2] - mu) * rs * as_f(r[1].z) + as_f(r[3].z), b3 = (sb[3] - mu) * rs * as_f(r[1].w) + as_f(r[3].w);
+        const unsigned ax = pack2bf(a0, a1), ay = pack2bf(a2, a3), bx = pack2bf(b0, b1), by = pack2bf(b2, b3);
+        // even lane: its four columns of tile 2jp, then the odd neighbour's; odd lane: the even neighbour's four columns of tile 2jp+1, then its own
+        const unsigned sx = odd ? ax : bx, sy = odd ? ay : by;
+        const unsigned rx = (unsigned)__builtin_amdgcn_update_dpp(0, (int)sx, 0xB1, 0xF, 0xF, false);
+        const unsigned ry = (unsigned)__builtin_amdgcn_update_dpp(0, (int)sy, 0xB1, 0xF, 0xF, false);
+        u32x4 o;
+        o.x = odd ? rx : ax; o.y = odd ? ry : ay; o.z = odd ? bx : rx; o.w = odd ? by : ry;
+        gst16_s<jp * 64>(hbase + (size_t)i * 16 * p.N, voffh, o);
+      }, std::make_integer_sequence<int, MT>{});
+    };
+    run_groups<NP, GLF, GSF>(load, finish);
+  }
+}
+
 // QKV / RoPE, head_dim 32 (natural map; a head = tiles 2h, 2h+1 of the wave's column block, the rotation partner of a column is the same
 // register of the other tile).  Group = one head.  The RoPE table rows of the wave's MT row groups are fetched once, before any store.
 template <bool HB, int MT, int NT>
@@ -475,6 +670,7 @@ __device__ __forceinline__ void epilogue_rope64(const GemmArgs& p, f32x4 (&acc)[
 
 // vector-memory stores one wave issues per tile (for the store-tolerant wait that follows the epilogue)
 template <int EPI, bool DUAL, int MT, int NT> constexpr int epilogue_stores() {
+  if (EPI == G8_EPI_RESID_LN) return MT * NT / 2;           // the bf16 stores behind the epilogue's own full wait (everything older has landed by then)
   if (EPI == ONEPROT_EPI_BIAS_GELU && DUAL) {               // out0 in 16-byte pieces; the one-byte out1 in 16-byte pieces for paired units, 8-byte for the lone half line
     const int lone_units = (((NT / 2) & 1) != 0) ? MT : 0;
     return MT * NT / 2 + lone_units + (MT * NT / 2 - lone_units) / 2;

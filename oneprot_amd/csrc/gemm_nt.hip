@@ -1074,6 +1074,23 @@ static int launch_gemm(const GemmArgs& a, hipStream_t s) {
   }
 }
 
+// x_out = resid + A W^T + bias and h = LayerNorm(x_out) in ONE launch of the 8-phase GEMM (gemm_epi8.h: epilogue_resid_ln): the FFN-2 GEMM of a pre-LN layer with
+// the LayerNorm that follows it (hf modeling_esm.py:442-463 -> :429 of the next layer / emb_layer_norm_after).  Whole 256 x 320 tiles, N in {320, 640, 1280}.
+extern "C" int oneprot_gemm_resid_ln8_eligible(int64_t M, int N, int K) { return gemm8_ln_eligible((long)M, N, K) ? 1 : 0; }
+extern "C" int oneprot_gemm_resid_ln8_error(void) { return gemm8_ln_error(); }
+extern "C" int oneprot_gemm_bf16_nt_resid_ln8(const void* A, const void* Bw, int64_t M, int N, int K, int lda, int ldb, const float* bias, const float* resid,
+                                              float* x_out, const float* gamma, const float* beta, float eps, void* h_bf16, float* stats, void* stream) {
+  if (!A || !Bw || !resid || !x_out || !gamma || !beta || !h_bf16 || M <= 0 || N <= 0 || K <= 0 || M > 0x7fffffff) return OP_EINVAL;
+  if ((N & 7) || (K & 7) || (lda & 7) || (ldb & 7) || lda < K || ldb < K) return OP_EINVAL;
+  if (((uintptr_t)A | (uintptr_t)Bw | (uintptr_t)resid | (uintptr_t)x_out | (uintptr_t)gamma | (uintptr_t)beta | (uintptr_t)h_bf16 | (uintptr_t)bias | (uintptr_t)stats) & 15) return OP_EINVAL;
+  GemmArgs a;
+  a.A = (const bf16_t*)A; a.B = (const bf16_t*)Bw; a.M = (int)M; a.N = N; a.K = K; a.lda = lda; a.ldb = ldb; a.bias = bias;
+  a.out0 = x_out; a.out1 = h_bf16; a.out2 = stats; a.aux = resid; a.cos = gamma; a.sin = beta; a.q_scale = eps; a.L = 0; a.H = 0; a.hd = 0;
+  a.tiles_m = 0; a.tiles_n = 0; a.sup_m = g_sup_m; a.sup_n = g_sup_n; a.nt_store = 0;
+  const int rc = launch_gemm8_ln(a, (hipStream_t)stream);
+  return rc == G8_NOT_ELIGIBLE ? OP_EINVAL : rc;
+}
+
 extern "C" int oneprot_gemm_bf16_nt(const void* A, const void* Bw, int64_t M, int N, int K, int lda, int ldb, int epilogue, const float* bias,
                                     void* out0, void* out1, void* out2, const void* aux, const float* rope_cos, const float* rope_sin, float q_scale,
                                     int L, int H, int hd, void* stream) {

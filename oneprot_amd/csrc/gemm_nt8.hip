@@ -28,6 +28,7 @@
 //                                                                          activation fragment set, its first half re-read from a 3-slot ring (Y3)
 // Whole tiles only, K % 128 == 0; everything else takes the per-tile kernels of gemm_nt.hip.
 #include "gemm_epi8.h"
+#include <atomic>
 
 namespace g8 {
 
@@ -460,7 +461,8 @@ __global__ void __launch_bounds__(512, 2) k_gemm8(const GemmArgs p, const int g8
       else if constexpr (EPI == ONEPROT_EPI_QKV_ROPE) {
         if (p.hd == 32) epilogue_rope32<HB, MT, NT>(p, acc, m0, n0, wr, wc, lane_e);
         else if constexpr ((NT * 16) % 64 == 0) epilogue_rope64<HB, MT, NT>(p, acc, m0, n0, wr, wc, lane_e);      // head_dim 64 (whole heads per wave column block)
-      } else epilogue_f32<EPI, HB, DUAL, MT, NT>(p, acc, m0, n0, wr, wc, lane_e);
+      } else if constexpr (EPI == G8_EPI_RESID_LN) epilogue_resid_ln<HB, MT, NT>(p, acc, m0, n0, wr, wc, lane_e);
+      else epilogue_f32<EPI, HB, DUAL, MT, NT>(p, acc, m0, n0, wr, wc, lane_e);
     }
     STAMP_E(3);
     lane_consts();
@@ -494,12 +496,17 @@ static int launch_cfg(GemmArgs a, hipStream_t s) {
   if (g_csplit > 0) cs = g_csplit;
   else if ((size_t)a.N * a.K * 2 > (size_t)(5 << 19) && a.K <= 1024) cs = 2;
   while (cs > 1 && (a.tiles_n % cs || a.tiles_m < 8 / cs)) cs >>= 1;
+  if (EPI == G8_EPI_RESID_LN) cs = 1;                       // the column tiles of a row panel must run side by side (gemm_epi8.h: epilogue_resid_ln)
   a.csplit = cs;
   const long per_xcd = (long)((a.tiles_m + 8 / cs - 1) / (8 / cs)) * (a.tiles_n / cs);
   int g8n = n_cu / 8;
   if (g8n > per_xcd) g8n = (int)per_xcd;
   if (g8n < 1) g8n = 1;
   if (g_g8n_cap > 0 && g8n > g_g8n_cap) g8n = g_g8n_cap;      // experiment hook: fewer work-groups per XCD
+  if (EPI == G8_EPI_RESID_LN) {                              // tile u = qi * g8n + w: the tiles_n tiles of a panel are in flight together iff g8n is a multiple of tiles_n
+    g8n -= g8n % a.tiles_n;
+    if (g8n < a.tiles_n) return G8_NOT_ELIGIBLE;
+  }
   hipLaunchKernelGGL((k_gemm8<C, EPI, HB, DUAL>), dim3(g8n * 8), dim3(512), C::LDS, s, a, g8n, g_dph_groups, g_dph_sleeps);
   return launch_status();
 }
@@ -539,6 +546,44 @@ static int launch_epi(int epi, const GemmArgs& a, hipStream_t s) {
 }
 
 }  // namespace g8
+
+// FFN-2 + bias + residual + the LayerNorm that follows, 256 x 320 tiles only (N = 320, 640 or 1280): see epilogue_resid_ln.  The partial statistics and the
+// arrival counters live in a process-wide device buffer, one of LN_SETS sets per launch in turn (launches in flight on different streams do not share a set
+// unless LN_SETS of them overlap); the counters of the set are zeroed on the launch's stream.
+#define LN_SETS 4
+static float* g_ln_part = nullptr; static unsigned* g_ln_flag = nullptr; static unsigned* g_ln_err = nullptr; static long g_ln_rows = 0;
+static std::atomic<unsigned> g_ln_launches{0};
+bool gemm8_ln_eligible(long M, int N, int K) {
+  typedef g8::C320 C;
+  if (M <= 0 || M % C::BM || N % C::BN || K % 128 || (N / C::BN != 1 && N / C::BN != 2 && N / C::BN != 4)) return false;
+  return (M / C::BM) * (long)(N / C::BN) >= 192;
+}
+int launch_gemm8_ln(GemmArgs a, hipStream_t s) {
+  typedef g8::C320 C;
+  if (!gemm8_ln_eligible(a.M, a.N, a.K) || !g8::eligible<C>(a, ONEPROT_EPI_BIAS_RESID)) return G8_NOT_ELIGIBLE;
+  if (g_ln_rows < a.M) {                                     // (grow only; an older buffer may still be in use by a launch in flight and is left alone)
+    const long rows = a.M > 262144 ? a.M : 262144;
+    float* part = nullptr; unsigned* flag = nullptr;
+    // uncached: the partials and counters are exchanged between work-groups that may sit behind different L2s
+    if (hipExtMallocWithFlags((void**)&part, (size_t)LN_SETS * rows * 8 * 2 * sizeof(float), hipDeviceMallocUncached) != hipSuccess) return OP_ELAUNCH;
+    if (hipExtMallocWithFlags((void**)&flag, ((size_t)LN_SETS * (rows / 64) + 1) * sizeof(unsigned), hipDeviceMallocUncached) != hipSuccess) return OP_ELAUNCH;
+    if (hipMemset(flag, 0, ((size_t)LN_SETS * (rows / 64) + 1) * sizeof(unsigned)) != hipSuccess) return OP_ELAUNCH;
+    g_ln_part = part; g_ln_flag = flag; g_ln_err = flag + (size_t)LN_SETS * (rows / 64); g_ln_rows = rows;
+  }
+  const unsigned set = g_ln_launches.fetch_add(1u) % LN_SETS;
+  a.ln_part = g_ln_part + (size_t)set * g_ln_rows * 16;
+  a.ln_flag = g_ln_flag + (size_t)set * (g_ln_rows / 64);
+  a.ln_err = g_ln_err;
+  a.ln_slots = 2 * (a.N / C::BN);
+  if (hipMemsetAsync(a.ln_flag, 0, (size_t)(a.M / 64) * sizeof(unsigned), s) != hipSuccess) return OP_ELAUNCH;
+  return a.bias ? g8::launch_cfg<C, G8_EPI_RESID_LN, true, false>(a, s) : g8::launch_cfg<C, G8_EPI_RESID_LN, false, false>(a, s);
+}
+int gemm8_ln_error() {                                        // 1: some wait for the other column tiles of a row panel ran out (results of that launch are wrong)
+  unsigned e = 0;
+  if (!g_ln_err) return 0;
+  if (hipMemcpy(&e, g_ln_err, sizeof(e), hipMemcpyDeviceToHost) != hipSuccess) return -1;
+  return (int)e;
+}
 
 // experiment hook (tools/ab/g8_ab.py): de-phasing of the persistent work-groups
 extern "C" void oneprot_gemm8_dephase(int groups, int sleeps) { g8::g_dph_groups = groups & 0xffff; g8::g_dph_sleeps = sleeps; g8::g_g8n_cap = groups >> 16; }

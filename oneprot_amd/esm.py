@@ -686,6 +686,11 @@ class EsmTransformer(ArenaModule):
         u = b16(T, f)
         eps = cfg.layer_norm_eps
         fused_ln = self._fused_ln_ok() and T % 128 == 0
+        # FFN-2 + residual AND the next layer's first LayerNorm in one launch of the 8-phase GEMM (row statistics completed across the work-groups of a row
+        # panel: oneprot_gemm_bf16_nt_resid_ln8); ONEPROT_FFN2_LN=0 keeps the pair (A/B runs)
+        ffn2_ln = (os.environ.get("ONEPROT_FFN2_LN", "1") != "0" and not self._padded and hip.query("oneprot_gemm_resid_ln8_eligible", T, d, f) == 1)
+        outproj_ln8 = (not fused_ln and os.environ.get("ONEPROT_FFN2_LN", "1") != "0" and not self._padded and hip.query("oneprot_gemm_resid_ln8_eligible", T, d, dp) == 1)
+        pre = None                                          # (h1, stats [2,T] or None) of this layer, already written by the previous layer's FFN-2 launch
         lora_two = self._lora_two_branch()
         if lora_two:      # every call draws its own dropout masks; the backward regenerates them from (seed, call, layer)
             lora_call = self._lora_calls
@@ -695,15 +700,18 @@ class EsmTransformer(ArenaModule):
         for i in range(self.n_layers):
             p = f"encoder.layer.{i}."
             if save:
-                st = dict(x_in=x, mean1=f32(T), rstd1=f32(T), mean2=f32(T), rstd2=f32(T), h1=b16(T, d), q=b16(B, H, L, hd), k=b16(B, H, L, hd),
-                          v=b16(B, H, L, hd), ctx=b16(T, dp), lse=f32(B, H, L), h2=b16(T, d), z=torch.empty(T, f, dtype=torch.uint8, device=dev), u=b16(T, f))
+                stats1 = pre[1] if pre is not None else f32(2, T)      # mean | rstd of the first LayerNorm
+                st = dict(x_in=x, mean1=stats1[0], rstd1=stats1[1], mean2=f32(T), rstd2=f32(T), h1=pre[0] if pre is not None else b16(T, d), q=b16(B, H, L, hd),
+                          k=b16(B, H, L, hd), v=b16(B, H, L, hd), ctx=b16(T, dp), lse=f32(B, H, L), h2=b16(T, d), z=torch.empty(T, f, dtype=torch.uint8, device=dev),
+                          u=b16(T, f))
                 h1, q, k, v, ctx_, h2, u, z = st["h1"], st["q"], st["k"], st["v"], st["ctx"], st["h2"], st["u"], st["z"]
                 m1, r1, m2, r2, lse = st["mean1"], st["rstd1"], st["mean2"], st["rstd2"], st["lse"]
             else:
                 h1 = h2 = h
                 z = m1 = r1 = m2 = r2 = lse = None
-            hip.call("oneprot_layernorm_fwd", x, 0, self.view(p + "attention.LayerNorm.weight"), self.view(p + "attention.LayerNorm.bias"), h1, None,
-                     m1, r1, T, d, eps)
+            if pre is None:
+                hip.call("oneprot_layernorm_fwd", x, 0, self.view(p + "attention.LayerNorm.weight"), self.view(p + "attention.LayerNorm.bias"), h1, None,
+                         m1, r1, T, d, eps)
             w_qkv, b_qkv, w_o = self._qkv_operands(i)
             if lora_two:      # peft's two branches in one launch: [h1 | dropout(h1) A^T] x [W | s B]^T  (K = Kc)
                 xc, lora_u = self._lora_branch_operand(i, h1, T, lora_call)
@@ -722,6 +730,13 @@ class EsmTransformer(ArenaModule):
                 # fused form is slower)
                 hip.call("oneprot_gemm_bf16_nt_resid_ln", ctx_, self._wo_packed[i], T, d, dp, dp, self.view(p + "attention.output.dense.bias"), x, x_mid,
                          self.view(p + "LayerNorm.weight"), self.view(p + "LayerNorm.bias"), eps, h2, m2, r2)
+            elif outproj_ln8:
+                # wider rows (ESM-2-650M, d = 1280): the same pair through the 8-phase GEMM with the statistics finished across its four column tiles
+                stats2 = f32(2, T) if save else None
+                hip.call("oneprot_gemm_bf16_nt_resid_ln8", ctx_, w_o, T, d, dp, dp, dp, self.view(p + "attention.output.dense.bias"), x, x_mid,
+                         self.view(p + "LayerNorm.weight"), self.view(p + "LayerNorm.bias"), eps, h2, stats2)
+                if save:
+                    st["mean2"], st["rstd2"] = stats2[0], stats2[1]
             else:
                 hip.call("oneprot_gemm_bf16_nt", ctx_, w_o, T, d, dp, dp, dp, hip.EPI_BIAS_RESID,
                          self.view(p + "attention.output.dense.bias"), x_mid, None, None, x, None, None, 1.0, 0, 0, 0)
@@ -729,8 +744,15 @@ class EsmTransformer(ArenaModule):
             hip.call("oneprot_gemm_bf16_nt", h2, self._w16(p + "intermediate.dense.weight"), T, f, d, d, d, hip.EPI_BIAS_GELU,
                      self.view(p + "intermediate.dense.bias"), u, z, None, None, None, None, 1.0, 0, 0, 0)
             x_out = f32(T, d) if save else x_mid
-            hip.call("oneprot_gemm_bf16_nt", u, self._w16(p + "output.dense.weight"), T, d, f, f, f, hip.EPI_BIAS_RESID,
-                     self.view(p + "output.dense.bias"), x_out, None, None, x_mid, None, None, 1.0, 0, 0, 0)
+            if ffn2_ln and i + 1 < self.n_layers:
+                pn = f"encoder.layer.{i + 1}.attention.LayerNorm."
+                pre = (b16(T, d), f32(2, T)) if save else (h, None)
+                hip.call("oneprot_gemm_bf16_nt_resid_ln8", u, self._w16(p + "output.dense.weight"), T, d, f, f, f, self.view(p + "output.dense.bias"), x_mid, x_out,
+                         self.view(pn + "weight"), self.view(pn + "bias"), eps, pre[0], pre[1])
+            else:
+                pre = None
+                hip.call("oneprot_gemm_bf16_nt", u, self._w16(p + "output.dense.weight"), T, d, f, f, f, hip.EPI_BIAS_RESID,
+                         self.view(p + "output.dense.bias"), x_out, None, None, x_mid, None, None, 1.0, 0, 0, 0)
             if save:
                 st["x_mid"] = x_mid
                 saved["layers"].append(st)

@@ -50,6 +50,9 @@ _SIGS = {
     "oneprot_gemm_bf16_nt": (I, [P, P, L64, I, I, I, I, I, P, P, P, P, P, P, P, F, I, I, I, P]),
     "oneprot_gemm_ln_pack_weight": (I, [P, P, I, I, P]),
     "oneprot_gemm_bf16_nt_resid_ln": (I, [P, P, L64, I, I, I, P, P, P, P, P, F, P, P, P, P]),
+    "oneprot_gemm_bf16_nt_resid_ln8": (I, [P, P, L64, I, I, I, I, P, P, P, P, P, F, P, P, P]),
+    "oneprot_gemm_resid_ln8_eligible": (I, [L64, I, I]),
+    "oneprot_gemm_resid_ln8_error": (I, []),
     "oneprot_gemm_ln_form": (None, [I]),
     "oneprot_gemm_force_shape": (None, [I]),
     "oneprot_gemm_tune": (None, [I, I]),
@@ -102,7 +105,7 @@ _PTR_DTYPES = {
     "oneprot_esm_embed_fwd": "lfff", "oneprot_esm_embed_bwd": "lfffb", "oneprot_bert_embed_fwd": "lffffffh", "oneprot_pool_fwd": "flf",
     "oneprot_pool_bwd": "flfh", "oneprot_embed_scatter_sorted": "flllf", "oneprot_rowsum_f32": "ff", "oneprot_attnpool_fwd": "flffff",
     "oneprot_attnpool_bwd": "fffffffb", "oneprot_layernorm_fwd": "*ffhfff", "oneprot_layernorm_bwd": "*f*fffffhffb", "oneprot_lnpool_fwd": "flffffffhf",
-    "oneprot_gemm_bf16_nt": "hhf**h*ff", "oneprot_gemm_ln_pack_weight": "hh", "oneprot_gemm_bf16_nt_resid_ln": "hhfffffhff", "oneprot_gemm_bf16_tn": "hhffb", "oneprot_sgemm": "fff", "oneprot_attn_fwd": "hhhfhf",
+    "oneprot_gemm_bf16_nt": "hhf**h*ff", "oneprot_gemm_ln_pack_weight": "hh", "oneprot_gemm_bf16_nt_resid_ln": "hhfffffhff", "oneprot_gemm_bf16_nt_resid_ln8": "hhfffffhf", "oneprot_gemm_bf16_tn": "hhffb", "oneprot_sgemm": "fff", "oneprot_attn_fwd": "hhhfhf",
     "oneprot_attn_bwd": "hhhfhhfffhb", "oneprot_attn_bwd_dropout": "hhhfhhfffhb", "oneprot_gelu_f32": "ff", "oneprot_gelu_bwd_f32": "fff", "oneprot_l2norm_fwd": "fff", "oneprot_l2norm_bwd": "ffff",
     "oneprot_ce_fwd_bwd": "fff", "oneprot_siglip_fwd_bwd": "fff", "oneprot_siglip_fwd_bwd_dev": "ffff", "oneprot_diag_rank": "fii", "oneprot_abs_sum": "ffb", "oneprot_dot_f32": "fffb", "oneprot_l1_bwd": "fff",
     "oneprot_scale_by_device_scalar": "ff", "oneprot_key_padding_bias": "lf", "oneprot_dropout_bf16": "hh", "oneprot_dropout_bwd_add_bf16": "hh", "oneprot_dropout_bwd_add_f32": "hf", "oneprot_dropout_f32": "ff", "oneprot_dropout_add_f32": "fff", "oneprot_dropout_add_layernorm_fwd": "fffffhfff", "oneprot_attn_fwd_dropout": "hhhfhf", "oneprot_attn_dropout_keep": "b", "oneprot_sumsq": "ffb", "oneprot_clip_coef": "fff", "oneprot_adam_step": "fffff",

@@ -149,6 +149,21 @@ if "attn64" in groups:      # head_dim 64 forwards: ESM-2-650M at 128 pairs (L =
                           (lambda h, q6=q6, k6=k6, v6=v6, kbx=kbx, ctx6=ctx6, lse6=lse6, B_=B_, H_=H_, L_=L_: (lambda: call(h, "oneprot_attn_fwd", q6, k6, v6, kbx, ctx6, lse6, B_, H_, L_, 64))),
                           [ctx6, lse6]))
 
+if "ln8" in groups:      # FFN-2 + residual + the next LayerNorm: the pair of launches against oneprot_gemm_bf16_nt_resid_ln8 (150M and 650M shapes)
+    for nm, T_, N_, K_ in (("ln8 150M FFN-2 N640 K2560", T, 640, 2560), ("ln8 650M FFN-2 N1280 K5120", 65536, 1280, 5120), ("ln8 650M out   N1280 K1280", 65536, 1280, 1280)):
+        A = rnd(T_, K_).to(torch.bfloat16); W = (rnd(N_, K_) * 0.05).to(torch.bfloat16); bias = rnd(N_); gamma = rnd(N_); beta = rnd(N_)
+        res = rnd(T_, N_); xo = torch.empty_like(res); hh = torch.empty(T_, N_, dtype=torch.bfloat16, device="cuda"); st = torch.empty(2, T_, device="cuda")
+
+        def mk_pair(h, A=A, W=W, bias=bias, gamma=gamma, beta=beta, res=res, xo=xo, hh=hh, st=st, T_=T_, N_=N_, K_=K_):
+            def f():
+                call(h, "oneprot_gemm_bf16_nt", A, W, T_, N_, K_, K_, K_, hip.EPI_BIAS_RESID, bias, xo, None, None, res, None, None, 1.0, 0, 0, 0)
+                call(h, "oneprot_layernorm_fwd", xo, 0, gamma, beta, hh, None, st[0], st[1], T_, N_, 1e-5)
+            return f
+        mk_fused = lambda h, A=A, W=W, bias=bias, gamma=gamma, beta=beta, res=res, xo=xo, hh=hh, st=st, T_=T_, N_=N_, K_=K_: (
+            lambda: call(h, "oneprot_gemm_bf16_nt_resid_ln8", A, W, T_, N_, K_, K_, K_, bias, res, xo, gamma, beta, 1e-5, hh, st))
+        cases.append((nm + " pair ", 2.0 * T_ * N_ * K_, mk_pair, [xo, hh, st]))
+        cases.append((nm + " fused", 2.0 * T_ * N_ * K_, mk_fused, [xo, hh, st]))
+
 if "tn" in groups:
     for nm, N, K in (("tn qkv  dW[1920,640]", 3 * d, d), ("tn out  dW[640,640]", d, d), ("tn ffn1 dW[2560,640]", f, d), ("tn ffn2 dW[640,2560]", d, f)):
         dY = rnd(T, N).to(torch.bfloat16); X = rnd(T, K).to(torch.bfloat16)
