@@ -434,7 +434,7 @@ __device__ __forceinline__ void epilogue_resid_ln(const GemmArgs& p, f32x4 (&acc
     int spins = 0;
     while (__hip_atomic_load(flag, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) < want) {
       __builtin_amdgcn_s_sleep(2);
-      if (++spins > (1 << 22)) { if (lane == 0) __hip_atomic_store(p.ln_err, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); break; }
+      if (++spins > (1 << 23)) { if (lane == 0) __hip_atomic_store(p.ln_err, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); break; }
     }
     asm volatile("" ::: "memory");
   }
