@@ -93,8 +93,9 @@ int oneprot_gemm_bf16_nt_resid_ln(const void* A, const void* Wp, int64_t M, int 
  * (FFN-2, K = 4 d): x_out = resid + A W^T + bias (fp32; may alias resid) and h = LayerNorm(x_out) (bf16), by the 8-phase GEMM on 256 x 320 tiles; the
  * column tiles of a row panel exchange (mean, M2) partials through device memory (hf modeling_esm.py:442-463 followed by :429 of the next layer or by
  * emb_layer_norm_after, sequence_encoder.py:76-81).  W as for oneprot_gemm_bf16_nt (not packed).  stats: fp32 [2][M] = mean | rstd, or NULL.
- * oneprot_gemm_resid_ln8_eligible: 1 when (M, N, K) is made of whole tiles this form serves (M % 256 == 0, N in {320, 640, 1280}, K % 128 == 0, >= 192 tiles),
- * else the caller runs oneprot_gemm_bf16_nt (ONEPROT_EPI_BIAS_RESID) + oneprot_layernorm_fwd.  oneprot_gemm_resid_ln8_error: 1 after a launch in which a
+ * oneprot_gemm_resid_ln8_eligible: 0 when (M, N, K) is not made of whole tiles this form serves (M % 256 == 0, N in {320, 640, 1280}, K % 128 == 0) -- the
+ * caller runs oneprot_gemm_bf16_nt (ONEPROT_EPI_BIAS_RESID) + oneprot_layernorm_fwd --, 2 when it is and has the >= 192 tiles from which a persistent
+ * work-group per CU pays, 1 when it is served but smaller (right, not faster: what the small-batch parity tests run).  oneprot_gemm_resid_ln8_error: 1 after a launch in which a
  * bounded wait for a neighbouring column tile ran out (host-synchronous query; never seen, the waits are short by construction). */
 int oneprot_gemm_resid_ln8_eligible(int64_t M, int N, int K);
 int oneprot_gemm_resid_ln8_error(void);

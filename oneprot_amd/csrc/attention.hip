@@ -1371,10 +1371,12 @@ static int launch_fwd3w(const void* q, const void* k, const void* v, const float
   // marks of this launch: a fresh epoch (no word is ever cleared) in one of REDO_SLOTS sets, so launches in flight on other streams do not share a set
   static std::atomic<unsigned> launches{0};
   const unsigned epoch = launches.fetch_add(1u) + 1u;
-  unsigned* any_w = nullptr; unsigned* slab_w = nullptr;
-  if (hipGetSymbolAddress((void**)&any_w, HIP_SYMBOL(g_fwd3w_redo_any)) != hipSuccess || hipGetSymbolAddress((void**)&slab_w, HIP_SYMBOL(g_fwd3w_redo_slab)) != hipSuccess)
-    return OP_ELAUNCH;
-  any_w += epoch % REDO_SLOTS; slab_w += (size_t)(epoch % REDO_SLOTS) * REDO_SLABS;
+  static unsigned* any0 = nullptr; static unsigned* slab0 = nullptr;      // (addresses of the marks, looked up once)
+  if (!any0 || !slab0) {
+    if (hipGetSymbolAddress((void**)&any0, HIP_SYMBOL(g_fwd3w_redo_any)) != hipSuccess || hipGetSymbolAddress((void**)&slab0, HIP_SYMBOL(g_fwd3w_redo_slab)) != hipSuccess)
+      return OP_ELAUNCH;
+  }
+  unsigned* any_w = any0 + epoch % REDO_SLOTS; unsigned* slab_w = slab0 + (size_t)(epoch % REDO_SLOTS) * REDO_SLABS;
   hipLaunchKernelGGL(k_attn_fwd3w<HD>, dim3(8 * nslot), dim3(64 * waves), Fwd3W<HD>::TOTAL, s, (const bf16_t*)q, (const bf16_t*)k, (const bf16_t*)v, key_bias,
                      (bf16_t*)ctx, lse, B, H, L, any_w, slab_w, epoch);
   if (launch_status() != OP_OK) return OP_ELAUNCH;

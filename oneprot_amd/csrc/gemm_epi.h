@@ -283,6 +283,6 @@ __device__ __forceinline__ void gemm_epilogue_direct(const GemmArgs& p, f32x4 (&
 // 8-phase form (gemm_nt8.hip).  cfg 0: 256 x 256 tiles, cfg 1: 256 x 320 tiles; G8_NOT_ELIGIBLE when the problem is not made of whole tiles.
 #define G8_NOT_ELIGIBLE (-100)
 int launch_gemm8(int epi, const GemmArgs& a, int cfg, long min_tiles, hipStream_t s);
-bool gemm8_ln_eligible(long M, int N, int K);
+int gemm8_ln_eligible(long M, int N, int K);
 int launch_gemm8_ln(GemmArgs a, hipStream_t s);      // G8_EPI_RESID_LN on 256 x 320 tiles
 int gemm8_ln_error();

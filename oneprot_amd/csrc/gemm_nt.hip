@@ -1076,7 +1076,7 @@ static int launch_gemm(const GemmArgs& a, hipStream_t s) {
 
 // x_out = resid + A W^T + bias and h = LayerNorm(x_out) in ONE launch of the 8-phase GEMM (gemm_epi8.h: epilogue_resid_ln): the FFN-2 GEMM of a pre-LN layer with
 // the LayerNorm that follows it (hf modeling_esm.py:442-463 -> :429 of the next layer / emb_layer_norm_after).  Whole 256 x 320 tiles, N in {320, 640, 1280}.
-extern "C" int oneprot_gemm_resid_ln8_eligible(int64_t M, int N, int K) { return gemm8_ln_eligible((long)M, N, K) ? 1 : 0; }
+extern "C" int oneprot_gemm_resid_ln8_eligible(int64_t M, int N, int K) { return gemm8_ln_eligible((long)M, N, K); }
 extern "C" int oneprot_gemm_resid_ln8_error(void) { return gemm8_ln_error(); }
 extern "C" int oneprot_gemm_bf16_nt_resid_ln8(const void* A, const void* Bw, int64_t M, int N, int K, int lda, int ldb, const float* bias, const float* resid,
                                               float* x_out, const float* gamma, const float* beta, float eps, void* h_bf16, float* stats, void* stream) {

@@ -553,14 +553,17 @@ static int launch_epi(int epi, const GemmArgs& a, hipStream_t s) {
 #define LN_SETS 4
 static float* g_ln_part = nullptr; static unsigned* g_ln_flag = nullptr; static unsigned* g_ln_err = nullptr; static long g_ln_rows = 0;
 static std::atomic<unsigned> g_ln_launches{0};
-bool gemm8_ln_eligible(long M, int N, int K) {
+// 0: the shape is not made of whole tiles this form serves; 1: it is, but with fewer than 192 tiles (a persistent work-group per CU does not pay: callers
+// keep the pair of launches unless told otherwise -- the parity tests against the oracle run small batches through it); 2: it is and it pays
+int gemm8_ln_eligible(long M, int N, int K) {
   typedef g8::C320 C;
-  if (M <= 0 || M % C::BM || N % C::BN || K % 128 || (N / C::BN != 1 && N / C::BN != 2 && N / C::BN != 4)) return false;
-  return (M / C::BM) * (long)(N / C::BN) >= 192;
+  if (M <= 0 || M % C::BM || N % C::BN || K % 128 || (N / C::BN != 1 && N / C::BN != 2 && N / C::BN != 4)) return 0;
+  if ((M / C::BM + 7) / 8 * (N / C::BN) < N / C::BN) return 0;
+  return (M / C::BM) * (long)(N / C::BN) >= 192 ? 2 : 1;
 }
 int launch_gemm8_ln(GemmArgs a, hipStream_t s) {
   typedef g8::C320 C;
-  if (!gemm8_ln_eligible(a.M, a.N, a.K) || !g8::eligible<C>(a, ONEPROT_EPI_BIAS_RESID)) return G8_NOT_ELIGIBLE;
+  if (gemm8_ln_eligible(a.M, a.N, a.K) == 0 || !g8::eligible<C>(a, ONEPROT_EPI_BIAS_RESID)) return G8_NOT_ELIGIBLE;
   if (g_ln_rows < a.M) {                                     // (grow only; an older buffer may still be in use by a launch in flight and is left alone)
     const long rows = a.M > 262144 ? a.M : 262144;
     float* part = nullptr; unsigned* flag = nullptr;

@@ -688,8 +688,10 @@ class EsmTransformer(ArenaModule):
         fused_ln = self._fused_ln_ok() and T % 128 == 0
         # FFN-2 + residual AND the next layer's first LayerNorm in one launch of the 8-phase GEMM (row statistics completed across the work-groups of a row
         # panel: oneprot_gemm_bf16_nt_resid_ln8); ONEPROT_FFN2_LN=0 keeps the pair (A/B runs)
-        ffn2_ln = (os.environ.get("ONEPROT_FFN2_LN", "1") != "0" and not self._padded and hip.query("oneprot_gemm_resid_ln8_eligible", T, d, f) == 1)
-        outproj_ln8 = (not fused_ln and os.environ.get("ONEPROT_FFN2_LN", "1") != "0" and not self._padded and hip.query("oneprot_gemm_resid_ln8_eligible", T, d, dp) == 1)
+        ln8_mode = os.environ.get("ONEPROT_FFN2_LN", "1")    # "0": never; "force": whenever the shape is served (tests: small batches against the oracle); else when it pays
+        ln8_min = 0 if ln8_mode == "0" else (1 if ln8_mode == "force" else 2)
+        ffn2_ln = ln8_min > 0 and not self._padded and hip.query("oneprot_gemm_resid_ln8_eligible", T, d, f) >= ln8_min
+        outproj_ln8 = not fused_ln and ln8_min > 0 and not self._padded and hip.query("oneprot_gemm_resid_ln8_eligible", T, d, dp) >= ln8_min
         pre = None                                          # (h1, stats [2,T] or None) of this layer, already written by the previous layer's FFN-2 launch
         lora_two = self._lora_two_branch()
         if lora_two:      # every call draws its own dropout masks; the backward regenerates them from (seed, call, layer)

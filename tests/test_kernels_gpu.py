@@ -220,14 +220,16 @@ def test_gemm_resid_layernorm_fused(M, K, inplace, form):
 
 
 @pytest.mark.parametrize("M,N,K,has_bias,inplace,stats", [(24576, 640, 256, True, False, True), (24832, 640, 2560, True, True, False), (49152, 320, 128, False, False, True),
-                                                          (12288, 1280, 384, True, True, True), (131072, 640, 2560, True, True, True), (33024, 640, 640, True, False, True)])
+                                                          (12288, 1280, 384, True, True, True), (131072, 640, 2560, True, True, True), (33024, 640, 640, True, False, True), (2048, 640, 2560, True, False, True),
+                                                          (256, 1280, 256, True, False, True), (768, 320, 128, False, True, True)])
 def test_gemm_resid_layernorm_across_work_groups(M, N, K, has_bias, inplace, stats):
     """oneprot_gemm_bf16_nt_resid_ln8 -- the 8-phase GEMM whose epilogue finishes the row statistics across the work-groups of a row panel (FFN-2 + the next
     layer's LayerNorm in one launch) -- against the pair it replaces, oneprot_gemm_bf16_nt(BIAS_RESID) + oneprot_layernorm_fwd: x bit for bit (same
     arithmetic), h / mean / rstd to the rounding of another summation order.  N = 320 / 640 / 1280 = one, two and four column tiles per row panel (2 / 4 / 8
     partial statistics per row); 24832 / 33024 rows = 97 / 129 panels (work-groups with different tile counts; the neighbours still meet); the cfg-2 shape;
     twice in a row (the arrival counters of consecutive launches live in different sets) and the bounded waits never ran out."""
-    assert hip.query("oneprot_gemm_resid_ln8_eligible", M, N, K) == 1
+    big = (M // 256) * (N // 320) >= 192
+    assert hip.query("oneprot_gemm_resid_ln8_eligible", M, N, K) == (2 if big else 1)
     assert hip.query("oneprot_gemm_resid_ln8_eligible", M + 64, N, K) == 0 and hip.query("oneprot_gemm_resid_ln8_eligible", M, 960, K) == 0
     g = torch.Generator().manual_seed(77 + N + K)
     A = bf(torch.randn(M, K, generator=g)).to(DEV)
@@ -246,10 +248,13 @@ def test_gemm_resid_layernorm_across_work_groups(M, N, K, has_bias, inplace, sta
         h = torch.full((M, N), float("nan"), dtype=torch.bfloat16, device=DEV)
         st = torch.full((2, M), float("nan"), device=DEV) if stats else None
         hip.call("oneprot_gemm_bf16_nt_resid_ln8", A, W, M, N, K, K, K, bias, x if inplace else resid, x, gamma, beta, 1e-5, h, st)
-        assert torch.equal(x, x_ref), f"x_out, launch {rep}"
+        if big:
+            assert torch.equal(x, x_ref), f"x_out, launch {rep}"
+        else:                                                    # (fewer than 192 tiles: the unfused GEMM runs on another kernel with another summation order)
+            assert_close(x, x_ref, 2e-5, 2e-4, f"x_out, launch {rep}")
         if stats:
-            assert_close(st[0], m_ref, 1e-5, 1e-5, "mean")
-            assert_close(st[1], r_ref, 2e-5, 0.0, "rstd")
+            assert_close(st[0], m_ref, 1e-5, 1e-5 if big else 1e-4, "mean")
+            assert_close(st[1], r_ref, 2e-5 if big else 2e-4, 0.0, "rstd")
         assert torch.isfinite(h.float()).all()
         assert_close(h.float(), h_ref.float(), 2 ** -7, 2e-3, f"h, launch {rep}")
         assert (h.float() - h_ref.float()).abs().gt(1e-6).float().mean() < 0.02      # a bf16 ulp here and there, not a different function
