@@ -20,10 +20,10 @@ struct GemmArgs {
   int nt_store;                 // output stores non-temporal (streamed past the L2 instead of displacing the operand panels and W)
   // G8_EPI_RESID_LN (8-phase kernels only): out0 = x_out fp32 = acc + bias + aux; out1 = bf16 LayerNorm(x_out) with gamma = cos, beta = sin, eps = q_scale;
   // out2 = fp32 [2][M]: mean | rstd (or null).  A row's statistics are completed across the column tiles through ln_part / ln_flag (gemm_epi8.h).
-  float* ln_part;               // [M][8] x (mean, M2): per row, one partial per wave column of every column tile
-  unsigned* ln_flag;            // [M / 64]: arrivals per 64-row wave block (zeroed before the launch)
+  void* ln_part;                // [M][8] x 16 bytes {tag, mean, M2, ~tag}: per row, one partial per wave column of every column tile (uncached memory)
   unsigned* ln_err;             // sticky: a wait for the other column tiles ran out
   int ln_slots;                 // partials per row = column tiles x wave columns
+  unsigned ln_epoch;            // this launch's tag (never 0)
 };
 #define G8_EPI_RESID_LN 6      // internal to gemm_nt8.hip / gemm_epi8.h (entry point oneprot_gemm_bf16_nt_resid_ln8), not part of the public epilogue enum
 // 16- / 8-byte output stores with the launch's cache policy (wave-uniform branch)

@@ -326,19 +326,44 @@ __device__ __forceinline__ void epilogue_f32(const GemmArgs& p, f32x4 (&acc)[MT]
 //      (row layout) and a running row sum per row block;
 //   B  per lane: mean and M2 = sum (s - mean)^2 over its 40 values of each of its 4 rows, in registers; the four lanes of a row (a quad) combine theirs by
 //      Chan's rule (DPP quad_perm): every lane then holds (mean, M2) of its wave block's 160 columns;
-//   C  lanes sq == 0 publish them -- ln_part[row][slot], slot = column tile x 2 + wave column, in UNCACHED device memory -- wait until the stores have
-//      landed and count the wave in on ln_flag[64-row block] (a relaxed atomic: no cache maintenance anywhere);
-//   D  the wave waits until all `ln_slots` wave blocks of its rows have arrived (they run the same tile at the same time: the work-groups of one row panel are
-//      neighbours in the launch and every work-group walks its tiles in step), bounded: a wait that runs out sets ln_err and goes on;
-//   E  lane sq reads partial sq (and sq + 4), the quad combines again: every lane has the row's statistics over all N columns;
+//   C  lanes sq == 0 publish them -- ln_part[row][slot], slot = column tile x 2 + wave column, in UNCACHED device memory, as ONE tagged 16-byte store;
+//   D  lane sq polls entry sq (and sq + 4) of its rows until all of them carry this launch's tag (the other wave blocks run the same tile at the same time:
+//      the work-groups of one row panel are neighbours in the launch and every work-group walks its tiles in step), bounded: a wait that runs out sets
+//      ln_err and goes on;
+//   E  the quad combines again: every lane has the row's statistics over all N columns;
 //   F  h = (s - mean) rstd gamma + beta from the registers, two column tiles at a time (gamma / beta two groups ahead like every epilogue operand),
 //      lane pairs swapping halves so that a lane stores 16 contiguous bytes; mean / rstd leave from slot 0.
 // The statistics are exact two-pass ones per wave block (the values are in registers) and Chan's combination is exact in exact arithmetic: the result
 // agrees with k_layernorm_fwd's two-pass form to fp32 rounding.  Deadlock: a wave only waits for waves of work-groups that were launched (the grid is one
 // work-group per CU, and a work-group that has to wait for a CU starts when the others finish: they never wait for IT twice).
-// 8-byte load that misses every cache on its way (system scope): the partial statistics of the other wave blocks
-template <int OFF> __device__ __forceinline__ void gload8_uc(u32x2& d, const void* ptr) {
-  asm volatile("global_load_dwordx2 %0, %1, off offset:%2 sc0 sc1" : "=v"(d) : "v"(ptr), "n"(OFF) : "memory");
+// 16-byte load / store that miss every cache on their way (system scope): the partial statistics of the wave blocks of a row
+template <int OFF> __device__ __forceinline__ void gload16_uc(u32x4& d, const void* ptr) {
+  asm volatile("global_load_dwordx4 %0, %1, off offset:%2 sc0 sc1" : "=v"(d) : "v"(ptr), "n"(OFF) : "memory");
+}
+template <int OFF> __device__ __forceinline__ void gst16_uc(const void* ptr, const u32x4& v) {
+  asm volatile("global_store_dwordx4 %0, %1, off offset:%2 sc0 sc1\n\ts_nop 1" ::"v"(ptr), "v"(v), "n"(OFF) : "memory");
+}
+// polls MT x NS tagged entries (row block i: 2 KB apart; second set: 4 entries on; `pl` two row blocks in) until every lane of the wave sees its own carry
+// the tag; bounded
+template <int MT, int NS>
+__device__ __forceinline__ void poll_entries(const u32x4* pl, unsigned tag, u32x4 (&e)[NS * MT], unsigned* err, int lane) {
+  int spins = 0;
+  bool ok;
+  do {
+    static_for([&](auto ic) {
+      constexpr int i = decltype(ic)::value;
+      gload16_uc<(i % MT) * 2048 - 4096 + (i / MT) * 64>(e[i], pl);
+    }, std::make_integer_sequence<int, NS * MT>{});
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    ok = true;
+#pragma unroll
+    for (int i = 0; i < NS * MT; ++i) { asm volatile("" : "+v"(e[i])); ok = ok && e[i].x == tag && e[i].w == ~tag; }
+    ok = __all(ok);
+    if (!ok) {
+      if (++spins > (1 << 22)) { if (lane == 0) __hip_atomic_store(err, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); ok = true; }
+      else __builtin_amdgcn_s_sleep(2);
+    }
+  } while (!ok);
 }
 __device__ __forceinline__ float dpp_quad_xor1(float v) { return __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), 0xB1, 0xF, 0xF, false)); }
 __device__ __forceinline__ float dpp_quad_xor2(float v) { return __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), 0x4E, 0xF, 0xF, false)); }
@@ -417,51 +442,41 @@ __device__ __forceinline__ void epilogue_resid_ln(const GemmArgs& p, f32x4 (&acc
     chan_merge(mean[i], m2[i], dpp_quad_xor1(mean[i]), dpp_quad_xor1(m2[i]), NL);
     chan_merge(mean[i], m2[i], dpp_quad_xor2(mean[i]), dpp_quad_xor2(m2[i]), 2.0f * NL);
   }
-  // ---- C  (ln_part / ln_flag are UNCACHED device memory, gemm_nt8.hip: plain stores and loads reach it, coherent across the XCDs' L2s; an agent-scope
-  // release / acquire on ordinary memory writes back and invalidates a whole L2 per fence on this part -- measured: the launch 360 us longer)
+  // ---- C  (ln_part is UNCACHED device memory, gemm_nt8.hip: plain stores and loads reach it, coherent across the XCDs' L2s; an agent-scope release /
+  // acquire on ordinary memory writes back and invalidates a whole L2 per fence on this part -- measured: the launch 360 us longer).  An entry is 16 bytes,
+  // {tag, mean, M2, ~tag} with tag = this launch's number, written by ONE 16-byte store: a reader that finds both ends current has the middle too, entries of
+  // older launches never match, and nothing has to be cleared or counted (the first form -- partials, a wait for them to land, an arrival counter, polls of
+  // the counter, then the loads -- was three round trips to uncached memory per tile and a memset per launch; this is the store and one or two polls).
   const int slot = (n0 / (2 * NT * 16)) * 2 + wc;          // column tile x 2 + wave column (a tile is two wave columns wide)
-  volatile float2* part = reinterpret_cast<volatile float2*>(p.ln_part) + (size_t)(row_w + sr) * 8;
+  const unsigned tag = p.ln_epoch;
+  const u32x4* ent = reinterpret_cast<const u32x4*>(p.ln_part) + (size_t)(row_w + sr) * 8;
   if (sq == 0) {
-#pragma unroll
-    for (int i = 0; i < MT; ++i) { float2 v2; v2.x = mean[i]; v2.y = m2[i]; const_cast<float2&>(part[(size_t)i * 16 * 8 + slot]) = v2; }
+    static_for([&](auto ic) {
+      constexpr int i = decltype(ic)::value;
+      u32x4 e; e.x = tag; e.y = __builtin_bit_cast(unsigned, mean[i]); e.z = __builtin_bit_cast(unsigned, m2[i]); e.w = ~tag;
+      gst16_uc<i * 2048 - 4096>(ent + slot + 256, e);      // (13-bit signed immediates: the base sits two row blocks in)
+    }, std::make_integer_sequence<int, MT>{});
   }
-  unsigned* flag = p.ln_flag + (row_w >> 6);
-  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");         // the partials (and everything older) have landed
-  if (lane == 0) __hip_atomic_fetch_add(flag, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-  // ---- D
-  {
-    const unsigned want = (unsigned)p.ln_slots;
-    int spins = 0;
-    while (__hip_atomic_load(flag, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) < want) {
-      __builtin_amdgcn_s_sleep(2);
-      if (++spins > (1 << 23)) { if (lane == 0) __hip_atomic_store(p.ln_err, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); break; }
-    }
-    asm volatile("" ::: "memory");
-  }
-  // ---- E  (all partial loads in flight together: uncached memory answers in a microsecond or two, one after the other they cost a tile 10 %)
+  // ---- D / E  every lane polls the entries it needs (slot sq -- and sq + 4 with four column tiles -- of its four rows) until all of them carry the tag
   const float nw = 4.0f * NL;                               // columns of a wave block
   float rstd[MT];
   {
     const int s0 = p.ln_slots >= 4 ? sq : (sq & 1);
-    const float2* pl = reinterpret_cast<const float2*>(p.ln_part) + (size_t)(row_w + sr) * 8 + s0;
-    u32x2 pa0[MT];
-    static_for([&](auto ic) {                                 // (row block i: + 16 rows x 8 slots x 8 bytes as an immediate)
-      constexpr int i = decltype(ic)::value;
-      gload8_uc<i * 1024>(pa0[i], pl);
-    }, std::make_integer_sequence<int, MT>{});
-    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     float cnt = nw;
+    if (p.ln_slots == 8) {                                    // four column tiles: entries sq and sq + 4, all eight loads of a poll in flight together
+      u32x4 e[2 * MT];
+      poll_entries<MT, 2>(ent + s0 + 256, tag, e, p.ln_err, lane);
 #pragma unroll
-    for (int i = 0; i < MT; ++i) { asm volatile("" : "+v"(pa0[i])); mean[i] = as_f(pa0[i].x); m2[i] = as_f(pa0[i].y); }
-    if (p.ln_slots == 8) {                                    // four column tiles: slots sq and sq + 4
-      static_for([&](auto ic) {
-        constexpr int i = decltype(ic)::value;
-        gload8_uc<i * 1024 + 32>(pa0[i], pl);
-      }, std::make_integer_sequence<int, MT>{});
-      asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-#pragma unroll
-      for (int i = 0; i < MT; ++i) { asm volatile("" : "+v"(pa0[i])); chan_merge(mean[i], m2[i], as_f(pa0[i].x), as_f(pa0[i].y), cnt); }
+      for (int i = 0; i < MT; ++i) {
+        mean[i] = as_f(e[i].y); m2[i] = as_f(e[i].z);
+        chan_merge(mean[i], m2[i], as_f(e[MT + i].y), as_f(e[MT + i].z), cnt);
+      }
       cnt *= 2.0f;
+    } else {
+      u32x4 e[MT];
+      poll_entries<MT, 1>(ent + s0 + 256, tag, e, p.ln_err, lane);
+#pragma unroll
+      for (int i = 0; i < MT; ++i) { mean[i] = as_f(e[i].y); m2[i] = as_f(e[i].z); }
     }
 #pragma unroll
     for (int i = 0; i < MT; ++i) {

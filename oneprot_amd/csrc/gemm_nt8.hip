@@ -547,11 +547,11 @@ static int launch_epi(int epi, const GemmArgs& a, hipStream_t s) {
 
 }  // namespace g8
 
-// FFN-2 + bias + residual + the LayerNorm that follows, 256 x 320 tiles only (N = 320, 640 or 1280): see epilogue_resid_ln.  The partial statistics and the
-// arrival counters live in a process-wide device buffer, one of LN_SETS sets per launch in turn (launches in flight on different streams do not share a set
-// unless LN_SETS of them overlap); the counters of the set are zeroed on the launch's stream.
+// FFN-2 + bias + residual + the LayerNorm that follows, 256 x 320 tiles only (N = 320, 640 or 1280): see epilogue_resid_ln.  The partial statistics live in a
+// process-wide uncached device buffer, one of LN_SETS sets per launch in turn (launches in flight on different streams do not share a set unless LN_SETS of
+// them overlap); entries are tagged with the launch number, nothing is cleared between launches.
 #define LN_SETS 4
-static float* g_ln_part = nullptr; static unsigned* g_ln_flag = nullptr; static unsigned* g_ln_err = nullptr; static long g_ln_rows = 0;
+static unsigned char* g_ln_part = nullptr; static unsigned* g_ln_err = nullptr; static long g_ln_rows = 0;
 static std::atomic<unsigned> g_ln_launches{0};
 // 0: the shape is not made of whole tiles this form serves; 1: it is, but with fewer than 192 tiles (a persistent work-group per CU does not pay: callers
 // keep the pair of launches unless told otherwise -- the parity tests against the oracle run small batches through it); 2: it is and it pays
@@ -565,20 +565,22 @@ int launch_gemm8_ln(GemmArgs a, hipStream_t s) {
   typedef g8::C320 C;
   if (gemm8_ln_eligible(a.M, a.N, a.K) == 0 || !g8::eligible<C>(a, ONEPROT_EPI_BIAS_RESID)) return G8_NOT_ELIGIBLE;
   if (g_ln_rows < a.M) {                                     // (grow only; an older buffer may still be in use by a launch in flight and is left alone)
-    const long rows = a.M > 262144 ? a.M : 262144;
-    float* part = nullptr; unsigned* flag = nullptr;
-    // uncached: the partials and counters are exchanged between work-groups that may sit behind different L2s
-    if (hipExtMallocWithFlags((void**)&part, (size_t)LN_SETS * rows * 8 * 2 * sizeof(float), hipDeviceMallocUncached) != hipSuccess) return OP_ELAUNCH;
-    if (hipExtMallocWithFlags((void**)&flag, ((size_t)LN_SETS * (rows / 64) + 1) * sizeof(unsigned), hipDeviceMallocUncached) != hipSuccess) return OP_ELAUNCH;
-    if (hipMemset(flag, 0, ((size_t)LN_SETS * (rows / 64) + 1) * sizeof(unsigned)) != hipSuccess) return OP_ELAUNCH;
-    g_ln_part = part; g_ln_flag = flag; g_ln_err = flag + (size_t)LN_SETS * (rows / 64); g_ln_rows = rows;
+    const long rows = a.M > 131072 ? a.M : 131072;
+    unsigned char* part = nullptr; unsigned* err = nullptr;
+    // uncached: the partials are exchanged between work-groups that may sit behind different L2s.  Zeroed once: tag 0 is never used.
+    if (hipExtMallocWithFlags((void**)&part, (size_t)LN_SETS * rows * 8 * 16, hipDeviceMallocUncached) != hipSuccess) return OP_ELAUNCH;
+    if (hipMemset(part, 0, (size_t)LN_SETS * rows * 8 * 16) != hipSuccess) return OP_ELAUNCH;
+    if (!g_ln_err) {
+      if (hipExtMallocWithFlags((void**)&err, 64, hipDeviceMallocUncached) != hipSuccess || hipMemset(err, 0, 64) != hipSuccess) return OP_ELAUNCH;
+      g_ln_err = err;
+    }
+    g_ln_part = part; g_ln_rows = rows;
   }
-  const unsigned set = g_ln_launches.fetch_add(1u) % LN_SETS;
-  a.ln_part = g_ln_part + (size_t)set * g_ln_rows * 16;
-  a.ln_flag = g_ln_flag + (size_t)set * (g_ln_rows / 64);
+  const unsigned n = g_ln_launches.fetch_add(1u);
+  a.ln_part = g_ln_part + (size_t)(n % LN_SETS) * g_ln_rows * 8 * 16;
   a.ln_err = g_ln_err;
   a.ln_slots = 2 * (a.N / C::BN);
-  if (hipMemsetAsync(a.ln_flag, 0, (size_t)(a.M / 64) * sizeof(unsigned), s) != hipSuccess) return OP_ELAUNCH;
+  a.ln_epoch = n + 1u == 0u ? 1u : n + 1u;
   return a.bias ? g8::launch_cfg<C, G8_EPI_RESID_LN, true, false>(a, s) : g8::launch_cfg<C, G8_EPI_RESID_LN, false, false>(a, s);
 }
 int gemm8_ln_error() {                                        // 1: some wait for the other column tiles of a row panel ran out (results of that launch are wrong)

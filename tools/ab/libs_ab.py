@@ -150,7 +150,7 @@ if "attn64" in groups:      # head_dim 64 forwards: ESM-2-650M at 128 pairs (L =
                           [ctx6, lse6]))
 
 if "ln8" in groups:      # FFN-2 + residual + the next LayerNorm: the pair of launches against oneprot_gemm_bf16_nt_resid_ln8 (150M and 650M shapes)
-    for nm, T_, N_, K_ in (("ln8 150M FFN-2 N640 K2560", T, 640, 2560), ("ln8 650M FFN-2 N1280 K5120", 65536, 1280, 5120), ("ln8 650M out   N1280 K1280", 65536, 1280, 1280)):
+    for nm, T_, N_, K_ in (("ln8 150M FFN-2 N640 K2560", T, 640, 2560), ("ln8 650M FFN-2 N1280 K5120", 65536, 1280, 5120), ("ln8 650M out   N1280 K1280", 65536, 1280, 1280), ("ln8 150M out   N640  K640 ", T, 640, 640)):
         A = rnd(T_, K_).to(torch.bfloat16); W = (rnd(N_, K_) * 0.05).to(torch.bfloat16); bias = rnd(N_); gamma = rnd(N_); beta = rnd(N_)
         res = rnd(T_, N_); xo = torch.empty_like(res); hh = torch.empty(T_, N_, dtype=torch.bfloat16, device="cuda"); st = torch.empty(2, T_, device="cuda")
 
