@@ -206,6 +206,13 @@ def summarise_kernels(prof):
         groups.setdefault((epi, N, K), []).append((ms, 2.0 * M * N * K))
     for (epi, N, K), items in sorted(groups.items()):
         add(f"NT GEMM {epi_names.get(epi, epi)} N={N} K={K}", items, sum(w for _, w in items), "TFLOP/s", PEAK_BF16_TFLOPS)
+    for name, label in (("oneprot_gemm_bf16_nt_resid_ln", "NT GEMM + residual + LayerNorm, full-row kernel (out-proj)"),
+                        ("oneprot_gemm_bf16_nt_resid_ln8", "NT GEMM + residual + LayerNorm across work-groups (FFN-2 + next LN)")):
+        fg = {}
+        for ms, sc in prof.get(name, []):
+            fg.setdefault((sc[1], sc[2]), []).append((ms, 2.0 * sc[0] * sc[1] * sc[2]))
+        for (N, K), items in sorted(fg.items()):
+            add(f"{label} N={N} K={K}", items, sum(w for _, w in items), "TFLOP/s", PEAK_BF16_TFLOPS)
     tn = [(ms, 2.0 * sc[0] * sc[1] * sc[2]) for ms, sc in prof.get("oneprot_gemm_bf16_tn", [])]
     add("TN GEMM (weight gradients, incl. slab reduce)", tn, sum(w for _, w in tn), "TFLOP/s", PEAK_BF16_TFLOPS)
     af = [(ms, 4.0 * sc[-4] * sc[-3] * sc[-2] * sc[-2] * sc[-1]) for ms, sc in prof.get("oneprot_attn_fwd", [])]
@@ -436,7 +443,8 @@ def main():
                                  "frac": round(fwd_tf / PEAK_BF16_TFLOPS, 4), "mfma_busy_pct": mfma_busy, "mfma_busy_source": mfma_src, "target_frac": 0.40}
     if not args.no_extras:
         # ---- one extra step with every kernel family bracketed by events (outside the timed region: the brackets cost launch time)
-        hip.profile_begin({k: None for k in ("oneprot_gemm_bf16_nt", "oneprot_gemm_bf16_tn", "oneprot_attn_fwd", "oneprot_attn_bwd", "oneprot_layernorm_fwd",
+        hip.profile_begin({k: None for k in ("oneprot_gemm_bf16_nt", "oneprot_gemm_bf16_nt_resid_ln", "oneprot_gemm_bf16_nt_resid_ln8", "oneprot_gemm_bf16_tn",
+                                             "oneprot_attn_fwd", "oneprot_attn_bwd", "oneprot_layernorm_fwd",
                                              "oneprot_layernorm_bwd", "oneprot_adam_step")})
         module.training_step(batch, 0)
         barrier()
@@ -444,7 +452,13 @@ def main():
         if rank == 0:
             extras["kernels"] = summarise_kernels(prof)
 
+    # the FFN-2 + LayerNorm launches wait, bounded, for their neighbours' partial statistics: a wait that ran out means wrong numbers, not a slow step
+    ln8_errors = hip.query("oneprot_gemm_resid_ln8_error")
+    if ln8_errors != 0:
+        raise RuntimeError("oneprot_gemm_bf16_nt_resid_ln8: a wait for the neighbouring column tiles ran out during the timed steps")
     if rank == 0:
+        extras["ffn2_ln"] = {"what": "FFN-2 GEMM with the next LayerNorm finished across work-groups (ONEPROT_FFN2_LN=0 keeps the pair of launches)",
+                             "enabled": os.environ.get("ONEPROT_FFN2_LN", "1") != "0", "waits_run_out": ln8_errors}
         ms_step = elapsed / args.steps * 1e3
         pairs_per_step = B * len(subs)
         value = world * pairs_per_step * args.steps / elapsed
