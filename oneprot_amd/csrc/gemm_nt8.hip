@@ -342,7 +342,7 @@ __global__ void __launch_bounds__(512, 2) k_gemm8(const GemmArgs p, const int g8
   };
 
   // ---- merged schedule (C::M2): one K-tile = TWO phases of two quadrants each (twice the MFMAs behind one pair of barriers: the barrier pair and
-  // the wake-up around it cost ~145 cycles per phase however long the MFMA run is -- ablation stamps).
+  // the wake-up around it cost ~145 cycles per phase however long the MFMA run is -- ablation stamps, NOTEBOOK 6c).
   //   phase A: read X0, Y0, Y1 | issue X1 of K-tile s+1                 | wait: X1 of K-tile s landed            | MFMAs X0 x (Y0, Y1)
   //   phase B: read X1         | issue X0, Y0, Y1 of K-tile s+2         | wait: those units of K-tile s+1 landed | MFMAs X1 x (Y1, Y0)
   // Every read is retired before the phase's first barrier, so the LDS a phase read may be refilled from the next phase on.  Each wait leaves

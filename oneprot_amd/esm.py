@@ -728,8 +728,8 @@ class EsmTransformer(ArenaModule):
             x_mid = f32(T, d) if save else x
             if fused_ln:
                 # out-projection + bias + residual AND the FFN's pre-LayerNorm in one full-row kernel: x_mid is not read back by a LayerNorm launch
-                # (measured on cfg-2: 0.28-0.29 ms against 0.31-0.32 ms for the pair; the FFN-2 / next-layer pair stays split -- there the
-                # fused form is slower)
+                # (measured on cfg-2: 0.28-0.29 ms against 0.31-0.32 ms for the pair; the FFN-2 / next-layer pair goes through the 8-phase GEMM with the
+                # statistics finished across work-groups instead, below -- this full-row form ties with the pair there, NOTEBOOK.md section 6c)
                 hip.call("oneprot_gemm_bf16_nt_resid_ln", ctx_, self._wo_packed[i], T, d, dp, dp, self.view(p + "attention.output.dense.bias"), x, x_mid,
                          self.view(p + "LayerNorm.weight"), self.view(p + "LayerNorm.bias"), eps, h2, m2, r2)
             elif outproj_ln8:

@@ -3,7 +3,7 @@
 // (160 registers, the GEMMs' pattern) and 14 operand fragments in registers and issues 80 v_mfma_f32_16x16x32_bf16 per iteration: no LDS, no
 // memory traffic, no barriers.  Launches are repeated for ~2 s before the measured one.  Prints shader cycles per MFMA (s_memtime), the in-kernel
 // clock (s_memtime / s_memrealtime x 100 MHz) and the chip-wide TFLOP/s by wall clock: the practical ceiling the GEMM K loops are compared with
-// in DESIGN.md section 6d (MI355X_MICROARCH.md, "DVFS give-back").  Reading the output: cycles and clock are those of wave 0 of every work-group; with
+// in NOTEBOOK.md section 6d (MI355X_MICROARCH.md, "DVFS give-back").  Reading the output: cycles and clock are those of wave 0 of every work-group; with
 // two waves per SIMD the older wave takes the pipe first (16.8 cycles per MFMA = the pipe's rate) and the younger one follows, so the chip-wide
 // figure is the one by wall clock.  The one-wave-per-SIMD rows (256 threads) are a code-generation artefact: hipcc then places the accumulators
 // in AGPRs and copies them around every MFMA (27.9 cycles).
