@@ -2109,7 +2109,7 @@ __global__ void __launch_bounds__(512, 1) k_attn_bwd_fused64(const bf16_t* __res
 
   // (experiment hook, ablation builds only -- dph is 0 in the product: the second wave of every SIMD starts dph x 64 cycles late.  Measured: 0 is best,
   // the waves drift apart by themselves; tools/attn_only.py ATTN_DPH)
-  if (wave >= 4) for (int i = 0; i < dph; ++i) __builtin_amdgcn_s_sleep(1);
+  if (wave >= 4 && dph < 900) for (int i = 0; i < dph; ++i) __builtin_amdgcn_s_sleep(1);
   if (active) {
     const int nkw = (L + 63) >> 6;                          // waves that own keys = visits per query block
     const int nqb = (L + 31) >> 5;                          // query blocks
@@ -2125,6 +2125,9 @@ __global__ void __launch_bounds__(512, 1) k_attn_bwd_fused64(const bf16_t* __res
       return dq;
     };
     auto dq_commit = [&](f32x16& dq) {
+#ifdef ONEPROT_ATTN_ABLATE      // timing only: 900 = no ticket wait, no read-add-write (what a dQ without the chain could save at most); results wrong
+      if (dph == 900 || dph == 901) { asm volatile("" :: "v"(dq[0]), "v"(dq[5]), "v"(dq[10]), "v"(dq[15])); return; }
+#endif
       if (lane == 0)
         while (sTicket[p_i] != p_turn) __builtin_amdgcn_s_sleep(1);
       asm volatile("" ::: "memory");
@@ -2185,7 +2188,11 @@ __global__ void __launch_bounds__(512, 1) k_attn_bwd_fused64(const bf16_t* __res
         chains(0);
         BWD64_T(1);
         f32x16 dqp = zero16();
+#ifdef ONEPROT_ATTN_ABLATE      // 901: no dQ MFMAs either (and no dS^T fragments back from the slabs)
+        if (p_i >= 0 && dph != 901) dqp = dq_mfmas();
+#else
         if (p_i >= 0) dqp = dq_mfmas();
+#endif
         __builtin_amdgcn_sched_barrier(0);
         if (p_i >= 0) dq_commit(dqp);
         BWD64_T(2);
