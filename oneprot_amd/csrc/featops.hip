@@ -479,4 +479,4 @@ extern "C" int oneprot_diag_rank(const float* logits, int* rank_row, int* rank_c
   return launch_status();
 }
 
-extern "C" int oneprot_abi_version(void) { return 6; }      // 6: oneprot_dropout_add_layernorm_fwd; 5: gelu' travels as one-byte codes (out1 of ONEPROT_EPI_BIAS_GELU / aux of ONEPROT_EPI_GELU_BWD are u8 tensors), oneprot_gemm_ln_form, oneprot_dropout_add_f32; 2: oneprot_gemm_bf16_tn takes workspace_bytes; 3: fused GEMM + LayerNorm entry points, oneprot_dot_f32; 4: oneprot_siglip_fwd_bwd_dev, oneprot_attn_force_fwd_path, oneprot_transpose_cast_f32_to_bf16_batched, oneprot_dropout_bf16 / _bwd_add_bf16 / _bwd_add_f32
+extern "C" int oneprot_abi_version(void) { return 6; }      // 6: oneprot_dropout_add_layernorm_fwd, oneprot_gemm_bf16_nt_resid_ln8 (+ _eligible, _error); 5: gelu' travels as one-byte codes (out1 of ONEPROT_EPI_BIAS_GELU / aux of ONEPROT_EPI_GELU_BWD are u8 tensors), oneprot_gemm_ln_form, oneprot_dropout_add_f32; 2: oneprot_gemm_bf16_tn takes workspace_bytes; 3: fused GEMM + LayerNorm entry points, oneprot_dot_f32; 4: oneprot_siglip_fwd_bwd_dev, oneprot_attn_force_fwd_path, oneprot_transpose_cast_f32_to_bf16_batched, oneprot_dropout_bf16 / _bwd_add_bf16 / _bwd_add_f32
