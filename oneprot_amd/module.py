@@ -269,8 +269,18 @@ class OneProtLitModule(_Base):
             out[modality] = loss
         return out
 
+    @staticmethod
+    def _check_kernel_waits():
+        """The FFN-2 + LayerNorm launches wait, bounded, for neighbouring work-groups (oneprot_gemm_bf16_nt_resid_ln8): a wait that ran out means wrong
+        activations in that launch.  A host-synchronous query, so it is made where the host waits anyway (end of a validation epoch, end of fit_steps)."""
+        from . import hip
+        if hip.query("oneprot_gemm_resid_ln8_error") != 0:
+            raise hip.HipKernelError("oneprot_gemm_bf16_nt_resid_ln8: a wait for the neighbouring column tiles ran out (fewer CUs available than column "
+                                     "tiles of a row panel?); set ONEPROT_FFN2_LN=0 to keep the GEMM and the LayerNorm as separate launches")
+
     def on_validation_epoch_end(self):
         """ref oneprot_module.py:123-135"""
+        self._check_kernel_waits()
         loss = self._epoch_val_loss()
         self.val_loss_best(loss)
         self.log("val/loss_best", self.val_loss_best.compute(), sync_dist=True, prog_bar=True)
@@ -341,4 +351,5 @@ class OneProtLitModule(_Base):
         last = None
         for i, batch in enumerate(batches):
             last = self.training_step(batch, i)
+        self._check_kernel_waits()
         return last
