@@ -21,6 +21,9 @@
 // of LDS -- the same arithmetic order class as the stand-alone kernel (mean, then centred squares); pass 2 normalises from the registers.
 // N = 640 only (d = 640 encoders), M % 128 == 0, K % 64 == 0; everything else keeps the GEMM + LayerNorm pair.
 #include "gemm_epi8.h"
+#ifndef GLN_X_NT
+#define GLN_X_NT 0      // non-temporal stores of the fp32 residual stream (A/B builds: measured no better, NOTEBOOK 6e)
+#endif
 
 namespace gln {
 using g8::gload16; using g8::lane_perm; using g8::as_f; using g8::to_rows_addr; using g8::run_groups;
@@ -232,8 +235,8 @@ __global__ void __launch_bounds__(512, 2) k_gemm_ln(const LnArgs p) {
           if constexpr ((u & 1) == 0) { h0 = x0; h1 = x1; h2 = x2; h3 = x3; }
           else {
             __builtin_amdgcn_sched_barrier(0);
-            gst(xo + i * rstep + (j - 1) * 16, h0, h1, h2, h3, 0);
-            gst(xo + i * rstep + j * 16, x0, x1, x2, x3, 0);
+            gst(xo + i * rstep + (j - 1) * 16, h0, h1, h2, h3, GLN_X_NT);
+            gst(xo + i * rstep + j * 16, x0, x1, x2, x3, GLN_X_NT);
             __builtin_amdgcn_sched_barrier(0);
           }
         }, std::make_integer_sequence<int, 4>{});
@@ -498,8 +501,8 @@ __global__ void __launch_bounds__(256, 2) k_gemm_ln4(const LnArgs p) {
           if constexpr ((u & 1) == 0) { h0 = x0; h1 = x1; h2 = x2; h3 = x3; }
           else {
             __builtin_amdgcn_sched_barrier(0);
-            gst(xo + i * rstep + (j - 1) * 16, h0, h1, h2, h3, 0);
-            gst(xo + i * rstep + j * 16, x0, x1, x2, x3, 0);
+            gst(xo + i * rstep + (j - 1) * 16, h0, h1, h2, h3, GLN_X_NT);
+            gst(xo + i * rstep + j * 16, x0, x1, x2, x3, GLN_X_NT);
             __builtin_amdgcn_sched_barrier(0);
           }
         }, std::make_integer_sequence<int, 4>{});
