@@ -26,7 +26,7 @@ for spec in sys.argv[1:]:
         h.oneprot_gemm_tune(int(os.environ["AB_TUNE"]), 0)
     if "@gln" in name and hasattr(h, "oneprot_gemm_ln_form"):      # e.g. old@gln0=product: the same library with the eight-wave fused GEMM + LN kernel
         h.oneprot_gemm_ln_form(int(name.split("@gln")[1]))          # (form | start delay of the second half of the grid in us << 8)
-    if "@bwd" in name:                                             # e.g. own@bwd3=tools/ab/lib_own.so: the attention backward path forced
+    if "@bwd" in name:                                             # e.g. split@bwd0=product: the attention backward path forced (0 split, 1 fused 16 waves, 2 fused 8 waves)
         h.oneprot_attn_force_bwd_path(int(name.split("@bwd")[1]))
     if "@fwd" in name:                                             # e.g. chunked@fwd2=product: the same library with the attention forward path forced
         h.oneprot_attn_force_fwd_path(int(name.split("@fwd")[1]))
