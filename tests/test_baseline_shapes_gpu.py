@@ -190,6 +190,83 @@ def test_cfg2_shape_150m_batch16_loss_delta_reported(frozen_seq):
     assert rec["rel_grad_norm_delta"] < 2e-2, rec
 
 
+def _oracle_features_in_micro_batches(spec, ids, sd, cfg, mb=16):
+    """Forward-only oracle over a large batch: `mb` rows at a time under no_grad so that the eager [mb, H, L, L] score tensors stay small.  Rows of an
+    encoder batch do not interact (per-row key mask, per-row token-dropout rescale: hf modeling_esm.py:252-268), so the concatenation equals the full-batch forward."""
+    with torch.no_grad():
+        return torch.cat([O.encoder_features(spec["kind"], ids[i:i + mb], sd, cfg, spec["pooling"], spec["proj_type"], spec["use_logit_scale"])
+                          for i in range(0, ids.shape[0], mb)])
+
+
+def _full_batch_loss_parity(pair, B):
+    """HIP sub-step loss and features at `B` pairs against the FORWARD-ONLY oracle: the loss the bench's batch produces -- B
+    candidates per softmax row, logits x14.29 -- cannot be checked with the oracle's autograd in test time, its forward can.  cfg-2: ESM-2-150M x2;
+    cfg-4: ESM-2-150M <-> BERT-base (T=256), both frozen as shipped, the text tower's dropout off (parity is defined on the eval-mode reference)."""
+    _env()
+    from src.models.components.sequence_encoder import SequenceEncoder
+    from src.models.components.struct_token_encoder import StructTokenEncoder
+    from src.models.components.text_encoder import TextEncoder
+    from src.models.oneprot_module import OneProtLitModule
+    from oneprot_amd.optim import FusedAdam
+    torch.manual_seed(256)
+    L, T = 512, 256
+    seq = SequenceEncoder("facebook/esm2_t30_150M_UR50D", output_dim=1024, pooling_type="mean", proj_type="mlp", use_lora=False, frozen=True)
+    gen = torch.Generator().manual_seed(1883)
+    lens = [L if i % 3 else int(torch.randint(L // 4, L + 1, (1,), generator=gen)) for i in range(B)]
+    seq_ids = _ragged_ids(B, L, 4, 23, lens, gen)
+    if pair == "cfg2":
+        mod = StructTokenEncoder("facebook/esm2_t30_150M_UR50D", output_dim=1024, pooling_type="mean", proj_type="linear", use_logit_scale=True, learnable_logit_scale=False)
+        mod_key, mod_cfg, mod_spec = "struct_token", CFG150, SPEC_ST
+        mod_ids = _ragged_ids(B, L, 33, 52, lens, gen)
+    else:
+        mod = TextEncoder("bert-base-uncased", output_dim=1024, pooling_type="cls", proj_type="mlp", use_logit_scale=True, learnable_logit_scale=False, frozen=True, use_lora=False)
+        mod.transformer.train_dropout = False
+        mod_key, mod_cfg, mod_spec = "text", CFG_BERT, SPEC_TXT
+        tlens = [T if i % 4 else int(torch.randint(8, T + 1, (1,), generator=gen)) for i in range(B)]
+        mod_ids = _ragged_ids(B, T, 1000, 30521, tlens, gen, cls=101, eos=102, pad=0)
+    _randomise_biases(seq, mod)
+    sd_seq = {k: v.detach().clone() for k, v in seq.state_dict().items()}
+    sd_mod = {k: v.detach().clone() for k, v in mod.state_dict().items()}
+    module = OneProtLitModule(components={"sequence": seq, mod_key: mod}, optimizer=functools.partial(FusedAdam, lr=1e-3), loss_fn="CLIP",
+                              use_l1_regularization=True, local_loss=True, gather_with_grad=True).to(DEV)
+    with torch.no_grad():
+        sf = module(seq_ids.to(DEV), "sequence").cpu()
+        mf = module(mod_ids.to(DEV), mod_key).cpu()
+    loss = float(module.training_step({mod_key: (seq_ids.to(DEV), mod_ids.to(DEV), mod_key, None)}, 0).detach())
+    rsf = _oracle_features_in_micro_batches(SPEC_SEQ, seq_ids, sd_seq, CFG150)
+    rmf = _oracle_features_in_micro_batches(mod_spec, mod_ids, sd_mod, mod_cfg)
+    # ref oneprot_module.py:99-103 (argument names swapped at the call site, symmetric)
+    rl = float(O.clip_loss(rsf, rmf) + 0.01 * (rsf.abs().mean() + rmf.abs().mean()))
+    # the loss the ORACLE's loss function gives on the HIP features: separates encoder error from loss-kernel error
+    l_mixed = float(O.clip_loss(sf, mf) + 0.01 * (sf.abs().mean() + mf.abs().mean()))
+    cs = torch.nn.functional.cosine_similarity(sf, rsf, dim=-1)
+    cm = torch.nn.functional.cosine_similarity(mf, rmf, dim=-1)
+    rec = {"what": f"{'ESM-2-150M x2' if pair == 'cfg2' else 'ESM-2-150M (L=512) <-> BERT-base (T=256), eval-mode dropout'}, L=512, D=1024, B={B}, frozen as shipped, CLIP + L1: "
+                   "HIP training_step loss vs forward-only CPU oracle (fp32, micro-batches of 16)",
+           "batch": B, "loss_hip": loss, "loss_oracle": rl, "rel_loss_delta": abs(loss - rl) / rl, "loss_oracle_fn_on_hip_features": l_mixed,
+           "rel_loss_kernel_only": abs(loss - l_mixed) / rl, "min_feature_cosine_sequence": float(cs.min()), "min_feature_cosine_modality": float(cm.min()),
+           "max_abs_feature_diff_sequence": float((sf - rsf).abs().max()), "max_abs_feature_diff_modality_over_scale": float((mf - rmf).abs().max() * 0.07)}
+    out = os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "gpurun_out")
+    os.makedirs(out, exist_ok=True)
+    with open(os.path.join(out, f"loss_delta_b{B}_{pair}.json"), "w") as f:
+        json.dump(rec, f, indent=1)
+    return rec
+
+
+_FULL = os.environ.get("ONEPROT_FULL_BATCH_PARITY") == "1"
+
+
+@pytest.mark.parametrize("pair,B", [("cfg2", 64), ("cfg4", 64),
+                                    pytest.param("cfg2", 256, marks=pytest.mark.skipif(not _FULL, reason="3 CPU-minutes: set ONEPROT_FULL_BATCH_PARITY=1 (record committed under profiles/)")),
+                                    pytest.param("cfg4", 256, marks=pytest.mark.skipif(not _FULL, reason="2 CPU-minutes: set ONEPROT_FULL_BATCH_PARITY=1 (record committed under profiles/)"))])
+def test_full_batch_loss_vs_forward_oracle(pair, B):
+    """north_star: "loss matching reference to 1e-3 rel" at the batch the bench quotes (256 pairs: 256 candidates per softmax row) and at 64 pairs in
+    the default suite.  Gates: loss rel <= 1e-3, every feature row cosine > 0.999 (SURVEY 8d parity tolerance)."""
+    rec = _full_batch_loss_parity(pair, B)
+    assert rec["rel_loss_delta"] < 1e-3, rec
+    assert rec["min_feature_cosine_sequence"] > 0.999 and rec["min_feature_cosine_modality"] > 0.999, rec
+
+
 @pytest.mark.parametrize("frozen_text", [True, False], ids=["frozen_text", "trainable_text"])
 def test_cfg4_shape_150m_vs_bert_base_substep_vs_oracle(frozen_text):
     """cfg-4: ESM-2-150M sequence tower (L=512, frozen) <-> BERT-base text tower (T=256; cls pooling, mlp head, logit scale: text.yaml)."""

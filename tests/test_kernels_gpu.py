@@ -917,10 +917,11 @@ def test_dropout_bf16_mask_is_a_function_of_seed_stream_and_element():
         hip.call("oneprot_dropout_bf16", x, y, n, 1.0, seed, 7)
 
 
-@pytest.mark.parametrize("world,local_loss", [(2, True), (3, True), (2, False)])
+@pytest.mark.parametrize("world,local_loss", [(2, True), (3, True), (2, False), (4, True), (4, False), (8, True), (8, False)])
 def test_clip_loss_node_multirank_semantics(golden_dir, world, local_loss):
     """The fused CLIP node (SGEMM logits + fused CE fwd/bwd) on gathered features, per rank, vs the losses/gradients the reference
-    produced on real ranks (gather_with_grad=False variant: the local gradient is exactly d loss_rank / d local features)."""
+    produced on real ranks (gather_with_grad=False variant: the local gradient is exactly d loss_rank / d local features).  World 8 = the node size of
+    cfg-3..5: label offsets rank * B_loc up to 7 * B_loc with B_glob = 8 * B_loc inside the fused CE kernel (ref loss.py:72-83)."""
     import os
     from oneprot_amd.loss import _ClipLossFn
     g = torch.load(os.path.join(golden_dir, f"loss_world{world}.pt"), weights_only=False)
