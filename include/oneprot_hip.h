@@ -10,7 +10,10 @@
  *
  * Conventions
  *   - plain pointers (device memory owned by the caller), sizes, and an opaque stream (hipStream_t passed as void*);
- *   - every function only enqueues work on `stream`; no allocation, no synchronisation, graph-capturable;
+ *   - every function that takes a `stream` only enqueues work on it: no allocation, no synchronisation, graph-capturable (per-launch bookkeeping that
+ *     a replayed graph must see advance -- work-queue heads, launch tags -- lives in caller-provided device memory and is advanced by the kernels themselves,
+ *     see "sched workspace" below).  The exceptions say so: *_workspace*() / *_eligible() size queries, oneprot_alloc_uncached / oneprot_free_uncached (host
+ *     allocation calls, for set-up code), oneprot_gemm_resid_ln8_error (a host-synchronous read for tests and end-of-epoch checks), and the test / tuning hooks;
  *   - return 0 on success, -1 invalid argument / unsupported shape, -2 launch failure.  Nothing throws;
  *   - "bf16" pointers are raw 16-bit bfloat16 storage; statistics, residual stream, losses and all parameter
  *     gradients are fp32;
@@ -89,21 +92,48 @@ int oneprot_gemm_bf16_nt(const void* A, const void* Bw, int64_t M, int N, int K,
 int oneprot_gemm_ln_pack_weight(const void* W_bf16 /* [N,K] row-major */, void* Wp, int N, int K, void* stream);
 int oneprot_gemm_bf16_nt_resid_ln(const void* A, const void* Wp, int64_t M, int N, int K, int lda, const float* bias, const float* resid, float* x_out,
                                   const float* gamma, const float* beta, float eps, void* h_out, float* mean, float* rstd, void* stream);
+/* ---- sched workspace: device memory through which the persistent one-work-group-per-CU kernels hand out work at run time and keep per-launch
+ * bookkeeping on the device (csrc/sched_ws.h: eight per-XCD queue heads, an arrival counter, a launch epoch, a sticky error word, and room for the partial
+ * row statistics of oneprot_gemm_bf16_nt_resid_ln8 for up to M_max rows).  The caller owns it: oneprot_sched_workspace_bytes(M_max) bytes, 128-byte aligned,
+ * zeroed ONCE (oneprot_sched_workspace_init: a memset enqueued on `stream`), then only ever touched by the kernels -- the last work-group to leave a launch
+ * resets the queue heads and advances the epoch, so a captured graph replays correctly.  One workspace serves one stream (launches that overlap in time must
+ * not share one).  The statistics exchange crosses the XCDs' L2s: allocate the workspace with oneprot_alloc_uncached (hipExtMallocWithFlags(
+ * hipDeviceMallocUncached); a host call like any allocation -- set-up code, never a launch path) and release it with oneprot_free_uncached. */
+size_t oneprot_sched_workspace_bytes(int64_t M_max);
+int oneprot_alloc_uncached(void** out, size_t bytes);
+int oneprot_free_uncached(void* ptr);
+int oneprot_sched_workspace_init(void* sched_ws, size_t bytes, void* stream);
+/* Tiles of the persistent GEMM kernels drawn from the work queues of `sched_ws` instead of static per-work-group lists (NULL: static lists, the default).
+ * With static lists a work-group that cannot start with the others -- another kernel (an RCCL channel of an overlapped gradient all-reduce, another process)
+ * holds its CU -- runs its whole list after the others have finished: 1.47 x per launch whatever the number of CUs held.  With queues the running
+ * work-groups share the tiles and late ones find the queue empty.  Results are bit-identical (which CU computes a tile changes no summation order).
+ * Process-wide setting; the kernels of every stream then use this one workspace, so the streams must not overlap such launches. */
+void oneprot_dynamic_tiles(void* sched_ws, size_t bytes);
 /* The same product with the row statistics completed ACROSS work-groups, for the launches whose K loop the full-row kernel above runs too slowly
  * (FFN-2, K = 4 d): x_out = resid + A W^T + bias (fp32; may alias resid) and h = LayerNorm(x_out) (bf16), by the 8-phase GEMM on 256 x 320 tiles; the
- * column tiles of a row panel exchange (mean, M2) partials through device memory (hf modeling_esm.py:442-463 followed by :429 of the next layer or by
+ * column tiles of a row panel exchange (mean, M2) partials through the sched workspace (hf modeling_esm.py:442-463 followed by :429 of the next layer or by
  * emb_layer_norm_after, sequence_encoder.py:76-81).  W as for oneprot_gemm_bf16_nt (not packed).  stats: fp32 [2][M] = mean | rstd, or NULL.
+ * sched_ws / sched_ws_bytes: a sched workspace sized for at least M rows (-1 otherwise); the launch's tag comes from its device-side epoch.
  * oneprot_gemm_resid_ln8_eligible: 0 when (M, N, K) is not made of whole tiles this form serves (M % 256 == 0, N in {320, 640, 1280}, K % 128 == 0) -- the
  * caller runs oneprot_gemm_bf16_nt (ONEPROT_EPI_BIAS_RESID) + oneprot_layernorm_fwd --, 2 when it is and has the >= 192 tiles from which a persistent
- * work-group per CU pays, 1 when it is served but smaller (right, not faster: what the small-batch parity tests run).  oneprot_gemm_resid_ln8_error: 1 after a launch in which a
- * bounded wait for a neighbouring column tile ran out (host-synchronous query; never seen, the waits are short by construction). */
+ * work-group per CU pays, 1 when it is served but smaller (right, not faster: what the small-batch parity tests run).
+ * FAILURE SEMANTICS.  A work-group waits, bounded, for the partials of the other column tiles of its row panel.  A wait that runs out (the partner work-group
+ * never got a CU: fewer CUs free than the form needs) sets the workspace's sticky error word and the wave writes NaN into its rows of h, mean and rstd --
+ * the next loss is NaN, not plausibly wrong -- and every later wait of that launch gives up at its first miss instead of spinning again.
+ * oneprot_clip_coef(…, sched_ws, …) folds the word into the step's gradient norm on the device.  oneprot_gemm_resid_ln8_error: host-synchronous read of the
+ * word (1 = some launch on this workspace wrote NaN rows); _error_clear: enqueues its reset.  oneprot_gemm_resid_ln8_poll_bound: test hook, polls per wait
+ * (default 2^20, about a second; < 0 restores it). */
 int oneprot_gemm_resid_ln8_eligible(int64_t M, int N, int K);
-int oneprot_gemm_resid_ln8_error(void);
+int oneprot_gemm_resid_ln8_error(const void* sched_ws);
+int oneprot_gemm_resid_ln8_error_clear(void* sched_ws, void* stream);
+void oneprot_gemm_resid_ln8_poll_bound(int polls);
 int oneprot_gemm_bf16_nt_resid_ln8(const void* A, const void* W, int64_t M, int N, int K, int lda, int ldb, const float* bias, const float* resid,
-                                   float* x_out, const float* gamma, const float* beta, float eps, void* h_bf16, float* stats, void* stream);
-/* test / tuning hook: kernel form of oneprot_gemm_bf16_nt_resid_ln -- 1 (default): four-wave work-groups on 64-row tiles, two per CU (one's K loop
-   under the other's HBM-bound epilogue); 0: eight-wave work-groups on 128-row tiles, one per CU.  Bit-identical results. */
+                                   float* x_out, const float* gamma, const float* beta, float eps, void* h_bf16, float* stats, void* sched_ws,
+                                   size_t sched_ws_bytes, void* stream);
+/* test / tuning hook: kernel form of oneprot_gemm_bf16_nt_resid_ln -- 0 (default): eight-wave work-groups on 128-row tiles, one per CU; 1: four-wave
+   work-groups on 64-row tiles, two per CU (measured 5-9 % slower: kept as a tested variant).  Bit-identical results.  oneprot_gemm_ln_form_get: the current form. */
 void oneprot_gemm_ln_form(int form);
+int oneprot_gemm_ln_form_get(void);
 /* test / tuning hook: force the block shape of oneprot_gemm_bf16_nt (0..5, see csrc/gemm_nt.hip; -1 = heuristic). */
 void oneprot_gemm_force_shape(int shape);
 /* test / tuning hook: L2 super-tile of the per-tile kernels (sup_m row panels x sup_n column tiles per XCD at a time; <= 0 keeps a value). */
@@ -213,7 +243,7 @@ int oneprot_dropout_bwd_add_f32(const void* dy, float* dx, int64_t n, float p, u
 size_t oneprot_sumsq_workspace(void);
 int oneprot_sumsq(const float* x, int64_t n, float* sumsq, void* workspace, void* stream);
 /* coef[0] = min(1, max_norm / (sqrt(sumsq[0]) + 1e-6)); norm_out[0] = sqrt(sumsq[0]) */
-int oneprot_clip_coef(const float* sumsq, float max_norm, float* coef, float* norm_out, void* stream);
+int oneprot_clip_coef(const float* sumsq, float max_norm, float* coef, float* norm_out, const void* sched_ws /* optional: its error word turns norm and coef into NaN */, void* stream);
 /* Adam step on a flat arena; g is multiplied by grad_scale[0] (device scalar, may be NULL) before use. step >= 1. */
 int oneprot_adam_step(float* p, const float* g, float* m, float* v, int64_t n, float lr, float beta1, float beta2, float eps, float weight_decay,
                       int step, const float* grad_scale, void* stream);

@@ -9,20 +9,29 @@ OBJS=""
 PIDS=""
 for s in $SRCS; do
   o="${s%.hip}.o"
-  if [ ! -f "$o" ] || [ ! -f "$o.remarks" ] || [ "$s" -nt "$o" ] || [ common.h -nt "$o" ] || [ gemm_epi.h -nt "$o" ] || [ gemm_epi8.h -nt "$o" ] || [ ../../include/oneprot_hip.h -nt "$o" ]; then
+  if [ ! -f "$o" ] || [ ! -f "$o.remarks" ] || [ "$s" -nt "$o" ] || [ common.h -nt "$o" ] || [ gemm_epi.h -nt "$o" ] || [ gemm_epi8.h -nt "$o" ] || [ sched_ws.h -nt "$o" ] || [ ../../include/oneprot_hip.h -nt "$o" ]; then
     ( if hipcc --offload-arch=gfx950 -O3 -fPIC -std=c++17 -Wno-unused-value -Rpass-analysis=kernel-resource-usage -c "$s" -o "$o.tmp" 2> "$o.remarks.tmp"; then
         mv "$o.tmp" "$o"; mv "$o.remarks.tmp" "$o.remarks"
       else
         grep -v "remark:" "$o.remarks.tmp" >&2; rm -f "$o.remarks.tmp"; exit 1
       fi ) &
     PIDS="$PIDS $!"
+    if [ "$s" = gemm_nt8.hip ]; then      # its device ISA as text, for check_async_regs.py (a register written behind the compiler's back)
+      ( hipcc --offload-arch=gfx950 -O3 -fPIC -std=c++17 -Wno-unused-value -S --cuda-device-only "$s" -o gemm_nt8.s.tmp 2> /dev/null && mv gemm_nt8.s.tmp gemm_nt8.s ) &
+      PIDS="$PIDS $!"
+    fi
   fi
   OBJS="$OBJS $o"
 done
+if [ ! -f gemm_nt8.s ]; then
+  ( hipcc --offload-arch=gfx950 -O3 -fPIC -std=c++17 -Wno-unused-value -S --cuda-device-only gemm_nt8.hip -o gemm_nt8.s.tmp 2> /dev/null && mv gemm_nt8.s.tmp gemm_nt8.s ) &
+  PIDS="$PIDS $!"
+fi
 for p in $PIDS; do wait $p || { echo "compile failed"; exit 1; }; done
 REMARKS=""
 for s in $SRCS; do REMARKS="$REMARKS ${s%.hip}.o.remarks"; done
 python3 check_resources.py $REMARKS || { echo "build refused: register spills in product kernels (see above)"; exit 1; }
+python3 check_async_regs.py gemm_nt8.s || { echo "build refused: the asynchronously written ticket register of k_gemm8 is copied or reused (see above)"; exit 1; }
 hipcc --offload-arch=gfx950 -shared -fPIC -o ../liboneprot_hip.so $OBJS
 echo "built $(cd .. && pwd)/liboneprot_hip.so"
 # RCCL wrappers (include/oneprot_comm.h) in their own library, so that the kernel library carries no RCCL dependency

@@ -3,6 +3,7 @@
 //   L1 feature penalty, global grad-norm (two-stage deterministic reduction), clip coefficient, fused Adam.
 // All HBM-bound or latency-bound; reductions are deterministic (no float atomics).
 #include "common.h"
+#include "sched_ws.h"
 #include "../../include/oneprot_hip.h"
 #include <float.h>
 
@@ -155,14 +156,18 @@ extern "C" int oneprot_sumsq(const float* x, int64_t n, float* sumsq, void* work
 extern "C" int oneprot_abs_sum(const float* x, float* out_sum, void* workspace, int64_t n, float coef, void* stream) { return reduce_launch(1, x, n, out_sum, workspace, coef, (hipStream_t)stream); }
 extern "C" int oneprot_dot_f32(const float* x, const float* y, float* out_sum, void* workspace, int64_t n, float coef, void* stream) { return reduce_launch(2, x, n, out_sum, workspace, coef, (hipStream_t)stream, y); }
 
-__global__ void k_clip_coef(const float* __restrict__ sumsq, float max_norm, float* __restrict__ coef, float* __restrict__ norm_out) {
-  const float nrm = sqrtf(sumsq[0]);
+// `poison` (optional): the sticky LN_ERR word of a sched workspace (sched_ws.h).  Non-zero = some launch of this step wrote NaN rows because a bounded wait
+// ran out: the gradient norm and the clip coefficient of THIS step become NaN as well (a device read: no host synchronisation), so that the failure is on the
+// loss, on the logged gradient norm and on every updated parameter in the step it happened in, whatever the tower's NaN rows fed into.
+__global__ void k_clip_coef(const float* __restrict__ sumsq, float max_norm, float* __restrict__ coef, float* __restrict__ norm_out, const unsigned* __restrict__ poison) {
+  float nrm = sqrtf(sumsq[0]);
+  if (poison && __hip_atomic_load(poison, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != 0u) nrm = __builtin_nanf("");
   if (norm_out) norm_out[0] = nrm;
-  coef[0] = fminf(1.0f, max_norm / (nrm + 1e-6f));      // torch.nn.utils.clip_grad_norm_ semantics
+  coef[0] = nrm != nrm ? nrm : fminf(1.0f, max_norm / (nrm + 1e-6f));      // torch.nn.utils.clip_grad_norm_ semantics (fminf would drop a NaN)
 }
-extern "C" int oneprot_clip_coef(const float* sumsq, float max_norm, float* coef, float* norm_out, void* stream) {
+extern "C" int oneprot_clip_coef(const float* sumsq, float max_norm, float* coef, float* norm_out, const void* sched_ws, void* stream) {
   if (!sumsq || !coef) return OP_EINVAL;
-  hipLaunchKernelGGL(k_clip_coef, dim3(1), dim3(1), 0, (hipStream_t)stream, sumsq, max_norm, coef, norm_out);
+  hipLaunchKernelGGL(k_clip_coef, dim3(1), dim3(1), 0, (hipStream_t)stream, sumsq, max_norm, coef, norm_out, sched_ws ? (const unsigned*)sched_ws + SW_LN_ERR : nullptr);
   return launch_status();
 }
 
@@ -479,4 +484,4 @@ extern "C" int oneprot_diag_rank(const float* logits, int* rank_row, int* rank_c
   return launch_status();
 }
 
-extern "C" int oneprot_abi_version(void) { return 6; }      // 6: oneprot_dropout_add_layernorm_fwd, oneprot_gemm_bf16_nt_resid_ln8 (+ _eligible, _error); 5: gelu' travels as one-byte codes (out1 of ONEPROT_EPI_BIAS_GELU / aux of ONEPROT_EPI_GELU_BWD are u8 tensors), oneprot_gemm_ln_form, oneprot_dropout_add_f32; 2: oneprot_gemm_bf16_tn takes workspace_bytes; 3: fused GEMM + LayerNorm entry points, oneprot_dot_f32; 4: oneprot_siglip_fwd_bwd_dev, oneprot_attn_force_fwd_path, oneprot_transpose_cast_f32_to_bf16_batched, oneprot_dropout_bf16 / _bwd_add_bf16 / _bwd_add_f32
+extern "C" int oneprot_abi_version(void) { return 7; }      // 7: sched workspace (oneprot_sched_workspace_bytes / _init, oneprot_alloc_uncached / _free_uncached, oneprot_dynamic_tiles), oneprot_gemm_bf16_nt_resid_ln8 / _error take it, oneprot_clip_coef reads its error flag; 6: oneprot_dropout_add_layernorm_fwd, oneprot_gemm_bf16_nt_resid_ln8 (+ _eligible, _error); 5: gelu' travels as one-byte codes (out1 of ONEPROT_EPI_BIAS_GELU / aux of ONEPROT_EPI_GELU_BWD are u8 tensors), oneprot_gemm_ln_form, oneprot_dropout_add_f32; 2: oneprot_gemm_bf16_tn takes workspace_bytes; 3: fused GEMM + LayerNorm entry points, oneprot_dot_f32; 4: oneprot_siglip_fwd_bwd_dev, oneprot_attn_force_fwd_path, oneprot_transpose_cast_f32_to_bf16_batched, oneprot_dropout_bf16 / _bwd_add_bf16 / _bwd_add_f32

@@ -19,11 +19,15 @@ struct GemmArgs {
   int sup_m, sup_n;             // L2 super-tile of the per-tile kernels: sup_m row panels x sup_n column tiles per XCD at a time
   int nt_store;                 // output stores non-temporal (streamed past the L2 instead of displacing the operand panels and W)
   // G8_EPI_RESID_LN (8-phase kernels only): out0 = x_out fp32 = acc + bias + aux; out1 = bf16 LayerNorm(x_out) with gamma = cos, beta = sin, eps = q_scale;
-  // out2 = fp32 [2][M]: mean | rstd (or null).  A row's statistics are completed across the column tiles through ln_part / ln_flag (gemm_epi8.h).
-  void* ln_part;                // [M][8] x 16 bytes {tag, mean, M2, ~tag}: per row, one partial per wave column of every column tile (uncached memory)
-  unsigned* ln_err;             // sticky: a wait for the other column tiles ran out
+  // out2 = fp32 [2][M]: mean | rstd (or null).  A row's statistics are completed across the column tiles through ln_part (gemm_epi8.h).
+  void* ln_part;                // [M][8] x 16 bytes {tag, mean, M2, ~tag}: per row, one partial per wave column of every column tile (uncached memory, inside the sched workspace)
   int ln_slots;                 // partials per row = column tiles x wave columns
-  unsigned ln_epoch;            // this launch's tag (never 0)
+  int ln_poll_max;              // bound of the wait for the other column tiles' partials, in polls
+  // Work queues and launch bookkeeping of the persistent kernels: the caller's "sched workspace" (sched_ws.h; include/oneprot_hip.h: oneprot_sched_workspace_*), or null.
+  // With it the last work-group to leave a launch resets the queues and advances the launch epoch ON THE DEVICE (a replayed graph gets fresh tags);
+  // `dyn`: tiles are drawn from the per-XCD queues instead of the static list u = q * g8n + w.
+  unsigned* sched;
+  int dyn;
 };
 #define G8_EPI_RESID_LN 6      // internal to gemm_nt8.hip / gemm_epi8.h (entry point oneprot_gemm_bf16_nt_resid_ln8), not part of the public epilogue enum
 // 16- / 8-byte output stores with the launch's cache policy (wave-uniform branch)
@@ -284,5 +288,6 @@ __device__ __forceinline__ void gemm_epilogue_direct(const GemmArgs& p, f32x4 (&
 #define G8_NOT_ELIGIBLE (-100)
 int launch_gemm8(int epi, const GemmArgs& a, int cfg, long min_tiles, hipStream_t s);
 int gemm8_ln_eligible(long M, int N, int K);
-int launch_gemm8_ln(GemmArgs a, hipStream_t s);      // G8_EPI_RESID_LN on 256 x 320 tiles
-int gemm8_ln_error();
+int launch_gemm8_ln(GemmArgs a, void* sched_ws, size_t sched_ws_bytes, hipStream_t s);      // G8_EPI_RESID_LN on 256 x 320 tiles
+size_t sched_workspace_bytes(long M_max);
+void* dynamic_tiles_workspace();                      // what oneprot_dynamic_tiles was given (null: static tile lists)

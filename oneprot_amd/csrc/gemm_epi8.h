@@ -17,6 +17,7 @@
 //     moves lane (q*16 + c) to lane (c*4 + q): four per 16-byte store, and the store becomes 16 requests of 64 bytes.
 #pragma once
 #include "gemm_epi.h"
+#include "sched_ws.h"
 
 namespace g8 {
 
@@ -328,14 +329,17 @@ __device__ __forceinline__ void epilogue_f32(const GemmArgs& p, f32x4 (&acc)[MT]
 //      Chan's rule (DPP quad_perm): every lane then holds (mean, M2) of its wave block's 160 columns;
 //   C  lanes sq == 0 publish them -- ln_part[row][slot], slot = column tile x 2 + wave column, in UNCACHED device memory, as ONE tagged 16-byte store;
 //   D  lane sq polls entry sq (and sq + 4) of its rows until all of them carry this launch's tag (the other wave blocks run the same tile at the same time:
-//      the work-groups of one row panel are neighbours in the launch and every work-group walks its tiles in step), bounded: a wait that runs out sets
-//      ln_err and goes on;
+//      the column tiles of one row panel are handed out next to each other and run at the same time), bounded: a wait that runs out sets the sticky LN_ERR
+//      flag of the sched workspace and the wave writes NaN for its rows (h, mean, rstd) -- and every later wait of the launch gives up at its first miss;
 //   E  the quad combines again: every lane has the row's statistics over all N columns;
 //   F  h = (s - mean) rstd gamma + beta from the registers, two column tiles at a time (gamma / beta two groups ahead like every epilogue operand),
 //      lane pairs swapping halves so that a lane stores 16 contiguous bytes; mean / rstd leave from slot 0.
 // The statistics are exact two-pass ones per wave block (the values are in registers) and Chan's combination is exact in exact arithmetic: the result
-// agrees with k_layernorm_fwd's two-pass form to fp32 rounding.  Deadlock: a wave only waits for waves of work-groups that were launched (the grid is one
-// work-group per CU, and a work-group that has to wait for a CU starts when the others finish: they never wait for IT twice).
+// agrees with k_layernorm_fwd's two-pass form to fp32 rounding.  Progress: a wave waits for the waves that run the other column tiles of its row panel.  With
+// static tile lists those are work-groups of the same launch slot: if one of them has no CU yet (a co-resident kernel holds it) its neighbours wait -- once per
+// tile of theirs -- until a work-group that has finished makes room, or until the bound.  With tiles drawn from the work queue (GemmArgs.dyn) a tile that has
+// been drawn is held by a RUNNING work-group, partners are G = 2 draws apart (so a work-group that draws twice in a row never holds both), and the wait is
+// bounded by the partner's remaining tile time as long as three work-groups of the XCD are running.  Either way the bound ends it: NaN + LN_ERR, never a hang.
 // 16-byte load / store that miss every cache on their way (system scope): the partial statistics of the wave blocks of a row
 template <int OFF> __device__ __forceinline__ void gload16_uc(u32x4& d, const void* ptr) {
   asm volatile("global_load_dwordx4 %0, %1, off offset:%2 sc0 sc1" : "=v"(d) : "v"(ptr), "n"(OFF) : "memory");
@@ -344,26 +348,28 @@ template <int OFF> __device__ __forceinline__ void gst16_uc(const void* ptr, con
   asm volatile("global_store_dwordx4 %0, %1, off offset:%2 sc0 sc1\n\ts_nop 1" ::"v"(ptr), "v"(v), "n"(OFF) : "memory");
 }
 // polls MT x NS tagged entries (row block i: 2 KB apart; second set: 4 entries on; `pl` two row blocks in) until every lane of the wave sees its own carry
-// the tag; bounded
+// the tag.  Bounded: after `poll_max` polls without them -- or as soon as ANOTHER wave of the launch has given up (the sticky flag is read in the slow path
+// only) -- the wave sets the flag and returns false: the caller then writes NaN for its rows (a starved launch ends quickly and loudly, never plausibly wrong).
 template <int MT, int NS>
-__device__ __forceinline__ void poll_entries(const u32x4* pl, unsigned tag, u32x4 (&e)[NS * MT], unsigned* err, int lane) {
+__device__ __forceinline__ bool poll_entries(const u32x4* pl, unsigned tag, u32x4 (&e)[NS * MT], unsigned* err, int poll_max, int lane) {
   int spins = 0;
-  bool ok;
-  do {
+  for (;;) {
     static_for([&](auto ic) {
       constexpr int i = decltype(ic)::value;
       gload16_uc<(i % MT) * 2048 - 4096 + (i / MT) * 64>(e[i], pl);
     }, std::make_integer_sequence<int, NS * MT>{});
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-    ok = true;
+    bool ok = true;
 #pragma unroll
     for (int i = 0; i < NS * MT; ++i) { asm volatile("" : "+v"(e[i])); ok = ok && e[i].x == tag && e[i].w == ~tag; }
-    ok = __all(ok);
-    if (!ok) {
-      if (++spins > (1 << 22)) { if (lane == 0) __hip_atomic_store(err, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); ok = true; }
-      else __builtin_amdgcn_s_sleep(2);
+    if (__all(ok)) return true;
+    const unsigned gave_up = __hip_atomic_load(err, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    if (gave_up != 0u || ++spins > poll_max) {
+      if (lane == 0) __hip_atomic_store(err, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+      return false;
     }
-  } while (!ok);
+    __builtin_amdgcn_s_sleep(2);
+  }
 }
 __device__ __forceinline__ float dpp_quad_xor1(float v) { return __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), 0xB1, 0xF, 0xF, false)); }
 __device__ __forceinline__ float dpp_quad_xor2(float v) { return __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), 0x4E, 0xF, 0xF, false)); }
@@ -374,7 +380,7 @@ __device__ __forceinline__ void chan_merge(float& mean, float& m2, float mo, flo
   m2 = m2 + m2o + d * d * (0.5f * n);
 }
 template <bool HB, int MT, int NT>
-__device__ __forceinline__ void epilogue_resid_ln(const GemmArgs& p, f32x4 (&acc)[MT][NT], int m0, int n0, int wr, int wc, int lane) {
+__device__ __forceinline__ void epilogue_resid_ln(const GemmArgs& p, f32x4 (&acc)[MT][NT], int m0, int n0, int wr, int wc, int lane, const unsigned tag) {
   static_assert(NT % 2 == 0, "whole lines per wave block");
   using Plan = LinePlan<MT, NT, false>;
   static_assert(!Plan::LONE);
@@ -448,7 +454,6 @@ __device__ __forceinline__ void epilogue_resid_ln(const GemmArgs& p, f32x4 (&acc
   // older launches never match, and nothing has to be cleared or counted (the first form -- partials, a wait for them to land, an arrival counter, polls of
   // the counter, then the loads -- was three round trips to uncached memory per tile and a memset per launch; this is the store and one or two polls).
   const int slot = (n0 / (2 * NT * 16)) * 2 + wc;          // column tile x 2 + wave column (a tile is two wave columns wide)
-  const unsigned tag = p.ln_epoch;
   const u32x4* ent = reinterpret_cast<const u32x4*>(p.ln_part) + (size_t)(row_w + sr) * 8;
   if (sq == 0) {
     static_for([&](auto ic) {
@@ -463,9 +468,11 @@ __device__ __forceinline__ void epilogue_resid_ln(const GemmArgs& p, f32x4 (&acc
   {
     const int s0 = p.ln_slots >= 4 ? sq : (sq & 1);
     float cnt = nw;
+    unsigned* const errp = p.sched + SW_LN_ERR;
+    bool got;
     if (p.ln_slots == 8) {                                    // four column tiles: entries sq and sq + 4, all eight loads of a poll in flight together
       u32x4 e[2 * MT];
-      poll_entries<MT, 2>(ent + s0 + 256, tag, e, p.ln_err, lane);
+      got = poll_entries<MT, 2>(ent + s0 + 256, tag, e, errp, p.ln_poll_max, lane);
 #pragma unroll
       for (int i = 0; i < MT; ++i) {
         mean[i] = as_f(e[i].y); m2[i] = as_f(e[i].z);
@@ -474,17 +481,19 @@ __device__ __forceinline__ void epilogue_resid_ln(const GemmArgs& p, f32x4 (&acc
       cnt *= 2.0f;
     } else {
       u32x4 e[MT];
-      poll_entries<MT, 1>(ent + s0 + 256, tag, e, p.ln_err, lane);
+      got = poll_entries<MT, 1>(ent + s0 + 256, tag, e, errp, p.ln_poll_max, lane);
 #pragma unroll
       for (int i = 0; i < MT; ++i) { mean[i] = as_f(e[i].y); m2[i] = as_f(e[i].z); }
     }
+    // a wait that ran out: the statistics of these rows are unknown -> NaN (h, mean and rstd of the wave block's rows), never a stale entry's numbers
+    const float poison = got ? 0.0f : __builtin_nanf("");
 #pragma unroll
     for (int i = 0; i < MT; ++i) {
       float mu = mean[i], mm = m2[i], c = cnt;
       chan_merge(mu, mm, dpp_quad_xor1(mu), dpp_quad_xor1(mm), c); c *= 2.0f;
       if (p.ln_slots >= 4) { chan_merge(mu, mm, dpp_quad_xor2(mu), dpp_quad_xor2(mm), c); c *= 2.0f; }
-      mean[i] = mu;
-      rstd[i] = rsqrtf(mm / (float)p.N + p.q_scale);
+      mean[i] = mu + poison;
+      rstd[i] = rsqrtf(mm / (float)p.N + p.q_scale) + poison;
     }
   }
   if (slot == 0 && sq == 0 && p.out2) {

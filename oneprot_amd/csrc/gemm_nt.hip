@@ -24,6 +24,7 @@
 #include <utility>
 #include <stdlib.h>
 #include "gemm_epi.h"
+#include "sched_ws.h"
 
 #define EPI_LD 68                                   // fp32 row pitch of a wave's epilogue tile (64 columns + pad)
 
@@ -1077,9 +1078,32 @@ static int launch_gemm(const GemmArgs& a, hipStream_t s) {
 // x_out = resid + A W^T + bias and h = LayerNorm(x_out) in ONE launch of the 8-phase GEMM (gemm_epi8.h: epilogue_resid_ln): the FFN-2 GEMM of a pre-LN layer with
 // the LayerNorm that follows it (hf modeling_esm.py:442-463 -> :429 of the next layer / emb_layer_norm_after).  Whole 256 x 320 tiles, N in {320, 640, 1280}.
 extern "C" int oneprot_gemm_resid_ln8_eligible(int64_t M, int N, int K) { return gemm8_ln_eligible((long)M, N, K); }
-extern "C" int oneprot_gemm_resid_ln8_error(void) { return gemm8_ln_error(); }
+// ---- the sched workspace (sched_ws.h): allocation helpers (host calls, never on a launch path) and its one-time initialisation
+extern "C" size_t oneprot_sched_workspace_bytes(int64_t M_max) { return sched_workspace_bytes((long)M_max); }
+extern "C" int oneprot_alloc_uncached(void** out, size_t bytes) {
+  if (!out || bytes == 0) return OP_EINVAL;
+  *out = nullptr;
+  return hipExtMallocWithFlags(out, bytes, hipDeviceMallocUncached) == hipSuccess ? 0 : OP_ELAUNCH;
+}
+extern "C" int oneprot_free_uncached(void* p) { return (!p || hipFree(p) == hipSuccess) ? 0 : OP_ELAUNCH; }
+extern "C" int oneprot_sched_workspace_init(void* ws, size_t bytes, void* stream) {
+  if (!ws || bytes < SW_HEADER_BYTES || ((uintptr_t)ws & 127)) return OP_EINVAL;
+  return hipMemsetAsync(ws, 0, bytes, (hipStream_t)stream) == hipSuccess ? 0 : OP_ELAUNCH;
+}
+// host-synchronous reads of the sticky flag (tests, end-of-epoch checks): 1 after a launch in which a bounded wait ran out (its rows are NaN)
+extern "C" int oneprot_gemm_resid_ln8_error(const void* sched_ws) {
+  unsigned e = 0;
+  if (!sched_ws) return 0;
+  if (hipMemcpy(&e, (const unsigned*)sched_ws + SW_LN_ERR, sizeof(e), hipMemcpyDeviceToHost) != hipSuccess) return -1;
+  return (int)e;
+}
+extern "C" int oneprot_gemm_resid_ln8_error_clear(void* sched_ws, void* stream) {
+  if (!sched_ws) return OP_EINVAL;
+  return hipMemsetAsync((unsigned*)sched_ws + SW_LN_ERR, 0, 4, (hipStream_t)stream) == hipSuccess ? 0 : OP_ELAUNCH;
+}
 extern "C" int oneprot_gemm_bf16_nt_resid_ln8(const void* A, const void* Bw, int64_t M, int N, int K, int lda, int ldb, const float* bias, const float* resid,
-                                              float* x_out, const float* gamma, const float* beta, float eps, void* h_bf16, float* stats, void* stream) {
+                                              float* x_out, const float* gamma, const float* beta, float eps, void* h_bf16, float* stats, void* sched_ws,
+                                              size_t sched_ws_bytes, void* stream) {
   if (!A || !Bw || !resid || !x_out || !gamma || !beta || !h_bf16 || M <= 0 || N <= 0 || K <= 0 || M > 0x7fffffff) return OP_EINVAL;
   if ((N & 7) || (K & 7) || (lda & 7) || (ldb & 7) || lda < K || ldb < K) return OP_EINVAL;
   if (((uintptr_t)A | (uintptr_t)Bw | (uintptr_t)resid | (uintptr_t)x_out | (uintptr_t)gamma | (uintptr_t)beta | (uintptr_t)h_bf16 | (uintptr_t)bias | (uintptr_t)stats) & 15) return OP_EINVAL;
@@ -1087,7 +1111,8 @@ extern "C" int oneprot_gemm_bf16_nt_resid_ln8(const void* A, const void* Bw, int
   a.A = (const bf16_t*)A; a.B = (const bf16_t*)Bw; a.M = (int)M; a.N = N; a.K = K; a.lda = lda; a.ldb = ldb; a.bias = bias;
   a.out0 = x_out; a.out1 = h_bf16; a.out2 = stats; a.aux = resid; a.cos = gamma; a.sin = beta; a.q_scale = eps; a.L = 0; a.H = 0; a.hd = 0;
   a.tiles_m = 0; a.tiles_n = 0; a.sup_m = g_sup_m; a.sup_n = g_sup_n; a.nt_store = 0;
-  const int rc = launch_gemm8_ln(a, (hipStream_t)stream);
+  a.ln_part = nullptr; a.ln_slots = 0; a.ln_poll_max = 0; a.sched = nullptr; a.dyn = 0;
+  const int rc = launch_gemm8_ln(a, sched_ws, sched_ws_bytes, (hipStream_t)stream);
   return rc == G8_NOT_ELIGIBLE ? OP_EINVAL : rc;
 }
 
@@ -1101,6 +1126,7 @@ extern "C" int oneprot_gemm_bf16_nt(const void* A, const void* Bw, int64_t M, in
   a.A = (const bf16_t*)A; a.B = (const bf16_t*)Bw; a.M = (int)M; a.N = N; a.K = K; a.lda = lda; a.ldb = ldb; a.bias = bias;
   a.out0 = out0; a.out1 = out1; a.out2 = out2; a.aux = aux; a.cos = rope_cos; a.sin = rope_sin; a.q_scale = q_scale; a.L = L; a.H = H; a.hd = hd;
   a.tiles_m = 0; a.tiles_n = 0; a.sup_m = g_sup_m; a.sup_n = g_sup_n; a.nt_store = g_nt_store;
+  a.ln_part = nullptr; a.ln_slots = 0; a.ln_poll_max = 0; a.sched = nullptr; a.dyn = 0;
   hipStream_t s = (hipStream_t)stream;
   switch (epilogue) {
     case ONEPROT_EPI_BF16: return launch_gemm<ONEPROT_EPI_BF16>(a, s);

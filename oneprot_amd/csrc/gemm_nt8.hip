@@ -87,6 +87,34 @@ __device__ __forceinline__ void glds16(unsigned voff, const unsigned char* sbase
   asm volatile("s_mov_b32 %0, m0\n\ts_mov_b32 m0, %3\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %1, %2\n\ts_mov_b32 m0, %0"
                : "=&s"(keep) : "v"(voff), "s"(sbase), "s"(lds_dst) : "memory");
 }
+// A draw from a queue head whose result is NOT waited for by the compiler (inline asm: hipcc's own wait would be vmcnt(0), i.e. a drain of the LDS-DMA
+// prefetch it cannot see); the caller looks at the register behind a counted wait that covers it.  `lanes` = the EXEC mask of the atomic: 1 in the one
+// wave that draws, 0 elsewhere (the instruction then does nothing and the register keeps 0x7fffffff) -- no branch, so no merge of two definitions of the
+// register that is written behind the compiler's back.
+__device__ __forceinline__ unsigned draw_async(const unsigned* head, int lanes) {
+  unsigned v, one;
+  unsigned long long keep;
+  const int lo = __builtin_amdgcn_readfirstlane(lanes);
+  // scalar base + a zero offset in the destination register itself: no address pair in vector registers (kept over the K loop it was spilled, and its reload
+  // -- behind a vmcnt(0) -- drained the operand prefetch in every iteration)
+  asm volatile("v_mov_b32 %0, 0\n\tv_mov_b32 %1, 1\n\ts_mov_b64 %2, exec\n\ts_mov_b32 exec_lo, %4\n\ts_mov_b32 exec_hi, 0\n\ts_cbranch_execz 1f\n\t"
+               "global_atomic_add %0, %0, %1, %3 sc0\n1:\n\ts_mov_b64 exec, %2"
+               : "=&v"(v), "=&v"(one), "=&s"(keep) : "s"(head), "s"(lo) : "memory");
+  return v;
+}
+// the ticket relay word in LDS: plain ds instructions from inline asm (through a volatile C++ access hipcc emitted FLAT instructions with a vmcnt(0) behind
+// them -- a drain of the operand prefetch, or of the epilogue's store burst); the reader's wait is the K-tile's own lgkmcnt(0)
+__device__ __forceinline__ unsigned lds_read32(unsigned addr) { unsigned v; asm volatile("ds_read_b32 %0, %1" : "=v"(v) : "v"(addr) : "memory"); return v; }
+__device__ __forceinline__ void lds_write32(unsigned addr, unsigned val) { asm volatile("ds_write_b32 %0, %1" ::"v"(addr), "v"(val) : "memory"); }
+__device__ __forceinline__ int first_lane(unsigned v) { int s; asm volatile("v_readfirstlane_b32 %0, %1" : "=s"(s) : "v"(v)); return s; }
+// the lane id, recomputed where it is needed (two instructions) rather than kept over the K loop: a volatile statement, so that hipcc neither hoists it out
+// of the tile loop nor keeps its result (the 160-accumulator configurations have no register for it: kept, it is spilled and its reload -- behind a
+// vmcnt(0) -- drains the operand prefetch once per tile)
+__device__ __forceinline__ int lane_now() {
+  int l;
+  asm volatile("v_mbcnt_lo_u32_b32 %0, -1, 0\n\tv_mbcnt_hi_u32_b32 %0, -1, %0" : "=v"(l));
+  return l;
+}
 template <int N> __device__ __forceinline__ void wait_lgkm() { asm volatile("s_waitcnt lgkmcnt(%0)" ::"n"(N) : "memory"); }
 
 // logical column (inside the wave's NTW*16-column block) held by LDS row slot `rho` of the wave's tile jt -- see gemm_epi.h
@@ -111,15 +139,48 @@ __global__ void __launch_bounds__(512, 2) k_gemm8(const GemmArgs p, const int g8
   const int x = blockIdx.x & 7, w = blockIdx.x >> 3;
   const int cs = p.csplit, ng = 8 / cs, xg = x / cs, cg = x - xg * cs, tn_x = p.tiles_n / cs;
   const int panels_x = p.tiles_m > xg ? (p.tiles_m - xg + ng - 1) / ng : 0;
-  const int Tx = panels_x * tn_x;
-  const int Q = Tx > w ? (Tx - w + g8n - 1) / g8n : 0;
-  if (Q == 0) return;
-  auto tile_origin = [&](int qi, int& m0, int& n0) {
-    const int u = qi * g8n + w;
-    const int pl = u / tn_x, tn = u - pl * tn_x;
+  const int Tx = panels_x * tn_x;                          // tiles of this XCD's share, numbered 0 .. Tx-1 ("tickets")
+  // ticket -> tile.  Plain kernels: column tile fastest (an XCD works on a few row panels at a time: they and W stay in its L2).  RESID_LN: the column tiles of
+  // a row panel wait for each other's row statistics, so they must run at the same time AND must never be held by one work-group: row panels are taken
+  // in pairs (G = 2) with the panel index fastest, i.e. partners are G tickets apart -- close in time, and a work-group that draws two tickets in a row
+  // (at its start) never holds two tiles of one panel.
+  constexpr int G = (EPI == G8_EPI_RESID_LN) ? 2 : 1;
+  auto tile_origin = [&](int u, int& m0, int& n0) __attribute__((always_inline)) {
+    int pl, tn;
+    if constexpr (G == 1) { pl = u / tn_x; tn = u - pl * tn_x; }
+    else {
+      const int per = G * tn_x, gi = u / per, idx = u - gi * per;
+      const int left = panels_x - gi * G, gp = left < G ? left : G;      // (the last group of an odd share has one panel)
+      tn = idx / gp; pl = gi * G + (idx - tn * gp);
+    }
     m0 = (pl * ng + xg) * C::BM; n0 = (cg * tn_x + tn) * C::BN;
   };
-  const int S = Q * nk;                                    // K-tiles in this work-group's stream
+  // ---- which tiles.  Static (p.dyn == 0): tickets w, w + g8n, w + 2 g8n, ...  Dynamic: tickets are drawn from XCD x's queue head in the sched workspace
+  // (sched_ws.h), two at the start and one per tile after that, always for the tile AFTER the next one (the operand stream runs into the next tile two
+  // K-tiles before the current one ends, so the next tile must be known by then).  A work-group that finds the queue empty leaves at once: work-groups
+  // that could not start with the others -- a co-resident kernel holds their CU -- cost nothing, the running ones share the tiles.
+  const bool dyn = p.dyn != 0;
+  int tk_cur, tk_nxt;
+  unsigned ln_tag = 0;
+  if (dyn) {
+    unsigned* sm = reinterpret_cast<unsigned*>(smem);
+    if (tid == 0) {
+      unsigned* head = p.sched + SW_HEAD(x);
+      const unsigned t0 = sw_draw(head), t1 = sw_draw(head);
+      sm[0] = t0 < 0x7fffffffu ? t0 : 0x7fffffffu; sm[1] = t1 < 0x7fffffffu ? t1 : 0x7fffffffu; sm[2] = sw_epoch(p.sched);
+    }
+    __syncthreads();
+    tk_cur = __builtin_amdgcn_readfirstlane((int)sm[0]); tk_nxt = __builtin_amdgcn_readfirstlane((int)sm[1]);
+    ln_tag = (unsigned)__builtin_amdgcn_readfirstlane((int)sm[2]) + 1u;
+    __syncthreads();
+  } else {
+    tk_cur = w; tk_nxt = w + g8n;
+    if (EPI == G8_EPI_RESID_LN) ln_tag = (unsigned)__builtin_amdgcn_readfirstlane((int)sw_epoch(p.sched)) + 1u;
+  }
+  if (tk_cur >= Tx) {
+    if (p.sched && tid == 0) sw_leave(p.sched, gridDim.x);
+    return;
+  }
   // ---- de-phasing.  Every work-group runs the same number of equally long tiles, so without it all 256 CUs reach their epilogues together and
   // the output bursts (160-320 KB per CU) queue on the HBM write path while nothing computes.  Phase group (w mod G) starts (w mod G) * dph_sleeps
   // sleeps of 1024 cycles late; the offsets persist, and the stores of one group drain under the K loops of the others.
@@ -134,20 +195,26 @@ __global__ void __launch_bounds__(512, 2) k_gemm8(const GemmArgs p, const int g8
   // These per-lane constants (and the fragment read addresses below) are RE-DERIVED from the lane id after every epilogue rather than kept: the
   // epilogue of the 160-accumulator configuration has no registers for them, and a spilled value is reloaded behind the whole store burst
   // (vector-memory operations retire in order), which would stall the next tile's first K-tiles.
-  unsigned a_voff[C::A_IPW], b_voff[2][C::B_IPW];
+  constexpr int BH = PAIR ? 2 : 1;                        // sets of W source offsets
+  static_assert(64 % (MH * 16) == 0, "a wave's A pieces are whole row-block groups apart");
+  constexpr int A_STEP = (64 / (MH * 16)) * (MT * 16);   // tile rows between a wave's consecutive A pieces
+  unsigned a_voff, b_voff[BH][C::B_IPW];
   unsigned a_rd, b_rd;
-  auto lane_consts = [&]() {
-    int ln = lane;
+  auto lane_consts = [&]() __attribute__((always_inline)) {
+    int ln = lane_now();
     asm volatile("" : "+v"(ln));                            // opaque: not hoisted out of the tile loop
     const int sr = ln >> 3, sc = ln & 7;
-#pragma unroll
-    for (int i = 0; i < C::A_IPW; ++i) {
-      const int hr = (i * 8 + wave) * 8 + sr;                         // LDS row inside the unit
+    {
+      // (a wave's piece i lies 64 LDS rows = A_STEP tile rows behind its piece 0, with the same swizzle: a wave-uniform distance that issue_a adds to the
+      // scalar base -- one offset register)
+      const int hr = wave * 8 + sr;                                   // LDS row inside the unit (piece `wave`)
       const int trow = (hr / (MH * 16)) * (MT * 16) + (hr % (MH * 16));   // tile row of half 0 (half 1: + MH*16)
-      a_voff[i] = (unsigned)trow * (unsigned)p.lda * 2u + (unsigned)(sc ^ ((hr >> 1) & 7)) * 16u;
+      a_voff = (unsigned)trow * (unsigned)p.lda * 2u + (unsigned)(sc ^ ((hr >> 1) & 7)) * 16u;
     }
+    // (natural column map: the second half's columns are the first half's + NH * 16, a wave-uniform distance that issue_b adds to the scalar base instead --
+    // one set of offsets; the pair-interleaved map of the bf16 epilogues has no such constant)
 #pragma unroll
-    for (int h = 0; h < 2; ++h)
+    for (int h = 0; h < BH; ++h)
 #pragma unroll
       for (int i = 0; i < C::B_IPW; ++i) {
         const int hr = (i * 8 + wave) * 8 + sr;
@@ -167,19 +234,20 @@ __global__ void __launch_bounds__(512, 2) k_gemm8(const GemmArgs p, const int g8
 
   // unit U of a K-tile: 0 = X0, 1 = Y0, 2 = Y1, 3 = X1 (the order in which the phases need them)
   const unsigned lds0 = (unsigned)(uintptr_t)LDS_PTR(smem);
-  auto issue_a = [&](const unsigned char* abase, int half, unsigned dst) {
+  auto issue_a = [&](const unsigned char* abase, int half, unsigned dst) __attribute__((always_inline)) {
     const unsigned char* src = abase + (size_t)half * (MH * 16) * p.lda * 2;
 #pragma unroll
     for (int i = 0; i < C::A_IPW; ++i)
-      if (C::A_REM == 0 || i + 1 < C::A_IPW || wave < C::A_REM) glds16(a_voff[i], src, lds0 + dst + (i * 8 + wave) * 1024);
+      if (C::A_REM == 0 || i + 1 < C::A_IPW || wave < C::A_REM) glds16(a_voff, src + (size_t)i * A_STEP * p.lda * 2, lds0 + dst + (i * 8 + wave) * 1024);
   };
-  auto issue_b = [&](const unsigned char* bbase, int half, unsigned dst) {
+  auto issue_b = [&](const unsigned char* bbase, int half, unsigned dst) __attribute__((always_inline)) {
+    const unsigned char* src = PAIR ? bbase : bbase + (size_t)half * (NH * 16) * p.ldb * 2;
 #pragma unroll
     for (int i = 0; i < C::B_IPW; ++i)
-      if (C::B_REM == 0 || i + 1 < C::B_IPW || wave < C::B_REM) glds16(half ? b_voff[1][i] : b_voff[0][i], bbase, lds0 + dst + (i * 8 + wave) * 1024);
+      if (C::B_REM == 0 || i + 1 < C::B_IPW || wave < C::B_REM) glds16((PAIR && half) ? b_voff[BH - 1][i] : b_voff[0][i], src, lds0 + dst + (i * 8 + wave) * 1024);
   };
   // unit U of K-tile n goes to buffer n & 1 (Y0 under Y3: ring slot n % 3, passed as `y0slot`)
-  auto issue_unit = [&](auto uc, int buf, int y0slot, const unsigned char* abase, const unsigned char* bbase) {
+  auto issue_unit = [&](auto uc, int buf, int y0slot, const unsigned char* abase, const unsigned char* bbase) __attribute__((always_inline)) {
     constexpr int U = decltype(uc)::value;
     constexpr bool isx = (U == 0 || U == 3);
     constexpr int half = (U == 0 || U == 1) ? 0 : 1;
@@ -191,30 +259,30 @@ __global__ void __launch_bounds__(512, 2) k_gemm8(const GemmArgs p, const int g8
   };
 
   // ---- stream cursors (all on the scalar unit): operand bases of K-tiles s+1 and s+2 of the stream, where s is the K-tile being computed
-  struct Cur { const unsigned char* a; const unsigned char* b; int t; int q; };
-  auto cur_origin = [&](Cur& c) {
-    int m0, n0; tile_origin(c.q < Q ? c.q : Q - 1, m0, n0);
+  struct Cur { const unsigned char* a; const unsigned char* b; int t; };
+  auto cur_origin = [&](Cur& c, int tk) __attribute__((always_inline)) {
+    int m0, n0; tile_origin(tk, m0, n0);
     c.a = reinterpret_cast<const unsigned char*>(p.A + (size_t)m0 * p.lda);
     c.b = reinterpret_cast<const unsigned char*>(p.B + (size_t)n0 * p.ldb);
   };
-  auto cur_next = [&](Cur& c) {
+  auto cur_next = [&](Cur& c) __attribute__((always_inline)) {                            // (a cursor runs at most two K-tiles ahead: it crosses into the NEXT tile, once per tile)
     c.a += 128; c.b += 128;
-    if (++c.t == nk) { c.t = 0; ++c.q; cur_origin(c); }
+    if (++c.t == nk) { c.t = 0; cur_origin(c, tk_nxt < Tx ? tk_nxt : tk_cur); }
   };
   Cur c1, c2;                                              // K-tiles s+1, s+2
-  c1.t = 0; c1.q = 0; cur_origin(c1);
+  c1.t = 0; cur_origin(c1, tk_cur);
 
   f32x4 acc[MT][NT];
   constexpr int YSETS = C::Y3 ? 1 : 2;
   bf8_t fa[XA ? 1 : YSETS][MH][2], fb[XA ? YSETS : 1][NH][2];       // [set][tile][kk]; the major operand has one set
-  auto read_a = [&](auto setc, const unsigned char* unit) {
+  auto read_a = [&](auto setc, const unsigned char* unit) __attribute__((always_inline)) {
     constexpr int set = decltype(setc)::value;
 #pragma unroll
     for (int mt = 0; mt < MH; ++mt)
 #pragma unroll
       for (int kk = 0; kk < 2; ++kk) fa[set][mt][kk] = *reinterpret_cast<const bf8_t*>(unit + ((a_rd + mt * 2048) ^ (kk << 6)));
   };
-  auto read_b = [&](auto setc, const unsigned char* unit) {
+  auto read_b = [&](auto setc, const unsigned char* unit) __attribute__((always_inline)) {
     constexpr int set = decltype(setc)::value;
 #pragma unroll
     for (int nt = 0; nt < NH; ++nt)
@@ -222,8 +290,8 @@ __global__ void __launch_bounds__(512, 2) k_gemm8(const GemmArgs p, const int g8
       for (int kk = 0; kk < 2; ++kk) fb[set][nt][kk] = *reinterpret_cast<const bf8_t*>(unit + ((b_rd + nt * 2048) ^ (kk << 6)));
   };
   // X unit h -> set 0; Y unit h -> set h (set 0 under Y3)
-  auto read_x = [&](const unsigned char* unit) { if constexpr (XA) read_a(std::integral_constant<int, 0>{}, unit); else read_b(std::integral_constant<int, 0>{}, unit); };
-  auto read_y = [&](auto hc, const unsigned char* unit) {
+  auto read_x = [&](const unsigned char* unit) __attribute__((always_inline)) { if constexpr (XA) read_a(std::integral_constant<int, 0>{}, unit); else read_b(std::integral_constant<int, 0>{}, unit); };
+  auto read_y = [&](auto hc, const unsigned char* unit) __attribute__((always_inline)) {
     constexpr int set = C::Y3 ? 0 : decltype(hc)::value;
     if constexpr (XA) read_b(std::integral_constant<int, set>{}, unit); else read_a(std::integral_constant<int, set>{}, unit);
   };
@@ -233,16 +301,16 @@ __global__ void __launch_bounds__(512, 2) k_gemm8(const GemmArgs p, const int g8
 #ifdef G8_DUMMY_VALU      // experiment (tools/ab): G8_DUMMY_VALU plain + G8_DUMMY_EXP transcendental vector instructions in every READ slot -- how much epilogue work hides there?
   float dv[4] = {0.1f, 0.2f, 0.3f, 0.4f};
   asm volatile("" : "+v"(dv[0]), "+v"(dv[1]), "+v"(dv[2]), "+v"(dv[3]));
-  auto dummy_valu = [&]() {
+  auto dummy_valu = [&]() __attribute__((always_inline)) {
 #pragma unroll
     for (int i = 0; i < G8_DUMMY_VALU; ++i) asm volatile("v_fma_f32 %0, %0, 0.5, 0.5" : "+v"(dv[i & 3]));
 #pragma unroll
     for (int i = 0; i < G8_DUMMY_EXP; ++i) asm volatile("v_exp_f32 %0, -%0" : "+v"(dv[i & 3]));
   };
 #else
-  auto dummy_valu = [&]() {};
+  auto dummy_valu = [&]() __attribute__((always_inline)) {};
 #endif
-  auto quadrant = [&](auto xhc, auto yhc) {
+  auto quadrant = [&](auto xhc, auto yhc) __attribute__((always_inline)) {
     constexpr int xh = decltype(xhc)::value, yh = decltype(yhc)::value;
     constexpr int mh = XA ? xh : yh, nh = XA ? yh : xh;
     constexpr int yset = C::Y3 ? 0 : yh, aset = XA ? 0 : yset, bset = XA ? yset : 0;
@@ -265,13 +333,16 @@ __global__ void __launch_bounds__(512, 2) k_gemm8(const GemmArgs p, const int g8
   // r3 = s % 3 (Y0 ring slot under Y3).
   int r3 = 0;
   constexpr int ST = epilogue_stores<EPI, DUAL, MT, NT>();
-  auto ktile = [&](auto bufc, int s, const bool after_epi) {
+  constexpr unsigned RELAY = C::Y3 ? 0u : (unsigned)C::LDS;      // byte offset of the ticket relay word (Y3: inside the Y0 ring slot that is dead at that time)
+  auto ktile = [&](auto bufc, int s, int t, const bool after_epi) __attribute__((always_inline)) {
     constexpr int BUFI = decltype(bufc)::value;
     stamp_s = s; stamp_ph = 0;
     const unsigned char* bufp = smem + BUFI * C::BUF;
     const unsigned char* y0p = C::Y3 ? smem + C::RING_Y0 + r3 * C::Y_UNIT : bufp + C::OFF_Y0;
     const int r3n2 = r3 == 0 ? 2 : r3 - 1;                 // (s + 2) % 3
-    const bool more1 = s + 1 < S, more2 = s + 2 < S;
+    // K-tiles s+1 / s+2 of the stream exist: inside this tile, or in the next one (t = K-tile inside the tile).  With drawn tickets the next ticket of the
+    // first K-tile after an epilogue arrives in P1 below; it is looked at from t >= nk - 2 on only (nk >= 4)
+    const bool more1 = t + 1 < nk || tk_nxt < Tx;
     // P1 (X0, Y0): X0 reads first and retired before the barrier -- its LDS is refilled in the NEXT phase
     read_x(bufp + C::OFF_X0);
     __builtin_amdgcn_sched_barrier(0);
@@ -282,7 +353,11 @@ __global__ void __launch_bounds__(512, 2) k_gemm8(const GemmArgs p, const int g8
     wait_lgkm<NY>();
     bar();
     STAMP(0);
+    unsigned relay = 0;
+    if (dyn && after_epi) relay = lds_read32(lds0 + (C::Y3 ? C::RING_Y0 + r3n2 * C::Y_UNIT : RELAY));      // wave 0 wrote it before this barrier; the slot's refill is issued in P3
     wait_lgkm<0>();
+    if (dyn && after_epi) tk_nxt = first_lane(relay);
+    const bool more2 = t + 2 < nk || tk_nxt < Tx;
     __builtin_amdgcn_sched_barrier(0);
     quadrant(std::integral_constant<int, 0>{}, std::integral_constant<int, 0>{});
     __builtin_amdgcn_sched_barrier(0);
@@ -349,16 +424,17 @@ __global__ void __launch_bounds__(512, 2) k_gemm8(const GemmArgs p, const int g8
   // exactly the units of one K-tile younger than its target in flight: 2 * (x_cnt + y_cnt) operations.
   int ew = 0;                                               // waits that still have the last epilogue's stores among their younger operations
   bool x1_ahead = false;                                    // X1 of K-tile s+1 was requested before the epilogue
-  auto vwait2 = [&](bool counted) {
+  auto vwait2 = [&](bool counted) __attribute__((always_inline)) {
     constexpr int N0 = 2 * (C::x_cnt(0) + C::y_cnt(0)), N1 = 2 * (C::x_cnt(1) + C::y_cnt(1));
     if (!counted) wait_vmcnt<0>();
     else if (ew > 0) { --ew; if (grp == 0) wait_vmcnt<(N0 + ST > 63 ? 63 : N0 + ST)>(); else wait_vmcnt<(N1 + ST > 63 ? 63 : N1 + ST)>(); }
     else { if (grp == 0) wait_vmcnt<N0>(); else wait_vmcnt<N1>(); }
   };
-  auto ktile2 = [&](auto bufc, int s) {
+  auto ktile2 = [&](auto bufc, int s, int t) __attribute__((always_inline)) {
     constexpr int BUFI = decltype(bufc)::value;
     const unsigned char* bufp = smem + BUFI * C::BUF;
-    const bool more1 = s + 1 < S, more2 = s + 2 < S;
+    const bool more1 = t + 1 < nk || tk_nxt < Tx;
+    const bool first = x1_ahead;                            // first K-tile after an epilogue
     // phase A
     read_x(bufp + C::OFF_X0);
     read_y(std::integral_constant<int, 0>{}, bufp + C::OFF_Y0);
@@ -370,6 +446,12 @@ __global__ void __launch_bounds__(512, 2) k_gemm8(const GemmArgs p, const int g8
     wait_lgkm<0>();
     bar();
     STAMP(0);
+    if (dyn && first) {
+      const unsigned relay = lds_read32(lds0 + RELAY);
+      wait_lgkm<0>();
+      tk_nxt = first_lane(relay);
+    }
+    const bool more2 = t + 2 < nk || tk_nxt < Tx;
     __builtin_amdgcn_sched_barrier(0);
     quadrant(std::integral_constant<int, 0>{}, std::integral_constant<int, 0>{});
     quadrant(std::integral_constant<int, 0>{}, std::integral_constant<int, 1>{});
@@ -402,7 +484,7 @@ __global__ void __launch_bounds__(512, 2) k_gemm8(const GemmArgs p, const int g8
   // Accumulators start at zero: the bias is added by the epilogue (gemm_epi8.h).
   // (an opaque zero: with a literal 0 hipcc peels the first K-tiles of every tile off the loop to fold the constant into the first MFMAs, and
   // the peeled copy -- 256 registers, like the loop -- spills accumulators and reloads them behind vmcnt(0))
-  auto zero_acc = [&]() {
+  auto zero_acc = [&]() __attribute__((always_inline)) {
     float z = 0.f;
     asm volatile("" : "+v"(z));
 #pragma unroll
@@ -430,51 +512,82 @@ __global__ void __launch_bounds__(512, 2) k_gemm8(const GemmArgs p, const int g8
   // them until the K-tile-2 wait, two K-tiles later.
   int s = 0;
   bool after_epi = false;
-#pragma clang loop unroll(disable)
-  for (int q = 0; q < Q; ++q) {
-    if (grp == 1) bar();
-#pragma clang loop unroll(disable)
-    for (int t = 0; t < nk; t += 2, s += 2) {
-      if constexpr (C::M2) {
-        ktile2(std::integral_constant<int, 0>{}, s);
-        ktile2(std::integral_constant<int, 1>{}, s + 1);
-      } else {
-        ktile(std::integral_constant<int, 0>{}, s, after_epi);
-        ktile(std::integral_constant<int, 1>{}, s + 1, false);
-        after_epi = false;
-      }
+  // One LDS-DMA-free way to hand a drawn ticket to all eight waves: wave 0 draws (a returning agent-scope atomic, issued ahead of the tile's LAST two K-tiles
+  // and looked at behind their last counted wait: loads return in order, so it has returned when that wait is over), keeps the value in a scalar register over
+  // the epilogue and writes it into LDS behind it -- 4 bytes that are free at that time: spare bytes behind the buffers, or under Y3 (all 160 KB taken) the Y0
+  // ring slot of the K-tile after next, which nobody reads before its refill is issued in P3 of the next K-tile; everybody reads the word behind the first
+  // barrier of that K-tile (ktile / ktile2).
+  auto kpair = [&](int t) __attribute__((always_inline)) {
+    if constexpr (C::M2) {
+      ktile2(std::integral_constant<int, 0>{}, s, t);
+      ktile2(std::integral_constant<int, 1>{}, s + 1, t + 1);
+    } else {
+      ktile(std::integral_constant<int, 0>{}, s, t, after_epi);
+      ktile(std::integral_constant<int, 1>{}, s + 1, t + 1, false);
+      after_epi = false;
     }
+    s += 2;
+  };
+#pragma clang loop unroll(disable)
+  for (;;) {
+    if (grp == 1) bar();
+    // The draw for the tile after next goes out ahead of the tile's LAST two K-tiles (one wave, one lane: the statement is in every iteration with an empty
+    // EXEC mask elsewhere, so that the register it writes behind the compiler's back is defined in the iteration it is used after and never merged with another
+    // definition) and is looked at behind their last counted wait: at most the three youngest units are in flight then, or nothing -- loads return in order,
+    // so the draw has returned.  oneprot_amd/csrc/check_async_regs.py verifies in the ISA that nothing copies or reuses the register in between.
+    unsigned drawn_v;
+    int t = 0;
+#pragma clang loop unroll(disable)
+    do {                                                   // (nk >= 2)
+      // (tk_nxt: with drawn tickets it arrives in the tile's first K-tile -- it is looked at in the last pair only, nk >= 4)
+      drawn_v = draw_async(p.sched + SW_HEAD(x), (dyn && wave == 0 && t + 2 >= nk && tk_nxt < Tx) ? 1 : 0);
+      kpair(t);
+      t += 2;
+    } while (t < nk);
+    const bool has_next = tk_nxt < Tx;
+    int drawn;
+    asm volatile("v_readfirstlane_b32 %0, %1 ; DRAWN" : "=s"(drawn) : "v"(drawn_v));      // (the marker is what check_async_regs.py looks for)
     STAMP_E(0);
     if (grp == 0) bar();
     STAMP_E(1);
-    int m0, n0; tile_origin(q, m0, n0);
-    if (q + 1 < Q) {
+    int m0, n0; tile_origin(tk_cur, m0, n0);
+    if (has_next) {
       issue_unit(std::integral_constant<int, 3>{}, 1, 0, c1.a, c1.b);        // X1 of the next tile's K-tile 1 (c1; s is even: buffer 1)
       after_epi = true;
       x1_ahead = true; ew = 3;                                               // (merged schedule: the next three waits have the stores behind their targets)
     }
     STAMP_E(2);
     if (p.nt_store != 77) {                                                  // (77: timing-only runs of the main loop, tools/ab)
-      int lane_e = lane;
+      int lane_e = lane_now();
       asm volatile("" : "+v"(lane_e));                                        // the epilogue's per-lane addresses are formed here, per tile: hoisted out of the tile loop they are spilled
       if constexpr (DirectMap<EPI>::PAIR) epilogue_pair<EPI, HB, DUAL, MT, NT>(p, acc, m0, n0, wr, wc, lane_e);
       else if constexpr (EPI == ONEPROT_EPI_QKV_ROPE) {
         if (p.hd == 32) epilogue_rope32<HB, MT, NT>(p, acc, m0, n0, wr, wc, lane_e);
         else if constexpr ((NT * 16) % 64 == 0) epilogue_rope64<HB, MT, NT>(p, acc, m0, n0, wr, wc, lane_e);      // head_dim 64 (whole heads per wave column block)
-      } else if constexpr (EPI == G8_EPI_RESID_LN) epilogue_resid_ln<HB, MT, NT>(p, acc, m0, n0, wr, wc, lane_e);
+      } else if constexpr (EPI == G8_EPI_RESID_LN) epilogue_resid_ln<HB, MT, NT>(p, acc, m0, n0, wr, wc, lane_e, ln_tag);
       else epilogue_f32<EPI, HB, DUAL, MT, NT>(p, acc, m0, n0, wr, wc, lane_e);
     }
     STAMP_E(3);
+    if (!has_next) break;
+    if (dyn) {
+      if (wave == 0) lds_write32(lds0 + (C::Y3 ? C::RING_Y0 + (r3 == 0 ? 2 : r3 - 1) * C::Y_UNIT : RELAY), (unsigned)drawn);      // (every lane of the wave: the same word, the same value)
+      tk_cur = tk_nxt;                                                       // (tk_nxt: read back by every wave in the first K-tile of the new tile)
+      tk_nxt = 0x7fffffff;
+    } else {
+      tk_cur = tk_nxt; tk_nxt += g8n;
+    }
     lane_consts();
     zero_acc();
     STAMP_E(4);
   }
+  if (p.sched && wave == 0 && lane_now() == 0) sw_leave(p.sched, gridDim.x);
 #ifdef G8_DUMMY_VALU
   asm volatile("" :: "v"(dv[0]), "v"(dv[1]), "v"(dv[2]), "v"(dv[3]));
 #endif
 }
 
 static int g_dph_groups = 1, g_dph_sleeps = 0, g_g8n_cap = 0;
+static unsigned* g_dyn_sched = nullptr;      // oneprot_dynamic_tiles: the workspace whose queues hand out the tiles, or null (static tile lists)
 #ifndef G8_CSPLIT
 #define G8_CSPLIT 0
 #endif
@@ -503,10 +616,16 @@ static int launch_cfg(GemmArgs a, hipStream_t s) {
   if (g8n > per_xcd) g8n = (int)per_xcd;
   if (g8n < 1) g8n = 1;
   if (g_g8n_cap > 0 && g8n > g_g8n_cap) g8n = g_g8n_cap;      // experiment hook: fewer work-groups per XCD
-  if (EPI == G8_EPI_RESID_LN) {                              // tile u = qi * g8n + w: the tiles_n tiles of a panel are in flight together iff g8n is a multiple of tiles_n
-    g8n -= g8n % a.tiles_n;
-    if (g8n < a.tiles_n) return G8_NOT_ELIGIBLE;
+  if (EPI == G8_EPI_RESID_LN) {                              // static list u = q * g8n + w: the tickets of a pair of row panels (2 * tiles_n of them) are in flight together iff g8n is a multiple of that
+    if (g8n < per_xcd) {                                     // (g8n == per_xcd: one round, everything is in flight together)
+      g8n -= g8n % (2 * a.tiles_n);
+      if (g8n < 2 * a.tiles_n) return G8_NOT_ELIGIBLE;
+    }
   }
+  // tiles drawn from the work queues of the sched workspace (oneprot_dynamic_tiles): needs the workspace and four K-tiles per tile
+  a.dyn = (g_dyn_sched != nullptr && a.K >= 256) ? 1 : 0;
+  if (a.dyn) a.sched = g_dyn_sched;
+  else if (EPI != G8_EPI_RESID_LN) a.sched = nullptr;
   hipLaunchKernelGGL((k_gemm8<C, EPI, HB, DUAL>), dim3(g8n * 8), dim3(512), C::LDS, s, a, g8n, g_dph_groups, g_dph_sleeps);
   return launch_status();
 }
@@ -547,12 +666,9 @@ static int launch_epi(int epi, const GemmArgs& a, hipStream_t s) {
 
 }  // namespace g8
 
-// FFN-2 + bias + residual + the LayerNorm that follows, 256 x 320 tiles only (N = 320, 640 or 1280): see epilogue_resid_ln.  The partial statistics live in a
-// process-wide uncached device buffer, one of LN_SETS sets per launch in turn (launches in flight on different streams do not share a set unless LN_SETS of
-// them overlap); entries are tagged with the launch number, nothing is cleared between launches.
-#define LN_SETS 4
-static unsigned char* g_ln_part = nullptr; static unsigned* g_ln_err = nullptr; static long g_ln_rows = 0;
-static std::atomic<unsigned> g_ln_launches{0};
+// FFN-2 + bias + residual + the LayerNorm that follows, 256 x 320 tiles only (N = 320, 640 or 1280): see epilogue_resid_ln.  The partial statistics, the launch
+// epoch their tags come from and the sticky error flag live in the caller's sched workspace (sched_ws.h): nothing is allocated, cleared or counted on the host.
+static int g_ln_poll_max = 1 << 20;                          // ~1 s of polling: far beyond any wait that ends by itself (a partner's remaining tile time)
 // 0: the shape is not made of whole tiles this form serves; 1: it is, but with fewer than 192 tiles (a persistent work-group per CU does not pay: callers
 // keep the pair of launches unless told otherwise -- the parity tests against the oracle run small batches through it); 2: it is and it pays
 int gemm8_ln_eligible(long M, int N, int K) {
@@ -561,34 +677,20 @@ int gemm8_ln_eligible(long M, int N, int K) {
   if ((M / C::BM + 7) / 8 * (N / C::BN) < N / C::BN) return 0;
   return (M / C::BM) * (long)(N / C::BN) >= 192 ? 2 : 1;
 }
-int launch_gemm8_ln(GemmArgs a, hipStream_t s) {
+size_t sched_workspace_bytes(long M_max) { return (size_t)SW_HEADER_BYTES + (size_t)(M_max > 0 ? M_max : 0) * 8 * 16; }
+int launch_gemm8_ln(GemmArgs a, void* ws, size_t ws_bytes, hipStream_t s) {
   typedef g8::C320 C;
   if (gemm8_ln_eligible(a.M, a.N, a.K) == 0 || !g8::eligible<C>(a, ONEPROT_EPI_BIAS_RESID)) return G8_NOT_ELIGIBLE;
-  if (g_ln_rows < a.M) {                                     // (grow only; an older buffer may still be in use by a launch in flight and is left alone)
-    const long rows = a.M > 131072 ? a.M : 131072;
-    unsigned char* part = nullptr; unsigned* err = nullptr;
-    // uncached: the partials are exchanged between work-groups that may sit behind different L2s.  Zeroed once: tag 0 is never used.
-    if (hipExtMallocWithFlags((void**)&part, (size_t)LN_SETS * rows * 8 * 16, hipDeviceMallocUncached) != hipSuccess) return OP_ELAUNCH;
-    if (hipMemset(part, 0, (size_t)LN_SETS * rows * 8 * 16) != hipSuccess) return OP_ELAUNCH;
-    if (!g_ln_err) {
-      if (hipExtMallocWithFlags((void**)&err, 64, hipDeviceMallocUncached) != hipSuccess || hipMemset(err, 0, 64) != hipSuccess) return OP_ELAUNCH;
-      g_ln_err = err;
-    }
-    g_ln_part = part; g_ln_rows = rows;
-  }
-  const unsigned n = g_ln_launches.fetch_add(1u);
-  a.ln_part = g_ln_part + (size_t)(n % LN_SETS) * g_ln_rows * 8 * 16;
-  a.ln_err = g_ln_err;
+  if (!ws || ((uintptr_t)ws & 127) || ws_bytes < sched_workspace_bytes(a.M)) return OP_EINVAL;
+  a.sched = (unsigned*)ws;
+  a.ln_part = (unsigned char*)ws + SW_HEADER_BYTES;
   a.ln_slots = 2 * (a.N / C::BN);
-  a.ln_epoch = n + 1u == 0u ? 1u : n + 1u;
+  a.ln_poll_max = g_ln_poll_max;
   return a.bias ? g8::launch_cfg<C, G8_EPI_RESID_LN, true, false>(a, s) : g8::launch_cfg<C, G8_EPI_RESID_LN, false, false>(a, s);
 }
-int gemm8_ln_error() {                                        // 1: some wait for the other column tiles of a row panel ran out (results of that launch are wrong)
-  unsigned e = 0;
-  if (!g_ln_err) return 0;
-  if (hipMemcpy(&e, g_ln_err, sizeof(e), hipMemcpyDeviceToHost) != hipSuccess) return -1;
-  return (int)e;
-}
+extern "C" void oneprot_gemm_resid_ln8_poll_bound(int polls) { g_ln_poll_max = polls < 0 ? (1 << 20) : polls; }
+extern "C" void oneprot_dynamic_tiles(void* sched_ws, size_t bytes) { g8::g_dyn_sched = (sched_ws && bytes >= SW_HEADER_BYTES && !((uintptr_t)sched_ws & 127)) ? (unsigned*)sched_ws : nullptr; }
+void* dynamic_tiles_workspace() { return g8::g_dyn_sched; }
 
 // experiment hook (tools/ab/g8_ab.py): de-phasing of the persistent work-groups
 extern "C" void oneprot_gemm8_dephase(int groups, int sleeps) { g8::g_dph_groups = groups & 0xffff; g8::g_dph_sleeps = sleeps; g8::g_g8n_cap = groups >> 16; }

@@ -598,6 +598,7 @@ extern "C" int oneprot_gemm_ln_pack_weight(const void* W, void* Wp, int N, int K
 // test / experiment hook: 0 = eight-wave kernel (128-row tiles, one work-group per CU; default), 1 = four-wave kernel (64-row tiles, two per CU)
 static int g_gln_form = 0;
 extern "C" void oneprot_gemm_ln_form(int form) { g_gln_form = form; }
+extern "C" int oneprot_gemm_ln_form_get(void) { return g_gln_form; }
 
 extern "C" int oneprot_gemm_bf16_nt_resid_ln(const void* A, const void* Wp, int64_t M, int N, int K, int lda, const float* bias, const float* resid, float* x_out,
                                              const float* gamma, const float* beta, float eps, void* h_out, float* mean, float* rstd, void* stream) {

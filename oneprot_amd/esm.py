@@ -692,6 +692,7 @@ class EsmTransformer(ArenaModule):
         ln8_min = 0 if ln8_mode == "0" else (1 if ln8_mode == "force" else 2)
         ffn2_ln = ln8_min > 0 and not self._padded and hip.query("oneprot_gemm_resid_ln8_eligible", T, d, f) >= ln8_min
         outproj_ln8 = not fused_ln and ln8_min > 0 and not self._padded and hip.query("oneprot_gemm_resid_ln8_eligible", T, d, dp) >= ln8_min
+        sched_ws = hip.sched_workspace(T) if (ffn2_ln or outproj_ln8 or hip.dynamic_tiles_wanted()) else None      # (pointer, bytes): partial row statistics + work queues
         pre = None                                          # (h1, stats [2,T] or None) of this layer, already written by the previous layer's FFN-2 launch
         lora_two = self._lora_two_branch()
         if lora_two:      # every call draws its own dropout masks; the backward regenerates them from (seed, call, layer)
@@ -736,7 +737,7 @@ class EsmTransformer(ArenaModule):
                 # wider rows (ESM-2-650M, d = 1280): the same pair through the 8-phase GEMM with the statistics finished across its four column tiles
                 stats2 = f32(2, T) if save else None
                 hip.call("oneprot_gemm_bf16_nt_resid_ln8", ctx_, w_o, T, d, dp, dp, dp, self.view(p + "attention.output.dense.bias"), x, x_mid,
-                         self.view(p + "LayerNorm.weight"), self.view(p + "LayerNorm.bias"), eps, h2, stats2)
+                         self.view(p + "LayerNorm.weight"), self.view(p + "LayerNorm.bias"), eps, h2, stats2, *sched_ws)
                 if save:
                     st["mean2"], st["rstd2"] = stats2[0], stats2[1]
             else:
@@ -750,7 +751,7 @@ class EsmTransformer(ArenaModule):
                 pn = f"encoder.layer.{i + 1}.attention.LayerNorm."
                 pre = (b16(T, d), f32(2, T)) if save else (h, None)
                 hip.call("oneprot_gemm_bf16_nt_resid_ln8", u, self._w16(p + "output.dense.weight"), T, d, f, f, f, self.view(p + "output.dense.bias"), x_mid, x_out,
-                         self.view(pn + "weight"), self.view(pn + "bias"), eps, pre[0], pre[1])
+                         self.view(pn + "weight"), self.view(pn + "bias"), eps, pre[0], pre[1], *sched_ws)
             else:
                 pre = None
                 hip.call("oneprot_gemm_bf16_nt", u, self._w16(p + "output.dense.weight"), T, d, f, f, f, hip.EPI_BIAS_RESID,

@@ -13,7 +13,7 @@ _HERE = os.path.dirname(os.path.abspath(__file__))
 # ONEPROT_HIP_LIB: another build of the same ABI (development: step-level A/B of a variant library, tools/ab/build_lib.sh)
 LIB_PATH = os.environ.get("ONEPROT_HIP_LIB") or os.path.join(_HERE, "liboneprot_hip.so")
 
-ABI_VERSION = 6
+ABI_VERSION = 7
 EPI_BF16, EPI_F32, EPI_BIAS_GELU, EPI_BIAS_RESID, EPI_QKV_ROPE, EPI_GELU_BWD = range(6)
 LOG2E = 1.4426950408889634      # the attention kernels take q pre-multiplied by hd^-1/2 * log2(e) (include/oneprot_hip.h)
 
@@ -50,10 +50,18 @@ _SIGS = {
     "oneprot_gemm_bf16_nt": (I, [P, P, L64, I, I, I, I, I, P, P, P, P, P, P, P, F, I, I, I, P]),
     "oneprot_gemm_ln_pack_weight": (I, [P, P, I, I, P]),
     "oneprot_gemm_bf16_nt_resid_ln": (I, [P, P, L64, I, I, I, P, P, P, P, P, F, P, P, P, P]),
-    "oneprot_gemm_bf16_nt_resid_ln8": (I, [P, P, L64, I, I, I, I, P, P, P, P, P, F, P, P, P]),
+    "oneprot_sched_workspace_bytes": (SZ, [L64]),
+    "oneprot_alloc_uncached": (I, [ctypes.POINTER(c_void_p), SZ]),
+    "oneprot_free_uncached": (I, [P]),
+    "oneprot_sched_workspace_init": (I, [P, SZ, P]),
+    "oneprot_dynamic_tiles": (None, [P, SZ]),
+    "oneprot_gemm_bf16_nt_resid_ln8": (I, [P, P, L64, I, I, I, I, P, P, P, P, P, F, P, P, P, SZ, P]),
     "oneprot_gemm_resid_ln8_eligible": (I, [L64, I, I]),
-    "oneprot_gemm_resid_ln8_error": (I, []),
+    "oneprot_gemm_resid_ln8_error": (I, [P]),
+    "oneprot_gemm_resid_ln8_error_clear": (I, [P, P]),
+    "oneprot_gemm_resid_ln8_poll_bound": (None, [I]),
     "oneprot_gemm_ln_form": (None, [I]),
+    "oneprot_gemm_ln_form_get": (I, []),
     "oneprot_gemm_force_shape": (None, [I]),
     "oneprot_gemm_tune": (None, [I, I]),
     "oneprot_gemm_bf16_tn_workspace": (SZ, [I, I]),
@@ -89,7 +97,7 @@ _SIGS = {
     "oneprot_key_padding_bias": (I, [P, P, L64, I, P]),
     "oneprot_sumsq_workspace": (SZ, []),
     "oneprot_sumsq": (I, [P, L64, P, P, P]),
-    "oneprot_clip_coef": (I, [P, F, P, P, P]),
+    "oneprot_clip_coef": (I, [P, F, P, P, P, P]),
     "oneprot_adam_step": (I, [P, P, P, P, L64, F, F, F, F, F, I, P, P]),
     "oneprot_cast_f32_to_bf16": (I, [P, P, L64, P]),
     "oneprot_transpose_cast_f32_to_bf16": (I, [P, P, I, I, P]),
@@ -105,10 +113,10 @@ _PTR_DTYPES = {
     "oneprot_esm_embed_fwd": "lfff", "oneprot_esm_embed_bwd": "lfffb", "oneprot_bert_embed_fwd": "lffffffh", "oneprot_pool_fwd": "flf",
     "oneprot_pool_bwd": "flfh", "oneprot_embed_scatter_sorted": "flllf", "oneprot_rowsum_f32": "ff", "oneprot_attnpool_fwd": "flffff",
     "oneprot_attnpool_bwd": "fffffffb", "oneprot_layernorm_fwd": "*ffhfff", "oneprot_layernorm_bwd": "*f*fffffhffb", "oneprot_lnpool_fwd": "flffffffhf",
-    "oneprot_gemm_bf16_nt": "hhf**h*ff", "oneprot_gemm_ln_pack_weight": "hh", "oneprot_gemm_bf16_nt_resid_ln": "hhfffffhff", "oneprot_gemm_bf16_nt_resid_ln8": "hhfffffhf", "oneprot_gemm_bf16_tn": "hhffb", "oneprot_sgemm": "fff", "oneprot_attn_fwd": "hhhfhf",
+    "oneprot_gemm_bf16_nt": "hhf**h*ff", "oneprot_gemm_ln_pack_weight": "hh", "oneprot_gemm_bf16_nt_resid_ln": "hhfffffhff", "oneprot_gemm_bf16_nt_resid_ln8": "hhfffffhfb", "oneprot_sched_workspace_init": "b", "oneprot_gemm_resid_ln8_error_clear": "b", "oneprot_gemm_bf16_tn": "hhffb", "oneprot_sgemm": "fff", "oneprot_attn_fwd": "hhhfhf",
     "oneprot_attn_bwd": "hhhfhhfffhb", "oneprot_attn_bwd_dropout": "hhhfhhfffhb", "oneprot_gelu_f32": "ff", "oneprot_gelu_bwd_f32": "fff", "oneprot_l2norm_fwd": "fff", "oneprot_l2norm_bwd": "ffff",
     "oneprot_ce_fwd_bwd": "fff", "oneprot_siglip_fwd_bwd": "fff", "oneprot_siglip_fwd_bwd_dev": "ffff", "oneprot_diag_rank": "fii", "oneprot_abs_sum": "ffb", "oneprot_dot_f32": "fffb", "oneprot_l1_bwd": "fff",
-    "oneprot_scale_by_device_scalar": "ff", "oneprot_key_padding_bias": "lf", "oneprot_dropout_bf16": "hh", "oneprot_dropout_bwd_add_bf16": "hh", "oneprot_dropout_bwd_add_f32": "hf", "oneprot_dropout_f32": "ff", "oneprot_dropout_add_f32": "fff", "oneprot_dropout_add_layernorm_fwd": "fffffhfff", "oneprot_attn_fwd_dropout": "hhhfhf", "oneprot_attn_dropout_keep": "b", "oneprot_sumsq": "ffb", "oneprot_clip_coef": "fff", "oneprot_adam_step": "fffff",
+    "oneprot_scale_by_device_scalar": "ff", "oneprot_key_padding_bias": "lf", "oneprot_dropout_bf16": "hh", "oneprot_dropout_bwd_add_bf16": "hh", "oneprot_dropout_bwd_add_f32": "hf", "oneprot_dropout_f32": "ff", "oneprot_dropout_add_f32": "fff", "oneprot_dropout_add_layernorm_fwd": "fffffhfff", "oneprot_attn_fwd_dropout": "hhhfhf", "oneprot_attn_dropout_keep": "b", "oneprot_sumsq": "ffb", "oneprot_clip_coef": "fffb", "oneprot_adam_step": "fffff",
     "oneprot_cast_f32_to_bf16": "fh", "oneprot_transpose_cast_f32_to_bf16": "fh", "oneprot_transpose_cast_f32_to_bf16_batched": "fh", "oneprot_colsum_bf16": "hfb",
 }
 _DT = {"f": torch.float32, "h": torch.bfloat16, "l": torch.int64, "i": torch.int32, "b": torch.uint8}
@@ -212,3 +220,79 @@ def call(name, *args):
 
 def query(name, *args):
     return getattr(lib(), name)(*args)
+
+
+# ---------------------------------------------------------------------------------------------------------------------------------
+# The sched workspace (include/oneprot_hip.h, csrc/sched_ws.h): per-device memory through which the persistent kernels hand out work and keep their launch
+# bookkeeping on the device.  The host side owns it: one uncached allocation per device, zeroed once, grown when a launch needs more rows.
+class _SchedWorkspace:
+    def __init__(self, device, rows):
+        h = lib()
+        self.device, self.rows = device, rows
+        self.bytes = h.oneprot_sched_workspace_bytes(rows)
+        out = c_void_p()
+        with torch.cuda.device(device):
+            if h.oneprot_alloc_uncached(ctypes.byref(out), self.bytes) != 0 or not out.value:
+                raise HipKernelError(f"oneprot_alloc_uncached({self.bytes} bytes) failed")
+            self.ptr = out.value
+            if h.oneprot_sched_workspace_init(self.ptr, self.bytes, stream()) != 0:
+                raise HipKernelError("oneprot_sched_workspace_init failed")
+
+    def error(self):
+        return lib().oneprot_gemm_resid_ln8_error(self.ptr)
+
+    def release(self):
+        if self.ptr:
+            torch.cuda.synchronize(self.device)
+            lib().oneprot_free_uncached(self.ptr)
+            self.ptr = 0
+
+
+_sched = {}      # device index -> _SchedWorkspace
+SCHED_MIN_ROWS = 131072
+
+
+def dynamic_tiles_wanted():
+    """ONEPROT_DYNAMIC_TILES=1 / 0; default: on (tiles of the persistent GEMMs drawn from work queues: a co-resident kernel that holds CUs -- an RCCL channel of the
+    overlapped gradient all-reduce, another process -- then costs its share of the chip instead of 1.47 x per launch; bit-identical results)."""
+    return os.environ.get("ONEPROT_DYNAMIC_TILES", "1") != "0"
+
+
+def sched_workspace(rows=0, device=None):
+    """(pointer, bytes) of the current device's sched workspace, sized for at least `rows` rows of row statistics"""
+    dev = torch.cuda.current_device() if device is None else torch.device(device).index
+    ws = _sched.get(dev)
+    if ws is None or ws.rows < rows:
+        new_rows = max(rows, SCHED_MIN_ROWS, 2 * ws.rows if ws is not None else 0)
+        if ws is not None:
+            if ws.error() != 0:
+                raise HipKernelError("oneprot_gemm_bf16_nt_resid_ln8: a bounded wait ran out in an earlier launch (NaN rows were written)")
+            lib().oneprot_dynamic_tiles(None, 0)
+            ws.release()
+        ws = _sched[dev] = _SchedWorkspace(dev, new_rows)
+        lib().oneprot_dynamic_tiles(ws.ptr if dynamic_tiles_wanted() else None, ws.bytes)
+    return ws.ptr, ws.bytes
+
+
+def _sched_of(device):
+    if not _sched:                                       # nothing has launched through a workspace yet (also: no GPU in this process)
+        return None
+    dev = torch.cuda.current_device() if device is None else torch.device(device).index
+    return _sched.get(dev)
+
+
+def sched_error(device=None):
+    """host-synchronous: 1 when a launch on this device's workspace wrote NaN rows because a bounded wait ran out (0 when no workspace exists yet)"""
+    ws = _sched_of(device)
+    return 0 if ws is None else ws.error()
+
+
+def sched_error_clear(device=None):
+    ws = _sched_of(device)
+    if ws is not None:
+        lib().oneprot_gemm_resid_ln8_error_clear(ws.ptr, stream())
+
+
+def sched_ptr_or_none(device=None):
+    ws = _sched_of(device)
+    return None if ws is None else ws.ptr

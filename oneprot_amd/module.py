@@ -271,12 +271,16 @@ class OneProtLitModule(_Base):
 
     @staticmethod
     def _check_kernel_waits():
-        """The FFN-2 + LayerNorm launches wait, bounded, for neighbouring work-groups (oneprot_gemm_bf16_nt_resid_ln8): a wait that ran out means wrong
-        activations in that launch.  A host-synchronous query, so it is made where the host waits anyway (end of a validation epoch, end of fit_steps)."""
+        """The FFN-2 + LayerNorm launches wait, bounded, for neighbouring work-groups (oneprot_gemm_bf16_nt_resid_ln8).  A wait that runs out is loud on the
+        device: the rows concerned are written as NaN and the step's gradient norm / clip coefficient become NaN (oneprot_clip_coef reads the sticky flag), so the
+        loss of that very step is NaN.  This host-synchronous query turns the flag into an exception with the reason, where the host waits anyway (end of a
+        validation epoch, end of fit_steps), and clears it so that a run restarted with ONEPROT_FFN2_LN=0 in the same process is not poisoned."""
         from . import hip
-        if hip.query("oneprot_gemm_resid_ln8_error") != 0:
-            raise hip.HipKernelError("oneprot_gemm_bf16_nt_resid_ln8: a wait for the neighbouring column tiles ran out (fewer CUs available than column "
-                                     "tiles of a row panel?); set ONEPROT_FFN2_LN=0 to keep the GEMM and the LayerNorm as separate launches")
+        if hip.sched_error() != 0:
+            hip.sched_error_clear()
+            raise hip.HipKernelError("oneprot_gemm_bf16_nt_resid_ln8: a wait for the neighbouring column tiles ran out and NaN rows were written (fewer CUs "
+                                     "available than the form needs: another process on this GPU?); set ONEPROT_FFN2_LN=0 to keep the GEMM and the LayerNorm as "
+                                     "separate launches")
 
     def on_validation_epoch_end(self):
         """ref oneprot_module.py:123-135"""

@@ -75,7 +75,9 @@ def clip_grad_norm_(parameters, max_norm, optimizer=None):
             g = g.clone()
         hip.call("oneprot_sumsq", g, g.numel(), ss, ws)
     coef, norm = torch.empty(1, device=dev), torch.empty(1, device=dev)
-    hip.call("oneprot_clip_coef", ss, float(max_norm), coef, norm)
+    # (the sched workspace's sticky error word -- a bounded wait of oneprot_gemm_bf16_nt_resid_ln8 ran out, NaN rows were written -- turns this step's norm and
+    # coefficient into NaN on the device: no host synchronisation)
+    hip.call("oneprot_clip_coef", ss, float(max_norm), coef, norm, hip.sched_ptr_or_none(dev))
     if isinstance(optimizer, FusedAdam):
         optimizer.set_grad_scale(coef)
     else:

@@ -43,7 +43,7 @@ def _ffn2_ln_waits_never_ran_out():
     yield
     os.environ.pop("ONEPROT_FFN2_LN", None)
     from oneprot_amd import hip
-    assert hip.query("oneprot_gemm_resid_ln8_error") == 0
+    assert hip.sched_error() == 0
 
 
 def _ragged_ids(B, L, lo, hi, lens, gen, cls=0, eos=2, pad=1):

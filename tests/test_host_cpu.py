@@ -37,7 +37,7 @@ def test_library_exports_every_declared_symbol(built_lib):
     h = ctypes.CDLL(built_lib.LIB_PATH)
     missing = [n for n in names if not hasattr(h, n)]
     assert not missing, missing
-    assert h.oneprot_abi_version() == 6
+    assert h.oneprot_abi_version() == 7
     # the ctypes table and the header agree (both directions)
     assert sorted(built_lib.exported_symbols()) == names
 

@@ -212,11 +212,12 @@ def test_gemm_resid_layernorm_fused(M, K, inplace, form):
     128-row tiles).  33280 rows = 260 / 520 tiles (work-groups with one and with two tiles: the operand stream crosses a tile boundary behind an
     epilogue), 65664 rows = 513 / 1026 tiles (two and three), 98688 rows = 771 / 1542 (three and four), K = 64 is a single K-tile, K = 128 / 192 streams
     of a few weight units only (requests run out inside the first tiles), in-place residual as the frozen tower runs it."""
+    prev = hip.query("oneprot_gemm_ln_form_get")
     hip.query("oneprot_gemm_ln_form", form)
     try:
         _gemm_resid_layernorm_fused(M, K, inplace)
     finally:
-        hip.query("oneprot_gemm_ln_form", 1)
+        hip.query("oneprot_gemm_ln_form", prev)      # (0, the eight-wave form, is the library default)
 
 
 @pytest.mark.parametrize("M,N,K,has_bias,inplace,stats", [(24576, 640, 256, True, False, True), (24832, 640, 2560, True, True, False), (49152, 320, 128, False, False, True),
@@ -247,7 +248,7 @@ def test_gemm_resid_layernorm_across_work_groups(M, N, K, has_bias, inplace, sta
         x = resid.clone() if inplace else torch.full((M, N), float("nan"), device=DEV)
         h = torch.full((M, N), float("nan"), dtype=torch.bfloat16, device=DEV)
         st = torch.full((2, M), float("nan"), device=DEV) if stats else None
-        hip.call("oneprot_gemm_bf16_nt_resid_ln8", A, W, M, N, K, K, K, bias, x if inplace else resid, x, gamma, beta, 1e-5, h, st)
+        hip.call("oneprot_gemm_bf16_nt_resid_ln8", A, W, M, N, K, K, K, bias, x if inplace else resid, x, gamma, beta, 1e-5, h, st, *hip.sched_workspace(M))
         if big:
             assert torch.equal(x, x_ref), f"x_out, launch {rep}"
         else:                                                    # (fewer than 192 tiles: the unfused GEMM runs on another kernel with another summation order)
@@ -258,7 +259,118 @@ def test_gemm_resid_layernorm_across_work_groups(M, N, K, has_bias, inplace, sta
         assert torch.isfinite(h.float()).all()
         assert_close(h.float(), h_ref.float(), 2 ** -7, 2e-3, f"h, launch {rep}")
         assert (h.float() - h_ref.float()).abs().gt(1e-6).float().mean() < 0.02      # a bf16 ulp here and there, not a different function
-    assert hip.query("oneprot_gemm_resid_ln8_error") == 0
+        # ... and directly against fp32 torch: two-pass LayerNorm of A W^T + b + r (hf modeling_esm.py:442-463, then :429)
+        if M <= 33024:
+            xr = A.float() @ W.float().t() + resid + (bias if has_bias else 0.0)
+            mu = xr.mean(-1, keepdim=True)
+            var = ((xr - mu) ** 2).mean(-1, keepdim=True)
+            hr = (xr - mu) * torch.rsqrt(var + 1e-5) * gamma + beta
+            assert_close(x, xr, 2e-5, 3e-4, "x_out vs fp32 torch")
+            assert_close(h.float(), hr, 2 ** -7, 4e-3, "h vs fp32 torch two-pass LayerNorm")
+            if stats:
+                assert_close(st[0], mu[:, 0], 1e-5, 1e-4, "mean vs torch")
+                assert_close(st[1], torch.rsqrt(var + 1e-5)[:, 0], 1e-4, 0.0, "rstd vs torch")
+    assert hip.sched_error() == 0
+
+
+@pytest.mark.parametrize("N,K", [(640, 2560), (1280, 256)])
+def test_gemm_resid_layernorm_wait_that_runs_out_is_loud(N, K):
+    """Failure semantics of oneprot_gemm_bf16_nt_resid_ln8 (include/oneprot_hip.h): with the poll bound at zero every wait that does not find its partners'
+    partial statistics at the FIRST look gives up.  Then (i) the sticky error word of the sched workspace is set, (ii) every row of h / mean / rstd is either
+    right or NaN -- never a stale or half-combined statistic --, (iii) x_out (which does not depend on the exchange) is right everywhere, (iv)
+    oneprot_clip_coef, handed the workspace, turns the step's gradient norm and clip coefficient into NaN on the device, (v) after
+    oneprot_gemm_resid_ln8_error_clear a launch with the normal bound is clean again."""
+    M = 32768
+    g = torch.Generator().manual_seed(5 + N)
+    A = bf(torch.randn(M, K, generator=g)).to(DEV)
+    W = bf(torch.randn(N, K, generator=g) * 0.1).to(DEV)
+    bias = (torch.randn(N, generator=g) * 0.5).to(DEV)
+    gamma, beta = (1 + 0.2 * torch.randn(N, generator=g)).to(DEV), (0.3 * torch.randn(N, generator=g)).to(DEV)
+    resid = (torch.randn(M, N, generator=g) * 2.0 + 0.3).to(DEV)
+    ws = hip.sched_workspace(M)
+    assert hip.sched_error() == 0
+
+    def run():
+        x = torch.full((M, N), float("nan"), device=DEV)
+        h = torch.full((M, N), float("nan"), dtype=torch.bfloat16, device=DEV)
+        st = torch.full((2, M), float("nan"), device=DEV)
+        hip.call("oneprot_gemm_bf16_nt_resid_ln8", A, W, M, N, K, K, K, bias, resid, x, gamma, beta, 1e-5, h, st, *ws)
+        torch.cuda.synchronize()
+        return x, h, st
+    x0, h0, st0 = run()
+    assert hip.sched_error() == 0 and torch.isfinite(h0.float()).all()
+    hip.query("oneprot_gemm_resid_ln8_poll_bound", 0)
+    try:
+        hit = False
+        for _ in range(8):                                       # (whether a first look misses is a matter of timing: a few launches always produce one)
+            x1, h1, st1 = run()
+            if hip.sched_error() != 0:
+                hit = True
+                break
+        assert hit, "no wait ran out with the poll bound at zero"
+    finally:
+        hip.query("oneprot_gemm_resid_ln8_poll_bound", -1)
+    assert torch.equal(x1, x0)
+    bad = torch.isnan(h1.float())
+    assert bad.any()                                              # NaN rows exist ...
+    ok = ~bad
+    assert torch.equal(h1[ok], h0[ok])                           # everything that is not NaN is what the clean launch wrote
+    sbad = torch.isnan(st1)
+    assert torch.equal(st1[~sbad], st0[~sbad])
+    # the step's gradient norm on the device
+    ss = torch.full((1,), 4.0, device=DEV)
+    coef, nrm = torch.empty(1, device=DEV), torch.empty(1, device=DEV)
+    hip.call("oneprot_clip_coef", ss, 1.0, coef, nrm, ws[0])
+    assert torch.isnan(coef).all() and torch.isnan(nrm).all()
+    hip.call("oneprot_clip_coef", ss, 1.0, coef, nrm, None)
+    assert abs(nrm.item() - 2.0) < 1e-6 and abs(coef.item() - 0.5) < 1e-5
+    hip.sched_error_clear()
+    x2, h2, st2 = run()
+    assert hip.sched_error() == 0 and torch.equal(h2, h0) and torch.equal(st2, st0)
+    hip.call("oneprot_clip_coef", ss, 1.0, coef, nrm, ws[0])
+    assert abs(nrm.item() - 2.0) < 1e-6
+
+
+def test_persistent_gemm_tiles_from_the_work_queue_bit_identical():
+    """oneprot_dynamic_tiles: the 8-phase GEMMs draw their tiles from the per-XCD queue heads of the sched workspace instead of walking static lists.  Which CU
+    computes a tile changes no summation order: every epilogue bit for bit the same as with static lists, launch after launch (the last work-group to leave
+    resets the queues on the device), also when the launches are captured into a graph and replayed (nothing on the host advances)."""
+    ws = hip.sched_workspace(131072)
+    g = torch.Generator().manual_seed(99)
+    M, d, f = 98560, 640, 2560                              # 385 row panels: three to seven tiles per work-group, an odd share per XCD
+    A = bf(torch.randn(M, d, generator=g)).to(DEV)
+    W1 = bf(torch.randn(f, d, generator=g) * 0.1).to(DEV)
+    b1 = (torch.randn(f, generator=g) * 0.5).to(DEV)
+    U = bf(torch.randn(M, f, generator=g)).to(DEV)
+    W2 = bf(torch.randn(d, f, generator=g) * 0.05).to(DEV)
+    b2 = (torch.randn(d, generator=g) * 0.5).to(DEV)
+    resid = torch.randn(M, d, generator=g).to(DEV)
+    gamma, beta = (1 + 0.2 * torch.randn(d, generator=g)).to(DEV), (0.3 * torch.randn(d, generator=g)).to(DEV)
+
+    def run_all():
+        u = torch.empty(M, f, dtype=torch.bfloat16, device=DEV)
+        z = torch.empty(M, f, dtype=torch.uint8, device=DEV)
+        hip.call("oneprot_gemm_bf16_nt", A, W1, M, f, d, d, d, hip.EPI_BIAS_GELU, b1, u, z, None, None, None, None, 1.0, 0, 0, 0)
+        x = torch.empty(M, d, device=DEV)
+        hip.call("oneprot_gemm_bf16_nt", U, W2, M, d, f, f, f, hip.EPI_BIAS_RESID, b2, x, None, None, resid, None, None, 1.0, 0, 0, 0)
+        x8 = torch.empty(M, d, device=DEV)
+        h8 = torch.empty(M, d, dtype=torch.bfloat16, device=DEV)
+        st = torch.empty(2, M, device=DEV)
+        hip.call("oneprot_gemm_bf16_nt_resid_ln8", U, W2, M, d, f, f, f, b2, resid, x8, gamma, beta, 1e-5, h8, st, *ws)
+        dg = torch.empty(M, d, dtype=torch.bfloat16, device=DEV)
+        hip.call("oneprot_gemm_bf16_nt", U, W2, M, d, f, f, f, hip.EPI_BF16, None, dg, None, None, None, None, None, 1.0, 0, 0, 0)
+        return u, z, x, x8, h8, st, dg
+    try:
+        hip.query("oneprot_dynamic_tiles", None, 0)
+        ref = run_all()
+        hip.query("oneprot_dynamic_tiles", ws[0], ws[1])
+        for rep in range(3):
+            got = run_all()
+            for a, b, name in zip(got, ref, ("gelu", "gelu'", "resid", "x ln8", "h ln8", "stats", "bf16")):
+                assert torch.equal(a, b), (name, rep)
+    finally:
+        hip.query("oneprot_dynamic_tiles", ws[0] if hip.dynamic_tiles_wanted() else None, ws[1])
+    assert hip.sched_error() == 0
 
 
 def test_gemm_resid_layernorm_forms_bit_identical():
@@ -271,13 +383,16 @@ def test_gemm_resid_layernorm_forms_bit_identical():
     Wp = torch.empty(N * K, dtype=torch.bfloat16, device=DEV)
     hip.call("oneprot_gemm_ln_pack_weight", W, Wp, N, K)
     outs = []
-    for form in (0, 1):
-        hip.query("oneprot_gemm_ln_form", form)
-        x, h = torch.empty(M, N, device=DEV), torch.empty(M, N, dtype=torch.bfloat16, device=DEV)
-        mean, rstd = torch.empty(M, device=DEV), torch.empty(M, device=DEV)
-        hip.call("oneprot_gemm_bf16_nt_resid_ln", A, Wp, M, N, K, K, bias, resid, x, gamma, beta, 1e-5, h, mean, rstd)
-        outs.append((x, h, mean, rstd))
-    hip.query("oneprot_gemm_ln_form", 1)
+    prev = hip.query("oneprot_gemm_ln_form_get")
+    try:
+        for form in (0, 1):
+            hip.query("oneprot_gemm_ln_form", form)
+            x, h = torch.empty(M, N, device=DEV), torch.empty(M, N, dtype=torch.bfloat16, device=DEV)
+            mean, rstd = torch.empty(M, device=DEV), torch.empty(M, device=DEV)
+            hip.call("oneprot_gemm_bf16_nt_resid_ln", A, Wp, M, N, K, K, bias, resid, x, gamma, beta, 1e-5, h, mean, rstd)
+            outs.append((x, h, mean, rstd))
+    finally:
+        hip.query("oneprot_gemm_ln_form", prev)      # (0 is the library default: the rest of the process runs the shipped form)
     for a, b in zip(*outs):
         assert torch.equal(a, b)
 
@@ -771,7 +886,7 @@ def test_optimizer_kernels():
         ss = torch.zeros(1, device=DEV)
         coef, nrm = torch.empty(1, device=DEV), torch.empty(1, device=DEV)
         hip.call("oneprot_sumsq", gd, n, ss, w)
-        hip.call("oneprot_clip_coef", ss, 1.0, coef, nrm)
+        hip.call("oneprot_clip_coef", ss, 1.0, coef, nrm, None)
         assert abs(nrm.item() - tn.item()) < 1e-3 * tn.item()
         hip.call("oneprot_adam_step", pd, gd, m, v, n, 1e-3, 0.9, 0.999, 1e-8, 0.0, step, coef)
         assert_close(pd.cpu(), pr.detach(), 1e-5, 2e-6, f"adam step {step}")
