@@ -109,6 +109,8 @@ int oneprot_sched_workspace_init(void* sched_ws, size_t bytes, void* stream);
  * work-groups share the tiles and late ones find the queue empty.  Results are bit-identical (which CU computes a tile changes no summation order).
  * Process-wide setting; the kernels of every stream then use this one workspace, so the streams must not overlap such launches. */
 void oneprot_dynamic_tiles(void* sched_ws, size_t bytes);
+/* diagnostic, host-synchronous: ticket draws that had not returned where the kernel first looked for them (each costs one drained operand prefetch; 0 expected) */
+int oneprot_sched_late_draws(const void* sched_ws);
 /* The same product with the row statistics completed ACROSS work-groups, for the launches whose K loop the full-row kernel above runs too slowly
  * (FFN-2, K = 4 d): x_out = resid + A W^T + bias (fp32; may alias resid) and h = LayerNorm(x_out) (bf16), by the 8-phase GEMM on 256 x 320 tiles; the
  * column tiles of a row panel exchange (mean, M2) partials through the sched workspace (hf modeling_esm.py:442-463 followed by :429 of the next layer or by
@@ -145,6 +147,10 @@ size_t oneprot_gemm_bf16_tn_workspace(int N, int K);
 /* test / tuning hook: -1 = auto (default: the 8-phase 320 x 128 form where the problem is made of whole tiles, else 2), 0 = 64-token stages x2 (LDS-DMA ring),
    1 = 32-token stages x3, 2 = 64-token stages x2 with register-staged fill, 3 = 8-phase form where eligible (else 2). */
 void oneprot_gemm_tn_variant(int v);
+/* CUs left to co-resident kernels (the RCCL channels of a gradient all-reduce overlapped with the backward) when oneprot_gemm_bf16_tn cuts the token range into
+   one-shot work items: at most (CUs - reserve) of them, so that none has to wait for a CU and run after the others (twice the launch time).  Changes the number of
+   token splits, i.e. the (fixed) summation order.  Process-wide; default 0. */
+void oneprot_cu_reserve(int cus);
 /* workspace_bytes = size of `workspace`; -1 (invalid argument) when it is smaller than oneprot_gemm_bf16_tn_workspace(N, K). */
 int oneprot_gemm_bf16_tn(const void* dY, const void* X, int64_t M, int N, int K, int ldy, int ldx, float* dW, float* dbias, void* workspace,
                          size_t workspace_bytes, int accumulate, void* stream);

@@ -16,9 +16,11 @@
 //   backward dK/dV kernel puts the key on the lane: S = Q K^T, dP = dO V^T, dV^T += dO^T P, dK^T += Q^T dS.
 // Tiles in LDS are row-major with a 16-byte-chunk XOR swizzle that keeps the ds_read_b128 row reads conflict-free.
 #include "common.h"
+#include "sched_ws.h"
 #include "../../include/oneprot_hip.h"
 #include <float.h>
 #include <atomic>
+void* dynamic_tiles_workspace();      // gemm_nt8.hip: what oneprot_dynamic_tiles was given (null: static work lists)
 
 #define LOG2E 1.4426950408889634f
 #define KC 256        // keys (or queries) staged per LDS chunk
@@ -919,7 +921,7 @@ struct Fwd3 {
 template <int HD>
 __global__ void __launch_bounds__(512, 2) k_attn_fwd3(const bf16_t* __restrict__ q, const bf16_t* __restrict__ k, const bf16_t* __restrict__ v,
                                                    const float* __restrict__ key_bias, bf16_t* __restrict__ ctx, float* __restrict__ lse_out, int B, int H,
-                                                   int L) {
+                                                   int L, unsigned* __restrict__ sched) {
   typedef Cfg<HD> C;
   static_assert(C::ROWB == 64, "k_attn_fwd3 stages 64-byte rows");
   extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
@@ -931,7 +933,26 @@ __global__ void __launch_bounds__(512, 2) k_attn_fwd3(const bf16_t* __restrict__
   const int nbh = B * H, per_xcd = (nbh + 7) >> 3, nslot = gridDim.x >> 3;
   const int xcd = blockIdx.x & 7;
   const int bh_end = min(nbh, (xcd + 1) * per_xcd);
-  int bh = xcd * per_xcd + (int)(blockIdx.x >> 3);
+  // Which slabs.  Static (sched == null): the work-group's own, stride (work-groups per XCD).  Dynamic: tickets drawn from XCD x's queue head of the sched
+  // workspace (sched_ws.h) -- two at the start, then one per slab, drawn (one lane, a returning agent-scope atomic) right behind the slab's barrier and
+  // looked at behind the NEXT slab's vmcnt(0), where it costs nothing; it reaches the other waves through a word of the LDS' spare room across that
+  // barrier.  A work-group that could not start with the others finds the queue empty and leaves; the running ones share the slabs.
+  unsigned* const relay = reinterpret_cast<unsigned*>(smem + Fwd3::TOTAL);      // 2 words (the launch asks for TOTAL + 16 bytes)
+  int bh, bh_next;
+  if (sched) {
+    if (threadIdx.x == 0) {
+      unsigned* head = sched + SW_HEAD(xcd);
+      const unsigned t0 = sw_draw(head), t1 = sw_draw(head);
+      relay[0] = t0 < 0x3fffffffu ? t0 : 0x3fffffffu; relay[1] = t1 < 0x3fffffffu ? t1 : 0x3fffffffu;
+    }
+    __syncthreads();
+    bh = xcd * per_xcd + __builtin_amdgcn_readfirstlane((int)relay[0]);
+    bh_next = xcd * per_xcd + __builtin_amdgcn_readfirstlane((int)relay[1]);
+    __syncthreads();
+  } else {
+    bh = xcd * per_xcd + (int)(blockIdx.x >> 3);
+    bh_next = bh + nslot;
+  }
   // the wave's two query blocks: rows [64 w, 64 w + 32) and [64 w + 32, 64 w + 64); the second one may lie beyond L (its rows then repeat row L - 1
   // and are not stored)
   const int q0 = wave * 64;
@@ -1002,19 +1023,37 @@ __global__ void __launch_bounds__(512, 2) k_attn_fwd3(const bf16_t* __restrict__
   RowOut<HD> pend[2];
   int pend_bh = -1, buf = 0;
   int slab_no = 0;
+  // (wave 0, lane 0) the ticket drawn during the previous slab -- for the slab AFTER `bh_next`.  The draw is an inline-asm atomic (sched_ws.h: through the
+  // builtin hipcc waits for it, vmcnt(0), right where it is issued: wave 0 then starts every slab a memory round trip late, +100 us per launch); its register
+  // is read behind the next slab's own vmcnt(0), where it has returned whatever the order of returns is (check_async_regs.py: nothing else touches it).
+  unsigned drawn_v = 0;
+  const unsigned relay_lds = lds0 + Fwd3::TOTAL;
+  const int draw_lane = (sched != nullptr && wave == 0) ? 1 : 0;
   while (bh < bh_end) {
     FWD3_T(0);
-    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");        // this wave's pieces of slab `bh` have landed (and its q fragments, and older stores)
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");        // this wave's pieces of slab `bh` have landed (and its q fragments, and older stores -- and the draw)
     FWD3_T(1);
+    if (sched && slab_no > 0) {
+      int late;
+      const int t = draw_result(drawn_v, late);
+      if (wave == 0) lds_write32(relay_lds + 4u * (slab_no & 1), (unsigned)(t < 0 || t > 0x3fffffff ? 0x3fffffff : t));
+      asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+    }
     __builtin_amdgcn_s_barrier();                           // ... everybody's have; everybody has left the other half of the LDS
     FWD3_T(2);
+    if (sched && slab_no > 0) {
+      const unsigned rv = lds_read32(relay_lds + 4u * (slab_no & 1));
+      asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+      bh_next = xcd * per_xcd + first_lane(rv);
+    }
+    drawn_v = draw_async(sched + SW_HEAD(xcd), draw_lane & (int)((unsigned)(bh_next - bh_end) >> 31));      // (EXEC mask empty unless this wave draws and a next slab exists)
     // hipcc does not see the wait above: it would put its own vmcnt(0) in front of the first use of the q fragments -- behind the LDS-DMA of the
     // NEXT slab, i.e. the compute would start only after that transfer.  Consuming the fragments here puts its wait where it is free.
 #pragma unroll
     for (int b = 0; b < 2; ++b)
 #pragma unroll
       for (int st = 0; st < C::KSTEPS; ++st) asm volatile("" : "+v"(qf[b][st]));
-    const int nxt = bh + nslot;
+    const int nxt = bh_next;
     const bool more = nxt < bh_end;
     // the q fragments of the next slab in one go (a load whose result registers are written under a condition inside the tile loop makes hipcc wait
     // for vmcnt(0) -- i.e. for the LDS-DMA too -- in every iteration)
@@ -1073,6 +1112,7 @@ __global__ void __launch_bounds__(512, 2) k_attn_fwd3(const bf16_t* __restrict__
     ++slab_no;
     pend_bh = bh;
     bh = nxt; buf ^= 1;
+    if (!sched) bh_next = bh + nslot;
 #pragma unroll
     for (int b = 0; b < 2; ++b)
 #pragma unroll
@@ -1080,6 +1120,7 @@ __global__ void __launch_bounds__(512, 2) k_attn_fwd3(const bf16_t* __restrict__
   }
   if (pend_bh >= 0 && active)
     for (int i = 0; i < NST; ++i) store1(pend, pend_bh, i);
+  if (sched && threadIdx.x == 0) sw_leave(sched, gridDim.x);
 }
 
 // ---- k_attn_fwd3w: the persistent form for 128-byte rows (hd = 64: BERT-base, ESM-2-650M), L <= 512 ------------------------------------------
@@ -1339,7 +1380,7 @@ template <int HD>
 static int launch_fwd3(const void* q, const void* k, const void* v, const float* key_bias, void* ctx, float* lse, int B, int H, int L, hipStream_t s) {
   static int ok = -1, n_cu = 0;
   if (ok < 0) {
-    ok = hipFuncSetAttribute((const void*)k_attn_fwd3<HD>, hipFuncAttributeMaxDynamicSharedMemorySize, Fwd3::TOTAL) == hipSuccess ? 1 : 0;
+    ok = hipFuncSetAttribute((const void*)k_attn_fwd3<HD>, hipFuncAttributeMaxDynamicSharedMemorySize, Fwd3::TOTAL + 16) == hipSuccess ? 1 : 0;
     int dev = 0; hipDeviceProp_t prop;
     if (hipGetDevice(&dev) != hipSuccess || hipGetDeviceProperties(&prop, dev) != hipSuccess) ok = 0; else n_cu = prop.multiProcessorCount;
   }
@@ -1349,8 +1390,8 @@ static int launch_fwd3(const void* q, const void* k, const void* v, const float*
   int nslot = n_cu / 8;                                   // one persistent work-group per CU
   if (nslot < 1) nslot = 1;
   if (nslot > per_xcd) nslot = per_xcd;
-  hipLaunchKernelGGL(k_attn_fwd3<HD>, dim3(8 * nslot), dim3(64 * waves), Fwd3::TOTAL, s, (const bf16_t*)q, (const bf16_t*)k, (const bf16_t*)v, key_bias,
-                     (bf16_t*)ctx, lse, B, H, L);
+  hipLaunchKernelGGL(k_attn_fwd3<HD>, dim3(8 * nslot), dim3(64 * waves), Fwd3::TOTAL + 16, s, (const bf16_t*)q, (const bf16_t*)k, (const bf16_t*)v, key_bias,
+                     (bf16_t*)ctx, lse, B, H, L, (unsigned*)dynamic_tiles_workspace());
   return launch_status();
 }
 

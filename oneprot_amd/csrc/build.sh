@@ -16,22 +16,24 @@ for s in $SRCS; do
         grep -v "remark:" "$o.remarks.tmp" >&2; rm -f "$o.remarks.tmp"; exit 1
       fi ) &
     PIDS="$PIDS $!"
-    if [ "$s" = gemm_nt8.hip ]; then      # its device ISA as text, for check_async_regs.py (a register written behind the compiler's back)
-      ( hipcc --offload-arch=gfx950 -O3 -fPIC -std=c++17 -Wno-unused-value -S --cuda-device-only "$s" -o gemm_nt8.s.tmp 2> /dev/null && mv gemm_nt8.s.tmp gemm_nt8.s ) &
+    if [ "$s" = gemm_nt8.hip ] || [ "$s" = attention.hip ]; then      # their device ISA as text, for check_async_regs.py (a register written behind the compiler's back)
+      ( hipcc --offload-arch=gfx950 -O3 -fPIC -std=c++17 -Wno-unused-value -S --cuda-device-only "$s" -o "${s%.hip}.s.tmp" 2> /dev/null && mv "${s%.hip}.s.tmp" "${s%.hip}.s" ) &
       PIDS="$PIDS $!"
     fi
   fi
   OBJS="$OBJS $o"
 done
-if [ ! -f gemm_nt8.s ]; then
-  ( hipcc --offload-arch=gfx950 -O3 -fPIC -std=c++17 -Wno-unused-value -S --cuda-device-only gemm_nt8.hip -o gemm_nt8.s.tmp 2> /dev/null && mv gemm_nt8.s.tmp gemm_nt8.s ) &
-  PIDS="$PIDS $!"
-fi
+for u in gemm_nt8 attention; do
+  if [ ! -f $u.s ]; then
+    ( hipcc --offload-arch=gfx950 -O3 -fPIC -std=c++17 -Wno-unused-value -S --cuda-device-only $u.hip -o $u.s.tmp 2> /dev/null && mv $u.s.tmp $u.s ) &
+    PIDS="$PIDS $!"
+  fi
+done
 for p in $PIDS; do wait $p || { echo "compile failed"; exit 1; }; done
 REMARKS=""
 for s in $SRCS; do REMARKS="$REMARKS ${s%.hip}.o.remarks"; done
 python3 check_resources.py $REMARKS || { echo "build refused: register spills in product kernels (see above)"; exit 1; }
-python3 check_async_regs.py gemm_nt8.s || { echo "build refused: the asynchronously written ticket register of k_gemm8 is copied or reused (see above)"; exit 1; }
+python3 check_async_regs.py gemm_nt8.s attention.s || { echo "build refused: the asynchronously written ticket register of k_gemm8 is copied or reused (see above)"; exit 1; }
 hipcc --offload-arch=gfx950 -shared -fPIC -o ../liboneprot_hip.so $OBJS
 echo "built $(cd .. && pwd)/liboneprot_hip.so"
 # RCCL wrappers (include/oneprot_comm.h) in their own library, so that the kernel library carries no RCCL dependency

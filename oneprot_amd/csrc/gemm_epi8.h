@@ -335,11 +335,10 @@ __device__ __forceinline__ void epilogue_f32(const GemmArgs& p, f32x4 (&acc)[MT]
 //   F  h = (s - mean) rstd gamma + beta from the registers, two column tiles at a time (gamma / beta two groups ahead like every epilogue operand),
 //      lane pairs swapping halves so that a lane stores 16 contiguous bytes; mean / rstd leave from slot 0.
 // The statistics are exact two-pass ones per wave block (the values are in registers) and Chan's combination is exact in exact arithmetic: the result
-// agrees with k_layernorm_fwd's two-pass form to fp32 rounding.  Progress: a wave waits for the waves that run the other column tiles of its row panel.  With
-// static tile lists those are work-groups of the same launch slot: if one of them has no CU yet (a co-resident kernel holds it) its neighbours wait -- once per
-// tile of theirs -- until a work-group that has finished makes room, or until the bound.  With tiles drawn from the work queue (GemmArgs.dyn) a tile that has
-// been drawn is held by a RUNNING work-group, partners are G = 2 draws apart (so a work-group that draws twice in a row never holds both), and the wait is
-// bounded by the partner's remaining tile time as long as three work-groups of the XCD are running.  Either way the bound ends it: NaN + LN_ERR, never a hang.
+// agrees with k_layernorm_fwd's two-pass form to fp32 rounding.  Progress: a wave waits for the waves that run the other column tiles of its row panel -- with
+// the static tile list (this epilogue never runs with drawn tickets: gemm_nt8.hip) those are work-groups of the same launch slot.  If one of them has no CU yet
+// (a co-resident kernel holds it) its neighbours wait -- once per tile of theirs -- until a work-group that has finished makes room, or until the bound.
+// The bound ends it either way: NaN + LN_ERR, never a hang and never a stale statistic.
 // 16-byte load / store that miss every cache on their way (system scope): the partial statistics of the wave blocks of a row
 template <int OFF> __device__ __forceinline__ void gload16_uc(u32x4& d, const void* ptr) {
   asm volatile("global_load_dwordx4 %0, %1, off offset:%2 sc0 sc1" : "=v"(d) : "v"(ptr), "n"(OFF) : "memory");

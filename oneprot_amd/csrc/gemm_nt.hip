@@ -1097,6 +1097,13 @@ extern "C" int oneprot_gemm_resid_ln8_error(const void* sched_ws) {
   if (hipMemcpy(&e, (const unsigned*)sched_ws + SW_LN_ERR, sizeof(e), hipMemcpyDeviceToHost) != hipSuccess) return -1;
   return (int)e;
 }
+// diagnostic (host-synchronous): ticket draws of the persistent GEMMs that had not returned where the kernel first looked (each cost one drained prefetch)
+extern "C" int oneprot_sched_late_draws(const void* sched_ws) {
+  unsigned e = 0;
+  if (!sched_ws) return 0;
+  if (hipMemcpy(&e, (const unsigned*)sched_ws + SW_LATE_DRAWS, sizeof(e), hipMemcpyDeviceToHost) != hipSuccess) return -1;
+  return (int)e;
+}
 extern "C" int oneprot_gemm_resid_ln8_error_clear(void* sched_ws, void* stream) {
   if (!sched_ws) return OP_EINVAL;
   return hipMemsetAsync((unsigned*)sched_ws + SW_LN_ERR, 0, 4, (hipStream_t)stream) == hipSuccess ? 0 : OP_ELAUNCH;

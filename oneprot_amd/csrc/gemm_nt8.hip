@@ -87,26 +87,6 @@ __device__ __forceinline__ void glds16(unsigned voff, const unsigned char* sbase
   asm volatile("s_mov_b32 %0, m0\n\ts_mov_b32 m0, %3\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %1, %2\n\ts_mov_b32 m0, %0"
                : "=&s"(keep) : "v"(voff), "s"(sbase), "s"(lds_dst) : "memory");
 }
-// A draw from a queue head whose result is NOT waited for by the compiler (inline asm: hipcc's own wait would be vmcnt(0), i.e. a drain of the LDS-DMA
-// prefetch it cannot see); the caller looks at the register behind a counted wait that covers it.  `lanes` = the EXEC mask of the atomic: 1 in the one
-// wave that draws, 0 elsewhere (the instruction then does nothing and the register keeps 0x7fffffff) -- no branch, so no merge of two definitions of the
-// register that is written behind the compiler's back.
-__device__ __forceinline__ unsigned draw_async(const unsigned* head, int lanes) {
-  unsigned v, one;
-  unsigned long long keep;
-  const int lo = __builtin_amdgcn_readfirstlane(lanes);
-  // scalar base + a zero offset in the destination register itself: no address pair in vector registers (kept over the K loop it was spilled, and its reload
-  // -- behind a vmcnt(0) -- drained the operand prefetch in every iteration)
-  asm volatile("v_mov_b32 %0, 0\n\tv_mov_b32 %1, 1\n\ts_mov_b64 %2, exec\n\ts_mov_b32 exec_lo, %4\n\ts_mov_b32 exec_hi, 0\n\ts_cbranch_execz 1f\n\t"
-               "global_atomic_add %0, %0, %1, %3 sc0\n1:\n\ts_mov_b64 exec, %2"
-               : "=&v"(v), "=&v"(one), "=&s"(keep) : "s"(head), "s"(lo) : "memory");
-  return v;
-}
-// the ticket relay word in LDS: plain ds instructions from inline asm (through a volatile C++ access hipcc emitted FLAT instructions with a vmcnt(0) behind
-// them -- a drain of the operand prefetch, or of the epilogue's store burst); the reader's wait is the K-tile's own lgkmcnt(0)
-__device__ __forceinline__ unsigned lds_read32(unsigned addr) { unsigned v; asm volatile("ds_read_b32 %0, %1" : "=v"(v) : "v"(addr) : "memory"); return v; }
-__device__ __forceinline__ void lds_write32(unsigned addr, unsigned val) { asm volatile("ds_write_b32 %0, %1" ::"v"(addr), "v"(val) : "memory"); }
-__device__ __forceinline__ int first_lane(unsigned v) { int s; asm volatile("v_readfirstlane_b32 %0, %1" : "=s"(s) : "v"(v)); return s; }
 // the lane id, recomputed where it is needed (two instructions) rather than kept over the K loop: a volatile statement, so that hipcc neither hoists it out
 // of the tile loop nor keeps its result (the 160-accumulator configurations have no register for it: kept, it is spilled and its reload -- behind a
 // vmcnt(0) -- drains the operand prefetch once per tile)
@@ -140,26 +120,20 @@ __global__ void __launch_bounds__(512, 2) k_gemm8(const GemmArgs p, const int g8
   const int cs = p.csplit, ng = 8 / cs, xg = x / cs, cg = x - xg * cs, tn_x = p.tiles_n / cs;
   const int panels_x = p.tiles_m > xg ? (p.tiles_m - xg + ng - 1) / ng : 0;
   const int Tx = panels_x * tn_x;                          // tiles of this XCD's share, numbered 0 .. Tx-1 ("tickets")
-  // ticket -> tile.  Plain kernels: column tile fastest (an XCD works on a few row panels at a time: they and W stay in its L2).  RESID_LN: the column tiles of
-  // a row panel wait for each other's row statistics, so they must run at the same time AND must never be held by one work-group: row panels are taken
-  // in pairs (G = 2) with the panel index fastest, i.e. partners are G tickets apart -- close in time, and a work-group that draws two tickets in a row
-  // (at its start) never holds two tiles of one panel.
-  constexpr int G = (EPI == G8_EPI_RESID_LN) ? 2 : 1;
+  // ticket -> tile: column tile fastest (an XCD works on a few row panels at a time: they and W stay in its L2)
   auto tile_origin = [&](int u, int& m0, int& n0) __attribute__((always_inline)) {
-    int pl, tn;
-    if constexpr (G == 1) { pl = u / tn_x; tn = u - pl * tn_x; }
-    else {
-      const int per = G * tn_x, gi = u / per, idx = u - gi * per;
-      const int left = panels_x - gi * G, gp = left < G ? left : G;      // (the last group of an odd share has one panel)
-      tn = idx / gp; pl = gi * G + (idx - tn * gp);
-    }
+    const int pl = u / tn_x, tn = u - pl * tn_x;
     m0 = (pl * ng + xg) * C::BM; n0 = (cg * tn_x + tn) * C::BN;
   };
   // ---- which tiles.  Static (p.dyn == 0): tickets w, w + g8n, w + 2 g8n, ...  Dynamic: tickets are drawn from XCD x's queue head in the sched workspace
   // (sched_ws.h), two at the start and one per tile after that, always for the tile AFTER the next one (the operand stream runs into the next tile two
   // K-tiles before the current one ends, so the next tile must be known by then).  A work-group that finds the queue empty leaves at once: work-groups
   // that could not start with the others -- a co-resident kernel holds their CU -- cost nothing, the running ones share the tiles.
-  const bool dyn = p.dyn != 0;
+  // RESID_LN is never dynamic: its work-groups WAIT for the other column tiles of their row panel, and a work-group that holds drawn tickets ahead of its
+  // current tile can be waited on, through such a ticket, by the very work-group it waits for (two work-groups that start together and draw alternately:
+  // observed as a bounded wait that ran out, round 6).  With the static list the partners are work-groups w, w + 1 of the same launch slot.  It is a
+  // forward-pass kernel: nothing is co-resident with it in a training step (the overlapped gradient all-reduce runs under the backward).
+  const bool dyn = EPI != G8_EPI_RESID_LN && p.dyn != 0;
   int tk_cur, tk_nxt;
   unsigned ln_tag = 0;
   if (dyn) {
@@ -333,16 +307,18 @@ __global__ void __launch_bounds__(512, 2) k_gemm8(const GemmArgs p, const int g8
   // r3 = s % 3 (Y0 ring slot under Y3).
   int r3 = 0;
   constexpr int ST = epilogue_stores<EPI, DUAL, MT, NT>();
+  unsigned relay_addr = 0;                                  // LDS byte address of the ticket relay word of the tile being entered
+  int lim = tk_nxt < Tx ? 0x7fffffff : nk;                 // K-tiles the operand stream may run ahead to, counted from the current tile's first
   constexpr unsigned RELAY = C::Y3 ? 0u : (unsigned)C::LDS;      // byte offset of the ticket relay word (Y3: inside the Y0 ring slot that is dead at that time)
-  auto ktile = [&](auto bufc, int s, int t, const bool after_epi) __attribute__((always_inline)) {
+  auto ktile = [&](auto bufc, int s, int t, const bool after_epi, const bool relay_now) __attribute__((always_inline)) {
     constexpr int BUFI = decltype(bufc)::value;
     stamp_s = s; stamp_ph = 0;
     const unsigned char* bufp = smem + BUFI * C::BUF;
     const unsigned char* y0p = C::Y3 ? smem + C::RING_Y0 + r3 * C::Y_UNIT : bufp + C::OFF_Y0;
     const int r3n2 = r3 == 0 ? 2 : r3 - 1;                 // (s + 2) % 3
-    // K-tiles s+1 / s+2 of the stream exist: inside this tile, or in the next one (t = K-tile inside the tile).  With drawn tickets the next ticket of the
-    // first K-tile after an epilogue arrives in P1 below; it is looked at from t >= nk - 2 on only (nk >= 4)
-    const bool more1 = t + 1 < nk || tk_nxt < Tx;
+    // K-tiles s+1 / s+2 of the stream exist: inside this tile, or in the next one (t = K-tile inside the tile; lim = nk, or "no end" when a next tile is
+    // known).  With drawn tickets the next ticket arrives in P1 of the first K-tile after an epilogue (relay_now) and lim with it; nk >= 4 there
+    const bool more1 = t + 1 < lim;
     // P1 (X0, Y0): X0 reads first and retired before the barrier -- its LDS is refilled in the NEXT phase
     read_x(bufp + C::OFF_X0);
     __builtin_amdgcn_sched_barrier(0);
@@ -354,10 +330,10 @@ __global__ void __launch_bounds__(512, 2) k_gemm8(const GemmArgs p, const int g8
     bar();
     STAMP(0);
     unsigned relay = 0;
-    if (dyn && after_epi) relay = lds_read32(lds0 + (C::Y3 ? C::RING_Y0 + r3n2 * C::Y_UNIT : RELAY));      // wave 0 wrote it before this barrier; the slot's refill is issued in P3
+    if (relay_now) relay = lds_read32(relay_addr);          // wave 0 wrote it before this barrier; under Y3 the slot's refill is issued in P3
     wait_lgkm<0>();
-    if (dyn && after_epi) tk_nxt = first_lane(relay);
-    const bool more2 = t + 2 < nk || tk_nxt < Tx;
+    if (relay_now) { tk_nxt = first_lane(relay); lim = tk_nxt < Tx ? 0x7fffffff : nk; }
+    const bool more2 = t + 2 < lim;
     __builtin_amdgcn_sched_barrier(0);
     quadrant(std::integral_constant<int, 0>{}, std::integral_constant<int, 0>{});
     __builtin_amdgcn_sched_barrier(0);
@@ -433,7 +409,7 @@ __global__ void __launch_bounds__(512, 2) k_gemm8(const GemmArgs p, const int g8
   auto ktile2 = [&](auto bufc, int s, int t) __attribute__((always_inline)) {
     constexpr int BUFI = decltype(bufc)::value;
     const unsigned char* bufp = smem + BUFI * C::BUF;
-    const bool more1 = t + 1 < nk || tk_nxt < Tx;
+    const bool more1 = t + 1 < lim;
     const bool first = x1_ahead;                            // first K-tile after an epilogue
     // phase A
     read_x(bufp + C::OFF_X0);
@@ -447,11 +423,12 @@ __global__ void __launch_bounds__(512, 2) k_gemm8(const GemmArgs p, const int g8
     bar();
     STAMP(0);
     if (dyn && first) {
-      const unsigned relay = lds_read32(lds0 + RELAY);
+      const unsigned relay = lds_read32(relay_addr);
       wait_lgkm<0>();
       tk_nxt = first_lane(relay);
+      lim = tk_nxt < Tx ? 0x7fffffff : nk;
     }
-    const bool more2 = t + 2 < nk || tk_nxt < Tx;
+    const bool more2 = t + 2 < lim;
     __builtin_amdgcn_sched_barrier(0);
     quadrant(std::integral_constant<int, 0>{}, std::integral_constant<int, 0>{});
     quadrant(std::integral_constant<int, 0>{}, std::integral_constant<int, 1>{});
@@ -512,6 +489,7 @@ __global__ void __launch_bounds__(512, 2) k_gemm8(const GemmArgs p, const int g8
   // them until the K-tile-2 wait, two K-tiles later.
   int s = 0;
   bool after_epi = false;
+  const int draw_lane = (dyn && wave == 0) ? 1 : 0;         // EXEC mask of the draw: lane 0 of wave 0
   // One LDS-DMA-free way to hand a drawn ticket to all eight waves: wave 0 draws (a returning agent-scope atomic, issued ahead of the tile's LAST two K-tiles
   // and looked at behind their last counted wait: loads return in order, so it has returned when that wait is over), keeps the value in a scalar register over
   // the epilogue and writes it into LDS behind it -- 4 bytes that are free at that time: spare bytes behind the buffers, or under Y3 (all 160 KB taken) the Y0
@@ -522,8 +500,8 @@ __global__ void __launch_bounds__(512, 2) k_gemm8(const GemmArgs p, const int g8
       ktile2(std::integral_constant<int, 0>{}, s, t);
       ktile2(std::integral_constant<int, 1>{}, s + 1, t + 1);
     } else {
-      ktile(std::integral_constant<int, 0>{}, s, t, after_epi);
-      ktile(std::integral_constant<int, 1>{}, s + 1, t + 1, false);
+      ktile(std::integral_constant<int, 0>{}, s, t, after_epi, after_epi && dyn);
+      ktile(std::integral_constant<int, 1>{}, s + 1, t + 1, false, false);
       after_epi = false;
     }
     s += 2;
@@ -535,18 +513,19 @@ __global__ void __launch_bounds__(512, 2) k_gemm8(const GemmArgs p, const int g8
     // EXEC mask elsewhere, so that the register it writes behind the compiler's back is defined in the iteration it is used after and never merged with another
     // definition) and is looked at behind their last counted wait: at most the three youngest units are in flight then, or nothing -- loads return in order,
     // so the draw has returned.  oneprot_amd/csrc/check_async_regs.py verifies in the ISA that nothing copies or reuses the register in between.
-    unsigned drawn_v;
+    unsigned drawn_v;                                        // (defined in the last iteration, used behind the loop)
     int t = 0;
 #pragma clang loop unroll(disable)
     do {                                                   // (nk >= 2)
       // (tk_nxt: with drawn tickets it arrives in the tile's first K-tile -- it is looked at in the last pair only, nk >= 4)
-      drawn_v = draw_async(p.sched + SW_HEAD(x), (dyn && wave == 0 && t + 2 >= nk && tk_nxt < Tx) ? 1 : 0);
+      if (t + 2 >= nk) drawn_v = draw_async(p.sched + SW_HEAD(x), draw_lane & (int)((unsigned)(tk_nxt - Tx) >> 31));      // (all scalar: tk_nxt < Tx <=> the difference is negative)
       kpair(t);
       t += 2;
     } while (t < nk);
     const bool has_next = tk_nxt < Tx;
-    int drawn;
-    asm volatile("v_readfirstlane_b32 %0, %1 ; DRAWN" : "=s"(drawn) : "v"(drawn_v));      // (the marker is what check_async_regs.py looks for)
+    int late;
+    const int drawn = draw_result(drawn_v, late);            // (its ; DRAWN marker is what check_async_regs.py looks for)
+    if (late && lane_now() == 0) __hip_atomic_fetch_add(p.sched + SW_LATE_DRAWS, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);      // diagnostic counter: draws that had not returned behind the counted wait
     STAMP_E(0);
     if (grp == 0) bar();
     STAMP_E(1);
@@ -570,11 +549,14 @@ __global__ void __launch_bounds__(512, 2) k_gemm8(const GemmArgs p, const int g8
     STAMP_E(3);
     if (!has_next) break;
     if (dyn) {
-      if (wave == 0) lds_write32(lds0 + (C::Y3 ? C::RING_Y0 + (r3 == 0 ? 2 : r3 - 1) * C::Y_UNIT : RELAY), (unsigned)drawn);      // (every lane of the wave: the same word, the same value)
+      // (under Y3 the word lies in the Y0 ring slot of K-tile s+2 = slot (r3 + 2) % 3, r3 being the slot of the new tile's first K-tile)
+      relay_addr = lds0 + (C::Y3 ? C::RING_Y0 + (r3 == 0 ? 2 : r3 - 1) * C::Y_UNIT : RELAY);
+      if (wave == 0) lds_write32(relay_addr, (unsigned)drawn);      // (every lane of the wave: the same word, the same value)
       tk_cur = tk_nxt;                                                       // (tk_nxt: read back by every wave in the first K-tile of the new tile)
-      tk_nxt = 0x7fffffff;
+      tk_nxt = 0x7fffffff; lim = nk;
     } else {
       tk_cur = tk_nxt; tk_nxt += g8n;
+      lim = tk_nxt < Tx ? 0x7fffffff : nk;
     }
     lane_consts();
     zero_acc();
@@ -597,7 +579,7 @@ static int launch_cfg(GemmArgs a, hipStream_t s) {
   static bool configured = false;
   static int n_cu = 0;
   if (!configured) {
-    if (hipFuncSetAttribute((const void*)k_gemm8<C, EPI, HB, DUAL>, hipFuncAttributeMaxDynamicSharedMemorySize, C::LDS) != hipSuccess) return OP_ELAUNCH;
+    if (hipFuncSetAttribute((const void*)k_gemm8<C, EPI, HB, DUAL>, hipFuncAttributeMaxDynamicSharedMemorySize, C::LDS + (C::Y3 ? 0 : 64)) != hipSuccess) return OP_ELAUNCH;
     int dev = 0; hipDeviceProp_t prop;
     if (hipGetDevice(&dev) != hipSuccess || hipGetDeviceProperties(&prop, dev) != hipSuccess) return OP_ELAUNCH;
     n_cu = prop.multiProcessorCount;
@@ -616,17 +598,15 @@ static int launch_cfg(GemmArgs a, hipStream_t s) {
   if (g8n > per_xcd) g8n = (int)per_xcd;
   if (g8n < 1) g8n = 1;
   if (g_g8n_cap > 0 && g8n > g_g8n_cap) g8n = g_g8n_cap;      // experiment hook: fewer work-groups per XCD
-  if (EPI == G8_EPI_RESID_LN) {                              // static list u = q * g8n + w: the tickets of a pair of row panels (2 * tiles_n of them) are in flight together iff g8n is a multiple of that
-    if (g8n < per_xcd) {                                     // (g8n == per_xcd: one round, everything is in flight together)
-      g8n -= g8n % (2 * a.tiles_n);
-      if (g8n < 2 * a.tiles_n) return G8_NOT_ELIGIBLE;
-    }
+  if (EPI == G8_EPI_RESID_LN) {                              // tile u = q * g8n + w: the tiles_n tiles of a panel are in flight together iff g8n is a multiple of tiles_n
+    g8n -= g8n % a.tiles_n;
+    if (g8n < a.tiles_n) return G8_NOT_ELIGIBLE;
   }
   // tiles drawn from the work queues of the sched workspace (oneprot_dynamic_tiles): needs the workspace and four K-tiles per tile
-  a.dyn = (g_dyn_sched != nullptr && a.K >= 256) ? 1 : 0;
+  a.dyn = (EPI != G8_EPI_RESID_LN && g_dyn_sched != nullptr && a.K >= 256) ? 1 : 0;
   if (a.dyn) a.sched = g_dyn_sched;
   else if (EPI != G8_EPI_RESID_LN) a.sched = nullptr;
-  hipLaunchKernelGGL((k_gemm8<C, EPI, HB, DUAL>), dim3(g8n * 8), dim3(512), C::LDS, s, a, g8n, g_dph_groups, g_dph_sleeps);
+  hipLaunchKernelGGL((k_gemm8<C, EPI, HB, DUAL>), dim3(g8n * 8), dim3(512), C::LDS + (C::Y3 ? 0 : 64), s, a, g8n, g_dph_groups, g_dph_sleeps);      // (+ the ticket relay word where the buffers leave room)
   return launch_status();
 }
 

@@ -486,13 +486,23 @@ static int tn8_config(int N, int K) {
   return 0;
 }
 static int tn8_tiles(int cfg, int N, int K) { return cfg == 1 ? ((N + 255) / 256) * (K / 320) : (N / 320) * (K / 256); }
-static int tn8_cus() {
+// oneprot_cu_reserve: CUs left to co-resident kernels (RCCL channels of an overlapped all-reduce) when the one-shot work items of the weight-gradient GEMM are
+// counted: its grid is at most one work-group per CU, and a work-group that finds no CU free runs AFTER the others -- twice the launch time whatever the
+// number of CUs held.  With a reserve the token range is cut into fewer, slightly longer splits instead (another summation order than with reserve 0:
+// still fixed, still deterministic).  Process-wide; 0 by default (single-GPU runs).
+static int g_cu_reserve = 0;
+extern "C" void oneprot_cu_reserve(int cus) { g_cu_reserve = cus < 0 ? 0 : cus; }
+static int tn8_cus_all() {
   static int n_cu = 0;
   if (n_cu == 0) {
     int dev = 0; hipDeviceProp_t prop;
     n_cu = (hipGetDevice(&dev) == hipSuccess && hipGetDeviceProperties(&prop, dev) == hipSuccess && prop.multiProcessorCount > 0) ? prop.multiProcessorCount : 256;
   }
   return n_cu;
+}
+static int tn8_cus() {
+  const int n = tn8_cus_all() - g_cu_reserve;
+  return n < 64 ? 64 : n;
 }
 // token splits: one work item per CU at most, at most 64, at least 8 units (256 tokens) per split; 0 = leave it to the 128 x 128 kernels
 static int tn8_splits(int64_t M, int tiles, int n_cu, int64_t max_by_workspace) {
@@ -526,7 +536,7 @@ extern "C" size_t oneprot_gemm_bf16_tn_workspace(int N, int K) {
   int S = tn_splits(0, tiles);
   const int cfg = tn8_config(N, K);
   if (cfg) {                                                  // the 8-phase form may split finer (fewer, larger tiles)
-    int S8 = tn8_cus() / tn8_tiles(cfg, N, K);
+    int S8 = tn8_cus_all() / tn8_tiles(cfg, N, K);
     if (S8 > 64) S8 = 64;
     if (S8 > S) S = S8;
   }

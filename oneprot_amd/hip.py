@@ -55,6 +55,7 @@ _SIGS = {
     "oneprot_free_uncached": (I, [P]),
     "oneprot_sched_workspace_init": (I, [P, SZ, P]),
     "oneprot_dynamic_tiles": (None, [P, SZ]),
+    "oneprot_sched_late_draws": (I, [P]),
     "oneprot_gemm_bf16_nt_resid_ln8": (I, [P, P, L64, I, I, I, I, P, P, P, P, P, F, P, P, P, SZ, P]),
     "oneprot_gemm_resid_ln8_eligible": (I, [L64, I, I]),
     "oneprot_gemm_resid_ln8_error": (I, [P]),
@@ -66,6 +67,7 @@ _SIGS = {
     "oneprot_gemm_tune": (None, [I, I]),
     "oneprot_gemm_bf16_tn_workspace": (SZ, [I, I]),
     "oneprot_gemm_tn_variant": (None, [I]),
+    "oneprot_cu_reserve": (None, [I]),
     "oneprot_gemm_bf16_tn": (I, [P, P, L64, I, I, I, I, P, P, P, SZ, I, P]),
     "oneprot_sgemm": (I, [P, P, P, I, I, I, I, I, F, I, P]),
     "oneprot_attn_fwd": (I, [P, P, P, P, P, P, I, I, I, I, P]),
@@ -258,6 +260,14 @@ def dynamic_tiles_wanted():
     return os.environ.get("ONEPROT_DYNAMIC_TILES", "1") != "0"
 
 
+def cu_reserve_wanted():
+    """ONEPROT_CU_RESERVE=<n>; default 16 when this process is one of several ranks (the overlapped gradient all-reduce's RCCL channels hold CUs), else 0"""
+    v = os.environ.get("ONEPROT_CU_RESERVE")
+    if v is not None:
+        return int(v)
+    return 16 if int(os.environ.get("WORLD_SIZE", "1")) > 1 else 0
+
+
 def sched_workspace(rows=0, device=None):
     """(pointer, bytes) of the current device's sched workspace, sized for at least `rows` rows of row statistics"""
     dev = torch.cuda.current_device() if device is None else torch.device(device).index
@@ -271,6 +281,7 @@ def sched_workspace(rows=0, device=None):
             ws.release()
         ws = _sched[dev] = _SchedWorkspace(dev, new_rows)
         lib().oneprot_dynamic_tiles(ws.ptr if dynamic_tiles_wanted() else None, ws.bytes)
+        lib().oneprot_cu_reserve(cu_reserve_wanted())
     return ws.ptr, ws.bytes
 
 
@@ -285,6 +296,11 @@ def sched_error(device=None):
     """host-synchronous: 1 when a launch on this device's workspace wrote NaN rows because a bounded wait ran out (0 when no workspace exists yet)"""
     ws = _sched_of(device)
     return 0 if ws is None else ws.error()
+
+
+def sched_late_draws(device=None):
+    ws = _sched_of(device)
+    return 0 if ws is None else lib().oneprot_sched_late_draws(ws.ptr)
 
 
 def sched_error_clear(device=None):

@@ -1,8 +1,8 @@
-// Development probe (GPU): a kernel that HOLDS k compute units for a fixed wall time -- a stand-in for the RCCL channels of an overlapped gradient
+// Test / development probe (GPU): a kernel that HOLDS k compute units for a fixed wall time -- a stand-in for the RCCL channels of an overlapped gradient
 // all-reduce (one work-group per channel, resident for the length of the collective).  Every work-group declares 100 KB of LDS, so no two of them
 // share a CU and none of the product's 160 KB persistent work-groups can co-reside with one: the CU is taken.  The spin ends on the wall clock
 // (s_memrealtime, 100 MHz), a condition every wave reaches.
-// build: hipcc --offload-arch=gfx950 -O2 -shared -fPIC tools/ab/cu_spin.hip -o tools/ab/libcu_spin.so
+// build: __graft_entry__.build() -> tests/libcu_spin.so (used by tests/test_kernels_gpu.py and tools/ab/cu_occupier.py)
 #include <hip/hip_runtime.h>
 __global__ void __launch_bounds__(64) k_cu_spin(long long ticks, int* sink) {
   extern __shared__ int lds[];

@@ -373,6 +373,70 @@ def test_persistent_gemm_tiles_from_the_work_queue_bit_identical():
     assert hip.sched_error() == 0
 
 
+def test_persistent_kernels_beside_a_kernel_that_holds_compute_units():
+    import os
+    """Co-residency (DESIGN section 5): a side-stream kernel holds k CUs (tests/cu_spin.hip: 100 KB of LDS per work-group, so no persistent work-group fits
+    beside one) in windows that start and end INSIDE the product's launches -- what the RCCL channels of an overlapped gradient all-reduce do to the backward.
+    Work-groups of the persistent kernels then start late, in the middle of a launch or after the others have finished.  With tiles / slabs drawn from the
+    work queues every output stays bit for bit what the undisturbed launch wrote (every tile computed exactly once, no ticket lost or handed out twice, the
+    queues reset by the last work-group), the FFN-2 + LayerNorm launch (static list: its work-groups wait for each other) finishes without a wait running
+    out, and no ticket draw was found late."""
+    import ctypes
+    import time
+    lib_path = os.path.join(os.path.dirname(os.path.abspath(__file__)), "libcu_spin.so")
+    if not os.path.exists(lib_path):
+        pytest.skip("tests/libcu_spin.so not built (python -c 'import __graft_entry__ as g; g.build()')")
+    spin = ctypes.CDLL(lib_path)
+    spin.cu_spin_launch.argtypes = [ctypes.c_int, ctypes.c_longlong, ctypes.c_void_p, ctypes.c_void_p]
+    ws = hip.sched_workspace(131072)
+    g = torch.Generator().manual_seed(31)
+    M, d, f, B, H, L, hd = 65536, 640, 2560, 128, 20, 512, 32
+    A = bf(torch.randn(M, d, generator=g)).to(DEV)
+    W1 = bf(torch.randn(f, d, generator=g) * 0.1).to(DEV)
+    b1 = (torch.randn(f, generator=g) * 0.5).to(DEV)
+    U = bf(torch.randn(M, f, generator=g)).to(DEV)
+    W2 = bf(torch.randn(d, f, generator=g) * 0.05).to(DEV)
+    b2 = (torch.randn(d, generator=g) * 0.5).to(DEV)
+    resid = torch.randn(M, d, generator=g).to(DEV)
+    gamma, beta = (1 + 0.2 * torch.randn(d, generator=g)).to(DEV), (0.3 * torch.randn(d, generator=g)).to(DEV)
+    q, k, v = [bf(torch.randn(B, H, L, hd, generator=g) * 0.7).to(DEV) for _ in range(3)]
+    kb = torch.zeros(B, L, device=DEV)
+    sink = torch.zeros(4, dtype=torch.int32, device=DEV)
+    side = torch.cuda.Stream()
+
+    def run_all():
+        u = torch.empty(M, f, dtype=torch.bfloat16, device=DEV)
+        hip.call("oneprot_gemm_bf16_nt", A, W1, M, f, d, d, d, hip.EPI_BIAS_GELU, b1, u, None, None, None, None, None, 1.0, 0, 0, 0)
+        x = torch.empty(M, d, device=DEV)
+        hip.call("oneprot_gemm_bf16_nt", U, W2, M, d, f, f, f, hip.EPI_BIAS_RESID, b2, x, None, None, resid, None, None, 1.0, 0, 0, 0)
+        x8 = torch.empty(M, d, device=DEV)
+        h8 = torch.empty(M, d, dtype=torch.bfloat16, device=DEV)
+        hip.call("oneprot_gemm_bf16_nt_resid_ln8", U, W2, M, d, f, f, f, b2, resid, x8, gamma, beta, 1e-5, h8, None, *ws)
+        dg = torch.empty(M, d, dtype=torch.bfloat16, device=DEV)
+        hip.call("oneprot_gemm_bf16_nt", U, W2, M, d, f, f, f, hip.EPI_BF16, None, dg, None, None, None, None, None, 1.0, 0, 0, 0)
+        ctx = torch.empty(B * L, H * hd, dtype=torch.bfloat16, device=DEV)
+        lse = torch.empty(B, H, L, device=DEV)
+        hip.call("oneprot_attn_fwd", q, k, v, kb, ctx, lse, B, H, L, hd)
+        return u, x, x8, h8, dg, ctx, lse
+    assert hip.dynamic_tiles_wanted(), "the default: tiles drawn from the work queues"
+    ref = run_all()
+    torch.cuda.synchronize()
+    late0 = hip.sched_late_draws()
+    for rep, (cus, win_us, gap_s) in enumerate([(8, 300, 0.0004), (24, 150, 0.0002), (4, 700, 0.0007), (32, 100, 0.0001), (8, 2000, 0.001)]):
+        outs = []
+        for _ in range(4):                                      # ~1 ms of launches per pass; the windows land at host-timed points inside them
+            spin.cu_spin_launch(cus, win_us, sink.data_ptr(), side.cuda_stream)
+            outs.append(run_all())
+            time.sleep(gap_s)
+            spin.cu_spin_launch(cus, win_us, sink.data_ptr(), side.cuda_stream)
+        torch.cuda.synchronize()
+        for got in outs:
+            for a_, b_, name in zip(got, ref, ("gelu", "resid", "x ln8", "h ln8", "bf16", "ctx", "lse")):
+                assert torch.equal(a_, b_), (name, rep, cus)
+    assert hip.sched_error() == 0
+    assert hip.sched_late_draws() == late0
+
+
 def test_gemm_resid_layernorm_forms_bit_identical():
     """the two kernel forms run the same arithmetic in the same order: equal bits"""
     M, K, N = 4096, 640, 640

@@ -1,9 +1,9 @@
 #!/usr/bin/env python3
-"""Development tool (GPU): what a co-resident kernel that holds k compute units (tools/ab/cu_spin.hip: the stand-in for the RCCL channels of an
+"""Development tool (GPU): what a co-resident kernel that holds k compute units (tests/cu_spin.hip: the stand-in for the RCCL channels of an
 overlapped gradient all-reduce) does to the persistent one-work-group-per-CU kernels of the training step.  Runs the cfg-2 sub-step of bench.py
 with k in {0, 4, 8, 16, 32} CUs held on a side stream (a) for the whole step and (b) for `--window-ms` windows inside the backward, as an
 all-reduce of one ~118 MB gradient range would (0.7 ms at the xGMI ring rate; five per tower and step), and prints ms per step.
-usage: cu_occupier.py [--steps 5] [--window-ms 0.7] [--windows 5]        (build: hipcc --offload-arch=gfx950 -O2 -shared -fPIC tools/ab/cu_spin.hip -o tools/ab/libcu_spin.so)"""
+usage: cu_occupier.py [--steps 5] [--window-ms 0.7] [--windows 5]        (tests/libcu_spin.so is built by __graft_entry__.build())"""
 import argparse, ctypes, os, statistics, sys, time
 ROOT = os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 sys.path.insert(0, ROOT)
@@ -16,8 +16,10 @@ ap.add_argument("--steps", type=int, default=5)
 ap.add_argument("--window-ms", type=float, default=0.7)
 ap.add_argument("--windows", type=int, default=5)
 ap.add_argument("--batch", type=int, default=256)
+ap.add_argument("--only", default="", help="whole | windows: only that part")
+ap.add_argument("--ks", default="4,8,16,32")
 a = ap.parse_args()
-spin = ctypes.CDLL(os.path.join(os.path.dirname(os.path.abspath(__file__)), "libcu_spin.so"))
+spin = ctypes.CDLL(os.path.join(ROOT, "tests", "libcu_spin.so"))
 spin.cu_spin_launch.argtypes = [ctypes.c_int, ctypes.c_longlong, ctypes.c_void_p, ctypes.c_void_p]
 dev = torch.device("cuda:0")
 _argv = sys.argv
@@ -63,14 +65,18 @@ for _ in range(3):
 torch.cuda.synchronize()
 base = statistics.median(timed(0) for _ in range(a.steps))
 print(f"cfg-2 sub-step, batch {a.batch}: {base:.1f} ms with nothing else on the GPU", flush=True)
+KS = [int(x) for x in a.ks.split(",")]
 print("k CUs held for the WHOLE step (spin resident before the first kernel):", flush=True)
-for k in (4, 8, 16, 32):
+for k in (KS if a.only in ("", "whole") else []):
     t = statistics.median(timed(k, whole_step_us=int(base * 1.6e3)) for _ in range(a.steps))
     print(f"  k = {k:3d}: {t:7.1f} ms  ({t / base:.3f} x)", flush=True)
     torch.cuda.synchronize(); time.sleep(0.3)
 win_us = int(a.window_ms * 1e3)
 gap = base * 0.6 / max(a.windows, 1)                        # spread over the backward (the last ~2/3 of the step)
 print(f"k CUs held for {a.windows} windows of {a.window_ms} ms inside the step (an overlapped all-reduce of five gradient ranges); exposed instead they would cost {a.windows * a.window_ms:.1f} ms:", flush=True)
-for k in (4, 8, 16, 32):
+for k in (KS if a.only in ("", "windows") else []):
     t = statistics.median(timed(k, windows=a.windows, window_us=win_us, gap_ms=gap) for _ in range(a.steps))
     print(f"  k = {k:3d}: {t:7.1f} ms  (+{t - base:.1f} ms)", flush=True)
+
+from oneprot_amd import hip
+print(f"sched workspace after the run: late ticket draws {hip.sched_late_draws()}, bounded waits that ran out {hip.sched_error()}", flush=True)

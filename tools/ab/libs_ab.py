@@ -28,6 +28,13 @@ for spec in sys.argv[1:]:
         h.oneprot_gemm_ln_form(int(name.split("@gln")[1]))          # (form | start delay of the second half of the grid in us << 8)
     if "@bwd" in name:                                             # e.g. split@bwd0=product: the attention backward path forced (0 split, 1 fused 16 waves, 2 fused 8 waves)
         h.oneprot_attn_force_bwd_path(int(name.split("@bwd")[1]))
+    if "@dyn" in name:                                             # e.g. dyn@dyn=tools/ab/lib_copy.so: tiles of the persistent GEMMs drawn from the work queues of a sched workspace
+        wsb = h.oneprot_sched_workspace_bytes(131072)
+        out = ctypes.c_void_p()
+        assert h.oneprot_alloc_uncached(ctypes.byref(out), wsb) == 0
+        assert h.oneprot_sched_workspace_init(out.value, wsb, None) == 0
+        torch.cuda.synchronize()
+        h.oneprot_dynamic_tiles(out.value, wsb)
     if "@fwd" in name:                                             # e.g. chunked@fwd2=product: the same library with the attention forward path forced
         h.oneprot_attn_force_fwd_path(int(name.split("@fwd")[1]))
 if not libs:
