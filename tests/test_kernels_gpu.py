@@ -38,7 +38,7 @@ def ws(nbytes):
 
 # ------------------------------------------------------------------------------------------------------
 def test_library_loads():
-    assert hip.query("oneprot_abi_version") == 6
+    assert hip.query("oneprot_abi_version") == hip.ABI_VERSION == 7
 
 
 @pytest.mark.parametrize("B,L,d,vocab", [(3, 17, 64, 33), (4, 130, 640, 54)])
