@@ -307,10 +307,13 @@ __global__ void __launch_bounds__(512, 2) k_gemm8(const GemmArgs p, const int g8
   // r3 = s % 3 (Y0 ring slot under Y3).
   int r3 = 0;
   constexpr int ST = epilogue_stores<EPI, DUAL, MT, NT>();
+  // the QKV + RoPE kernel with a bias on 256 x 320 tiles sits at 256 registers: the ticket is read at the head of P1's MFMA slot there (the form that fits;
+  // ~1 % of that launch), everywhere else in P2's read slot
+  constexpr bool RELAY_IN_P1 = C::Y3 && EPI == ONEPROT_EPI_QKV_ROPE && HB;
   unsigned relay_addr = 0;                                  // LDS byte address of the ticket relay word of the tile being entered
   int lim = tk_nxt < Tx ? 0x7fffffff : nk;                 // K-tiles the operand stream may run ahead to, counted from the current tile's first
   constexpr unsigned RELAY = C::Y3 ? 0u : (unsigned)C::LDS;      // byte offset of the ticket relay word (Y3: inside the Y0 ring slot that is dead at that time)
-  auto ktile = [&](auto bufc, int s, int t, const bool after_epi, const bool relay_now) __attribute__((always_inline)) {
+  auto ktile = [&](auto bufc, int s, int t, const bool after_epi, const int relay_flag) __attribute__((always_inline)) {
     constexpr int BUFI = decltype(bufc)::value;
     stamp_s = s; stamp_ph = 0;
     const unsigned char* bufp = smem + BUFI * C::BUF;
@@ -329,17 +332,30 @@ __global__ void __launch_bounds__(512, 2) k_gemm8(const GemmArgs p, const int g8
     wait_lgkm<NY>();
     bar();
     STAMP(0);
-    unsigned relay = 0;
-    if (relay_now) relay = lds_read32(relay_addr);          // wave 0 wrote it before this barrier; under Y3 the slot's refill is issued in P3
-    wait_lgkm<0>();
-    if (relay_now) { tk_nxt = first_lane(relay); lim = tk_nxt < Tx ? 0x7fffffff : nk; }
-    const bool more2 = t + 2 < lim;
+    if constexpr (RELAY_IN_P1) {                            // (see P2: this instantiation has no register to spare there)
+      unsigned relay = 0;
+      if (relay_flag != 0) relay = lds_read32(relay_addr);
+      wait_lgkm<0>();
+      if (relay_flag != 0) { tk_nxt = first_lane(relay); lim = tk_nxt < Tx ? 0x7fffffff : nk; }
+    } else {
+      wait_lgkm<0>();
+    }
     __builtin_amdgcn_sched_barrier(0);
     quadrant(std::integral_constant<int, 0>{}, std::integral_constant<int, 0>{});
     __builtin_amdgcn_sched_barrier(0);
     bar();
     STAMP(1);
-    // P2 (X0, Y1)
+    // P2 (X0, Y1).  First K-tile after an epilogue with drawn tickets: the next tile's ticket arrives here, in a READ slot (wave 0 wrote the word before
+    // P1's first barrier; under Y3 the slot it lies in is refilled from P3 on) -- not at the head of an MFMA slot, where every instruction delays the run
+    if constexpr (!RELAY_IN_P1) {
+      if (relay_flag != 0) {
+        const unsigned relay = lds_read32(relay_addr);
+        wait_lgkm<0>();
+        tk_nxt = first_lane(relay);
+        lim = tk_nxt < Tx ? 0x7fffffff : nk;
+      }
+    }
+    const bool more2 = t + 2 < lim;
     c2 = c1; cur_next(c2);
     read_y(std::integral_constant<int, 1>{}, bufp + C::OFF_Y1);
     __builtin_amdgcn_sched_barrier(0);
@@ -422,19 +438,19 @@ __global__ void __launch_bounds__(512, 2) k_gemm8(const GemmArgs p, const int g8
     wait_lgkm<0>();
     bar();
     STAMP(0);
-    if (dyn && first) {
-      const unsigned relay = lds_read32(relay_addr);
-      wait_lgkm<0>();
-      tk_nxt = first_lane(relay);
-      lim = tk_nxt < Tx ? 0x7fffffff : nk;
-    }
-    const bool more2 = t + 2 < lim;
     __builtin_amdgcn_sched_barrier(0);
     quadrant(std::integral_constant<int, 0>{}, std::integral_constant<int, 0>{});
     quadrant(std::integral_constant<int, 0>{}, std::integral_constant<int, 1>{});
     __builtin_amdgcn_sched_barrier(0);
     bar();
     STAMP(1);
+    if (dyn && first) {                                     // (the next tile's ticket: see ktile)
+      const unsigned relay = lds_read32(relay_addr);
+      wait_lgkm<0>();
+      tk_nxt = first_lane(relay);
+      lim = tk_nxt < Tx ? 0x7fffffff : nk;
+    }
+    const bool more2 = t + 2 < lim;
     // phase B
     c2 = c1; cur_next(c2);
     read_x(bufp + C::OFF_X1);
@@ -490,6 +506,7 @@ __global__ void __launch_bounds__(512, 2) k_gemm8(const GemmArgs p, const int g8
   int s = 0;
   bool after_epi = false;
   const int draw_lane = (dyn && wave == 0) ? 1 : 0;         // EXEC mask of the draw: lane 0 of wave 0
+  int relay_flag = 0;                                       // 1 in the first K-tile of a tile whose successor's ticket was drawn (it arrives there)
   // One LDS-DMA-free way to hand a drawn ticket to all eight waves: wave 0 draws (a returning agent-scope atomic, issued ahead of the tile's LAST two K-tiles
   // and looked at behind their last counted wait: loads return in order, so it has returned when that wait is over), keeps the value in a scalar register over
   // the epilogue and writes it into LDS behind it -- 4 bytes that are free at that time: spare bytes behind the buffers, or under Y3 (all 160 KB taken) the Y0
@@ -500,8 +517,9 @@ __global__ void __launch_bounds__(512, 2) k_gemm8(const GemmArgs p, const int g8
       ktile2(std::integral_constant<int, 0>{}, s, t);
       ktile2(std::integral_constant<int, 1>{}, s + 1, t + 1);
     } else {
-      ktile(std::integral_constant<int, 0>{}, s, t, after_epi, after_epi && dyn);
-      ktile(std::integral_constant<int, 1>{}, s + 1, t + 1, false, false);
+      ktile(std::integral_constant<int, 0>{}, s, t, after_epi, relay_flag);
+      ktile(std::integral_constant<int, 1>{}, s + 1, t + 1, false, 0);
+      relay_flag = 0;
       after_epi = false;
     }
     s += 2;
@@ -553,7 +571,7 @@ __global__ void __launch_bounds__(512, 2) k_gemm8(const GemmArgs p, const int g8
       relay_addr = lds0 + (C::Y3 ? C::RING_Y0 + (r3 == 0 ? 2 : r3 - 1) * C::Y_UNIT : RELAY);
       if (wave == 0) lds_write32(relay_addr, (unsigned)drawn);      // (every lane of the wave: the same word, the same value)
       tk_cur = tk_nxt;                                                       // (tk_nxt: read back by every wave in the first K-tile of the new tile)
-      tk_nxt = 0x7fffffff; lim = nk;
+      tk_nxt = 0x7fffffff; lim = nk; relay_flag = 1;
     } else {
       tk_cur = tk_nxt; tk_nxt += g8n;
       lim = tk_nxt < Tx ? 0x7fffffff : nk;

@@ -64,6 +64,6 @@ __device__ __forceinline__ int draw_result(unsigned v, int& late) {
 }
 // the ticket relay word in LDS: plain ds instructions from inline asm (through a volatile C++ access hipcc emitted FLAT instructions with a vmcnt(0) behind
 // them -- a drain of the operand prefetch, or of the epilogue's store burst); the reader's wait is the K-tile's own lgkmcnt(0)
-__device__ __forceinline__ unsigned lds_read32(unsigned addr) { unsigned v; asm volatile("ds_read_b32 %0, %1" : "=v"(v) : "v"(addr) : "memory"); return v; }
+__device__ __forceinline__ unsigned lds_read32(unsigned addr) { unsigned v = addr; asm volatile("ds_read_b32 %0, %0" : "+v"(v) : : "memory"); return v; }      // (address and result in ONE register)
 __device__ __forceinline__ void lds_write32(unsigned addr, unsigned val) { asm volatile("ds_write_b32 %0, %1" ::"v"(addr), "v"(val) : "memory"); }
 __device__ __forceinline__ int first_lane(unsigned v) { int s; asm volatile("v_readfirstlane_b32 %0, %1" : "=s"(s) : "v"(v)); return s; }

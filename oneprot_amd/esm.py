@@ -99,7 +99,7 @@ class ArenaModule(nn.Module):
 
     # Counter-based dropout streams (Philox key = seed, counter high words = stream id): every consumer gets a domain of its own so that no two
     # of them can draw the same mask -- bits 60..63 the purpose (1: BERT hidden / attention dropout, 2: LoRA dropout), bits 44..59 the tower
-    # (construction order within the process), bits 0..43 the consumer's own (call, layer, site) numbering.
+    # (construction order within the process until OneProtLitModule re-numbers it by modality name; saved / restored with the stream state), bits 0..43 the consumer's own (call, layer, site) numbering.
     RNG_DOMAIN_BERT, RNG_DOMAIN_LORA = 1, 2
     _next_rng_uid = 0
 
@@ -116,10 +116,13 @@ class ArenaModule(nn.Module):
     def rng_state(self):
         """Seeds and call counters of the dropout streams (plain ints): what a checkpoint has to carry for a resumed run to continue the mask
         sequence instead of replaying it from call 0 (OneProtLitModule.on_save_checkpoint / on_load_checkpoint)."""
-        return {k: int(getattr(self, k)) for k in ("_lora_seed", "_lora_calls", "_drop_seed", "_drop_calls") if getattr(self, k, None) is not None}
+        st = {k: int(getattr(self, k)) for k in ("_lora_seed", "_lora_calls", "_drop_seed", "_drop_calls") if getattr(self, k, None) is not None}
+        if st:
+            st["_rng_uid"] = int(self._rng_uid)              # the tower id inside the stream ids: a resumed process continues THESE streams
+        return st
 
     def set_rng_state(self, state):
-        for k in ("_lora_seed", "_lora_calls", "_drop_seed", "_drop_calls"):
+        for k in ("_lora_seed", "_lora_calls", "_drop_seed", "_drop_calls", "_rng_uid"):
             if k in state:
                 setattr(self, k, int(state[k]))
 

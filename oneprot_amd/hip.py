@@ -255,9 +255,14 @@ SCHED_MIN_ROWS = 131072
 
 
 def dynamic_tiles_wanted():
-    """ONEPROT_DYNAMIC_TILES=1 / 0; default: on (tiles of the persistent GEMMs drawn from work queues: a co-resident kernel that holds CUs -- an RCCL channel of the
-    overlapped gradient all-reduce, another process -- then costs its share of the chip instead of 1.47 x per launch; bit-identical results)."""
-    return os.environ.get("ONEPROT_DYNAMIC_TILES", "1") != "0"
+    """ONEPROT_DYNAMIC_TILES=1 / 0; default: on when this process is one of several ranks (WORLD_SIZE > 1), off otherwise.  On = the tiles of the persistent NT GEMMs
+    and the slabs of the attention forward are drawn from work queues: a co-resident kernel that holds CUs -- an RCCL channel of the overlapped gradient
+    all-reduce -- then costs its share of the chip instead of 1.47 x per launch (profiles/r06_cu_occupier.txt); bit-identical results either way, a tie in
+    time on a GPU that runs nothing else."""
+    v = os.environ.get("ONEPROT_DYNAMIC_TILES")
+    if v is not None:
+        return v != "0"
+    return int(os.environ.get("WORLD_SIZE", "1")) > 1
 
 
 def cu_reserve_wanted():

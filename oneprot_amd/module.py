@@ -153,6 +153,13 @@ class OneProtLitModule(_Base):
             self.hparams = SimpleNamespace(optimizer=optimizer, scheduler=scheduler)
         self.network = torch.nn.ModuleDict(components)
         self.modalities = list(components.keys())
+        # dropout stream ids carry the tower: tie it to the MODALITY NAME (stable across processes, whatever order the towers were built in; two copies of one
+        # tower under two names draw different masks) rather than to the construction order the tower numbered itself with
+        import zlib
+        for name, enc in self.network.items():
+            tr = getattr(enc, "transformer", None)
+            if hasattr(tr, "_rng_uid"):
+                tr._rng_uid = zlib.crc32(name.encode()) & 0xFFFF
         self.train_on_all_modalities_after_step = train_on_all_modalities_after_step
         self.use_l1_regularization = use_l1_regularization
         self.loss_fn = self._create_loss_fn(loss_fn, local_loss, gather_with_grad)
@@ -342,10 +349,17 @@ class OneProtLitModule(_Base):
                                                  if hasattr(getattr(enc, "transformer", None), "rng_state")}
 
     def on_load_checkpoint(self, checkpoint):
-        for m, state in (checkpoint.get("oneprot_amd_dropout_rng") or {}).items():
+        saved = checkpoint.get("oneprot_amd_dropout_rng") or {}
+        for m, state in saved.items():
             tr = getattr(self.network[m], "transformer", None) if m in self.network else None
             if hasattr(tr, "set_rng_state"):
                 tr.set_rng_state(state)
+        if saved:      # a tower with dropout streams that the checkpoint knows nothing about would silently restart its mask sequence
+            missing = [m for m, enc in self.network.items() if m not in saved and getattr(enc, "transformer", None) is not None
+                       and hasattr(enc.transformer, "rng_state") and enc.transformer.rng_state()]
+            if missing:
+                import warnings
+                warnings.warn(f"checkpoint carries no dropout stream state for {missing}: their mask sequences restart from call 0")
 
     # ------------------------------------------------------------------------------------------- minimal driver
     def fit_steps(self, batches):

@@ -275,13 +275,16 @@ def test_checkpoint_wire_format(golden_dir, tmp_path, monkeypatch):
     tr1.enable_lora(4, 8, ["query", "key", "value"], dropout=0.1)
     tr1._lora_calls = 17
     save_checkpoint(m1, ck)
-    assert torch.load(ck, weights_only=True)["oneprot_amd_dropout_rng"]["struct_token"] == {"_lora_seed": tr1._lora_seed, "_lora_calls": 17}
+    import zlib
+    assert tr1._rng_uid == zlib.crc32(b"struct_token") & 0xFFFF      # the tower id of the stream ids = the modality name, not the construction order
+    assert torch.load(ck, weights_only=True)["oneprot_amd_dropout_rng"]["struct_token"] == {"_lora_seed": tr1._lora_seed, "_lora_calls": 17, "_rng_uid": tr1._rng_uid}
     m3 = make()
     tr3 = m3.network["struct_token"].transformer
     tr3.enable_lora(4, 8, ["query", "key", "value"], dropout=0.1)
     tr3._lora_seed = 1
+    tr3._rng_uid = 5                                                # (a process that numbered its towers differently)
     load_weights_only(m3, ck)
-    assert (tr3._lora_seed, tr3._lora_calls) == (tr1._lora_seed, 17)
+    assert (tr3._lora_seed, tr3._lora_calls, tr3._rng_uid) == (tr1._lora_seed, 17, tr1._rng_uid)
     # every consumer of the counter-based generator has a stream domain of its own: purpose and tower enter the stream id
     seq_tr = m1.network["sequence"].transformer
     assert tr1._rng_uid != seq_tr._rng_uid

@@ -418,8 +418,9 @@ def test_persistent_kernels_beside_a_kernel_that_holds_compute_units():
         lse = torch.empty(B, H, L, device=DEV)
         hip.call("oneprot_attn_fwd", q, k, v, kb, ctx, lse, B, H, L, hd)
         return u, x, x8, h8, dg, ctx, lse
-    assert hip.dynamic_tiles_wanted(), "the default: tiles drawn from the work queues"
-    ref = run_all()
+    hip.query("oneprot_dynamic_tiles", None, 0)
+    ref = run_all()                                              # static lists, nothing else on the GPU
+    hip.query("oneprot_dynamic_tiles", ws[0], ws[1])             # (the multi-rank default)
     torch.cuda.synchronize()
     late0 = hip.sched_late_draws()
     for rep, (cus, win_us, gap_s) in enumerate([(8, 300, 0.0004), (24, 150, 0.0002), (4, 700, 0.0007), (32, 100, 0.0001), (8, 2000, 0.001)]):
@@ -433,6 +434,7 @@ def test_persistent_kernels_beside_a_kernel_that_holds_compute_units():
         for got in outs:
             for a_, b_, name in zip(got, ref, ("gelu", "resid", "x ln8", "h ln8", "bf16", "ctx", "lse")):
                 assert torch.equal(a_, b_), (name, rep, cus)
+    hip.query("oneprot_dynamic_tiles", ws[0] if hip.dynamic_tiles_wanted() else None, ws[1])
     assert hip.sched_error() == 0
     assert hip.sched_late_draws() == late0
 
