@@ -93,6 +93,11 @@ class _Out:
         return (self.last_hidden_state, self.pooler_output)[i]
 
 
+# experiment hook: ONEPROT_GELU_CODE_DROP_BITS=n rounds the saved one-byte gelu'(z) codes to 8 - n bits (n = 1: twice the quantisation step).  Used by
+# tests/test_baseline_shapes_gpu.py to attribute the backward's deviation from the fp32 oracle; 0 (default) leaves the codes alone.
+_GELU_CODE_DROP_BITS = int(os.environ.get("ONEPROT_GELU_CODE_DROP_BITS", "0"))
+
+
 class ArenaModule(nn.Module):
     """Parameters of a whole encoder in one fp32 arena (`flat`) with named views, a bf16 mirror for the MFMA GEMMs, and
     state-dict hooks that expose / accept the HF key names."""
@@ -749,6 +754,9 @@ class EsmTransformer(ArenaModule):
                 hip.call("oneprot_layernorm_fwd", x_mid, 0, self.view(p + "LayerNorm.weight"), self.view(p + "LayerNorm.bias"), h2, None, m2, r2, T, d, eps)
             hip.call("oneprot_gemm_bf16_nt", h2, self._w16(p + "intermediate.dense.weight"), T, f, d, d, d, hip.EPI_BIAS_GELU,
                      self.view(p + "intermediate.dense.bias"), u, z, None, None, None, None, 1.0, 0, 0, 0)
+            if z is not None and _GELU_CODE_DROP_BITS:      # experiment hook (tests: what the one-byte gelu' codes cost the gradient): keep only the top 8 - n bits
+                nb = _GELU_CODE_DROP_BITS
+                z.add_(1 << (nb - 1)).bitwise_and_(0xFF & ~((1 << nb) - 1))
             x_out = f32(T, d) if save else x_mid
             if ffn2_ln and i + 1 < self.n_layers:
                 pn = f"encoder.layer.{i + 1}.attention.LayerNorm."

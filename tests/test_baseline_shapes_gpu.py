@@ -182,6 +182,22 @@ def test_cfg2_shape_150m_batch16_loss_delta_reported(frozen_seq):
     if not frozen_seq:
         # (the sequence tower sits at 0.99990 in five digits -- rounds 4 and 5: 0.9999009, 0.9998994 -- so its gate is the next digit down)
         rec["whole_gradient_cosine_sequence_tower"] = _check_arena_grads(grads["sequence"], ref["grads"], "seq.", whole=0.99985)
+        # Attribution: which part of 1 - cosine do the one-byte gelu'(z) codes of round 5 own?  The same sub-step with the codes rounded to 7 and
+        # to 6 bits (2 x and 4 x the quantisation step: 4 x and 16 x the variance of that error).  If e2 is the codes' share of the deficit D = 1 - cos and r
+        # everything else (bf16 operands, bf16 dqkv, ...): D8 = r + e2, D7 = r + 4 e2, D6 = r + 16 e2.
+        from oneprot_amd import esm as esm_mod
+        deficits = {8: 1.0 - rec["whole_gradient_cosine_sequence_tower"]}
+        try:
+            for nb in (1, 2):
+                esm_mod._GELU_CODE_DROP_BITS = nb
+                _, _, g_nb, _ = _cfg2_case(16, lens, frozen_seq, seed=1882)
+                deficits[8 - nb] = 1.0 - _check_arena_grads(g_nb["sequence"], ref["grads"], "seq.", whole=0.999, per_tensor=0.99)
+        finally:
+            esm_mod._GELU_CODE_DROP_BITS = 0
+        e2 = (deficits[7] - deficits[8]) / 3.0
+        rec["gelu_code_attribution"] = {"one_minus_cosine_by_code_bits": {str(k): v for k, v in sorted(deficits.items())},
+                                        "share_of_the_8_bit_codes": e2, "everything_else": deficits[8] - e2,
+                                        "check_6_bits_predicted": deficits[8] - e2 + 16.0 * e2, "check_6_bits_measured": deficits[6]}
     out = os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "gpurun_out")
     os.makedirs(out, exist_ok=True)
     with open(os.path.join(out, "loss_delta_b16.json" if frozen_seq else "loss_delta_b16_trainable_seq.json"), "w") as f:
