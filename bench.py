@@ -45,7 +45,7 @@ import time
 ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, ROOT)
 
-PROFILE_ROUND = "r05"         # committed rocprofv3 summaries this file quotes (profiles/<round>_*.json, tools/profile_round.sh)
+PROFILE_ROUND = "r06"         # committed rocprofv3 summaries this file quotes (profiles/<round>_*.json, tools/profile_round.sh)
 PEAK_BF16_TFLOPS = 2500.0
 PEAK_HBM_GBS = 8000.0
 ESM = {"8M": "facebook/esm2_t6_8M_UR50D", "35M": "facebook/esm2_t12_35M_UR50D", "150M": "facebook/esm2_t30_150M_UR50D", "650M": "facebook/esm2_t33_650M_UR50D"}
