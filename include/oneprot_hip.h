@@ -111,6 +111,8 @@ int oneprot_sched_workspace_init(void* sched_ws, size_t bytes, void* stream);
 void oneprot_dynamic_tiles(void* sched_ws, size_t bytes);
 /* diagnostic, host-synchronous: ticket draws that had not returned where the kernel first looked for them (each costs one drained operand prefetch; 0 expected) */
 int oneprot_sched_late_draws(const void* sched_ws);
+/* diagnostic, host-synchronous: launches completed on this workspace = its device-side epoch (-1: read failed) */
+int64_t oneprot_sched_epoch(const void* sched_ws);
 /* The same product with the row statistics completed ACROSS work-groups, for the launches whose K loop the full-row kernel above runs too slowly
  * (FFN-2, K = 4 d): x_out = resid + A W^T + bias (fp32; may alias resid) and h = LayerNorm(x_out) (bf16), by the 8-phase GEMM on 256 x 320 tiles; the
  * column tiles of a row panel exchange (mean, M2) partials through the sched workspace (hf modeling_esm.py:442-463 followed by :429 of the next layer or by

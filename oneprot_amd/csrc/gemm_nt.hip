@@ -1104,6 +1104,12 @@ extern "C" int oneprot_sched_late_draws(const void* sched_ws) {
   if (hipMemcpy(&e, (const unsigned*)sched_ws + SW_LATE_DRAWS, sizeof(e), hipMemcpyDeviceToHost) != hipSuccess) return -1;
   return (int)e;
 }
+// diagnostic (host-synchronous): launches that have completed on this workspace (the device-side epoch the tags come from)
+extern "C" int64_t oneprot_sched_epoch(const void* sched_ws) {
+  unsigned e = 0;
+  if (!sched_ws || hipMemcpy(&e, (const unsigned*)sched_ws + SW_EPOCH, sizeof(e), hipMemcpyDeviceToHost) != hipSuccess) return -1;
+  return (int64_t)e;
+}
 extern "C" int oneprot_gemm_resid_ln8_error_clear(void* sched_ws, void* stream) {
   if (!sched_ws) return OP_EINVAL;
   return hipMemsetAsync((unsigned*)sched_ws + SW_LN_ERR, 0, 4, (hipStream_t)stream) == hipSuccess ? 0 : OP_ELAUNCH;

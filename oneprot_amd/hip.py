@@ -56,6 +56,7 @@ _SIGS = {
     "oneprot_sched_workspace_init": (I, [P, SZ, P]),
     "oneprot_dynamic_tiles": (None, [P, SZ]),
     "oneprot_sched_late_draws": (I, [P]),
+    "oneprot_sched_epoch": (L64, [P]),
     "oneprot_gemm_bf16_nt_resid_ln8": (I, [P, P, L64, I, I, I, I, P, P, P, P, P, F, P, P, P, SZ, P]),
     "oneprot_gemm_resid_ln8_eligible": (I, [L64, I, I]),
     "oneprot_gemm_resid_ln8_error": (I, [P]),

@@ -373,6 +373,54 @@ def test_persistent_gemm_tiles_from_the_work_queue_bit_identical():
     assert hip.sched_error() == 0
 
 
+def test_sched_workspace_launches_replay_from_a_graph():
+    """include/oneprot_hip.h: "every function that takes a stream only enqueues work on it ... graph-capturable".  The launches that keep bookkeeping between
+    launches -- the FFN-2 + LayerNorm GEMM (tagged partial statistics) and the GEMMs that draw their tiles from the work queues -- are captured ONCE into a HIP graph
+    and replayed: nothing on the host advances between replays, so the tags and the queue heads must be advanced by the kernels themselves (the last work-group
+    to leave).  Every replay reproduces the eager results bit for bit on fresh inputs' outputs, no wait runs out, and the device-side epoch has moved by one per launch."""
+    ws = hip.sched_workspace(131072)
+    g = torch.Generator().manual_seed(41)
+    M, d, f = 33024, 640, 2560
+    U = bf(torch.randn(M, f, generator=g)).to(DEV)
+    W2 = bf(torch.randn(d, f, generator=g) * 0.05).to(DEV)
+    b2 = (torch.randn(d, generator=g) * 0.5).to(DEV)
+    resid = torch.randn(M, d, generator=g).to(DEV)
+    gamma, beta = (1 + 0.2 * torch.randn(d, generator=g)).to(DEV), (0.3 * torch.randn(d, generator=g)).to(DEV)
+    x8 = torch.empty(M, d, device=DEV); h8 = torch.empty(M, d, dtype=torch.bfloat16, device=DEV); st = torch.empty(2, M, device=DEV)
+    xg = torch.empty(M, d, device=DEV)
+
+    def launches():
+        hip.call("oneprot_gemm_bf16_nt_resid_ln8", U, W2, M, d, f, f, f, b2, resid, x8, gamma, beta, 1e-5, h8, st, *ws)
+        hip.call("oneprot_gemm_bf16_nt", U, W2, M, d, f, f, f, hip.EPI_BIAS_RESID, b2, xg, None, None, resid, None, None, 1.0, 0, 0, 0)
+
+    try:
+        hip.query("oneprot_dynamic_tiles", ws[0], ws[1])
+        launches()
+        torch.cuda.synchronize()
+        ref = [t.clone() for t in (x8, h8, st, xg)]
+        side = torch.cuda.Stream()
+        side.wait_stream(torch.cuda.current_stream())
+        graph = torch.cuda.CUDAGraph()
+        with torch.cuda.stream(side):
+            launches()                                           # warm-up on the capture stream
+            torch.cuda.synchronize()
+            with torch.cuda.graph(graph, stream=side):
+                launches()
+        torch.cuda.synchronize()
+        e0 = hip.query("oneprot_sched_epoch", ws[0])
+        for rep in range(4):
+            for t in (x8, h8, st, xg):
+                t.fill_(float("nan"))
+            graph.replay()
+            torch.cuda.synchronize()
+            for a_, b_, name in zip((x8, h8, st, xg), ref, ("x ln8", "h ln8", "stats", "x plain")):
+                assert torch.equal(a_, b_), (name, rep)
+        assert hip.query("oneprot_sched_epoch", ws[0]) - e0 == 4 * 2          # two launches per replay went through the workspace: the device counted them
+        assert hip.sched_error() == 0 and hip.sched_late_draws() == 0
+    finally:
+        hip.query("oneprot_dynamic_tiles", ws[0] if hip.dynamic_tiles_wanted() else None, ws[1])
+
+
 def test_persistent_kernels_beside_a_kernel_that_holds_compute_units():
     import os
     """Co-residency (DESIGN section 5): a side-stream kernel holds k CUs (tests/cu_spin.hip: 100 KB of LDS per work-group, so no persistent work-group fits
