@@ -1046,7 +1046,7 @@ __global__ void __launch_bounds__(512, 2) k_attn_fwd3(const bf16_t* __restrict__
       asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
       bh_next = xcd * per_xcd + first_lane(rv);
     }
-    drawn_v = draw_async(sched + SW_HEAD(xcd), draw_lane & (int)((unsigned)(bh_next - bh_end) >> 31));      // (EXEC mask empty unless this wave draws and a next slab exists)
+    drawn_v = draw_async(sched ? sched + SW_HEAD(xcd) : nullptr, draw_lane & (int)((unsigned)(bh_next - bh_end) >> 31));      // (EXEC mask empty unless this wave draws and a next slab exists)
     // hipcc does not see the wait above: it would put its own vmcnt(0) in front of the first use of the q fragments -- behind the LDS-DMA of the
     // NEXT slab, i.e. the compute would start only after that transfer.  Consuming the fragments here puts its wait where it is free.
 #pragma unroll
@@ -1120,7 +1120,7 @@ __global__ void __launch_bounds__(512, 2) k_attn_fwd3(const bf16_t* __restrict__
   }
   if (pend_bh >= 0 && active)
     for (int i = 0; i < NST; ++i) store1(pend, pend_bh, i);
-  if (sched && threadIdx.x == 0) sw_leave(sched, gridDim.x);
+  if (sched && threadIdx.x == 0) sw_leave(sched, gridDim.x, (unsigned)slab_no, (unsigned)nbh);
 }
 
 // ---- k_attn_fwd3w: the persistent form for 128-byte rows (hd = 64: BERT-base, ESM-2-650M), L <= 512 ------------------------------------------

@@ -151,8 +151,9 @@ __global__ void __launch_bounds__(512, 2) k_gemm8(const GemmArgs p, const int g8
     tk_cur = w; tk_nxt = w + g8n;
     if (EPI == G8_EPI_RESID_LN) ln_tag = (unsigned)__builtin_amdgcn_readfirstlane((int)sw_epoch(p.sched)) + 1u;
   }
+  const unsigned tiles_expected = (unsigned)(p.tiles_m * p.tiles_n);
   if (tk_cur >= Tx) {
-    if (p.sched && tid == 0) sw_leave(p.sched, gridDim.x);
+    if (p.sched && tid == 0) sw_leave(p.sched, gridDim.x, 0u, tiles_expected);
     return;
   }
   // ---- de-phasing.  Every work-group runs the same number of equally long tiles, so without it all 256 CUs reach their epilogues together and
@@ -506,6 +507,8 @@ __global__ void __launch_bounds__(512, 2) k_gemm8(const GemmArgs p, const int g8
   int s = 0;
   bool after_epi = false;
   const int draw_lane = (dyn && wave == 0) ? 1 : 0;         // EXEC mask of the draw: lane 0 of wave 0
+  const unsigned* const headp = dyn ? p.sched + SW_HEAD(x) : nullptr;
+  int tiles_mine = 0;                                       // output tiles this work-group has written (sw_leave checks the launch's total)
   int relay_flag = 0;                                       // 1 in the first K-tile of a tile whose successor's ticket was drawn (it arrives there)
   // One LDS-DMA-free way to hand a drawn ticket to all eight waves: wave 0 draws (a returning agent-scope atomic, issued ahead of the tile's LAST two K-tiles
   // and looked at behind their last counted wait: loads return in order, so it has returned when that wait is over), keeps the value in a scalar register over
@@ -536,7 +539,7 @@ __global__ void __launch_bounds__(512, 2) k_gemm8(const GemmArgs p, const int g8
 #pragma clang loop unroll(disable)
     do {                                                   // (nk >= 2)
       // (tk_nxt: with drawn tickets it arrives in the tile's first K-tile -- it is looked at in the last pair only, nk >= 4)
-      if (t + 2 >= nk) drawn_v = draw_async(p.sched + SW_HEAD(x), draw_lane & (int)((unsigned)(tk_nxt - Tx) >> 31));      // (all scalar: tk_nxt < Tx <=> the difference is negative)
+      if (t + 2 >= nk) drawn_v = draw_async(headp, draw_lane & (int)((unsigned)(tk_nxt - Tx) >> 31));      // (all scalar: tk_nxt < Tx <=> the difference is negative)
       kpair(t);
       t += 2;
     } while (t < nk);
@@ -565,6 +568,7 @@ __global__ void __launch_bounds__(512, 2) k_gemm8(const GemmArgs p, const int g8
       else epilogue_f32<EPI, HB, DUAL, MT, NT>(p, acc, m0, n0, wr, wc, lane_e);
     }
     STAMP_E(3);
+    ++tiles_mine;
     if (!has_next) break;
     if (dyn) {
       // (under Y3 the word lies in the Y0 ring slot of K-tile s+2 = slot (r3 + 2) % 3, r3 being the slot of the new tile's first K-tile)
@@ -580,7 +584,7 @@ __global__ void __launch_bounds__(512, 2) k_gemm8(const GemmArgs p, const int g8
     zero_acc();
     STAMP_E(4);
   }
-  if (p.sched && wave == 0 && lane_now() == 0) sw_leave(p.sched, gridDim.x);
+  if (p.sched && wave == 0 && lane_now() == 0) sw_leave(p.sched, gridDim.x, (unsigned)tiles_mine, tiles_expected);
 #ifdef G8_DUMMY_VALU
   asm volatile("" :: "v"(dv[0]), "v"(dv[1]), "v"(dv[2]), "v"(dv[3]));
 #endif

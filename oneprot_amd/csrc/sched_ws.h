@@ -2,10 +2,11 @@
 // at run time and keep per-launch bookkeeping ON THE DEVICE (include/oneprot_hip.h: oneprot_sched_workspace_bytes / _init, oneprot_alloc_uncached).
 //
 //   words   0 .. 255   eight per-XCD queue heads, one 128-byte line each (HEAD(x)): the next undrawn tile / slab of XCD x's share of a launch
-//   word  256          DONE: work-groups that have left the current launch.  The LAST one to leave resets the heads and DONE to zero and adds one to
+//   words 256-257      DONE (64 bits: low word = work-groups that have left the current launch, high word = tiles / slabs they computed).  The LAST one to leave resets the heads and DONE to zero and adds one to
 //   word  288          EPOCH: launches completed on this workspace.  A kernel reads it once when it starts: epoch + 1 is the launch's tag (the tagged
 //                      partial statistics of epilogue_resid_ln).  Because the counter lives on the device a captured graph gets a fresh tag on every replay.
-//   word  320          LN_ERR: sticky; a bounded wait of epilogue_resid_ln ran out (its rows were written as NaN)
+//   word  320          LN_ERR: sticky; 1 = a bounded wait of epilogue_resid_ln ran out (its rows were written as NaN), 2 = a launch did not compute exactly the
+//                      tiles it was given (sw_leave): either way oneprot_clip_coef turns the step's gradient norm into NaN and the host raises
 //   word  352          LATE_DRAWS: diagnostic; ticket draws of k_gemm8 that had not returned behind the counted wait that should cover them (gemm_nt8.hip: draw_result)
 //   bytes 32768 ..     ln_part: [rows][8] 16-byte entries {tag, mean, M2, ~tag} (gemm_epi8.h)
 //
@@ -23,13 +24,18 @@
 
 __device__ __forceinline__ unsigned sw_draw(unsigned* head) { return __hip_atomic_fetch_add(head, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }
 __device__ __forceinline__ unsigned sw_epoch(const unsigned* sched) { return __hip_atomic_load(sched + SW_EPOCH, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }
-// ONE lane per work-group, after the work-group's last draw has returned; every work-group of the launch calls it exactly once (also those that found no work)
-__device__ __forceinline__ void sw_leave(unsigned* sched, unsigned n_wg) {
-  const unsigned before = __hip_atomic_fetch_add(sched + SW_DONE, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-  if (before == n_wg - 1u) {                               // everybody else has left: nobody draws any more, nobody reads the epoch any more
+// ONE lane per work-group, after the work-group's last draw has returned; every work-group of the launch calls it exactly once (also those that found no work).
+// `units` = tiles / slabs this work-group computed, `expected` = what the whole launch must compute: arrival count and unit count travel in ONE 64-bit atomic
+// (low / high word), so the last work-group to leave sees the launch's total -- a ticket handed out twice, lost, or a queue that did not start at zero (a
+// previous launch on this workspace that never finished) sets the sticky error word (value 2) instead of leaving output tiles silently unwritten.
+__device__ __forceinline__ void sw_leave(unsigned* sched, unsigned n_wg, unsigned units, unsigned expected) {
+  unsigned long long* done = reinterpret_cast<unsigned long long*>(sched + SW_DONE);
+  const unsigned long long before = __hip_atomic_fetch_add(done, 1ull | ((unsigned long long)units << 32), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+  if ((unsigned)before == n_wg - 1u) {                     // everybody else has left: nobody draws any more, nobody reads the epoch any more
+    if ((unsigned)(before >> 32) + units != expected) __hip_atomic_store(sched + SW_LN_ERR, 2u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
 #pragma unroll
     for (int x = 0; x < 8; ++x) __hip_atomic_store(sched + SW_HEAD(x), 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-    __hip_atomic_store(sched + SW_DONE, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    __hip_atomic_store(done, 0ull, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
     __hip_atomic_fetch_add(sched + SW_EPOCH, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
   }
 }

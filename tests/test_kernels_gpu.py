@@ -373,6 +373,43 @@ def test_persistent_gemm_tiles_from_the_work_queue_bit_identical():
     assert hip.sched_error() == 0
 
 
+def test_work_queue_that_does_not_start_at_zero_is_loud():
+    """A queue head that is not zero when a launch starts (a previous launch on the workspace that never finished, a second stream sharing it) would leave output
+    tiles silently unwritten.  The last work-group to leave compares the tiles the launch computed with the tiles it was given: the sticky error word becomes 2,
+    oneprot_clip_coef poisons the step, the heads are reset and the next launch is clean."""
+    ws = hip.sched_workspace(131072)
+    g = torch.Generator().manual_seed(43)
+    M, N, K = 65536, 640, 640
+    A = bf(torch.randn(M, K, generator=g)).to(DEV)
+    W = bf(torch.randn(N, K, generator=g) * 0.1).to(DEV)
+    out = torch.empty(M, N, dtype=torch.bfloat16, device=DEV)
+    run = lambda: hip.call("oneprot_gemm_bf16_nt", A, W, M, N, K, K, K, hip.EPI_BF16, None, out, None, None, None, None, None, 1.0, 0, 0, 0)
+    try:
+        hip.query("oneprot_dynamic_tiles", ws[0], ws[1])
+        run(); torch.cuda.synchronize()
+        ref = out.clone()
+        assert hip.sched_error() == 0
+        class _Raw:                                              # a zero-copy torch view of the workspace's first words (test only: the product never touches them from the host)
+            __cuda_array_interface__ = {"shape": (8,), "typestr": "<i4", "data": (ws[0], False), "version": 2}
+        torch.as_tensor(_Raw(), device=DEV)[0] = 3               # queue head of XCD 0 := 3
+        torch.cuda.synchronize()
+        out.fill_(float("nan"))
+        run(); torch.cuda.synchronize()
+        assert hip.sched_error() == 2
+        assert torch.isnan(out.float()).any()                    # three tiles of XCD 0's share were never handed out
+        ss = torch.full((1,), 4.0, device=DEV)
+        coef, nrm = torch.empty(1, device=DEV), torch.empty(1, device=DEV)
+        hip.call("oneprot_clip_coef", ss, 1.0, coef, nrm, ws[0])
+        assert torch.isnan(nrm).all() and torch.isnan(coef).all()
+        hip.sched_error_clear()
+        out.fill_(float("nan"))
+        run(); torch.cuda.synchronize()
+        assert hip.sched_error() == 0 and torch.equal(out, ref)  # the failed launch reset the queues itself
+    finally:
+        hip.sched_error_clear()
+        hip.query("oneprot_dynamic_tiles", ws[0] if hip.dynamic_tiles_wanted() else None, ws[1])
+
+
 def test_sched_workspace_launches_replay_from_a_graph():
     """include/oneprot_hip.h: "every function that takes a stream only enqueues work on it ... graph-capturable".  The launches that keep bookkeeping between
     launches -- the FFN-2 + LayerNorm GEMM (tagged partial statistics) and the GEMMs that draw their tiles from the work queues -- are captured ONCE into a HIP graph
