@@ -44,6 +44,8 @@ def check(name, lines):
             m = re.match(r"v_readfirstlane_b32 s\d+, v(\d+)", t)
             if m:
                 read = (i, int(m.group(1)))
+    if draw is None and read is None:
+        return None                                         # a static-list instantiation: no draw in it
     if draw is None or read is None:
         return f"{name}: draw / read statements not found"
     if draw[1] != read[1]:

@@ -100,7 +100,7 @@ template <int N> __device__ __forceinline__ void wait_lgkm() { asm volatile("s_w
 // logical column (inside the wave's NTW*16-column block) held by LDS row slot `rho` of the wave's tile jt -- see gemm_epi.h
 template <bool PAIR> __device__ __forceinline__ int slot_col(int jt, int rho) { return direct_nmap<PAIR>(jt, rho); }
 
-template <class C, int EPI, bool HB, bool DUAL>
+template <class C, int EPI, bool HB, bool DUAL, bool DYN>
 __global__ void __launch_bounds__(512, 2) k_gemm8(const GemmArgs p, const int g8n, const int dph_groups, const int dph_sleeps) {
   constexpr int MT = C::MTW, NT = C::NTW, MH = C::MH, NH = C::NH;
   constexpr bool XA = C::XA;
@@ -133,10 +133,12 @@ __global__ void __launch_bounds__(512, 2) k_gemm8(const GemmArgs p, const int g8
   // current tile can be waited on, through such a ticket, by the very work-group it waits for (two work-groups that start together and draw alternately:
   // observed as a bounded wait that ran out, round 6).  With the static list the partners are work-groups w, w + 1 of the same launch slot.  It is a
   // forward-pass kernel: nothing is co-resident with it in a training step (the overlapped gradient all-reduce runs under the backward).
-  const bool dyn = EPI != G8_EPI_RESID_LN && p.dyn != 0;
+  // DYN is a template parameter: the static instantiation carries none of the draw / relay code in its K loop (0.5-1 % of a launch in round 6's first form)
+  static_assert(!(DYN && EPI == G8_EPI_RESID_LN), "RESID_LN runs on static lists");
+  constexpr bool dyn = DYN;
   int tk_cur, tk_nxt;
   unsigned ln_tag = 0;
-  if (dyn) {
+  if constexpr (dyn) {
     unsigned* sm = reinterpret_cast<unsigned*>(smem);
     if (tid == 0) {
       unsigned* head = p.sched + SW_HEAD(x);
@@ -333,7 +335,7 @@ __global__ void __launch_bounds__(512, 2) k_gemm8(const GemmArgs p, const int g8
     wait_lgkm<NY>();
     bar();
     STAMP(0);
-    if constexpr (RELAY_IN_P1) {                            // (see P2: this instantiation has no register to spare there)
+    if constexpr (RELAY_IN_P1 && DYN) {                     // (see P2: this instantiation has no register to spare there)
       unsigned relay = 0;
       if (relay_flag != 0) relay = lds_read32(relay_addr);
       wait_lgkm<0>();
@@ -348,7 +350,7 @@ __global__ void __launch_bounds__(512, 2) k_gemm8(const GemmArgs p, const int g8
     STAMP(1);
     // P2 (X0, Y1).  First K-tile after an epilogue with drawn tickets: the next tile's ticket arrives here, in a READ slot (wave 0 wrote the word before
     // P1's first barrier; under Y3 the slot it lies in is refilled from P3 on) -- not at the head of an MFMA slot, where every instruction delays the run
-    if constexpr (!RELAY_IN_P1) {
+    if constexpr (!RELAY_IN_P1 && DYN) {
       if (relay_flag != 0) {
         const unsigned relay = lds_read32(relay_addr);
         wait_lgkm<0>();
@@ -445,7 +447,7 @@ __global__ void __launch_bounds__(512, 2) k_gemm8(const GemmArgs p, const int g8
     __builtin_amdgcn_sched_barrier(0);
     bar();
     STAMP(1);
-    if (dyn && first) {                                     // (the next tile's ticket: see ktile)
+    if constexpr (DYN) if (first) {                         // (the next tile's ticket: see ktile)
       const unsigned relay = lds_read32(relay_addr);
       wait_lgkm<0>();
       tk_nxt = first_lane(relay);
@@ -539,14 +541,17 @@ __global__ void __launch_bounds__(512, 2) k_gemm8(const GemmArgs p, const int g8
 #pragma clang loop unroll(disable)
     do {                                                   // (nk >= 2)
       // (tk_nxt: with drawn tickets it arrives in the tile's first K-tile -- it is looked at in the last pair only, nk >= 4)
-      if (t + 2 >= nk) drawn_v = draw_async(headp, draw_lane & (int)((unsigned)(tk_nxt - Tx) >> 31));      // (all scalar: tk_nxt < Tx <=> the difference is negative)
+      if constexpr (DYN) if (t + 2 >= nk) drawn_v = draw_async(headp, draw_lane & (int)((unsigned)(tk_nxt - Tx) >> 31));      // (all scalar: tk_nxt < Tx <=> the difference is negative)
       kpair(t);
       t += 2;
     } while (t < nk);
     const bool has_next = tk_nxt < Tx;
-    int late;
-    const int drawn = draw_result(drawn_v, late);            // (its ; DRAWN marker is what check_async_regs.py looks for)
-    if (late && lane_now() == 0) __hip_atomic_fetch_add(p.sched + SW_LATE_DRAWS, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);      // diagnostic counter: draws that had not returned behind the counted wait
+    int drawn = 0x7fffffff;
+    if constexpr (DYN) {
+      int late;
+      drawn = draw_result(drawn_v, late);                    // (its ; DRAWN marker is what check_async_regs.py looks for)
+      if (late && lane_now() == 0) __hip_atomic_fetch_add(p.sched + SW_LATE_DRAWS, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);      // diagnostic counter: draws that had not returned behind the counted wait
+    }
     STAMP_E(0);
     if (grp == 0) bar();
     STAMP_E(1);
@@ -570,7 +575,7 @@ __global__ void __launch_bounds__(512, 2) k_gemm8(const GemmArgs p, const int g8
     STAMP_E(3);
     ++tiles_mine;
     if (!has_next) break;
-    if (dyn) {
+    if constexpr (dyn) {
       // (under Y3 the word lies in the Y0 ring slot of K-tile s+2 = slot (r3 + 2) % 3, r3 being the slot of the new tile's first K-tile)
       relay_addr = lds0 + (C::Y3 ? C::RING_Y0 + (r3 == 0 ? 2 : r3 - 1) * C::Y_UNIT : RELAY);
       if (wave == 0) lds_write32(relay_addr, (unsigned)drawn);      // (every lane of the wave: the same word, the same value)
@@ -601,7 +606,9 @@ static int launch_cfg(GemmArgs a, hipStream_t s) {
   static bool configured = false;
   static int n_cu = 0;
   if (!configured) {
-    if (hipFuncSetAttribute((const void*)k_gemm8<C, EPI, HB, DUAL>, hipFuncAttributeMaxDynamicSharedMemorySize, C::LDS + (C::Y3 ? 0 : 64)) != hipSuccess) return OP_ELAUNCH;
+    if (hipFuncSetAttribute((const void*)k_gemm8<C, EPI, HB, DUAL, false>, hipFuncAttributeMaxDynamicSharedMemorySize, C::LDS + (C::Y3 ? 0 : 64)) != hipSuccess) return OP_ELAUNCH;
+    if constexpr (EPI != G8_EPI_RESID_LN)
+      if (hipFuncSetAttribute((const void*)k_gemm8<C, EPI, HB, DUAL, true>, hipFuncAttributeMaxDynamicSharedMemorySize, C::LDS + (C::Y3 ? 0 : 64)) != hipSuccess) return OP_ELAUNCH;
     int dev = 0; hipDeviceProp_t prop;
     if (hipGetDevice(&dev) != hipSuccess || hipGetDeviceProperties(&prop, dev) != hipSuccess) return OP_ELAUNCH;
     n_cu = prop.multiProcessorCount;
@@ -628,7 +635,13 @@ static int launch_cfg(GemmArgs a, hipStream_t s) {
   a.dyn = (EPI != G8_EPI_RESID_LN && g_dyn_sched != nullptr && a.K >= 256) ? 1 : 0;
   if (a.dyn) a.sched = g_dyn_sched;
   else if (EPI != G8_EPI_RESID_LN) a.sched = nullptr;
-  hipLaunchKernelGGL((k_gemm8<C, EPI, HB, DUAL>), dim3(g8n * 8), dim3(512), C::LDS + (C::Y3 ? 0 : 64), s, a, g8n, g_dph_groups, g_dph_sleeps);      // (+ the ticket relay word where the buffers leave room)
+  if constexpr (EPI != G8_EPI_RESID_LN) {
+    if (a.dyn) {
+      hipLaunchKernelGGL((k_gemm8<C, EPI, HB, DUAL, true>), dim3(g8n * 8), dim3(512), C::LDS + (C::Y3 ? 0 : 64), s, a, g8n, g_dph_groups, g_dph_sleeps);      // (+ the ticket relay word where the buffers leave room)
+      return launch_status();
+    }
+  }
+  hipLaunchKernelGGL((k_gemm8<C, EPI, HB, DUAL, false>), dim3(g8n * 8), dim3(512), C::LDS + (C::Y3 ? 0 : 64), s, a, g8n, g_dph_groups, g_dph_sleeps);
   return launch_status();
 }
 
