@@ -529,6 +529,10 @@ def main():
     if rank == 0:
         extras["ffn2_ln"] = {"what": "FFN-2 GEMM with the next LayerNorm finished across work-groups (ONEPROT_FFN2_LN=0 keeps the pair of launches)",
                              "enabled": os.environ.get("ONEPROT_FFN2_LN", "1") != "0", "waits_run_out": ln8_errors}
+        # how the persistent kernels share the chip with co-resident kernels (the RCCL channels of the overlapped all-reduce when N > 1): DESIGN section 5
+        extras["work_queues"] = {"dynamic_tiles": hip.dynamic_tiles_wanted(), "cu_reserve_weight_gradient_gemm": hip.cu_reserve_wanted(),
+                                 "late_ticket_draws": hip.sched_late_draws(), "what": "ONEPROT_DYNAMIC_TILES / ONEPROT_CU_RESERVE (defaults: on / 16 when WORLD_SIZE > 1): NT GEMM tiles and "
+                                 "attention-forward slabs drawn from per-XCD work queues, weight-gradient GEMM cut into (CUs - reserve) work items; rank 0's diagnostic counters"}
         ms_step = elapsed / args.steps * 1e3
         pairs_per_step = B * len(subs)
         value = world * pairs_per_step * args.steps / elapsed
