@@ -96,7 +96,7 @@ int oneprot_gemm_bf16_nt_resid_ln(const void* A, const void* Wp, int64_t M, int 
  * bookkeeping on the device (csrc/sched_ws.h: eight per-XCD queue heads, an arrival counter, a launch epoch, a sticky error word, and room for the partial
  * row statistics of oneprot_gemm_bf16_nt_resid_ln8 for up to M_max rows).  The caller owns it: oneprot_sched_workspace_bytes(M_max) bytes, 128-byte aligned,
  * zeroed ONCE (oneprot_sched_workspace_init: a memset enqueued on `stream`), then only ever touched by the kernels -- the last work-group to leave a launch
- * resets the queue heads and advances the epoch, so a captured graph replays correctly.  One workspace serves one stream (launches that overlap in time must
+ * checks that the launch computed exactly the tiles it was given, resets the queue heads and advances the epoch, so a captured graph replays correctly.  One workspace serves one stream (launches that overlap in time must
  * not share one).  The statistics exchange crosses the XCDs' L2s: allocate the workspace with oneprot_alloc_uncached (hipExtMallocWithFlags(
  * hipDeviceMallocUncached); a host call like any allocation -- set-up code, never a launch path) and release it with oneprot_free_uncached. */
 size_t oneprot_sched_workspace_bytes(int64_t M_max);
@@ -125,7 +125,8 @@ int64_t oneprot_sched_epoch(const void* sched_ws);
  * never got a CU: fewer CUs free than the form needs) sets the workspace's sticky error word and the wave writes NaN into its rows of h, mean and rstd --
  * the next loss is NaN, not plausibly wrong -- and every later wait of that launch gives up at its first miss instead of spinning again.
  * oneprot_clip_coef(…, sched_ws, …) folds the word into the step's gradient norm on the device.  oneprot_gemm_resid_ln8_error: host-synchronous read of the
- * word (1 = some launch on this workspace wrote NaN rows); _error_clear: enqueues its reset.  oneprot_gemm_resid_ln8_poll_bound: test hook, polls per wait
+ * word (0 = clean; 1 = some launch on this workspace wrote NaN rows; 2 = a launch that drew its tiles from the work queues did not compute exactly the tiles it was
+ * given -- a queue head that was not zero when it started: another stream sharing the workspace, a launch that never finished); _error_clear: enqueues its reset.  oneprot_gemm_resid_ln8_poll_bound: test hook, polls per wait
  * (default 2^20, about a second; < 0 restores it). */
 int oneprot_gemm_resid_ln8_eligible(int64_t M, int N, int K);
 int oneprot_gemm_resid_ln8_error(const void* sched_ws);
