@@ -1063,22 +1063,59 @@ __global__ void __launch_bounds__(512, 2) k_attn_fwd3(const bf16_t* __restrict__
 #else
     for (int b = 0; b < 2; ++b) for (int st = 0; st < C::KSTEPS; ++st) qn[b][st] = qf[b][st];
 #endif
-    // the slab's list of spread memory instructions: [DMA pieces of nxt][stores of pend_bh]
-    const int e_dma = more ? n_dma : 0, e_all = e_dma + ((pend_bh >= 0 && active) ? NST : 0);
+    // The slab's memory instructions, spread over its key tiles (in one burst behind the barrier they queue on the CU's one memory pipe while nobody
+    // computes: NOTEBOOK 6d).  Round 6: a SHORT list with a cheap step -- slot j < n_pairs: K piece j and V piece j of this wave for the next slab (two
+    // instructions, addresses = a per-slab scalar base + p * constant); then the bias piece; then all stores of block 0; then all stores of block 1.
+    // The first form was a generic list of single instructions behind a ladder of compares (which of ~17 entries is entry i?): ~30 scalar
+    // instructions per step, two steps per tile, in every wave.
+    const int n_pairs = more ? my_pieces : 0;
+    const bool bias_piece = more && key_bias && wave < n_biasp;
+    const bool have_stores = pend_bh >= 0 && active;
+    const int n_slots = n_pairs + 3;
+    const unsigned char* const kbase = reinterpret_cast<const unsigned char*>(k + (size_t)nxt * L * HD);
+    const unsigned char* const vbase = reinterpret_cast<const unsigned char*>(v + (size_t)nxt * L * HD);
+    const unsigned dst_next = lds0 + (buf ^ 1) * Fwd3::BUF;
     int vm_i = 0;
     auto vm_step = [&]() {
       const int i = vm_i;
-      if (i >= e_all) return;
+      if (i >= n_slots) return;
       vm_i = i + 1;
+      if (i < n_pairs) {
 #ifndef FWD3_ABL_NODMA
-      if (i < e_dma) dma_piece(nxt, buf ^ 1, i);
-#else
-      if (i < e_dma) {}
+        const int p = wave + nw * i;
+        const unsigned dk = dst_next + p * 1024;
+        if (16 * p + 16 <= L) {
+          glds16_s(kv_lane_off, kbase + (size_t)p * (16 * HD * 2), dk);
+          glds16_s(kv_lane_off, vbase + (size_t)p * (16 * HD * 2), dk + Fwd3::TILE);
+        } else {                                            // the piece that straddles L: per-lane addresses, the zero page behind rows >= L
+          const int row = 16 * p + (lane >> 2);
+          const int ch = (lane & 3) ^ ((row >> 2) & 3);
+          const bool ok = row < L && ch < HD / 8;
+          glds16_addr(ok ? kbase + (size_t)row * (HD * 2) + ch * 16 : zero, dk);
+          glds16_addr(ok ? vbase + (size_t)row * (HD * 2) + ch * 16 : zero, dk + Fwd3::TILE);
+        }
 #endif
+      } else if (i == n_pairs) {
+#ifndef FWD3_ABL_NODMA
+        if (bias_piece) {
+          const float* br = key_bias + (size_t)(nxt / H) * L + 64 * wave;
+          if (64 * wave + 64 <= L) glds4_s((unsigned)lane * 4u, br, dst_next + 2 * Fwd3::TILE + wave * 256);
+          else glds4_addr(64 * wave + lane < L ? (const void*)(br + lane) : (const void*)zero, dst_next + 2 * Fwd3::TILE + wave * 256);
+        }
+#endif
+      } else if (have_stores) {
 #ifndef FWD3_ABL_NOSTORE
-      else store1(pend, pend_bh, i - e_dma);
+        if (i == n_pairs + 1) {
+#pragma unroll
+          for (int j = 0; j < NST / 2; ++j) store1(pend, pend_bh, j);
+        } else {
+#pragma unroll
+          for (int j = NST / 2; j < NST; ++j) store1(pend, pend_bh, j);
+        }
 #endif
+      }
     };
+    const int e_all = n_slots;
     FWD3_T(3);
     if (active) {
       const unsigned char* sK = smem + buf * Fwd3::BUF;
@@ -1090,7 +1127,7 @@ __global__ void __launch_bounds__(512, 2) k_attn_fwd3(const bf16_t* __restrict__
       const int nt = nrows >> 5;
       RowState<HD> st[2];
       st[0].reset(h); st[1].reset(h);
-      fwd_chunk_fast<HD, 2>(sK, sV, sBias, have_bias, L, nt, NZ, DEAD, qf, st, lane, [&] { vm_step(); vm_step(); });
+      fwd_chunk_fast<HD, 2>(sK, sV, sBias, have_bias, L, nt, NZ, DEAD, qf, st, lane, [&] { vm_step(); });      // one list entry per key tile (7 entries at L = 512, 16 tiles)
       while (vm_i < e_all) vm_step();                       // (short sequences / skipped tiles: whatever is left of the list)
       st[0].finish_sum(); st[1].finish_sum();
       FWD3_T(4);
