@@ -13,6 +13,7 @@ RULES = [
     (r"^void k_gemm_tn8<", 0),                  # 8-phase weight-gradient GEMM
     (r"^void gln::k_gemm_ln", 0),               # out-projection + residual + LayerNorm
     (r"^void k_attn_fwd3<", 0),                 # persistent attention forward
+    (r"^void k_attn_fwd3w<", 0),                # ... for 128-byte rows (hd 64): 256 registers; the short per-tile list of k_attn_fwd3 (round 6) spilled 20 bytes here and was not taken over
     (r"^void k_attn_fwd2<", 16),                # (long-sequence / hd 64 path: the output address computed at entry is parked in scratch until the final store -- outside every loop)
     (r"^void k_attn_bwd_fused<\(int\)32>", 0),
     (r"^void k_attn_bwd_fused64<\(int\)32>", 0),   # 8-wave fused backward (two key blocks per wave): 254 of 256 registers, see the kernel's comments before adding a live value
