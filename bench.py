@@ -306,8 +306,26 @@ def host_cpu_share():
                      "threads_used": threads, "rule": "min(affinity, cgroup quota)" if share is not None else "min(affinity, 16): no cgroup quota visible, the pool's CPU share per GPU"}
 
 
-def other_workloads(args, dev, steps=3):
-    """pairs/s of `--pair text` (cfg-4 shape, B pairs) and `--pair roundrobin --batch 128` (cfg-5 shape), 1 warm-up + `steps` timed steps each"""
+def _steps_timed(mod, bt, steps):
+    """2 warm-up steps, then `steps` steps between HIP events on the current stream (no host synchronisation inside): (median seconds per step, each step's ms,
+    last loss).  The median, with every step listed beside it: these side workloads run few steps, and one step that meets a host hiccup would otherwise own the figure."""
+    import statistics
+    import torch
+    for _ in range(2):
+        mod.training_step(bt, 0)
+    torch.cuda.synchronize()
+    ev = [torch.cuda.Event(enable_timing=True) for _ in range(steps + 1)]
+    ev[0].record()
+    for i in range(steps):
+        ls = mod.training_step(bt, 0)
+        ev[i + 1].record()
+    torch.cuda.synchronize()
+    each = [round(ev[i].elapsed_time(ev[i + 1]), 2) for i in range(steps)]
+    return statistics.median(each) * 1e-3, each, ls
+
+
+def other_workloads(args, dev, steps=5):
+    """pairs/s of `--pair text` (cfg-4 shape, B pairs) and `--pair roundrobin --batch 128` (cfg-5 shape): 2 warm-up + `steps` timed steps each, median step"""
     import copy
     import gc
     import torch
@@ -318,27 +336,16 @@ def other_workloads(args, dev, steps=3):
         w = build_workload(a, dev, 0)
         _log(f"{tag} built")
         mod, bt = w["module"], w["batch"]
-        mod.training_step(bt, 0)
-        torch.cuda.synchronize()
-        t0 = time.perf_counter()
-        for _ in range(steps):
-            ls = mod.training_step(bt, 0)
-        torch.cuda.synchronize()
-        dt = (time.perf_counter() - t0) / steps
+        dt, per_step, ls = _steps_timed(mod, bt, steps)
         res[tag] = {"value": round(batch * len(w["subs"]) / dt, 1), "unit": "protein-pairs/sec (1 GPU)", "ms_per_step": round(dt * 1e3, 2), "steps": steps,
+                    "ms_each_step": per_step,
                     "pairs_per_gpu_per_modality": batch, "sub_steps_per_step": len(w["subs"]), "loss": round(float(ls.detach()), 5), "workload": w["desc"]}
         if "text" in mod.network:
             # the text tower runs HF's train-mode dropout as the reference does (frozen tower included, ref text_encoder.py:56-62); the same step with it
             # switched off (transformer.train_dropout = False: what rounds 1-4 measured) beside it
             res[tag]["text_tower_dropout"] = "on (reference behaviour; ONEPROT_BERT_DROPOUT=0 / transformer.train_dropout = False switch it off)"
             mod.network["text"].transformer.train_dropout = False
-            mod.training_step(bt, 0)
-            torch.cuda.synchronize()
-            t0 = time.perf_counter()
-            for _ in range(steps):
-                mod.training_step(bt, 0)
-            torch.cuda.synchronize()
-            dt0 = (time.perf_counter() - t0) / steps
+            dt0, _, _ = _steps_timed(mod, bt, steps)
             res[tag]["value_text_dropout_off"] = round(batch * len(w["subs"]) / dt0, 1)
             res[tag]["ms_per_step_text_dropout_off"] = round(dt0 * 1e3, 2)
         del mod, bt, w, ls
