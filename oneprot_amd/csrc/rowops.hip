@@ -660,103 +660,163 @@ extern "C" int oneprot_rowsum_f32(const float* x, float* out, int R, int64_t n, 
 // --------------------------------------------------------------------------------------------------------
 // Attention1dPooling (ref base_encoder.py:88-103; MaskedConv1d with kernel 1 = one dot product per token):
 //   s_l = x_l . w + b ; s_l = -inf where the token is padding ; a = softmax_l(s) ; pooled = sum_l a_l x_l
-// One 256-thread block per sequence; scores and weights live in LDS ([L] floats), x is read twice (fp32, float4).
+// One 16-wave block per sequence; scores and weights live in LDS ([L] floats); x (fp32) is read twice, 16 bytes per lane:
+//   pass 1  a wave per row (two rows in flight): the row's dot product with a [d] vector
+//   pass 2  a wave per (64 float4 columns, row group): sum_l weight_l x_l over its rows, groups combined through LDS in a fixed order
+// (round 6: the 4-wave form read 4 bytes per lane in pass 2 and kept one row per wave in flight: 700 / 870 us for 128 x 512 x 1280 fwd / bwd)
 // --------------------------------------------------------------------------------------------------------
-__global__ void __launch_bounds__(256) k_attnpool_fwd(const float* __restrict__ x, const long long* __restrict__ ids, int pad_id, const float* __restrict__ w,
-                                                      const float* __restrict__ bias, float* __restrict__ pooled, float* __restrict__ attn, int L, int d) {
-  extern __shared__ __attribute__((aligned(16))) float s_a[];      // [L]
-  __shared__ float s_red[4];
-  const int b = blockIdx.x, lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+constexpr int AP_WAVES = 16;
+// pass 1: out_l = x_l . v (+ bias) for the rows of one sequence; lane 0 of the row's wave hands (l, value) to `put`
+template <class Put>
+__device__ __forceinline__ void ap_row_dots(const float* __restrict__ xb, const float* __restrict__ v, int L, int d, int lane, int wave, Put put) {
   const int nv4 = d >> 2;
-  const float* xb = x + (size_t)b * L * d;
-  for (int l = wave; l < L; l += 4) {
-    float s = 0.f;
+  const float4* v4 = reinterpret_cast<const float4*>(v);
+  for (int l = wave; l < L; l += 2 * AP_WAVES) {
+    const int l1 = l + AP_WAVES;
+    const bool two = l1 < L;
+    const float4* r0 = reinterpret_cast<const float4*>(xb + (size_t)l * d);
+    const float4* r1 = reinterpret_cast<const float4*>(xb + (size_t)(two ? l1 : l) * d);
+    float s0 = 0.f, s1 = 0.f;
     for (int c = lane; c < nv4; c += 64) {
-      const float4 xv = reinterpret_cast<const float4*>(xb + (size_t)l * d)[c];
-      const float4 wv = reinterpret_cast<const float4*>(w)[c];
-      s += (xv.x * wv.x + xv.y * wv.y) + (xv.z * wv.z + xv.w * wv.w);
+      const float4 a = r0[c], bq = r1[c], wv = v4[c];
+      s0 += (a.x * wv.x + a.y * wv.y) + (a.z * wv.z + a.w * wv.w);
+      s1 += (bq.x * wv.x + bq.y * wv.y) + (bq.z * wv.z + bq.w * wv.w);
     }
-    s = wave_sum(s);
-    if (lane == 0) s_a[l] = (ids[(size_t)b * L + l] != pad_id) ? s + bias[0] : -INFINITY;
+    s0 = wave_sum(s0); s1 = wave_sum(s1);
+    if (lane == 0) { put(l, s0); if (two) put(l1, s1); }
   }
+}
+// pass 2: out[j] = sum_l wt[l] x[l][j] (wt in LDS); with DX also dx[l][j] = at[l] g[j] + wt[l] w[j].  s_part: [groups][d] floats of LDS.
+template <bool DX>
+__device__ __forceinline__ void ap_weighted_sum(const float* __restrict__ xb, const float* s_wt, float* s_part, float* __restrict__ out, int L, int d, int lane, int wave,
+                                                const float* __restrict__ at, const float* __restrict__ g, const float* __restrict__ w, float* __restrict__ dxb) {
+  const int nv4 = d >> 2;
+  const int nch = (nv4 + 63) >> 6;                                   // chunks of 64 float4 columns
+  const int G = nch >= AP_WAVES ? 1 : AP_WAVES / nch;                // row groups that work on a chunk side by side
+  for (int c0 = 0; c0 < nch; c0 += AP_WAVES) {                       // (one trip unless d > 4096)
+    const int c = c0 + (G > 1 ? wave % nch : wave), grp = G > 1 ? wave / nch : 0;
+    const int j4 = c * 64 + lane;
+    const bool live = c < nch && grp < G && j4 < nv4;
+    float4 acc = {0.f, 0.f, 0.f, 0.f};
+    if (live) {
+      float4 gv = {0.f, 0.f, 0.f, 0.f}, wv = gv;
+      if constexpr (DX) { gv = reinterpret_cast<const float4*>(g)[j4]; wv = reinterpret_cast<const float4*>(w)[j4]; }
+      const float4* col = reinterpret_cast<const float4*>(xb) + j4;
+      int l = grp;
+#pragma unroll 1
+      for (; l + 3 * G < L; l += 4 * G) {                            // four rows in flight
+        const float4 x0 = col[(size_t)l * nv4], x1 = col[(size_t)(l + G) * nv4], x2 = col[(size_t)(l + 2 * G) * nv4], x3 = col[(size_t)(l + 3 * G) * nv4];
+        const float a0 = s_wt[l], a1 = s_wt[l + G], a2 = s_wt[l + 2 * G], a3 = s_wt[l + 3 * G];
+        acc.x += a0 * x0.x; acc.y += a0 * x0.y; acc.z += a0 * x0.z; acc.w += a0 * x0.w;
+        acc.x += a1 * x1.x; acc.y += a1 * x1.y; acc.z += a1 * x1.z; acc.w += a1 * x1.w;
+        acc.x += a2 * x2.x; acc.y += a2 * x2.y; acc.z += a2 * x2.z; acc.w += a2 * x2.w;
+        acc.x += a3 * x3.x; acc.y += a3 * x3.y; acc.z += a3 * x3.z; acc.w += a3 * x3.w;
+        if constexpr (DX) {
+          float4* dcol = reinterpret_cast<float4*>(dxb) + j4;
+          const float p0 = at[l], p1 = at[l + G], p2 = at[l + 2 * G], p3 = at[l + 3 * G];
+          dcol[(size_t)l * nv4] = float4{p0 * gv.x + a0 * wv.x, p0 * gv.y + a0 * wv.y, p0 * gv.z + a0 * wv.z, p0 * gv.w + a0 * wv.w};
+          dcol[(size_t)(l + G) * nv4] = float4{p1 * gv.x + a1 * wv.x, p1 * gv.y + a1 * wv.y, p1 * gv.z + a1 * wv.z, p1 * gv.w + a1 * wv.w};
+          dcol[(size_t)(l + 2 * G) * nv4] = float4{p2 * gv.x + a2 * wv.x, p2 * gv.y + a2 * wv.y, p2 * gv.z + a2 * wv.z, p2 * gv.w + a2 * wv.w};
+          dcol[(size_t)(l + 3 * G) * nv4] = float4{p3 * gv.x + a3 * wv.x, p3 * gv.y + a3 * wv.y, p3 * gv.z + a3 * wv.z, p3 * gv.w + a3 * wv.w};
+        }
+      }
+      for (; l < L; l += G) {
+        const float4 x0 = col[(size_t)l * nv4];
+        const float a0 = s_wt[l];
+        acc.x += a0 * x0.x; acc.y += a0 * x0.y; acc.z += a0 * x0.z; acc.w += a0 * x0.w;
+        if constexpr (DX) {
+          const float p0 = at[l];
+          (reinterpret_cast<float4*>(dxb) + j4)[(size_t)l * nv4] = float4{p0 * gv.x + a0 * wv.x, p0 * gv.y + a0 * wv.y, p0 * gv.z + a0 * wv.z, p0 * gv.w + a0 * wv.w};
+        }
+      }
+      if (G > 1) reinterpret_cast<float4*>(s_part + (size_t)grp * d)[j4] = acc;
+    }
+    if (G > 1) {
+      __syncthreads();
+      if (live && grp == 0) {
+        for (int q = 1; q < G; ++q) {
+          const float4 o = reinterpret_cast<const float4*>(s_part + (size_t)q * d)[j4];
+          acc.x += o.x; acc.y += o.y; acc.z += o.z; acc.w += o.w;
+        }
+      }
+      __syncthreads();
+    }
+    if (live && grp == 0) reinterpret_cast<float4*>(out)[j4] = acc;
+  }
+}
+static size_t ap_lds_bytes(int L, int d) {
+  const int nch = ((d >> 2) + 63) >> 6, G = nch >= AP_WAVES ? 1 : AP_WAVES / nch;
+  return ((size_t)((L + 3) & ~3) + (G > 1 ? (size_t)G * d : 0)) * sizeof(float);
+}
+__device__ __forceinline__ float ap_block_sum(float v, float* s_red, int lane, int wave) {      // every thread gets the total; s_red: [AP_WAVES]
+  v = wave_sum(v);
+  __syncthreads();
+  if (lane == 0) s_red[wave] = v;
+  __syncthreads();
+  float t = 0.f;
+  for (int q = 0; q < AP_WAVES; ++q) t += s_red[q];
+  return t;
+}
+
+__global__ void __launch_bounds__(AP_WAVES * 64) k_attnpool_fwd(const float* __restrict__ x, const long long* __restrict__ ids, int pad_id, const float* __restrict__ w,
+                                                                const float* __restrict__ bias, float* __restrict__ pooled, float* __restrict__ attn, int L, int d) {
+  extern __shared__ __attribute__((aligned(16))) float s_a[];      // [L rounded to 4] weights, then [groups][d] partial sums
+  __shared__ float s_red[AP_WAVES];
+  const int b = blockIdx.x, lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  const float* xb = x + (size_t)b * L * d;
+  const long long* idb = ids + (size_t)b * L;
+  const float bs = bias[0];
+  ap_row_dots(xb, w, L, d, lane, wave, [&](int l, float s) { s_a[l] = (idb[l] != pad_id) ? s + bs : -INFINITY; });
   __syncthreads();
   float mx = -INFINITY;
-  for (int l = threadIdx.x; l < L; l += 256) mx = fmaxf(mx, s_a[l]);
+  for (int l = threadIdx.x; l < L; l += AP_WAVES * 64) mx = fmaxf(mx, s_a[l]);
   mx = wave_max(mx);
   if (lane == 0) s_red[wave] = mx;
   __syncthreads();
-  mx = fmaxf(fmaxf(s_red[0], s_red[1]), fmaxf(s_red[2], s_red[3]));
-  __syncthreads();
+  mx = s_red[0];
+  for (int q = 1; q < AP_WAVES; ++q) mx = fmaxf(mx, s_red[q]);
   float se = 0.f;
-  for (int l = threadIdx.x; l < L; l += 256) { const float e = __expf(s_a[l] - mx); s_a[l] = e; se += e; }
-  se = wave_sum(se);
-  if (lane == 0) s_red[wave] = se;
+  for (int l = threadIdx.x; l < L; l += AP_WAVES * 64) { const float e = __expf(s_a[l] - mx); s_a[l] = e; se += e; }
+  const float inv = 1.0f / ap_block_sum(se, s_red, lane, wave);
+  for (int l = threadIdx.x; l < L; l += AP_WAVES * 64) { const float a = s_a[l] * inv; s_a[l] = a; if (attn) attn[(size_t)b * L + l] = a; }
   __syncthreads();
-  const float inv = 1.0f / (s_red[0] + s_red[1] + s_red[2] + s_red[3]);
-  for (int l = threadIdx.x; l < L; l += 256) { const float a = s_a[l] * inv; s_a[l] = a; if (attn) attn[(size_t)b * L + l] = a; }
-  __syncthreads();
-  for (int j = threadIdx.x; j < d; j += 256) {
-    float acc = 0.f;
-    for (int l = 0; l < L; ++l) acc += s_a[l] * xb[(size_t)l * d + j];
-    pooled[(size_t)b * d + j] = acc;
-  }
+  ap_weighted_sum<false>(xb, s_a, s_a + ((L + 3) & ~3), pooled + (size_t)b * d, L, d, lane, wave, nullptr, nullptr, nullptr, nullptr);
 }
 extern "C" int oneprot_attnpool_fwd(const float* x, const int64_t* ids, int pad_id, const float* w, const float* bias, float* pooled, float* attn, int B, int L,
                                     int d, void* stream) {
-  if (!x || !ids || !w || !bias || !pooled || B <= 0 || L <= 0 || (d & 3) || (size_t)L * 4 > 60 * 1024) return OP_EINVAL;
-  hipLaunchKernelGGL(k_attnpool_fwd, dim3(B), dim3(256), (size_t)L * sizeof(float), (hipStream_t)stream, x, (const long long*)ids, pad_id, w, bias, pooled, attn, L, d);
+  if (!x || !ids || !w || !bias || !pooled || B <= 0 || L <= 0 || (d & 3) || ap_lds_bytes(L, d) > 60 * 1024) return OP_EINVAL;
+  hipLaunchKernelGGL(k_attnpool_fwd, dim3(B), dim3(AP_WAVES * 64), ap_lds_bytes(L, d), (hipStream_t)stream, x, (const long long*)ids, pad_id, w, bias, pooled, attn, L, d);
   return launch_status();
 }
 // backward: da_l = x_l . dp ; ds = a * (da - sum a da) ; dw_partial[b] = sum_l ds_l x_l ; db_partial[b] = sum_l ds_l ;
 //           dx_l = a_l dp + ds_l w (optional)
-__global__ void __launch_bounds__(256) k_attnpool_bwd(const float* __restrict__ x, const float* __restrict__ attn, const float* __restrict__ w,
-                                                      const float* __restrict__ dpooled, float* __restrict__ dw_part, float* __restrict__ db_part,
-                                                      float* __restrict__ dx, int L, int d) {
-  extern __shared__ __attribute__((aligned(16))) float s_ds[];     // [L]
-  __shared__ float s_red[4];
+__global__ void __launch_bounds__(AP_WAVES * 64) k_attnpool_bwd(const float* __restrict__ x, const float* __restrict__ attn, const float* __restrict__ w,
+                                                                const float* __restrict__ dpooled, float* __restrict__ dw_part, float* __restrict__ db_part,
+                                                                float* __restrict__ dx, int L, int d) {
+  extern __shared__ __attribute__((aligned(16))) float s_ds[];     // [L rounded to 4], then [groups][d] partial sums
+  __shared__ float s_red[AP_WAVES];
   const int b = blockIdx.x, lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
-  const int nv4 = d >> 2;
   const float* xb = x + (size_t)b * L * d;
   const float* dp = dpooled + (size_t)b * d;
+  const float* ab = attn + (size_t)b * L;
+  ap_row_dots(xb, dp, L, d, lane, wave, [&](int l, float s) { s_ds[l] = s; });
+  __syncthreads();
   float dot = 0.f;
-  for (int l = wave; l < L; l += 4) {
-    float s = 0.f;
-    for (int c = lane; c < nv4; c += 64) {
-      const float4 xv = reinterpret_cast<const float4*>(xb + (size_t)l * d)[c];
-      const float4 gv = reinterpret_cast<const float4*>(dp)[c];
-      s += (xv.x * gv.x + xv.y * gv.y) + (xv.z * gv.z + xv.w * gv.w);
-    }
-    s = wave_sum(s);
-    const float a = attn[(size_t)b * L + l];
-    if (lane == 0) { s_ds[l] = s; }
-    dot += a * s;                 // identical in every lane of the wave
-  }
-  if (lane == 0) s_red[wave] = dot;
-  __syncthreads();
-  const float tot = s_red[0] + s_red[1] + s_red[2] + s_red[3];
+  for (int l = threadIdx.x; l < L; l += AP_WAVES * 64) dot += ab[l] * s_ds[l];
+  const float tot = ap_block_sum(dot, s_red, lane, wave);
   float dbs = 0.f;
-  for (int l = threadIdx.x; l < L; l += 256) { const float v = attn[(size_t)b * L + l] * (s_ds[l] - tot); s_ds[l] = v; dbs += v; }
-  __syncthreads();
-  dbs = wave_sum(dbs);
-  if (lane == 0) s_red[wave] = dbs;
-  __syncthreads();
-  if (threadIdx.x == 0) db_part[b] = s_red[0] + s_red[1] + s_red[2] + s_red[3];
-  for (int j = threadIdx.x; j < d; j += 256) {
-    float acc = 0.f;
-    const float wj = w[j], gj = dp[j];
-    for (int l = 0; l < L; ++l) {
-      const float dsl = s_ds[l];
-      acc += dsl * xb[(size_t)l * d + j];
-      if (dx) dx[((size_t)b * L + l) * d + j] = attn[(size_t)b * L + l] * gj + dsl * wj;
-    }
-    dw_part[(size_t)b * d + j] = acc;
-  }
+  for (int l = threadIdx.x; l < L; l += AP_WAVES * 64) { const float v = ab[l] * (s_ds[l] - tot); s_ds[l] = v; dbs += v; }
+  dbs = ap_block_sum(dbs, s_red, lane, wave);                       // (its barriers also publish s_ds)
+  if (threadIdx.x == 0) db_part[b] = dbs;
+  float* part = s_ds + ((L + 3) & ~3);
+  if (dx) ap_weighted_sum<true>(xb, s_ds, part, dw_part + (size_t)b * d, L, d, lane, wave, ab, dp, w, dx + (size_t)b * L * d);
+  else    ap_weighted_sum<false>(xb, s_ds, part, dw_part + (size_t)b * d, L, d, lane, wave, nullptr, nullptr, nullptr, nullptr);
 }
 extern "C" int oneprot_attnpool_bwd(const float* x, const float* attn, const float* w, const float* dpooled, float* dw, float* db, float* dx, void* workspace,
                                     int B, int L, int d, void* stream) {
-  if (!x || !attn || !w || !dpooled || !dw || !db || !workspace || B <= 0 || L <= 0 || (d & 3) || (size_t)L * 4 > 60 * 1024) return OP_EINVAL;
+  if (!x || !attn || !w || !dpooled || !dw || !db || !workspace || B <= 0 || L <= 0 || (d & 3) || ap_lds_bytes(L, d) > 60 * 1024) return OP_EINVAL;
   float* part = (float*)workspace;              // [B][d] dw partials then [B] db partials
-  hipLaunchKernelGGL(k_attnpool_bwd, dim3(B), dim3(256), (size_t)L * sizeof(float), (hipStream_t)stream, x, attn, w, dpooled, part, part + (size_t)B * d, dx, L, d);
+  hipLaunchKernelGGL(k_attnpool_bwd, dim3(B), dim3(AP_WAVES * 64), ap_lds_bytes(L, d), (hipStream_t)stream, x, attn, w, dpooled, part, part + (size_t)B * d, dx, L, d);
   hipLaunchKernelGGL(k_reduce_partials, dim3((d + 255) / 256), dim3(256), 0, (hipStream_t)stream, (const float*)part, dw, B, (size_t)d, 0);
   hipLaunchKernelGGL(k_reduce_partials, dim3(1), dim3(256), 0, (hipStream_t)stream, (const float*)(part + (size_t)B * d), db, B, (size_t)1, 0);
   return launch_status();

@@ -1338,6 +1338,39 @@ def test_clip_loss_tensor_logit_scale_stays_on_device_and_gets_a_gradient():
     assert abs(ld.grad.item() - lr.grad.item()) < 1e-4 * abs(lr.grad.item()) + 1e-6
 
 
+@pytest.mark.parametrize("B,L,d,with_dx", [(3, 19, 1280, True), (2, 512, 1280, False), (5, 77, 640, True), (2, 1026, 320, True), (3, 130, 64, True),
+                                            (2, 33, 2304, False), (1, 1, 1280, True), (2, 40, 4352, True)])
+def test_attention1d_pooling_kernels_vs_fp64_torch(B, L, d, with_dx):
+    """oneprot_attnpool_fwd / _bwd (ref base_encoder.py:88-103) against the same arithmetic in fp64 torch: widths with 1..17 chunks of 64 float4 columns
+    (row groups side by side or not), lengths that are no multiple of the 16 waves / of the 4-row unroll, padding, with and without dx."""
+    g = torch.Generator().manual_seed(B * 1000 + L + d)
+    x = torch.randn(B, L, d, generator=g)
+    w, bias = torch.randn(d, generator=g) * 0.05, torch.tensor([0.2])
+    ids = torch.randint(4, 24, (B, L), generator=g)
+    if L > 3:
+        ids[-1, L // 2:] = 1                                      # padding id 1
+    dp = torch.randn(B, d, generator=g)
+    xr, wr, br = x.double().requires_grad_(True), w.double().requires_grad_(True), bias.double().requires_grad_(True)
+    s = (xr * wr).sum(-1) + br
+    s = s.masked_fill(ids == 1, float("-inf"))
+    a = torch.softmax(s, dim=-1)
+    ref = (a[..., None] * xr).sum(1)
+    (ref * dp.double()).sum().backward()
+    xd, wd, bd, idd, dpd = x.to(DEV), w.to(DEV), bias.to(DEV), ids.to(DEV), dp.to(DEV)
+    pooled, attn = torch.empty(B, d, device=DEV), torch.empty(B, L, device=DEV)
+    hip.call("oneprot_attnpool_fwd", xd, idd, 1, wd, bd, pooled, attn, B, L, d)
+    assert_close(pooled.cpu().double(), ref.detach(), 2e-5, 2e-6, "attnpool pooled")
+    assert_close(attn.cpu().double(), a.detach(), 2e-5, 1e-7, "attnpool weights")
+    dw, db = torch.empty(d, device=DEV), torch.empty(1, device=DEV)
+    dx = torch.empty(B, L, d, device=DEV) if with_dx else None
+    ws = torch.empty(hip.query("oneprot_attnpool_bwd_workspace", B, d), dtype=torch.uint8, device=DEV)
+    hip.call("oneprot_attnpool_bwd", xd, attn, wd, dpd, dw, db, dx, ws, B, L, d)
+    assert_close(dw.cpu().double(), wr.grad, 1e-4, 1e-5 * float(wr.grad.abs().max()) + 1e-7, "attnpool dw")
+    assert_close(db.cpu().double(), br.grad, 1e-4, 1e-5 * float(wr.grad.abs().max()) + 1e-6, "attnpool db")
+    if with_dx:
+        assert_close(dx.cpu().double(), xr.grad, 1e-4, 1e-6, "attnpool dx")
+
+
 def test_public_pooling_and_normalize_modules():
     """`encoder.pooling` / `encoder.norm` are attributes other code reaches into: their forward must work stand-alone, with autograd
     (inside the encoders the same arithmetic is fused into the final-LayerNorm kernel).  ref base_encoder.py:6-12, 88-126."""

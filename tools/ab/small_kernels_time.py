@@ -24,3 +24,18 @@ def timeit(fn, iters=10):
     return e0.elapsed_time(e1) / iters * 1e3
 print(f"embed bwd {timeit(lambda: hip.call('oneprot_esm_embed_bwd', ids, x, rs, dW, ws, B, L, d, V, 1, 32, 1, 0)):.1f} us   "
       f"lnpool fwd {timeit(lambda: hip.call('oneprot_lnpool_fwd', x, ids, 1, gamma, beta, pooled, mean, rstd, wrow, None, None, B, L, d, 1e-5, 0)):.1f} us")
+
+# cfg-5 anchor head (ESM-2-650M width, attention1d pooling): final LayerNorm that also writes the normalised hidden state, then the pooling kernels
+B, L, d = 128, 512, 1280
+ids = torch.randint(4, 24, (B, L), device="cuda", generator=g)
+x = torch.randn(B * L, d, device="cuda", generator=g)
+hidden = torch.empty(B, L, d, device="cuda")
+gamma, beta = torch.ones(d, device="cuda"), torch.zeros(d, device="cuda")
+pooled, mean, rstd, wrow, attn = torch.empty(B, d, device="cuda"), torch.empty(B * L, device="cuda"), torch.empty(B * L, device="cuda"), torch.empty(B * L, device="cuda"), torch.empty(B, L, device="cuda")
+w, bias, dp = torch.randn(d, device="cuda", generator=g) * 0.05, torch.zeros(1, device="cuda"), torch.randn(B, d, device="cuda", generator=g)
+dw, db = torch.empty(d, device="cuda"), torch.empty(1, device="cuda")
+ws = torch.empty(hip.query("oneprot_attnpool_bwd_workspace", B, d), dtype=torch.uint8, device="cuda")
+print(f"128 x 512 x 1280: lnpool fwd (+hidden) {timeit(lambda: hip.call('oneprot_lnpool_fwd', x, ids, 1, gamma, beta, pooled, mean, rstd, wrow, None, hidden, B, L, d, 1e-5, 0)):.1f} us   "
+      f"attnpool fwd {timeit(lambda: hip.call('oneprot_attnpool_fwd', hidden, ids, 1, w, bias, pooled, attn, B, L, d)):.1f} us   "
+      f"attnpool bwd (no dx) {timeit(lambda: hip.call('oneprot_attnpool_bwd', hidden, attn, w, dp, dw, db, None, ws, B, L, d)):.1f} us   "
+      f"(with dx) {timeit(lambda: hip.call('oneprot_attnpool_bwd', hidden, attn, w, dp, dw, db, hidden.new_empty(B, L, d), ws, B, L, d)):.1f} us")
