@@ -1047,6 +1047,9 @@ __global__ void __launch_bounds__(512, 2) k_attn_fwd3(const bf16_t* __restrict__
       bh_next = xcd * per_xcd + first_lane(rv);
     }
     drawn_v = draw_async(sched ? sched + SW_HEAD(xcd) : nullptr, draw_lane & (int)((unsigned)(bh_next - bh_end) >> 31));      // (EXEC mask empty unless this wave draws and a next slab exists)
+#ifdef FWD3_DEPHASE
+    if (wave >= 4) __builtin_amdgcn_s_sleep(FWD3_DEPHASE);    // (ablation) the second wave of every SIMD starts the slab FWD3_DEPHASE x 64 cycles behind the first
+#endif
     // hipcc does not see the wait above: it would put its own vmcnt(0) in front of the first use of the q fragments -- behind the LDS-DMA of the
     // NEXT slab, i.e. the compute would start only after that transfer.  Consuming the fragments here puts its wait where it is free.
 #pragma unroll
