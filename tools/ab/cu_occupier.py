@@ -18,6 +18,7 @@ ap.add_argument("--windows", type=int, default=5)
 ap.add_argument("--batch", type=int, default=256)
 ap.add_argument("--only", default="", help="whole | windows: only that part")
 ap.add_argument("--ks", default="4,8,16,32")
+ap.add_argument("--soak-seconds", type=float, default=0.0, help="instead of the timing tables: train for this long with k = 8 / 16 windows arriving at random moments; finite loss, counters at the end")
 a = ap.parse_args()
 spin = ctypes.CDLL(os.path.join(ROOT, "tests", "libcu_spin.so"))
 spin.cu_spin_launch.argtypes = [ctypes.c_int, ctypes.c_longlong, ctypes.c_void_p, ctypes.c_void_p]
@@ -63,6 +64,35 @@ def timed(hold_cus, whole_step_us=0, windows=0, window_us=0, gap_ms=0.0):
 for _ in range(3):
     step()
 torch.cuda.synchronize()
+if a.soak_seconds > 0:
+    import random, threading
+    from oneprot_amd import hip
+    stop = threading.Event()
+    fired = [0]
+    def feeder():
+        rng = random.Random(7)
+        while not stop.is_set():
+            time.sleep(rng.uniform(0.002, 0.05))
+            spin.cu_spin_launch(rng.choice((4, 8, 16, 32)), int(rng.uniform(200, 1500)), sink.data_ptr(), side.cuda_stream)
+            fired[0] += 1
+    th = threading.Thread(target=feeder); th.start()
+    t0, n, worst = time.time(), 0, 0.0
+    try:
+        while time.time() - t0 < a.soak_seconds:
+            for _ in range(25):
+                loss = module.training_step(batch, 0)
+                n += 1
+            v = float(loss.detach())                        # (synchronises)
+            if not (v == v and abs(v) < 1e4):                # a poisoned launch (sched_error != 0) or a training run that diverged on its one fixed batch
+                print(f"  loss {v} after {n} steps; sched error word {hip.sched_error()}", flush=True)
+                break
+            print(f"  {n:6d} steps, {fired[0]:6d} windows, {time.time() - t0:6.0f} s, loss {v:.5f}", flush=True)
+    finally:
+        stop.set(); th.join()
+    torch.cuda.synchronize()
+    print(f"soak: {n} steps beside {fired[0]} windows of 4-32 held CUs (0.2-1.5 ms each) in {time.time() - t0:.0f} s; late ticket draws {hip.sched_late_draws()}, "
+          f"bounded waits that ran out / tile-count mismatches {hip.sched_error()}, dynamic tiles {hip.dynamic_tiles_wanted()}", flush=True)
+    sys.exit(0)
 base = statistics.median(timed(0) for _ in range(a.steps))
 print(f"cfg-2 sub-step, batch {a.batch}: {base:.1f} ms with nothing else on the GPU", flush=True)
 KS = [int(x) for x in a.ks.split(",")]
