@@ -536,6 +536,12 @@ template <int HD> struct TileFrags {
 // fast pass, one 32-key tile for NB blocks of 32 queries held by the wave: p = 2^s, no maximum.  BOOK: the tile has key biases (class 1).
 // `cur` holds the tile's fragments; when `nxt` is given, the fragments of tile t_next are requested right behind the score chains, so that they
 // land under this tile's exponentials instead of in front of the next tile's first MFMA (two waves per SIMD do not cover an LDS round trip).
+// FWD3_PRIO: s_setprio around the phases of a tile.  3 (default, round 6): the score chains and each block's packs + row-sum / P.V MFMAs at priority 1, the
+// exponentials at 0 -- the partner wave of the SIMD gets its MFMAs out while this one is in its exponentials: -2 % per launch (hd 32), bit-identical.
+// 1: score chains only (-1.5 %); 2: the vector phase raised instead (+0.5 %); 0: none.
+#ifndef FWD3_PRIO
+#define FWD3_PRIO 3
+#endif
 template <int HD, int NB, bool BOOK, class Side>
 __device__ __forceinline__ void fwd_tile_fast(const unsigned char* sK, const unsigned char* sV, const float* sBias, bool have_bias, int nkeys, int t,
                                               const bf8_t (&qf)[NB][Cfg<HD>::KSTEPS], RowState<HD> (&st)[NB], int lane, const FragOff<HD>& fo,
@@ -544,6 +550,11 @@ __device__ __forceinline__ void fwd_tile_fast(const unsigned char* sK, const uns
   const int h = lane >> 5;
   const bf8_t (&kf)[C::KSTEPS] = cur.k;
   f32x16 s[NB];
+#if FWD3_PRIO == 1 || FWD3_PRIO == 3
+  __builtin_amdgcn_s_setprio(1);                             // (ablation) the score chains ahead of the partner wave's instructions
+#elif FWD3_PRIO == 2
+  __builtin_amdgcn_s_setprio(0);
+#endif
 #ifdef FWD2_ABL_NOQK
 #pragma unroll
   for (int b = 0; b < NB; ++b) { s[b] = zero16(); asm volatile("" : "+v"(s[b])); }
@@ -572,12 +583,23 @@ __device__ __forceinline__ void fwd_tile_fast(const unsigned char* sK, const uns
   // all score chains are issued before the first exponential: left alone hipcc reuses one register tile for the blocks' scores and sinks the second
   // block's chain behind the first block's exponentials (one exposed MFMA latency per block and tile)
   __builtin_amdgcn_sched_barrier(0);
+#if FWD3_PRIO == 1 || FWD3_PRIO == 3
+  __builtin_amdgcn_s_setprio(0);
+#elif FWD3_PRIO == 2
+  __builtin_amdgcn_s_setprio(1);                             // (ablation) the exponentials / packs ahead of the partner wave's instructions
+#endif
   side();      // the caller's per-tile share of memory instructions (k_attn_fwd3: LDS-DMA of the next slab, stores of the previous one)
 #pragma unroll
   for (int b = 0; b < NB; ++b) {
+#if FWD3_PRIO == 3
+    __builtin_amdgcn_s_setprio(0);
+#endif
 #ifndef FWD2_ABL_NOEXP
 #pragma unroll
     for (int e = 0; e < 16; ++e) s[b][e] = __builtin_amdgcn_exp2f(s[b][e]);
+#endif
+#if FWD3_PRIO == 3
+    __builtin_amdgcn_s_setprio(1);
 #endif
 #pragma unroll
     for (int sb = 0; sb < 2; ++sb) {
