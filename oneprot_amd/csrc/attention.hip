@@ -2033,6 +2033,9 @@ __global__ void __launch_bounds__(1024, 1) k_attn_bwd_fused(const bf16_t* __rest
   }
 }
 
+#ifndef BWD64_PRIO
+#define BWD64_PRIO 1
+#endif
 #ifdef BWD64_STAMP      // diagnostic build (tools/ab/bwd64_stamps.py): s_memtime at the stage boundaries of every step of one work-group's eight waves
 __device__ unsigned long long g_bwd64_stamps[8 * 16 * 8];
 extern "C" int oneprot_attn_debug_bwd64_stamps(unsigned long long* host_out) {
@@ -2288,6 +2291,13 @@ __global__ void __launch_bounds__(512, 1) k_attn_bwd_fused64(const bf16_t* __res
             dp[kb] = MFMA32(dof[st], vf[kb][st], dp[kb]);
           }
         };
+        // BWD64_PRIO 1 (default, round 6): the MFMA-only head of the step (key block 0's chains, the deferred dQ chain and its read-add-write) at priority 1, the
+        // mixed vector / MFMA part at 0: -0.7 % per launch, bit-identical; 2 (the reverse): nothing; 0: none
+#if BWD64_PRIO == 1
+        __builtin_amdgcn_s_setprio(1);
+#elif BWD64_PRIO == 2
+        __builtin_amdgcn_s_setprio(0);
+#endif
         chains(0);
         BWD64_T(1);
         f32x16 dqp = zero16();
@@ -2300,6 +2310,11 @@ __global__ void __launch_bounds__(512, 1) k_attn_bwd_fused64(const bf16_t* __res
         if (p_i >= 0) dq_commit(dqp);
         BWD64_T(2);
         __builtin_amdgcn_sched_barrier(0);
+#if BWD64_PRIO == 1
+        __builtin_amdgcn_s_setprio(0);
+#elif BWD64_PRIO == 2
+        __builtin_amdgcn_s_setprio(1);
+#endif
         const bf8_t tdo0 = tr_frag(tdO, 0), tdo1 = tr_frag(tdO, 1), tq0 = tr_frag(tQ, 0), tq1 = tr_frag(tQ, 1);      // (requested here, not with the row fragments: 16 registers less across the deferred dQ)
         bf8_t pf[2], dsf[2];
         auto vector_part = [&](int kb) {      // P = 2^s, dS = P * dP', both packed to bf16 fragments
