@@ -551,7 +551,7 @@ __device__ __forceinline__ void fwd_tile_fast(const unsigned char* sK, const uns
   const bf8_t (&kf)[C::KSTEPS] = cur.k;
   f32x16 s[NB];
 #if FWD3_PRIO == 1 || FWD3_PRIO == 3
-  __builtin_amdgcn_s_setprio(1);                             // (ablation) the score chains ahead of the partner wave's instructions
+  __builtin_amdgcn_s_setprio(1);                             // the score chains ahead of the partner wave's instructions
 #elif FWD3_PRIO == 2
   __builtin_amdgcn_s_setprio(0);
 #endif
@@ -586,7 +586,7 @@ __device__ __forceinline__ void fwd_tile_fast(const unsigned char* sK, const uns
 #if FWD3_PRIO == 1 || FWD3_PRIO == 3
   __builtin_amdgcn_s_setprio(0);
 #elif FWD3_PRIO == 2
-  __builtin_amdgcn_s_setprio(1);                             // (ablation) the exponentials / packs ahead of the partner wave's instructions
+  __builtin_amdgcn_s_setprio(1);                             // (variant 2, measured slower) the exponentials / packs ahead of the partner wave's instructions
 #endif
   side();      // the caller's per-tile share of memory instructions (k_attn_fwd3: LDS-DMA of the next slab, stores of the previous one)
 #pragma unroll
