@@ -419,6 +419,63 @@ def _log(msg):
     print(f"[bench {time.perf_counter() - _T0:7.1f}s] {msg}", file=sys.stderr, flush=True)
 
 
+class BoardSampler:
+    """Board power and shader clock of the GPU this rank drives while the timed steps run: the amdgpu hwmon files (power1_average / power1_input, freq1_input,
+    power1_cap; readable without root), sampled every 50 ms by a helper thread.  The card is the one whose PCI address torch reports for the device.  Why it is in
+    the bench line: the step runs AT the board's power cap with the shader clock pulled below its 2.4 GHz maximum (tools/ab/power_probe.py), so
+    the bf16 MFMA peak the silicon offers during the run is 2.5 PFLOP/s x sclk / 2.4 GHz, not 2.5."""
+
+    def __init__(self, torch_device):
+        import glob
+        import threading
+        import torch
+        self.hw, self.rows, self._stop, self._thread = None, [], threading.Event(), None
+        try:
+            pr = torch.cuda.get_device_properties(torch_device)
+            want = f"{getattr(pr, 'pci_domain_id', 0):04x}:{pr.pci_bus_id:02x}:{pr.pci_device_id:02x}."
+            for hw in glob.glob("/sys/class/drm/card*/device/hwmon/hwmon*"):
+                if want in os.path.realpath(os.path.join(hw, "..", "..")) + "/" or want in (self._rd(os.path.join(hw, "..", "..", "uevent")) or ""):
+                    self.hw = hw
+        except Exception:
+            self.hw = None
+
+    @staticmethod
+    def _rd(path):
+        try:
+            with open(path) as f:
+                return f.read().strip()
+        except Exception:
+            return None
+
+    def _run(self):
+        while not self._stop.is_set():
+            p = self._rd(self.hw + "/power1_average") or self._rd(self.hw + "/power1_input")
+            f = self._rd(self.hw + "/freq1_input")
+            if p and f:
+                self.rows.append((float(p) / 1e6, float(f) / 1e6))
+            self._stop.wait(0.05)
+
+    def start(self):
+        import threading
+        if self.hw is not None:
+            self._thread = threading.Thread(target=self._run, daemon=True)
+            self._thread.start()
+
+    def stop(self):
+        if self._thread is not None:
+            self._stop.set()
+            self._thread.join()
+        if len(self.rows) < 3:
+            return None
+        ps, fs = [r[0] for r in self.rows], [r[1] for r in self.rows]
+        cap = self._rd(self.hw + "/power1_cap")
+        sclk = sum(fs) / len(fs)
+        return {"power_w_mean": round(sum(ps) / len(ps), 0), "power_w_max": round(max(ps), 0), "power_cap_w": round(float(cap) / 1e6, 0) if cap else None,
+                "sclk_mhz_mean": round(sclk, 0), "sclk_mhz_min": round(min(fs), 0), "sclk_mhz_max": round(max(fs), 0), "samples": len(ps),
+                "bf16_mfma_peak_at_that_clock_tflops": round(PEAK_BF16_TFLOPS * sclk / 2400.0, 0),
+                "source": "amdgpu hwmon (power1_average, freq1_input) of this rank's card, every 50 ms over the timed steps; the spec peak of 2.5 PFLOP/s is 4096 FLOP/clk/CU x 256 CUs at 2.4 GHz"}
+
+
 def main():
     args = parse_args()
     if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
@@ -462,11 +519,15 @@ def main():
     xt = D.ExchangeTimer.enable() if world > 1 else None
     # live per-launch timing of the dominant kernel (FFN-1 GEMM, bias+GELU epilogue) with events on the launch stream
     hip.profile_begin({"oneprot_gemm_bf16_nt": hip.EPI_BIAS_GELU})
+    board = BoardSampler(dev) if (rank == 0 and not args.no_extras) else None
+    if board is not None:
+        board.start()
     t0 = time.perf_counter()
     for _ in range(args.steps):
         loss = module.training_step(batch, 0)
     barrier()
     elapsed = time.perf_counter() - t0
+    board_stats = board.stop() if board is not None else None
     launches = hip.profile_end()["oneprot_gemm_bf16_nt"]
     _log(f"timed region done: {elapsed / args.steps * 1e3:.1f} ms/step")
     exchange = None
@@ -588,6 +649,11 @@ def main():
                                       "frac": round(alg_bytes / gemm_s / 1e9 / PEAK_HBM_GBS, 4) if gemm_s > 0 else 0.0,
                                       "algorithmic_GB_per_launch": round(alg_bytes / max(len(launches), 1) / 1e9, 3)}},
         }
+        if board_stats is not None:
+            # the dominant kernel against the peak the clock of THIS run allows (the step sits at the board's power cap: the clock is what gives)
+            board_stats["roofline_frac_at_that_clock"] = round(achieved / max(board_stats["bf16_mfma_peak_at_that_clock_tflops"], 1.0), 4)
+            board_stats["step_frac_at_that_clock"] = round(flops / (ms_step * 1e-3) / 1e12 / max(board_stats["bf16_mfma_peak_at_that_clock_tflops"], 1.0), 4)
+            out["board"] = board_stats
         out.update(extras)
         if exchange is not None:
             from oneprot_amd.distributed import grad_overlap_enabled

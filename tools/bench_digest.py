@@ -10,3 +10,5 @@ for k in j.get("kernels", []): print(f"  {k['avg_ms']:8.4f} ms x{k['launches']:4
 for k, v in (j.get("other_workloads") or {}).items(): print(f"  {k}: {v['value']} pairs/s {v['ms_per_step']} ms/step loss {v['loss']}")
 c = j.get("cpu_baseline")
 if c: print(f"cpu {c['value']} pairs/s on {c['cores']} cores {c.get('host_cores')} | cfg1 {c['cfg1']['value']}")
+b = j.get("board")
+if b: print(f"board {b['power_w_mean']:.0f} W of {b['power_cap_w']} cap, sclk {b['sclk_mhz_mean']:.0f} MHz ({b['sclk_mhz_min']:.0f}-{b['sclk_mhz_max']:.0f}) -> MFMA peak at that clock {b['bf16_mfma_peak_at_that_clock_tflops']:.0f} TFLOP/s: FFN-1 {b['roofline_frac_at_that_clock']}, step {b['step_frac_at_that_clock']}")
