@@ -27,8 +27,11 @@ Extra objects on the JSON line:
                the MFMA peak, timed with events after the timed region; MFMA-busy % from the committed PMC pass.
   kernels      per-kernel-family rates from one extra, event-bracketed step after the timed region: MFMA kernels in TFLOP/s, LayerNorm / Adam
                in HBM GB/s against 8 TB/s.
-  other_workloads  cfg-4 (seq <-> text) and the cfg-5-shaped round-robin step (650M anchor, batch 128): pairs/s of 3 steps each, run after the timed
-               region (default workload, N=1 only).
+  board        board power and shader clock of rank 0's GPU over the timed steps (amdgpu hwmon files, a helper thread every 50 ms): the step runs at
+               the board's power cap with the clock below its 2.4 GHz maximum; the bf16 MFMA peak at the measured clock and the roofline / step
+               fractions against THAT (roofline.peak stays the 2.5 PFLOP/s spec figure).
+  other_workloads  cfg-4 (seq <-> text) and the cfg-5-shaped round-robin step (650M anchor, batch 128): pairs/s (median of 5 steps each, 2 warm-ups),
+               run after the timed region (default workload, N=1 only).
   cpu_baseline the CPU oracle (oracle/oneprot_oracle.py, fp32 torch restatement of the reference) timed on this box's host cores on a
                bounded sample of the same workload (reduced batch; 1 warm-up + 5 timed runs, median), plus the cfg-1 CPU headline point
                (ESM-2-8M x2, L=128, batch 32); rank 0 at N=1 only.
