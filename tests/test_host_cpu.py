@@ -349,3 +349,28 @@ def test_gradient_wire_dtype_option(monkeypatch):
     assert D.grad_comm_dtype() is torch.bfloat16 and D.grad_comm_dtype("fp32") is None
     with pytest.raises(ValueError):
         D.grad_comm_dtype("fp8")
+
+
+def test_bench_board_sampler_reads_hwmon_files(tmp_path):
+    """bench.BoardSampler (the `board` object of the bench line: power and shader clock over the timed steps) on a fake hwmon directory: units (uW, Hz),
+    the MFMA peak at the measured clock, and no thread / no result when the card has no readable node."""
+    import time
+    import bench
+    s = bench.BoardSampler.__new__(bench.BoardSampler)
+    import threading
+    hw = tmp_path / "hwmon0"
+    hw.mkdir()
+    (hw / "power1_average").write_text("1300000000\n")
+    (hw / "freq1_input").write_text("2000000000\n")
+    (hw / "power1_cap").write_text("1400000000\n")
+    s.hw, s.rows, s._stop, s._thread = str(hw), [], threading.Event(), None
+    s.start()
+    time.sleep(0.3)
+    out = s.stop()
+    assert out is not None and out["samples"] >= 3
+    assert out["power_w_mean"] == 1300 and out["power_cap_w"] == 1400 and out["sclk_mhz_mean"] == 2000
+    assert abs(out["bf16_mfma_peak_at_that_clock_tflops"] - bench.PEAK_BF16_TFLOPS * 2000 / 2400) <= 1
+    none = bench.BoardSampler.__new__(bench.BoardSampler)
+    none.hw, none.rows, none._stop, none._thread = None, [], threading.Event(), None
+    none.start()
+    assert none._thread is None and none.stop() is None
