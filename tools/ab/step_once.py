@@ -1,0 +1,27 @@
+#!/usr/bin/env python3
+"""Development tool (GPU): ms per cfg-2 training step with the kernel library named by G8_LIB (default: the product's) -- one process per library, so that
+builds that differ at compile time can be ranked INSIDE the step (tools/ab/step_libs_ab.sh alternates them on one box).  usage: step_once.py [steps]"""
+import os, sys
+ROOT = os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+sys.path.insert(0, ROOT)
+os.environ.setdefault("RANK", "0"); os.environ.setdefault("WORLD_SIZE", "1"); os.environ["ONEPROT_ALLOW_RANDOM_INIT"] = "1"
+import warnings
+warnings.filterwarnings("ignore")
+import torch
+from oneprot_amd import hip
+if os.environ.get("G8_LIB"):
+    hip.LIB_PATH = os.path.abspath(os.environ["G8_LIB"])
+import bench
+steps = int(sys.argv[1]) if len(sys.argv) > 1 else 12
+_argv = sys.argv; sys.argv = [_argv[0], "--no-cpu-baseline", "--no-extras"]; args = bench.parse_args(); sys.argv = _argv
+work = bench.build_workload(args, torch.device("cuda:0"), 0)
+module, batch = work["module"], work["batch"]
+for _ in range(4):
+    module.training_step(batch, 0)
+torch.cuda.synchronize()
+e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+e0.record()
+for _ in range(steps):
+    loss = module.training_step(batch, 0)
+e1.record(); torch.cuda.synchronize()
+print(f"{e0.elapsed_time(e1) / steps:.3f} {float(loss.detach()):.6f}")
