@@ -12,6 +12,8 @@ import bench
 from oneprot_amd import hip
 ap = argparse.ArgumentParser()
 ap.add_argument("--steps", type=int, default=8); ap.add_argument("--rounds", type=int, default=3); ap.add_argument("--only", default="")
+ap.add_argument("--windows", type=int, default=0, help="co-resident windows per step (tests/cu_spin.hip on a side stream: the stand-in for the RCCL channels of an overlapped all-reduce)")
+ap.add_argument("--window-ms", type=float, default=0.7); ap.add_argument("--hold-cus", type=int, default=16)
 a = ap.parse_args()
 _argv = sys.argv; sys.argv = [_argv[0], "--no-cpu-baseline", "--no-extras"]; args = bench.parse_args(); sys.argv = _argv
 dev = torch.device("cuda:0")
@@ -47,18 +49,38 @@ CONFIGS = {
     "ONEPROT_FFN2_LN=0 (FFN-2, then LayerNorm)": (env("ONEPROT_FFN2_LN", "0"), env("ONEPROT_FFN2_LN", None)),
     "tiles from the work queues": (dyn(True), dyn(False)),
     "weight-gradient GEMM with a 16-CU reserve": (lambda: Q("oneprot_cu_reserve", 16), lambda: Q("oneprot_cu_reserve", 0)),
+    "work queues + 16-CU reserve (the multi-rank defaults)": (lambda: (dyn(True)(), Q("oneprot_cu_reserve", 16)), lambda: (dyn(False)(), Q("oneprot_cu_reserve", 0))),
 }
 names = [n for n in CONFIGS if not a.only or any(o in n for o in a.only.split(",")) or n == "default"]
+
+
+if a.windows:
+    import ctypes, threading, time
+    spin = ctypes.CDLL(os.path.join(ROOT, "tests", "libcu_spin.so"))
+    spin.cu_spin_launch.argtypes = [ctypes.c_int, ctypes.c_longlong, ctypes.c_void_p, ctypes.c_void_p]
+    sink = torch.zeros(4, dtype=torch.int32, device=dev)
+    side = torch.cuda.Stream()
 
 
 def timed():
     module.training_step(batch, 0)
     torch.cuda.synchronize()
     e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    stop = None
+    if a.windows:                                           # windows spread evenly over the wall time of a step (~0.215 s), for as long as the timed steps run
+        stop = threading.Event()
+        def feeder():
+            gap = 0.215 / a.windows
+            while not stop.is_set():
+                time.sleep(gap)
+                spin.cu_spin_launch(a.hold_cus, int(a.window_ms * 1e3), sink.data_ptr(), side.cuda_stream)
+        th = threading.Thread(target=feeder); th.start()
     e0.record()
     for _ in range(a.steps):
         module.training_step(batch, 0)
     e1.record(); torch.cuda.synchronize()
+    if stop is not None:
+        stop.set(); th.join(); torch.cuda.synchronize()
     return e0.elapsed_time(e1) / a.steps
 
 
@@ -73,7 +95,8 @@ for r in range(a.rounds):
         finally:
             CONFIGS[n][1]()
 base = statistics.median(res["default"])
-print(f"cfg-2 sub-step, median of {a.rounds} interleaved rounds of {a.steps} steps; sched error word {hip.sched_error()}")
+print(f"cfg-2 sub-step, median of {a.rounds} interleaved rounds of {a.steps} steps; sched error word {hip.sched_error()}"
+      + (f"; beside {a.windows} windows per step of {a.hold_cus} held CUs for {a.window_ms} ms each" if a.windows else ""))
 for n in names:
     m = statistics.median(res[n])
     print(f"  {n:58s} {m:8.2f} ms  ({(m / base - 1) * 100:+5.1f} %)   rounds: " + " ".join(f"{x:.1f}" for x in res[n]))
