@@ -375,10 +375,12 @@ extern "C" int oneprot_attn_dropout_keep(void* keep, int B, int H, int L, float 
 // vector form (301 against 293 us, tools/ab/attn_ab.py).
 // Row sum of one packed fragment, two forms.  MFMA: an all-ones MFMA per fragment (no vector instructions, a 16-register accumulator tile whose
 // registers all hold the sum).  DOT2: v_dot2c_f32_bf16 against (1, 1), two ROUNDED probabilities per vector instruction, one register, no matrix-pipe
-// time; the lane then holds the sum over ITS 16 keys of every 32 (the other 16 sit in lane ^ 32) and the halves meet once, in finish_sum.  hd <= 32
-// kernels are bound by the vector pipe and keep the MFMA form (same time either way, tools/ab/libs_ab.py); the hd-64 kernels are matrix-bound and
-// short of registers and take DOT2.  (Inline asm: hipcc 7.2 compiles __builtin_amdgcn_fdot2_f32_bf16 on the four words of a fragment into four
-// instructions that all read word 0.)
+// time; the lane then holds the sum over ITS 16 keys of every 32 (the other 16 sit in lane ^ 32) and the halves meet once, in finish_sum.  The hd-64
+// kernels are matrix-bound and short of registers and have taken DOT2 since round 5.  hd = 32: in kernel-only loops the two forms tie (round 5; round 6:
+// -4.7 % without padding, +2.9 % ragged), but INSIDE the training step -- which runs at the board's power cap, DESIGN section 6 -- the form without the
+// four all-ones MFMAs per key tile (16 K multiply-adds each, to add up 32 numbers) is worth 1.4 ms of a 215.6 ms step, four runs of four
+// (tools/ab/step_libs_ab.sh, profiles/r06_step_ab.txt): DOT2 from hd = 32 up since round 6; hd = 16 (the padded 8M-model heads of cfg-1) keeps the MFMA form.
+// (Inline asm: hipcc 7.2 compiles __builtin_amdgcn_fdot2_f32_bf16 on the four words of a fragment into four instructions that all read word 0.)
 template <bool DOT2> struct RowSum;
 template <> struct RowSum<false> {
   f32x16 lacc;
@@ -405,7 +407,7 @@ template <> struct RowSum<true> {
   static __device__ __forceinline__ float whole(float l) { return l + __shfl_xor(l, 32, 64); }
 };
 #ifndef ROWSUM_DOT2_MIN_HD
-#define ROWSUM_DOT2_MIN_HD 64
+#define ROWSUM_DOT2_MIN_HD 32
 #endif
 template <int HD> struct RowState {
   f32x16 acc[Cfg<HD>::DBLK];
