@@ -16,6 +16,16 @@ steps = int(sys.argv[1]) if len(sys.argv) > 1 else 12
 _argv = sys.argv; sys.argv = [_argv[0], "--no-cpu-baseline", "--no-extras"]; args = bench.parse_args(); sys.argv = _argv
 work = bench.build_workload(args, torch.device("cuda:0"), 0)
 module, batch = work["module"], work["batch"]
+if os.environ.get("STEP_RAGGED"):      # sequence lengths L/2 .. L (the reference pads a batch to its longest row): <eos> at the end of each row, <pad> = 1 behind it
+    g = torch.Generator().manual_seed(5)
+    for m, (s_ids, x_ids, _, _) in batch.items():
+        B, L = s_ids.shape
+        lens = torch.randint(L // 2, L + 1, (B,), generator=g)
+        for ids, eos in ((s_ids, 2), (x_ids, 2)):
+            for b in range(B):
+                n = int(lens[b])
+                ids[b, n - 1] = eos
+                ids[b, n:] = 1
 for _ in range(4):
     module.training_step(batch, 0)
 torch.cuda.synchronize()
