@@ -555,12 +555,15 @@ def main():
         with torch.no_grad():
             seq_tr.run_layers(seq_ids, save=False)
             e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
-            reps = 3
+            reps = 10                                       # ~0.5 s: long enough for the board sampler (50 ms) to see the clock the forward runs at
+            fwd_board = BoardSampler(dev)
+            fwd_board.start()
             e0.record()
             for _ in range(reps):
                 seq_tr.run_layers(seq_ids, save=False)
             e1.record()
             torch.cuda.synchronize()
+            fwd_board = fwd_board.stop()
         fwd_ms = e0.elapsed_time(e1) / reps
         fwd_tf = seq_ids.shape[0] * tower_fwd_flops(seq_tr, seq_ids.shape[1]) / (fwd_ms * 1e-3) / 1e12
         # MFMA-busy % comes from a committed rocprofv3 PMC pass (counters cannot be read from inside this process): quoted only when this run IS the
@@ -582,6 +585,12 @@ def main():
                                  "ms": round(fwd_ms, 3), "achieved": round(fwd_tf, 1), "unit": "TFLOP/s", "peak": PEAK_BF16_TFLOPS,
                                  "frac": round(fwd_tf / PEAK_BF16_TFLOPS, 4), "mfma_busy_pct": mfma_busy, "mfma_busy_source": mfma_src, "mfma_busy_kernels": mfma_kernels,
                                  "target_frac": 0.40}
+        if fwd_board is not None:
+            # the forward runs at the board's power cap too: its FLOP rate against the MFMA peak at the clock it ran at.  (The busy counter above counts every
+            # MFMA cycle, useful or not: it DROPPED by ~2 points in round 6 when the attention forward's all-ones row-sum MFMAs were replaced by v_dot2c -- and
+            # the forward got faster.  MFMAs now do the dense contractions only.)
+            extras["encoder_fwd"]["board"] = {k: fwd_board[k] for k in ("power_w_mean", "power_cap_w", "sclk_mhz_mean", "samples", "bf16_mfma_peak_at_that_clock_tflops")}
+            extras["encoder_fwd"]["frac_at_that_clock"] = round(fwd_tf / max(fwd_board["bf16_mfma_peak_at_that_clock_tflops"], 1.0), 4)
     if not args.no_extras:
         # ---- one extra step with every kernel family bracketed by events (outside the timed region: the brackets cost launch time)
         hip.profile_begin({k: None for k in ("oneprot_gemm_bf16_nt", "oneprot_gemm_bf16_nt_resid_ln", "oneprot_gemm_bf16_nt_resid_ln8", "oneprot_gemm_bf16_tn",
